@@ -1,0 +1,362 @@
+#!/usr/bin/env python
+"""Golden-vector generator: runs the REAL reference (imported from /root/reference, build
+container only) on deterministic synthetic inputs and stores its OUTPUTS as small fixtures.
+
+Nothing of the reference is copied: inputs and weights come from temporalalignnet_amd.synth
+(a pure function of a seed), the reference is imported with three shims that are applied here
+(never edits to the reference), and only result arrays are written to tests/golden/*.npz.
+
+    python tests/golden/make_goldens.py            # regenerates every fixture (~2-3 min on CPU)
+
+Shims:
+  1. tan_model.Word2VecModel -> parameter-less stub (word2vec assets are not shipped; the hot
+     path never calls the language model).
+  2. TemporalAligner.get_text_visual_sim = get_text_visual_sim_joint, so that the released
+     TwinTemporalAligner constructor (tan_model.py:328) does not raise AttributeError.
+  3. empty module stubs for ffmpeg / torchvision(.transforms) / tensorboardX so train/loss.py and
+     eval/eval_zeroshot_align.py import.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+from temporalalignnet_amd import synth  # noqa: E402
+
+REF = "/root/reference"
+sys.path.insert(0, f"{REF}/model")
+import tan_model as ref_tan  # noqa: E402  (imports transformers; must precede the stubs)
+
+
+class _NoLM(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+
+
+ref_tan.Word2VecModel = _NoLM
+ref_tan.TemporalAligner.get_text_visual_sim = ref_tan.TemporalAligner.get_text_visual_sim_joint
+for _m in ("ffmpeg", "torchvision", "torchvision.transforms", "tensorboardX"):
+    sys.modules.setdefault(_m, types.ModuleType(_m))
+sys.path.insert(0, REF)
+sys.path.insert(0, f"{REF}/train")
+import loss as ref_loss  # noqa: E402
+sys.path.insert(0, f"{REF}/eval")
+import eval.eval_zeroshot_align as ref_eval  # noqa: E402
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+
+def args_ns(**kw):
+    a = dict(model="init", sim="cos", learn_agreement=0, temporal_agreement_type="keep",
+             loss_threshold=0.0, use_alignability_head=0, optim_policy="default", seq_len=64)
+    a.update(kw)
+    if a["model"] == "cotrain":
+        a["learn_agreement"] = 1
+        a["use_alignability_head"] = 1
+    return types.SimpleNamespace(**a)
+
+
+def load_params(model, params, prefix=""):
+    sd = {prefix + k: torch.from_numpy(v) for k, v in params.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(prefix not in k or k.startswith("target.") or "bert" in k for k in missing) or not missing, missing
+
+
+def make_ref_model(seed, E, D, head, **kw):
+    m = ref_tan.TemporalAligner(num_encoder_layers=E, num_decoder_layers=D, use_alignability_head=int(head), **kw)
+    load_params(m, synth.make_params(seed, E, D, head))
+    return m
+
+
+def tb(batch):
+    return {
+        "video": torch.from_numpy(batch["video"]),
+        "text_embed": torch.from_numpy(batch["text_embed"]),
+        "padding_mask": torch.from_numpy(batch["padding_mask"]),
+        "text_padding_mask": torch.from_numpy(batch["text_padding_mask"]),
+        "abs_text_pos": torch.from_numpy(batch["abs_text_pos"]),
+    }
+
+
+def ref_forward(model, batch, ema=False):
+    t = tb(batch)
+    B, N = t["text_embed"].shape[:2]
+    T = t["video"].shape[1]
+    ts, _, _ = ref_loss.get_mask_from_time(batch["start"], batch["end"], T, N, device="cpu")
+    fn = model.forward_from_ema if ema else model
+    return fn(t["video"], t["text_embed"], video_padding_mask=t["padding_mask"].bool(),
+              lang_padding_mask=t["text_padding_mask"].bool(), text_timestamp=ts)
+
+
+def capture_locals(fn, *a, **kw):
+    """Run fn and return (result, locals at its return) via a profile hook -- lets us read the
+    reference's intermediates (max_position, agreement_self_tgt, ...) without touching its source."""
+    box = {}
+    code = getattr(fn, "__wrapped__", fn).__code__      # look through @torch.no_grad()
+
+    def prof(frame, event, arg):
+        if event == "return" and frame.f_code is code:
+            box.update(frame.f_locals)
+
+    sys.setprofile(prof)
+    try:
+        r = fn(*a, **kw)
+    finally:
+        sys.setprofile(None)
+    return r, box
+
+
+def ref_get_loss(batch, logits, args, with_abs=True):
+    t = tb(batch)
+    return capture_locals(ref_loss.get_loss, input_data=batch, video_seq=t["video"], text_embed=t["text_embed"],
+                          video_padding_mask=t["padding_mask"], text_padding_mask=t["text_padding_mask"],
+                          logits=logits, args=args, abs_text_pos=t["abs_text_pos"] if with_abs else None)
+
+
+def grad_stats(named_grads):
+    """Per-parameter (sum, l2, 16 strided samples) -- small fingerprints of full gradients."""
+    out = {}
+    for k, g in named_grads:
+        g = g.detach().double().flatten()
+        idx = torch.linspace(0, g.numel() - 1, 16).long()
+        out[k] = np.concatenate([[g.sum().item(), g.norm().item()], g[idx].numpy()]).astype(np.float64)
+    return out
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"wrote {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# ------------------------------------------------------------------------------------------
+def g1_forward_small():
+    """G1: E1D1 T=16 B=4 N<=5, padding in both modalities, randomised affine params, head on,
+    random_pos_start=1 with np.random.seed(123): every output of TemporalAligner.forward."""
+    batch = synth.make_batch(11, B=4, T=16, n_min=2, n_max=5, video_pad_tail=3)
+    m = make_ref_model(101, 1, 1, True)
+    np.random.seed(123)
+    with torch.no_grad():
+        out = ref_forward(m, batch)
+    save("g1_forward_e1d1", **{k: v.numpy() for k, v in out.items()})
+
+
+def g2_forward_e6d6():
+    """G2: E6D6 T=64 B=2 N<=12: all logits + alignability logits (random_pos_start=0)."""
+    batch = synth.make_batch(12, B=2, T=64, n_min=8, n_max=12)
+    m = make_ref_model(102, 6, 6, True, random_pos_start=0)
+    with torch.no_grad():
+        out = ref_forward(m, batch)
+    save("g2_forward_e6d6", **{k: v.numpy() for k, v in out.items() if "feature" not in k})
+
+
+def g7_long_and_interp():
+    """G7: T=256 forward (config 4; E2D2 B=1 to stay small) + interpolate_from paths of the eval
+    entry points (tan_model.py:157-160,238-243) + circulant known answer (loss.py:19-20)."""
+    batch = synth.make_batch(17, B=1, T=256, n_min=8, n_max=8)
+    m = make_ref_model(107, 2, 3, True, random_pos_start=0)
+    t = tb(batch)
+    with torch.no_grad():
+        out = ref_forward(m, batch)
+        sj = m.get_text_visual_sim_joint(t["video"][:, :100], t["text_embed"], interpolate_from=64)
+        sd = m.get_text_visual_sim_dual(t["video"][:, :100], t["text_embed"], interpolate_from=64)
+        al = m.get_alignability(t["video"][:, :100], t["text_embed"], interpolate_from=(64, 16))
+        vf = m.get_visual_feature(t["video"][:, :40], torch.zeros(1, 40).bool())
+    save("g7_long_interp", logits_dual=out["logits_dual"].numpy(), logits_joint=out["logits_joint"].numpy(),
+         sim_joint_interp=sj.numpy(), sim_dual_interp=sd.numpy(),
+         align_dual_interp=al["alignability-dual"].numpy(), align_joint_interp=al["alignability-joint"].numpy(),
+         visual_feature_T40=vf.numpy(),
+         circulant_012=ref_loss.circulant(torch.tensor([0, 1, 2]), 0).numpy())
+
+
+def g3_loss_init():
+    """G3: get_loss for model='init' (defaults, then learn_agreement=1 with video padding to pin the
+    in-place masking quirk) on the E1D1 batch: scalars, d loss / d logits, parameter-gradient stats."""
+    batch = synth.make_batch(11, B=4, T=16, n_min=2, n_max=5, video_pad_tail=3)
+    m = make_ref_model(101, 1, 1, True, random_pos_start=0)
+    arrs = {}
+    for tag, args in (("default", args_ns()), ("agree", args_ns(learn_agreement=1)),
+                      ("th", args_ns(loss_threshold=0.5))):
+        m.zero_grad()
+        out = ref_forward(m, batch)
+        for k in ("logits_dual", "logits_joint"):
+            out[k].retain_grad()
+        ld, loc = ref_get_loss(batch, out, args)
+        ld["loss"].backward()
+        for k, v in ld.items():
+            arrs[f"{tag}/{k}"] = v.detach().numpy()
+        arrs[f"{tag}/dlogits_dual"] = out["logits_dual"].grad.numpy()
+        arrs[f"{tag}/dlogits_joint"] = out["logits_joint"].grad.numpy()
+        if tag == "default":
+            for k, v in grad_stats((n, p.grad) for n, p in m.named_parameters() if p.grad is not None).items():
+                arrs[f"{tag}/pgrad/{k}"] = v
+        if tag == "agree":
+            arrs[f"{tag}/dual_max_position"] = loc["max_position"].numpy()
+            arrs[f"{tag}/joint_self_tgt"] = loc["joint_self_tgt"].numpy().astype(np.uint8)
+            arrs[f"{tag}/agreement_self_tgt"] = loc["agreement_self_tgt"].numpy().astype(np.uint8)
+    save("g3_loss_init", **arrs)
+
+
+def g4_loss_cotrain():
+    """G4: cotrain E3D3 T=32 B=6, loss_threshold=0.5, all four temporal_agreement_type values:
+    scalars + the integer/bool tensors that must match bit-exactly."""
+    batch = synth.make_batch(14, B=6, T=32, n_min=3, n_max=7)
+    tw = ref_tan.TwinTemporalAligner(m=0.999, num_encoder_layers=3, num_decoder_layers=3,
+                                     use_alignability_head=1, random_pos_start=0)
+    load_params(tw.online, synth.make_params(104, 3, 3, True))
+    load_params(tw.target, synth.make_params(204, 3, 3, True))     # distinct EMA weights
+    arrs = {}
+    for kind in ("keep", "keep-joint", "i", "u"):
+        args = args_ns(model="cotrain", loss_threshold=0.5, temporal_agreement_type=kind)
+        tw.zero_grad()
+        out = ref_forward(tw, batch)
+        with torch.no_grad():
+            ema = ref_forward(tw, batch, ema=True)
+        logits = {**out, **{f"ema-{k}": v for k, v in ema.items()}}
+        for k in ("logits_dual", "logits_joint", "joint_logits_alignability"):
+            out[k].retain_grad()
+        ld, loc = ref_get_loss(batch, logits, args)
+        ld["loss"].backward()
+        for k, v in ld.items():
+            arrs[f"{kind}/{k}"] = v.detach().numpy()
+        arrs[f"{kind}/agreement_self_tgt"] = loc["agreement_self_tgt"].numpy().astype(np.uint8)
+        arrs[f"{kind}/t_th_mask"] = loc["t_th_mask"].numpy()
+        arrs[f"{kind}/t_align_th_mask"] = loc["t_align_th_mask"].numpy()
+        arrs[f"{kind}/confidence_mask"] = loc["confidence_mask"].numpy()
+        arrs[f"{kind}/self_tgt_iou"] = loc["self_tgt_iou"].numpy()
+        arrs[f"{kind}/dual_max_position"] = loc["max_position"].numpy()          # last assignment = dual branch
+        arrs[f"{kind}/dual_self_tgt"] = loc["dual_self_tgt"].numpy().astype(np.uint8)
+        arrs[f"{kind}/joint_self_tgt"] = loc["joint_self_tgt"].numpy().astype(np.uint8)
+        arrs[f"{kind}/joint_max_logits_per_text"] = loc["joint_max_logits_per_text"].numpy()
+        arrs[f"{kind}/dual_max_logits_per_text"] = loc["dual_max_logits_per_text"].numpy()
+        arrs[f"{kind}/dlogits_dual"] = out["logits_dual"].grad.numpy()
+        arrs[f"{kind}/dlogits_joint"] = out["logits_joint"].grad.numpy()
+        arrs[f"{kind}/dalign_joint"] = out["joint_logits_alignability"].grad.numpy()
+    save("g4_loss_cotrain", **arrs)
+
+
+def _optim(model, cotrain, lr=1e-4, wd=1e-5):
+    """optim_policy 'default' of train/main.py:330-356 + AdamW (main.py:397)."""
+    no_decay_tok = [".ln_", ".bias", ".logit_scale", ".entropy_scale"]
+    g0, g1 = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (g0 if any(t in name for t in no_decay_tok) else g1).append(p)
+    return torch.optim.AdamW([{"params": g0, "lr": lr, "weight_decay": 0.0},
+                              {"params": g1, "lr": lr, "weight_decay": wd}], lr=lr, weight_decay=wd)
+
+
+def g5_train_steps():
+    """G5: three optimizer steps of the train() sequence (main.py:33-122) on a fixed batch, for
+    'init' (E1D1, random_pos_start=1 + np.random.seed) and 'cotrain' (E1D3): per-step losses and
+    parameter fingerprints after step 3 (online and EMA target)."""
+    arrs = {}
+    # --- init
+    batch = synth.make_batch(15, B=8, T=16, n_min=2, n_max=5)
+    m = make_ref_model(105, 1, 1, False)          # random_pos_start=1 default
+    opt = _optim(m, False, lr=1e-3, wd=1e-2)      # larger lr/wd so 3 steps move the weights measurably
+    np.random.seed(7)
+    losses = []
+    for it in range(3):
+        opt.zero_grad()
+        out = ref_forward(m, batch)
+        ld, _ = ref_get_loss(batch, out, args_ns())
+        ld["loss"].backward()
+        opt.step()
+        losses.append(ld["loss"].item())
+    arrs["init/losses"] = np.array(losses)
+    for k, v in grad_stats((n, p.data) for n, p in m.named_parameters()).items():
+        arrs[f"init/param/{k}"] = v
+    # --- cotrain
+    batch = synth.make_batch(16, B=6, T=16, n_min=2, n_max=5)
+    tw = ref_tan.TwinTemporalAligner(m=0.99, num_encoder_layers=1, num_decoder_layers=3,
+                                     use_alignability_head=1, random_pos_start=0)
+    load_params(tw.online, synth.make_params(106, 1, 3, True))
+    tw._copy_param()
+    opt = _optim(tw, True, lr=1e-3, wd=1e-2)
+    args = args_ns(model="cotrain", loss_threshold=0.5)
+    losses = []
+    for it in range(3):
+        opt.zero_grad()
+        out = ref_forward(tw, batch)
+        with torch.no_grad():
+            ema = ref_forward(tw, batch, ema=True)
+        ld, _ = ref_get_loss(batch, {**out, **{f"ema-{k}": v for k, v in ema.items()}}, args)
+        ld["loss"].backward()
+        opt.step()
+        tw._momentum_update()
+        losses.append(ld["loss"].item())
+    arrs["cotrain/losses"] = np.array(losses)
+    for k, v in grad_stats((n, p.data) for n, p in tw.named_parameters()).items():
+        arrs[f"cotrain/param/{k}"] = v
+    save("g5_train_steps", **arrs)
+
+
+def g6_eval_harness():
+    """G6: the reference's test_alignment_htm (eval/eval_zeroshot_align.py:97-252) on a synthetic
+    HTM-Align-shaped fixture (3 videos, vlen~200, K~30) with a callback built on the reference
+    model (closure of train/main.py:171-189); HTM_Align / DataLoaderFast are replaced by an
+    in-memory iterable in the eval module's namespace (the real ones need the 80 videos' features)."""
+    m = make_ref_model(108, 1, 3, True, random_pos_start=0)
+    m.eval()
+    videos = synth.align_videos()
+    emb = {s: torch.from_numpy(e) for v in videos for s, e in zip(v["str"], v["emb"])}
+
+    class FakeDS:
+        def __init__(self, *a, **k): pass
+
+    def fake_loader(ds, **kw):
+        for v in videos:
+            yield {"video": torch.from_numpy(v["video"])[None], "start": torch.tensor(v["start"])[None],
+                   "end": torch.tensor(v["end"])[None], "vid": [v["vid"]], "str": [(s,) for s in v["str"]],
+                   "aligned": torch.tensor(v["aligned"])[None]}
+
+    class Loader(list):
+        pass
+
+    def loader_factory(ds, **kw):
+        L = Loader(fake_loader(ds))
+        return L
+
+    ref_eval.HTM_Align = FakeDS
+    ref_eval.DataLoaderFast = loader_factory
+    captured = []
+
+    def get_text_visual_sim(video_embed, text_str, interpolate_from=None, abs_text_pos=None):
+        text_embed = torch.stack([emb[s] for s in text_str])
+        j = m.get_text_visual_sim_joint(video_embed, text_embed[None, :], interpolate_from)
+        d = m.get_text_visual_sim_dual(video_embed, text_embed[None, :], interpolate_from)
+        out = {"sim": j.transpose(-1, -2) / 0.07, "dual-sim": d.transpose(-1, -2) / 0.07}
+        out.update(m.get_alignability(video_embed, text_embed[None, :], interpolate_from))
+        return out
+
+    args = args_ns(use_alignability_head=1, seq_len=64)
+    # capture per-video stitched sim/argmax through the locals of the harness at return is not
+    # possible (loop variables are overwritten), so also run per video.
+    metric = ref_eval.test_alignment_htm(get_text_visual_sim, "cpu", args)
+    arrs = {"Recall": metric["Recall"], "AUC": metric["AUC"]}
+    for i, v in enumerate(videos):
+        ref_eval.DataLoaderFast = lambda ds, _i=i, **kw: Loader(list(fake_loader(ds))[_i:_i + 1])
+        (mi, loc) = capture_locals(ref_eval.test_alignment_htm, get_text_visual_sim, "cpu", args)
+        arrs[f"v{i}/Recall"] = mi["Recall"]
+        if "prob" in loc:
+            arrs[f"v{i}/argmax"] = loc["prob"].argmax(-1).numpy()
+            arrs[f"v{i}/sim_aligned"] = loc["sim"].numpy()
+            arrs[f"v{i}/align_score"] = loc["align_score"].numpy()
+    save("g6_eval_harness", **arrs)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    table = {"g1": g1_forward_small, "g2": g2_forward_e6d6, "g3": g3_loss_init, "g4": g4_loss_cotrain,
+             "g5": g5_train_steps, "g6": g6_eval_harness, "g7": g7_long_and_interp}
+    for w in which:
+        table[w]()

@@ -1,0 +1,221 @@
+"""Pins the CPU oracle (oracle/) against golden vectors produced by the real reference
+(tests/golden/make_goldens.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import eval_ref, loss_ref, tan_ref, train_ref
+from temporalalignnet_amd import synth
+
+TOL = dict(rtol=1e-5, atol=2e-6)
+
+
+def P(seed, E, D, head):
+    return {k: torch.from_numpy(v) for k, v in synth.make_params(seed, E, D, head).items()}
+
+
+def TB(b):
+    return train_ref.to_torch_batch(b)
+
+
+def fwd(p, b, E, D, head=True, **kw):
+    t = TB(b)
+    return tan_ref.forward(p, t["video"], t["text_embed"], t["padding_mask"], t["text_padding_mask"].bool(),
+                           E=E, D=D, use_alignability_head=head, **kw)
+
+
+def test_circulant_known_answer(golden):
+    # the reference's only in-repo known answer (loss.py:19-20)
+    want = np.array([[0, 1, 2], [2, 0, 1], [1, 2, 0]])
+    got = loss_ref.circulant(torch.tensor([0, 1, 2]), 0).numpy()
+    assert (got == want).all()
+    assert (golden("g7_long_interp")["circulant_012"] == want).all()
+    x = torch.arange(24).reshape(2, 3, 4)
+    c = loss_ref.circulant(x, -1)
+    assert c.shape == (2, 3, 4, 4)
+    for i in range(4):
+        assert (c[..., i, :] == torch.roll(x, i, -1)).all()
+
+
+def test_g1_forward_e1d1(golden):
+    g = golden("g1_forward_e1d1")
+    b = synth.make_batch(11, B=4, T=16, n_min=2, n_max=5, video_pad_tail=3)
+    np.random.seed(123)
+    out = fwd(P(101, 1, 1, True), b, 1, 1, random_pos_start=True)
+    assert set(out) == set(g.files)
+    for k in g.files:
+        np.testing.assert_allclose(out[k].numpy(), g[k], err_msg=k, **TOL)
+
+
+def test_g2_forward_e6d6(golden):
+    g = golden("g2_forward_e6d6")
+    b = synth.make_batch(12, B=2, T=64, n_min=8, n_max=12)
+    out = fwd(P(102, 6, 6, True), b, 6, 6)
+    for k in g.files:
+        np.testing.assert_allclose(out[k].numpy(), g[k], err_msg=k, **TOL)
+
+
+def test_g7_long_and_interp(golden):
+    g = golden("g7_long_interp")
+    b = synth.make_batch(17, B=1, T=256, n_min=8, n_max=8)
+    p = P(107, 2, 3, True)
+    t = TB(b)
+    out = fwd(p, b, 2, 3)
+    np.testing.assert_allclose(out["logits_dual"].numpy(), g["logits_dual"], **TOL)
+    np.testing.assert_allclose(out["logits_joint"].numpy(), g["logits_joint"], **TOL)
+    v100 = t["video"][:, :100]
+    np.testing.assert_allclose(tan_ref.text_visual_sim_joint(p, v100, t["text_embed"], D=3, interpolate_from=64).numpy(),
+                               g["sim_joint_interp"], **TOL)
+    np.testing.assert_allclose(tan_ref.text_visual_sim_dual(p, v100, t["text_embed"], E=2, interpolate_from=64).numpy(),
+                               g["sim_dual_interp"], **TOL)
+    al = tan_ref.alignability(p, v100, t["text_embed"], D=3, interpolate_from=(64, 16))
+    np.testing.assert_allclose(al["alignability-dual"].numpy(), g["align_dual_interp"], **TOL)
+    np.testing.assert_allclose(al["alignability-joint"].numpy(), g["align_joint_interp"], **TOL)
+    vf = tan_ref.visual_feature(t["video"][:, :40], torch.zeros(1, 40).bool(), p, 2)
+    np.testing.assert_allclose(vf.numpy(), g["visual_feature_T40"], **TOL)
+
+
+def assert_stats(got, want, rtol, name):
+    """fingerprint = [sum, l2, 16 samples]; the sum cancels, so its tolerance scales with l2."""
+    scale = abs(want[1]) + 1e-30
+    if name.endswith("in_proj_bias"):
+        # the key-bias third has an exactly-zero true gradient (softmax shift invariance): what any
+        # implementation feeds Adam there is rounding noise, which Adam normalises to +-lr steps.
+        # Compare only the q/v samples.
+        idx = np.linspace(0, 1535, 16).astype(np.int64)
+        ok = (idx < 512) | (idx >= 1024)
+        np.testing.assert_allclose(got[2:][ok], want[2:][ok], rtol=rtol, atol=rtol * 1e-2, err_msg=name)
+        return
+    assert abs(got[0] - want[0]) <= rtol * scale * 4 + 1e-7, (name, got[0], want[0])
+    np.testing.assert_allclose(got[1:], want[1:], rtol=rtol, atol=rtol * scale * 1e-2 + 1e-9, err_msg=name)
+
+
+def _grad_stats(g):
+    g = g.detach().double().flatten()
+    idx = torch.linspace(0, g.numel() - 1, 16).long()
+    return np.concatenate([[g.sum().item(), g.norm().item()], g[idx].numpy()])
+
+
+@pytest.mark.parametrize("tag,kw", [("default", {}), ("agree", {"learn_agreement": 1}), ("th", {"loss_threshold": 0.5})])
+def test_g3_loss_init(golden, tag, kw):
+    g = golden("g3_loss_init")
+    b = synth.make_batch(11, B=4, T=16, n_min=2, n_max=5, video_pad_tail=3)
+    p = {k: v.requires_grad_(True) for k, v in P(101, 1, 1, True).items()}
+    out = fwd(p, b, 1, 1)
+    for k in ("logits_dual", "logits_joint"):
+        out[k].retain_grad()
+    t = TB(b)
+    ld, aux = loss_ref.get_loss(b, t["video"], t["text_embed"], t["padding_mask"], t["text_padding_mask"], out,
+                                loss_ref.default_args(**kw), t["abs_text_pos"])
+    ld["loss"].backward()
+    keys = [k[len(tag) + 1:] for k in g.files if k.startswith(tag + "/") and "/pgrad/" not in k
+            and not k.endswith(("dlogits_dual", "dlogits_joint", "dual_max_position", "joint_self_tgt", "agreement_self_tgt"))]
+    assert set(keys) == set(ld), (keys, list(ld))
+    for k in keys:
+        np.testing.assert_allclose(ld[k].detach().numpy(), g[f"{tag}/{k}"], rtol=2e-5, atol=1e-6, err_msg=k)
+    np.testing.assert_allclose(out["logits_dual"].grad.numpy(), g[f"{tag}/dlogits_dual"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(out["logits_joint"].grad.numpy(), g[f"{tag}/dlogits_joint"], rtol=1e-4, atol=1e-7)
+    if tag == "default":
+        for k in g.files:
+            if k.startswith("default/pgrad/"):
+                name = k[len("default/pgrad/"):]
+                assert_stats(_grad_stats(p[name].grad), g[k], 2e-4, name)
+        # parameters the reference never touches stay gradient-free (tan_model.py:65,68)
+        assert p["mlp.weight"].grad is None and p["text_temporal_pos_embed"].grad is None
+    if tag == "agree":
+        assert (aux["max_position_dual"].numpy() == g["agree/dual_max_position"]).all()
+        assert (aux["agreement_self_tgt"].numpy().astype(np.uint8) == g["agree/agreement_self_tgt"]).all()
+
+
+@pytest.mark.parametrize("kind", ["keep", "keep-joint", "i", "u"])
+def test_g4_loss_cotrain(golden, kind):
+    g = golden("g4_loss_cotrain")
+    b = synth.make_batch(14, B=6, T=32, n_min=3, n_max=7)
+    p = {k: v.requires_grad_(True) for k, v in P(104, 3, 3, True).items()}
+    pt = P(204, 3, 3, True)
+    out = fwd(p, b, 3, 3)
+    with torch.no_grad():
+        ema = fwd(pt, b, 3, 3)
+    for k in ("logits_dual", "logits_joint", "joint_logits_alignability"):
+        out[k].retain_grad()
+    t = TB(b)
+    args = loss_ref.default_args(model="cotrain", loss_threshold=0.5, temporal_agreement_type=kind)
+    ld, aux = loss_ref.get_loss(b, t["video"], t["text_embed"], t["padding_mask"], t["text_padding_mask"],
+                                {**out, **{f"ema-{k}": v for k, v in ema.items()}}, args, t["abs_text_pos"])
+    ld["loss"].backward()
+    # integer / boolean tensors: bit-exact
+    assert (aux["max_position_dual"].numpy() == g[f"{kind}/dual_max_position"]).all()
+    assert (aux["agreement_self_tgt"].numpy().astype(np.uint8) == g[f"{kind}/agreement_self_tgt"]).all()
+    assert (aux["t_th_mask"].numpy() == g[f"{kind}/t_th_mask"]).all()
+    assert (aux["t_align_th_mask"].numpy() == g[f"{kind}/t_align_th_mask"]).all()
+    assert (aux["confidence_mask"].numpy() == g[f"{kind}/confidence_mask"]).all()
+    np.testing.assert_allclose(aux["iou"].numpy(), g[f"{kind}/self_tgt_iou"], rtol=1e-6)
+    np.testing.assert_allclose(aux["max_logits_joint"].numpy(), g[f"{kind}/joint_max_logits_per_text"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(aux["max_logits_dual"].numpy(), g[f"{kind}/dual_max_logits_per_text"], rtol=1e-4, atol=1e-5)
+    scalars = ["loss", "loss-dual", "loss-joint", "loss-dual-all", "loss-joint-all", "loss-total", "loss-joint-bce",
+               "alignability_top1", "confidence-ratio", "iou-threshold"]
+    assert set(scalars) == set(ld)
+    for k in scalars:
+        np.testing.assert_allclose(ld[k].detach().numpy(), g[f"{kind}/{k}"], rtol=2e-5, atol=1e-6, err_msg=k)
+    np.testing.assert_allclose(out["logits_dual"].grad.numpy(), g[f"{kind}/dlogits_dual"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(out["logits_joint"].grad.numpy(), g[f"{kind}/dlogits_joint"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(out["joint_logits_alignability"].grad.numpy(), g[f"{kind}/dalign_joint"], rtol=1e-4, atol=1e-7)
+
+
+def test_g5_train_steps(golden):
+    g = golden("g5_train_steps")
+    # init: E1D1, random_pos_start=1
+    b = TB(synth.make_batch(15, B=8, T=16, n_min=2, n_max=5))
+    tr = train_ref.RefTrainer(synth.make_params(105, 1, 1, False), E=1, D=1, args=loss_ref.default_args(),
+                              lr=1e-3, wd=1e-2)
+    np.random.seed(7)
+    losses = [tr.step(b)[0]["loss"].item() for _ in range(3)]
+    np.testing.assert_allclose(losses, g["init/losses"], rtol=1e-5)
+    for k in g.files:
+        if k.startswith("init/param/"):
+            name = k[len("init/param/"):]
+            assert_stats(_grad_stats(tr.p[name]), g[k], 1e-4, name)
+    # cotrain: E1D3 with EMA
+    b = TB(synth.make_batch(16, B=6, T=16, n_min=2, n_max=5))
+    tr = train_ref.RefTrainer(synth.make_params(106, 1, 3, True), E=1, D=3,
+                              args=loss_ref.default_args(model="cotrain", loss_threshold=0.5), lr=1e-3, wd=1e-2, m=0.99)
+    losses = [tr.step(b)[0]["loss"].item() for _ in range(3)]
+    np.testing.assert_allclose(losses, g["cotrain/losses"], rtol=1e-5)
+    for k in g.files:
+        if k.startswith("cotrain/param/online."):
+            name = k[len("cotrain/param/online."):]
+            assert_stats(_grad_stats(tr.p[name]), g[k], 1e-4, name)
+        elif k.startswith("cotrain/param/target."):
+            name = k[len("cotrain/param/target."):]
+            assert_stats(_grad_stats(tr.pt[name]), g[k], 1e-4, name)
+
+
+def test_g6_eval_harness(golden):
+    g = golden("g6_eval_harness")
+    p = P(108, 1, 3, True)
+    videos = synth.align_videos()
+    emb = {s: torch.from_numpy(e) for v in videos for s, e in zip(v["str"], v["emb"])}
+
+    def cb(video, text_str, interpolate_from=None, abs_text_pos=None):
+        te = torch.stack([emb[s] for s in text_str])[None]
+        out = {"sim": tan_ref.text_visual_sim_joint(p, video, te, D=3, interpolate_from=interpolate_from).transpose(-1, -2) / 0.07,
+               "dual-sim": tan_ref.text_visual_sim_dual(p, video, te, E=1, interpolate_from=interpolate_from).transpose(-1, -2) / 0.07}
+        out.update(tan_ref.alignability(p, video, te, D=3, interpolate_from=interpolate_from))
+        return out
+
+    metric, per_video = eval_ref.test_alignment(videos, cb, seq_len=64, use_alignability_head=True)
+    assert metric["Recall"] == pytest.approx(float(g["Recall"]), abs=1e-12)
+    assert metric["AUC"] == pytest.approx(float(g["AUC"]), abs=1e-9)
+    for i, pv in enumerate(per_video):
+        al = torch.from_numpy(np.asarray(videos[i]["aligned"]).astype(bool))
+        assert (pv["argmax"].numpy() == g[f"v{i}/argmax"]).all()
+        np.testing.assert_allclose(pv["sim"][al].numpy(), g[f"v{i}/sim_aligned"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(pv["score"].numpy(), g[f"v{i}/align_score"], rtol=1e-4, atol=1e-5)
+
+
+def test_auc_matches_sklearn():
+    from sklearn import metrics
+    rng = np.random.RandomState(0)
+    y = rng.randint(0, 2, 200)
+    s = np.round(rng.randn(200), 1)      # ties
+    assert eval_ref.roc_auc(y, s) == pytest.approx(metrics.roc_auc_score(y, s), abs=1e-12)
