@@ -1,0 +1,78 @@
+"""tan_gemm vs torch fp32/fp64 references on the GPU (through the C ABI)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(shape, dtype, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(*shape, generator=g).to("cuda").to(dtype)
+
+
+def _tol(dtype, K):
+    # f32 MFMA is an exact f32 fma chain; bf16 operands are exact products accumulated in f32
+    return (1e-5 * max(1.0, K ** 0.5) if dtype == torch.float32 else 2e-2 * max(1.0, (K / 512) ** 0.5))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 136), (64, 520, 512), (33, 20, 24), (256, 1536, 512)])
+def test_gemm_layouts(dtype, a_kc, b_kc, M, N, K):
+    from temporalalignnet_amd import ops
+    A = _mk((M, K) if a_kc else (K, M), dtype, 1)
+    B = _mk((N, K) if b_kc else (K, N), dtype, 2)
+    Cout = torch.full((M, N), float("nan"), device="cuda", dtype=dtype)
+    ops.gemm(A, B, Cout, M=M, N=N, K=K, a_kc=a_kc, b_kc=b_kc)
+    Af = (A if a_kc else A.t()).double()
+    Bf = (B.t() if b_kc else B).double()
+    ref = Af @ Bf
+    err = (Cout.double() - ref).abs().max().item()
+    assert err < _tol(dtype, K) * (ref.abs().max().item() + 1.0), err
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(dtype):
+    from temporalalignnet_amd import ops
+    M, N, K = 192, 2048, 512
+    X, W = _mk((M, K), dtype, 3), _mk((N, K), dtype, 4) * 0.05
+    bias = _mk((N,), torch.float32, 5)
+    res = _mk((M, N), dtype, 6)
+    ref_pre = X.double() @ W.double().t() + bias.double()
+    # bias + residual
+    out = torch.empty(M, N, device="cuda", dtype=dtype)
+    ops.gemm(X, W, out, M=M, N=N, K=K, bias=bias, residual=res)
+    tol = 1e-4 if dtype == torch.float32 else 6e-2
+    assert (out.double() - (ref_pre + res.double())).abs().max().item() < tol
+    # quickgelu with pre-activation side output
+    pre = torch.empty(M, N, device="cuda", dtype=dtype)
+    ops.gemm(X, W, out, M=M, N=N, K=K, bias=bias, act=ops.ACT_QUICKGELU, aux=pre)
+    assert (pre.double() - ref_pre).abs().max().item() < tol
+    assert (out.double() - ref_pre * torch.sigmoid(1.702 * ref_pre)).abs().max().item() < tol
+    # gelu-grad epilogue: out = (X W^T) * gelu'(pre)
+    g = torch.empty(M, N, device="cuda", dtype=dtype)
+    ops.gemm(X, W, g, M=M, N=N, K=K, act=ops.ACT_QUICKGELU_GRAD, aux=pre)
+    p = pre.double()
+    s = torch.sigmoid(1.702 * p)
+    want = (X.double() @ W.double().t()) * (s + 1.702 * p * s * (1 - s))
+    assert (g.double() - want).abs().max().item() < tol * 2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_splitk_accumulate_and_batch(dtype):
+    from temporalalignnet_amd import ops
+    # dW-style: contraction over a long, non-multiple-of-tile M
+    Mc, N, K = 1000, 96, 72
+    dY, X = _mk((Mc, N), dtype, 7), _mk((Mc, K), dtype, 8)
+    dW = torch.ones(N, K, device="cuda", dtype=torch.float32)
+    ops.gemm(dY, X, dW, M=N, N=K, K=Mc, a_kc=False, b_kc=False, lda=N, ldb=K, accumulate=True, split_k=4)
+    ref = dY.double().t() @ X.double() + 1.0
+    tol = 1e-3 if dtype == torch.float32 else 0.3
+    assert (dW.double() - ref).abs().max().item() < tol
+    # batched (similarity-style) with f32 output
+    S, R, Mp, Cc = 3, 70, 20, 512
+    V, T_ = _mk((S, R, Cc), dtype, 9), _mk((S, Mp, Cc), dtype, 10)
+    out = torch.empty(S, R, Mp, device="cuda", dtype=torch.float32)
+    ops.gemm(V, T_, out, M=R, N=Mp, K=Cc, batch=S, sA=R * Cc, sB=Mp * Cc, sC=R * Mp)
+    ref = torch.einsum("src,smc->srm", V.double(), T_.double())
+    assert (out.double() - ref).abs().max().item() < (1e-3 if dtype == torch.float32 else 0.5)
