@@ -57,6 +57,56 @@ typedef struct tan_gemm_desc {
 } tan_gemm_desc;
 int tan_gemm(const tan_gemm_desc* d, void* stream);
 
+/* ---- LayerNorm(C), eps, affine; one wave per row; C in {256,512,1024} -------------------------------------
+ * fwd: y = (x-mean)*rstd*gamma+beta (+ add[row % add_period], the broadcast position term of
+ *      tan_model.py:167,199).  reference: tfm_model.py:22,28,35,37; tan_model.py:50-54,155,174,206.
+ *      mean/rstd [rows] f32 are saved for backward (may be NULL).
+ * bwd: dx = (dres +) LN'(dy); dgamma/dbeta (f32, may be NULL) are ACCUMULATED (+=).  ws: f32 scratch of
+ *      tan_layernorm_bwd_ws_floats(C) elements.                                                            */
+int tan_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      const void* add, int add_period, long rows, int C, float eps, int dtype, void* stream);
+long tan_layernorm_bwd_ws_floats(int C);
+int tan_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                      const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, long rows, int C, int dtype,
+                      void* stream);
+
+/* ---- L2 normalisation over channels, no epsilon (tan_model.py:116-117,136-137) ---------------------------
+ * Output rows r = 0..rows-1 are gathered from x row (r/grp)*src_grp_rows + src_off + r%grp, which extracts the
+ * video rows (off 0, grp T) or the text rows (off T, grp N) of a joint [B, T+N, C] stage output; bwd scatters
+ * dx = (dy - y<y,dy>) * inv_norm back to the same rows (plain store).                                        */
+int tan_l2norm_fwd(const void* x, void* y, float* inv_norm, long rows, int C, int grp, int src_grp_rows, int src_off,
+                   int dtype, void* stream);
+int tan_l2norm_bwd(const void* dy, const void* y, const float* inv_norm, void* dx, long rows, int C, int grp,
+                   int dst_grp_rows, int dst_off, int dtype, void* stream);
+
+/* ---- small HBM-bound helpers ----------------------------------------------------------------------------- */
+/* out[c] += sum_r x[r][c]  (nn.Linear bias gradients) */
+int tan_colsum_acc(const void* x, float* out, long rows, int C, int dtype, void* stream);
+/* dst[(g*dst_grp_rows+dst_off+r)][c] (=|+=) src[(g*src_grp_rows+src_off+r)][c], g<G, r<R  (torch.cat at
+ * tan_model.py:201 and its backward split) */
+int tan_rows_copy(const void* src, void* dst, int G, int R, int C, long src_grp_rows, long src_off, long dst_grp_rows,
+                  long dst_off, int accumulate, int dtype, void* stream);
+/* out[r][c] = sum_g x[g*R + r][c]  (backward of the broadcast position add) */
+int tan_group_sum(const void* x, void* out, int G, int R, int C, int dtype, void* stream);
+int tan_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
+/* binary_head = nn.Linear(512,1) (tan_model.py:70,147-148): out[r] = <x[r],w> + b (f32 out); bwd accumulates dw, db */
+int tan_head_fwd(const void* x, const float* w, const float* b, float* out, long rows, int C, int dtype, void* stream);
+int tan_head_bwd(const float* dout, const void* x, const float* w, void* dx, float* dw, float* db, long rows, int C,
+                 int accumulate_dx, int dtype, void* stream);
+/* F.interpolate(mode='linear', align_corners=False) of a [L_in,C] f32 table (tan_model.py:157-160,189-192); bwd adds */
+int tan_interp_linear(const float* src, float* dst, int L_in, int L_out, int C, void* stream);
+int tan_interp_linear_bwd(const float* ddst, float* dsrc, int L_in, int L_out, int C, void* stream);
+
+/* ---- attention core: softmax_k(q k^T / sqrt(64) + key_padding) v per (video, head) -------------------------
+ * replaces the scaled-dot-product inside nn.MultiheadAttention (tfm_model.py:21,30-32); head dim 64, C = 64*H.
+ * qkv [B*L, 3C] (output of the packed in-proj GEMM, q|k|v), key_padding_mask [B,L] bytes (1 = ignore) or NULL,
+ * o [B*L, C], lse [B,H,L] f32 (saved for backward).  bwd recomputes P from lse and writes dqkv [B*L, 3C].
+ * L <= 448 (f32) / 320 (bf16): the score panel of a 64-query tile lives in the 160 KB LDS.                      */
+int tan_attn_fwd(const void* qkv, const unsigned char* key_padding_mask, void* o, float* lse, int B, int L, int H,
+                 int dtype, void* stream);
+int tan_attn_bwd(const void* qkv, const unsigned char* key_padding_mask, const void* o, const float* lse,
+                 const void* d_o, void* dqkv, int B, int L, int H, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,7 +43,7 @@ def declared_symbols() -> list[str]:
     with open(HEADER) as f:
         src = f.read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(tan_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|long)\s+(tan_[a-z0-9_]+)\s*\(", src)))
 
 
 def lib() -> C.CDLL:
@@ -55,7 +55,7 @@ def lib() -> C.CDLL:
                 "(the HIP path has no CPU fallback)")
         _lib = C.CDLL(LIB_PATH)
         for name in declared_symbols():
-            getattr(_lib, name).restype = C.c_int
+            getattr(_lib, name).restype = C.c_long if name.endswith("_floats") or name.endswith("_bytes") else C.c_int
     return _lib
 
 

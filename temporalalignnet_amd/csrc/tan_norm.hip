@@ -1,0 +1,470 @@
+// Row-wise normalisation and small HBM-bound helpers (gfx950).  One 64-lane wave owns one row of C channels
+// (C = 512 -> 8 channels per lane as two 16-byte / 8-byte vectors), reductions are wave shuffles, no LDS.
+#include "tan_common.h"
+
+namespace tal {
+
+constexpr int ROWS_PER_BLOCK = 4;  // 256 threads
+
+// ------------------------------------------------------------------------------------------------------
+// LayerNorm forward: y = (x - mean) * rstd * gamma + beta (+ add[row % add_period])
+// reference: nn.LayerNorm(512) at tfm_model.py:22,28,35,37 and tan_model.py:50-54,155,167,174,206
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                     const T* __restrict__ add, int add_period, long rows, float eps) {
+    constexpr int C = NCH * 256;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + row * C;
+    float4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        v[i] = ld4(xr + (i * 64 + lane) * 4);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + eps);
+    if (lane == 0) {
+        if (mean_o) mean_o[row] = mean;
+        if (rstd_o) rstd_o[row] = rstd;
+    }
+    const T* ar = add ? add + (long)(row % add_period) * C : nullptr;
+    T* yr = y + row * C;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 b = *reinterpret_cast<const float4*>(beta + c);
+        float4 o = make_float4(v[i].x * rstd * g.x + b.x, v[i].y * rstd * g.y + b.y, v[i].z * rstd * g.z + b.z,
+                               v[i].w * rstd * g.w + b.w);
+        if (ar) {
+            const float4 a = ld4(ar + c);
+            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
+        st4(yr + c, o);
+    }
+}
+
+// LayerNorm backward.  dx = (dres) + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.
+// Each block walks a strided set of rows and keeps per-lane partial d_gamma / d_beta, written to
+// ws[block][2][C]; ln_bwd_finalize adds them into the f32 parameter gradients.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean_i,
+                                                     const float* __restrict__ rstd_i, const T* __restrict__ dres,
+                                                     T* __restrict__ dx, float* __restrict__ ws, long rows) {
+    constexpr int C = NCH * 256;
+    __shared__ float red[ROWS_PER_BLOCK][2][C];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float4 dg[NCH], db[NCH], gm[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        dg[i] = make_float4(0, 0, 0, 0); db[i] = make_float4(0, 0, 0, 0);
+        gm[i] = *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 4);
+    }
+    for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + w; row < rows; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        float4 xh[NCH], g[NCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            const float4 xv = ld4(x + row * C + c), d = ld4(dy + row * C + c);
+            xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+            g[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
+            s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+            s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+            dg[i].x += d.x * xh[i].x; dg[i].y += d.y * xh[i].y; dg[i].z += d.z * xh[i].z; dg[i].w += d.w * xh[i].w;
+            db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+        }
+        const float m1 = wave_sum(s1) * (1.0f / C), m2 = wave_sum(s2) * (1.0f / C);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            float4 o = make_float4(rstd * (g[i].x - m1 - xh[i].x * m2), rstd * (g[i].y - m1 - xh[i].y * m2),
+                                   rstd * (g[i].z - m1 - xh[i].z * m2), rstd * (g[i].w - m1 - xh[i].w * m2));
+            if (dres) {
+                const float4 r = ld4(dres + row * C + c);
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            st4(dx + row * C + c, o);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        *reinterpret_cast<float4*>(&red[w][0][c]) = dg[i];
+        *reinterpret_cast<float4*>(&red[w][1][c]) = db[i];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * C; idx += 256) {
+        const int which = idx / C, c = idx % C;
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < ROWS_PER_BLOCK; ++r) s += red[r][which][c];
+        ws[((long)blockIdx.x * 2 + which) * C + c] = s;
+    }
+}
+
+__global__ void ln_bwd_finalize(const float* __restrict__ ws, int nblk, int C, float* __restrict__ dgamma,
+                                float* __restrict__ dbeta) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * C) return;
+    const int which = idx / C, c = idx % C;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += ws[((long)b * 2 + which) * C + c];
+    float* out = which == 0 ? dgamma : dbeta;
+    if (out) out[c] += s;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// L2 normalisation over channels (no epsilon): tan_model.py:116-117,136-137.  Rows may be gathered from
+// / scattered to a grouped layout: src row = (r / grp) * src_grp_rows + src_off + r % grp.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void l2n_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ inv_o,
+                                                      long rows, int grp, int src_grp_rows, int src_off) {
+    constexpr int C = NCH * 256;
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const long sr = (r / grp) * src_grp_rows + src_off + r % grp;
+    float4 v[NCH];
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        v[i] = ld4(x + sr * C + (i * 64 + lane) * 4);
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float inv = 1.0f / sqrtf(wave_sum(q));
+    if (lane == 0 && inv_o) inv_o[r] = inv;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        st4(y + r * C + (i * 64 + lane) * 4, make_float4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv));
+}
+
+// dx = (dy - y * <y, dy>) * inv_norm, scattered back to the grouped layout (plain store)
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void l2n_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                      const float* __restrict__ inv_i, T* __restrict__ dx, long rows,
+                                                      int grp, int dst_grp_rows, int dst_off) {
+    constexpr int C = NCH * 256;
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const long dr = (r / grp) * dst_grp_rows + dst_off + r % grp;
+    float4 d[NCH], yv[NCH];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        d[i] = ld4(dy + r * C + (i * 64 + lane) * 4);
+        yv[i] = ld4(y + r * C + (i * 64 + lane) * 4);
+        dot += (d[i].x * yv[i].x + d[i].y * yv[i].y) + (d[i].z * yv[i].z + d[i].w * yv[i].w);
+    }
+    dot = wave_sum(dot);
+    const float inv = inv_i[r];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        st4(dx + dr * C + (i * 64 + lane) * 4,
+            make_float4((d[i].x - yv[i].x * dot) * inv, (d[i].y - yv[i].y * dot) * inv, (d[i].z - yv[i].z * dot) * inv,
+                        (d[i].w - yv[i].w * dot) * inv));
+}
+
+// ------------------------------------------------------------------------------------------------------
+// column sum (bias gradients): out[c] += sum_r x[r][c]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long rows, int C,
+                                                     int rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += ld_f(x + r * C + c);
+    unsafeAtomicAdd(out + c, s);
+}
+
+// grouped row copy / add: dst[(g*dgs + doff + r)*C + c] (=|+=) src[(g*sgs + soff + r)*C + c]
+template <typename T>
+__global__ __launch_bounds__(256) void rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int G, int R, int C,
+                                                   long sgs, long soff, long dgs, long doff, int accumulate) {
+    const long n4 = (long)G * R * C / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long e = i * 4;
+        const int c = (int)(e % C);
+        const long gr = e / C;
+        const int r = (int)(gr % R);
+        const long g = gr / R;
+        const T* s = src + ((g * sgs + soff + r) * C + c);
+        T* d = dst + ((g * dgs + doff + r) * C + c);
+        float4 v = ld4(s);
+        if (accumulate) {
+            const float4 o = ld4(d);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        st4(d, v);
+    }
+}
+
+// out[r][c] = sum_g x[(g*R + r)][c]   (broadcast-add backward: position embedding gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void group_sum_kernel(const T* __restrict__ x, T* __restrict__ out, int G, int R, int C) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)R * C) return;
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += ld_f(x + (long)g * R * C + i);
+    st_f(out + i, s);
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, long n) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 4 <= n) st4(d + i, ld4(s + i));
+        else for (long j = i; j < n; ++j) st_f(d + j, ld_f(s + j));
+    }
+}
+
+// binary_head (nn.Linear(512,1), tan_model.py:70,147-148): out[r] = <x[r], w> + b   (f32 out)
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* __restrict__ out, long rows) {
+    constexpr int C = NCH * 256;
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        const float4 v = ld4(x + r * C + c), ww = *reinterpret_cast<const float4*>(w + c);
+        s += (v.x * ww.x + v.y * ww.y) + (v.z * ww.z + v.w * ww.w);
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s + b[0];
+}
+
+// dx[r] (=|+=) dout[r] * w ; dw += sum_r dout[r] * x[r] ; db += sum_r dout[r]
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ x,
+                                                       const float* __restrict__ w, T* __restrict__ dx,
+                                                       float* __restrict__ dw, float* __restrict__ db, long rows,
+                                                       int accumulate_dx) {
+    constexpr int C = NCH * 256;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float4 acc[NCH];
+    float accb = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) acc[i] = make_float4(0, 0, 0, 0);
+    for (long r = (long)blockIdx.x * ROWS_PER_BLOCK + wv; r < rows; r += (long)gridDim.x * ROWS_PER_BLOCK) {
+        const float g = dout[r];
+        accb += g;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            const float4 v = ld4(x + r * C + c), ww = *reinterpret_cast<const float4*>(w + c);
+            acc[i].x += g * v.x; acc[i].y += g * v.y; acc[i].z += g * v.z; acc[i].w += g * v.w;
+            float4 o = make_float4(g * ww.x, g * ww.y, g * ww.z, g * ww.w);
+            if (accumulate_dx) {
+                const float4 p = ld4(dx + r * C + c);
+                o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+            }
+            st4(dx + r * C + c, o);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        unsafeAtomicAdd(dw + c + 0, acc[i].x); unsafeAtomicAdd(dw + c + 1, acc[i].y);
+        unsafeAtomicAdd(dw + c + 2, acc[i].z); unsafeAtomicAdd(dw + c + 3, acc[i].w);
+    }
+    if (lane == 0) unsafeAtomicAdd(db, accb);
+}
+
+// linear interpolation of a [L_in, C] table to [L_out, C], align_corners=False (F.interpolate, tan_model.py:157-160)
+__global__ void interp_kernel(const float* __restrict__ src, float* __restrict__ dst, int L_in, int L_out, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)L_out * C) return;
+    const int t = (int)(i / C), c = (int)(i % C);
+    const float scale = (float)L_in / (float)L_out;
+    float pos = ((float)t + 0.5f) * scale - 0.5f;
+    pos = fmaxf(pos, 0.0f);
+    int i0 = min((int)floorf(pos), L_in - 1);
+    const int i1 = min(i0 + 1, L_in - 1);
+    const float w1 = pos - (float)i0;
+    dst[i] = src[(long)i0 * C + c] * (1.0f - w1) + src[(long)i1 * C + c] * w1;
+}
+
+// transpose-add of the interpolation: dsrc[L_in, C] += W^T ddst[L_out, C]
+__global__ void interp_bwd_kernel(const float* __restrict__ ddst, float* __restrict__ dsrc, int L_in, int L_out, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)L_out * C) return;
+    const int t = (int)(i / C), c = (int)(i % C);
+    const float scale = (float)L_in / (float)L_out;
+    float pos = fmaxf(((float)t + 0.5f) * scale - 0.5f, 0.0f);
+    int i0 = min((int)floorf(pos), L_in - 1);
+    const int i1 = min(i0 + 1, L_in - 1);
+    const float w1 = pos - (float)i0;
+    unsafeAtomicAdd(dsrc + (long)i0 * C + c, ddst[i] * (1.0f - w1));
+    unsafeAtomicAdd(dsrc + (long)i1 * C + c, ddst[i] * w1);
+}
+
+#define DISPATCH_NCH(C, ...)                                   \
+    switch (C) {                                               \
+        case 256: { constexpr int NCH = 1; __VA_ARGS__; break; }  \
+        case 512: { constexpr int NCH = 2; __VA_ARGS__; break; }  \
+        case 1024: { constexpr int NCH = 4; __VA_ARGS__; break; } \
+        default: return TAN_ERR_BAD_ARG;                       \
+    }
+#define DISPATCH_T(dtype, ...)                                        \
+    if (dtype == TAN_F32) { typedef float T; __VA_ARGS__; }           \
+    else if (dtype == TAN_BF16) { typedef bf16_t T; __VA_ARGS__; }    \
+    else return TAN_ERR_BAD_ARG;
+
+}  // namespace tal
+
+using namespace tal;
+
+extern "C" int tan_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                 const void* add, int add_period, long rows, int C, float eps, int dtype, void* stream) {
+    TAN_REQUIRE(x && gamma && beta && y && rows > 0);
+    if (add) TAN_REQUIRE(add_period > 0);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, DISPATCH_NCH(C, hipLaunchKernelGGL((ln_fwd_kernel<T, NCH>), dim3(cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0,
+                                                         st, (const T*)x, gamma, beta, (T*)y, mean, rstd, (const T*)add,
+                                                         add_period, rows, eps)));
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" long tan_layernorm_bwd_ws_floats(int C) { return 256L * 2 * C; }
+
+extern "C" int tan_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                 const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, long rows, int C,
+                                 int dtype, void* stream) {
+    TAN_REQUIRE(dy && x && gamma && mean && rstd && dx && ws && rows > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = (int)min((long)256, (long)cdiv(rows, ROWS_PER_BLOCK));
+    DISPATCH_T(dtype, DISPATCH_NCH(C, hipLaunchKernelGGL((ln_bwd_kernel<T, NCH>), dim3(nblk), dim3(256), 0, st, (const T*)dy,
+                                                         (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, ws, rows)));
+    TAN_LAUNCH_CHECK();
+    if (dgamma || dbeta) {
+        hipLaunchKernelGGL(ln_bwd_finalize, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, ws, nblk, C, dgamma, dbeta);
+        TAN_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int tan_l2norm_fwd(const void* x, void* y, float* inv_norm, long rows, int C, int grp, int src_grp_rows,
+                              int src_off, int dtype, void* stream) {
+    TAN_REQUIRE(x && y && rows > 0 && grp > 0);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, DISPATCH_NCH(C, hipLaunchKernelGGL((l2n_fwd_kernel<T, NCH>), dim3(cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0,
+                                                         st, (const T*)x, (T*)y, inv_norm, rows, grp, src_grp_rows, src_off)));
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_l2norm_bwd(const void* dy, const void* y, const float* inv_norm, void* dx, long rows, int C, int grp,
+                              int dst_grp_rows, int dst_off, int dtype, void* stream) {
+    TAN_REQUIRE(dy && y && inv_norm && dx && rows > 0 && grp > 0);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, DISPATCH_NCH(C, hipLaunchKernelGGL((l2n_bwd_kernel<T, NCH>), dim3(cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0,
+                                                         st, (const T*)dy, (const T*)y, inv_norm, (T*)dx, rows, grp,
+                                                         dst_grp_rows, dst_off)));
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_colsum_acc(const void* x, float* out, long rows, int C, int dtype, void* stream) {
+    TAN_REQUIRE(x && out && rows > 0 && C > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int rpb = 64;
+    dim3 grid(cdiv(C, 256), cdiv(rows, rpb));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, st, (const T*)x, out, rows, C, rpb));
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_rows_copy(const void* src, void* dst, int G, int R, int C, long src_grp_rows, long src_off,
+                             long dst_grp_rows, long dst_off, int accumulate, int dtype, void* stream) {
+    TAN_REQUIRE(src && dst && G > 0 && R > 0 && C > 0 && C % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    const long n4 = (long)G * R * C / 4;
+    const unsigned grid = (unsigned)min((long)4096, (long)cdiv(n4, 256));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((rows_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)src, (T*)dst, G, R, C,
+                                         src_grp_rows, src_off, dst_grp_rows, dst_off, accumulate));
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_group_sum(const void* x, void* out, int G, int R, int C, int dtype, void* stream) {
+    TAN_REQUIRE(x && out && G > 0 && R > 0 && C > 0);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((group_sum_kernel<T>), dim3(cdiv((long)R * C, 256)), dim3(256), 0, st, (const T*)x,
+                                         (T*)out, G, R, C));
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream) {
+    TAN_REQUIRE(src && dst && n > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)min((long)4096, (long)cdiv(n, 1024));
+    if (src_dtype == TAN_F32 && dst_dtype == TAN_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
+    else if (src_dtype == TAN_BF16 && dst_dtype == TAN_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
+    else if (src_dtype == TAN_F32 && dst_dtype == TAN_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+    else if (src_dtype == TAN_BF16 && dst_dtype == TAN_BF16)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+    else return TAN_ERR_BAD_ARG;
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_head_fwd(const void* x, const float* w, const float* b, float* out, long rows, int C, int dtype,
+                            void* stream) {
+    TAN_REQUIRE(x && w && b && out && rows > 0);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, DISPATCH_NCH(C, hipLaunchKernelGGL((head_fwd_kernel<T, NCH>), dim3(cdiv(rows, ROWS_PER_BLOCK)), dim3(256),
+                                                         0, st, (const T*)x, w, b, out, rows)));
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_head_bwd(const float* dout, const void* x, const float* w, void* dx, float* dw, float* db, long rows,
+                            int C, int accumulate_dx, int dtype, void* stream) {
+    TAN_REQUIRE(dout && x && w && dx && dw && db && rows > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = (int)min((long)64, (long)cdiv(rows, ROWS_PER_BLOCK));
+    DISPATCH_T(dtype, DISPATCH_NCH(C, hipLaunchKernelGGL((head_bwd_kernel<T, NCH>), dim3(nblk), dim3(256), 0, st, dout,
+                                                         (const T*)x, w, (T*)dx, dw, db, rows, accumulate_dx)));
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_interp_linear(const float* src, float* dst, int L_in, int L_out, int C, void* stream) {
+    TAN_REQUIRE(src && dst && L_in > 0 && L_out > 0 && C > 0);
+    hipLaunchKernelGGL(interp_kernel, dim3(cdiv((long)L_out * C, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, L_in,
+                       L_out, C);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_interp_linear_bwd(const float* ddst, float* dsrc, int L_in, int L_out, int C, void* stream) {
+    TAN_REQUIRE(ddst && dsrc && L_in > 0 && L_out > 0 && C > 0);
+    hipLaunchKernelGGL(interp_bwd_kernel, dim3(cdiv((long)L_out * C, 256)), dim3(256), 0, (hipStream_t)stream, ddst, dsrc,
+                       L_in, L_out, C);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}

@@ -53,3 +53,115 @@ def gemm(A, B, C_out, *, M, N, K, a_kc=True, b_kc=True, lda=None, ldb=None, ldc=
     d.batch, d.sA, d.sB, d.sC = batch, sA, sB, sC
     _lib.check(_lib.lib().tan_gemm(C.byref(d), _stream()), "tan_gemm")
     return C_out
+
+
+def _f32(t):
+    assert t is None or t.dtype == torch.float32
+    return _ptr(t)
+
+
+_ln_ws = {}
+
+
+def _ws_f32(n, device):
+    key = (device, "ln")
+    buf = _ln_ws.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(n, device=device, dtype=torch.float32)
+        _ln_ws[key] = buf
+    return buf
+
+
+def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, add=None, add_period=0, eps=1e-5):
+    rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
+    _lib.check(_lib.lib().tan_layernorm_fwd(_ptr(x), _f32(gamma), _f32(beta), _ptr(y), _f32(mean), _f32(rstd), _ptr(add),
+                                             C.c_int(add_period), C.c_long(rows), C.c_int(Cc), C.c_float(eps), _dt(x),
+                                             _stream()), "tan_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma=None, dbeta=None, dres=None):
+    rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
+    L = _lib.lib()
+    ws = _ws_f32(L.tan_layernorm_bwd_ws_floats(C.c_int(Cc)), x.device)
+    _lib.check(L.tan_layernorm_bwd(_ptr(dy), _ptr(x), _f32(gamma), _f32(mean), _f32(rstd), _ptr(dres), _ptr(dx),
+                                   _f32(dgamma), _f32(dbeta), _ptr(ws), C.c_long(rows), C.c_int(Cc), _dt(x), _stream()),
+               "tan_layernorm_bwd")
+    return dx
+
+
+def l2norm_fwd(x, y, inv_norm, rows, Cc, grp=None, src_grp_rows=None, src_off=0):
+    grp = grp or rows
+    _lib.check(_lib.lib().tan_l2norm_fwd(_ptr(x), _ptr(y), _f32(inv_norm), C.c_long(rows), C.c_int(Cc), C.c_int(grp),
+                                          C.c_int(src_grp_rows if src_grp_rows is not None else grp), C.c_int(src_off),
+                                          _dt(x), _stream()), "tan_l2norm_fwd")
+    return y
+
+
+def l2norm_bwd(dy, y, inv_norm, dx, rows, Cc, grp=None, dst_grp_rows=None, dst_off=0):
+    grp = grp or rows
+    _lib.check(_lib.lib().tan_l2norm_bwd(_ptr(dy), _ptr(y), _f32(inv_norm), _ptr(dx), C.c_long(rows), C.c_int(Cc),
+                                          C.c_int(grp), C.c_int(dst_grp_rows if dst_grp_rows is not None else grp),
+                                          C.c_int(dst_off), _dt(y), _stream()), "tan_l2norm_bwd")
+    return dx
+
+
+def colsum_acc(x, out, rows, Cc):
+    _lib.check(_lib.lib().tan_colsum_acc(_ptr(x), _f32(out), C.c_long(rows), C.c_int(Cc), _dt(x), _stream()), "tan_colsum_acc")
+    return out
+
+
+def rows_copy(src, dst, G, R, Cc, src_grp_rows, src_off, dst_grp_rows, dst_off, accumulate=False):
+    assert _dt(src) == _dt(dst)
+    _lib.check(_lib.lib().tan_rows_copy(_ptr(src), _ptr(dst), C.c_int(G), C.c_int(R), C.c_int(Cc), C.c_long(src_grp_rows),
+                                         C.c_long(src_off), C.c_long(dst_grp_rows), C.c_long(dst_off), C.c_int(int(accumulate)),
+                                         _dt(src), _stream()), "tan_rows_copy")
+    return dst
+
+
+def group_sum(x, out, G, R, Cc):
+    _lib.check(_lib.lib().tan_group_sum(_ptr(x), _ptr(out), C.c_int(G), C.c_int(R), C.c_int(Cc), _dt(x), _stream()),
+               "tan_group_sum")
+    return out
+
+
+def cast(src, dst):
+    assert src.numel() == dst.numel()
+    _lib.check(_lib.lib().tan_cast(_ptr(src), _dt(src), _ptr(dst), _dt(dst), C.c_long(src.numel()), _stream()), "tan_cast")
+    return dst
+
+
+def head_fwd(x, w, b, out, rows, Cc):
+    _lib.check(_lib.lib().tan_head_fwd(_ptr(x), _f32(w), _f32(b), _f32(out), C.c_long(rows), C.c_int(Cc), _dt(x), _stream()),
+               "tan_head_fwd")
+    return out
+
+
+def head_bwd(dout, x, w, dx, dw, db, rows, Cc, accumulate_dx=False):
+    _lib.check(_lib.lib().tan_head_bwd(_f32(dout), _ptr(x), _f32(w), _ptr(dx), _f32(dw), _f32(db), C.c_long(rows), C.c_int(Cc),
+                                        C.c_int(int(accumulate_dx)), _dt(x), _stream()), "tan_head_bwd")
+    return dx
+
+
+def interp_linear(src, dst, L_in, L_out, Cc):
+    _lib.check(_lib.lib().tan_interp_linear(_f32(src), _f32(dst), C.c_int(L_in), C.c_int(L_out), C.c_int(Cc), _stream()),
+               "tan_interp_linear")
+    return dst
+
+
+def interp_linear_bwd(ddst, dsrc, L_in, L_out, Cc):
+    _lib.check(_lib.lib().tan_interp_linear_bwd(_f32(ddst), _f32(dsrc), C.c_int(L_in), C.c_int(L_out), C.c_int(Cc), _stream()),
+               "tan_interp_linear_bwd")
+    return dsrc
+
+
+def attn_fwd(qkv, keypad_u8, o, lse, B, L, H):
+    _lib.check(_lib.lib().tan_attn_fwd(_ptr(qkv), _ptr(keypad_u8), _ptr(o), _f32(lse), C.c_int(B), C.c_int(L), C.c_int(H),
+                                        _dt(qkv), _stream()), "tan_attn_fwd")
+    return o
+
+
+def attn_bwd(qkv, keypad_u8, o, lse, d_o, dqkv, B, L, H):
+    _lib.check(_lib.lib().tan_attn_bwd(_ptr(qkv), _ptr(keypad_u8), _ptr(o), _f32(lse), _ptr(d_o), _ptr(dqkv), C.c_int(B),
+                                        C.c_int(L), C.c_int(H), _dt(qkv), _stream()), "tan_attn_bwd")
+    return dqkv

@@ -1,0 +1,171 @@
+"""Per-kernel parity of the HIP ops (through the C ABI) against plain PyTorch fp32/fp64 references."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DT = [torch.float32, torch.bfloat16]
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to("cuda").to(dtype)
+
+
+def close(a, b, tol):
+    err = (a.double() - b.double()).abs().max().item()
+    assert err < tol, err
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,period", [(7, 0), (130, 13)])
+def test_layernorm_fwd_bwd(dtype, rows, period):
+    from temporalalignnet_amd import ops
+    C = 512
+    x = rnd((rows, C), dtype, 1, 2.0)
+    g = 1 + rnd((C,), torch.float32, 2, 0.1)
+    b = rnd((C,), torch.float32, 3, 0.1)
+    add = rnd((period, C), dtype, 4) if period else None
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device="cuda")
+    rstd = torch.empty(rows, device="cuda")
+    ops.layernorm_fwd(x, g, b, y, mean, rstd, add, period)
+    xr = x.double().requires_grad_(True)
+    gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    if period:
+        ref = ref + add.double().repeat((rows + period - 1) // period, 1)[:rows]
+    tol = 1e-5 if dtype == torch.float32 else 5e-2
+    close(y, ref, tol)
+    dy = rnd((rows, C), dtype, 5)
+    dres = rnd((rows, C), dtype, 6)
+    ref.backward(dy.double())
+    dx = torch.empty_like(x)
+    dg = torch.ones(C, device="cuda")
+    db = torch.ones(C, device="cuda")
+    ops.layernorm_bwd(dy, x, g, mean, rstd, dx, dg, db, dres)
+    close(dx, xr.grad + dres.double(), 1e-4 if dtype == torch.float32 else 8e-2)
+    close(dg, gr.grad + 1, 1e-3 if dtype == torch.float32 else 0.3)
+    close(db, br.grad + 1, 1e-3 if dtype == torch.float32 else 0.3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_l2norm_grouped(dtype):
+    from temporalalignnet_amd import ops
+    B, T, N, C = 3, 5, 4, 512
+    L = T + N
+    x = rnd((B * L, C), dtype, 7)
+    for grp, off in ((T, 0), (N, T)):
+        rows = B * grp
+        y = torch.empty(rows, C, device="cuda", dtype=dtype)
+        inv = torch.empty(rows, device="cuda")
+        ops.l2norm_fwd(x, y, inv, rows, C, grp, L, off)
+        xs = x.view(B, L, C)[:, off:off + grp].reshape(rows, C).double().requires_grad_(True)
+        ref = xs / xs.norm(dim=-1, keepdim=True)
+        close(y, ref, 1e-6 if dtype == torch.float32 else 1e-2)
+        dy = rnd((rows, C), dtype, 8)
+        ref.backward(dy.double())
+        dx = torch.zeros(B * L, C, device="cuda", dtype=dtype)
+        ops.l2norm_bwd(dy, y, inv, dx, rows, C, grp, L, off)
+        got = dx.view(B, L, C)[:, off:off + grp].reshape(rows, C)
+        close(got, xs.grad, 1e-5 if dtype == torch.float32 else 2e-2)
+        other = torch.ones(L, dtype=torch.bool)
+        other[off:off + grp] = False
+        assert dx.view(B, L, C)[:, other].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_small_helpers(dtype):
+    from temporalalignnet_amd import ops
+    rows, C = 300, 1536
+    x = rnd((rows, C), dtype, 9)
+    out = torch.ones(C, device="cuda")
+    ops.colsum_acc(x, out, rows, C)
+    close(out, x.double().sum(0) + 1, 1e-3 if dtype == torch.float32 else 0.5)
+    # cat / split with accumulate
+    B, T, N, C = 3, 5, 4, 512
+    L = T + N
+    v, t = rnd((B * T, C), dtype, 10), rnd((B * N, C), dtype, 11)
+    j = torch.zeros(B * L, C, device="cuda", dtype=dtype)
+    ops.rows_copy(v, j, B, T, C, T, 0, L, 0)
+    ops.rows_copy(t, j, B, N, C, N, 0, L, T)
+    want = torch.cat([v.view(B, T, C), t.view(B, N, C)], 1)
+    assert torch.equal(j.view(B, L, C), want)
+    acc = v.clone()
+    ops.rows_copy(j, acc, B, T, C, L, 0, T, 0, accumulate=True)
+    close(acc, 2 * v.double(), 1e-6 if dtype == torch.float32 else 5e-2)
+    gs = torch.empty(T, C, device="cuda", dtype=dtype)
+    ops.group_sum(v, gs, B, T, C)
+    close(gs, v.double().view(B, T, C).sum(0), 1e-5 if dtype == torch.float32 else 5e-2)
+    # cast round trip
+    f = rnd((1000 + 3,), torch.float32, 12)
+    h = torch.empty(1003, device="cuda", dtype=torch.bfloat16)
+    ops.cast(f, h)
+    assert torch.equal(h, f.to(torch.bfloat16))
+    f2 = torch.empty_like(f)
+    ops.cast(h, f2)
+    assert torch.equal(f2, h.float())
+    # binary head
+    rows = 37
+    x = rnd((rows, 512), dtype, 13)
+    w, b = rnd((512,), torch.float32, 14, 0.1), rnd((1,), torch.float32, 15)
+    o = torch.empty(rows, device="cuda")
+    ops.head_fwd(x, w, b, o, rows, 512)
+    close(o, x.double() @ w.double() + b.double(), 1e-4 if dtype == torch.float32 else 1e-2)
+    do = rnd((rows,), torch.float32, 16)
+    dx = torch.ones(rows, 512, device="cuda", dtype=dtype)
+    dw, db = torch.zeros(512, device="cuda"), torch.zeros(1, device="cuda")
+    ops.head_bwd(do, x, w, dx, dw, db, rows, 512, accumulate_dx=True)
+    close(dx, 1 + do.double()[:, None] * w.double()[None], 1e-5 if dtype == torch.float32 else 3e-2)
+    close(dw, do.double() @ x.double(), 1e-3 if dtype == torch.float32 else 1e-1)
+    close(db, do.double().sum(), 1e-4)
+
+
+def test_interp_linear():
+    from temporalalignnet_amd import ops
+    src = rnd((64, 512), torch.float32, 17)
+    for L_out in (100, 40, 64):
+        dst = torch.empty(L_out, 512, device="cuda")
+        ops.interp_linear(src, dst, 64, L_out, 512)
+        ref = F.interpolate(src.t()[None], size=L_out, mode="linear", align_corners=False)[0].t()
+        close(dst, ref, 1e-5)
+        dd = rnd((L_out, 512), torch.float32, 18)
+        ds = torch.zeros(64, 512, device="cuda")
+        ops.interp_linear_bwd(dd, ds, 64, L_out, 512)
+        s2 = src.clone().requires_grad_(True)
+        F.interpolate(s2.t()[None], size=L_out, mode="linear", align_corners=False)[0].t().backward(dd)
+        close(ds, s2.grad, 1e-4)
+
+
+def _attn_ref(qkv, keypad, B, L, H):
+    C = H * 64
+    q, k, v = qkv.view(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q * 0.125) @ k.transpose(-1, -2)
+    if keypad is not None:
+        s = s.masked_fill(keypad.bool()[:, None, None, :], float("-inf"))
+    o = torch.softmax(s, -1) @ v
+    return o.transpose(1, 2).reshape(B * L, C)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,L,pad", [(2, 64, False), (3, 80, True), (1, 272, True), (2, 17, True)])
+def test_attention_fwd_bwd(dtype, B, L, pad):
+    from temporalalignnet_amd import ops
+    H, C = 8, 512
+    qkv = rnd((B * L, 3 * C), dtype, 20, 1.5)
+    keypad = None
+    if pad:
+        keypad = torch.zeros(B, L, dtype=torch.uint8, device="cuda")
+        keypad[0, L - L // 5:] = 1
+        keypad[-1, 3] = 1
+    o = torch.empty(B * L, C, device="cuda", dtype=dtype)
+    lse = torch.empty(B, H, L, device="cuda")
+    ops.attn_fwd(qkv, keypad, o, lse, B, L, H)
+    qr = qkv.double().requires_grad_(True)
+    ref = _attn_ref(qr, keypad, B, L, H)
+    close(o, ref, 2e-5 if dtype == torch.float32 else 4e-2)
+    d_o = rnd((B * L, C), dtype, 21)
+    ref.backward(d_o.double())
+    dqkv = torch.full_like(qkv, float("nan"))
+    ops.attn_bwd(qkv, keypad, o, lse, d_o, dqkv, B, L, H)
+    close(dqkv, qr.grad, 1e-4 if dtype == torch.float32 else 1e-1)
