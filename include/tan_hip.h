@@ -107,6 +107,90 @@ int tan_attn_fwd(const void* qkv, const unsigned char* key_padding_mask, void* o
 int tan_attn_bwd(const void* qkv, const unsigned char* key_padding_mask, const void* o, const float* lse,
                  const void* d_o, void* dqkv, int B, int L, int H, int dtype, void* stream);
 
+/* ---- loss side (train/loss.py:get_loss) -------------------------------------------------------------------
+ * logits: raw cosines, stage-major [S, R=B*T, Mp=B*N] f32 (the reference's [B,S,T,B,N] is a permuted view).
+ * tgt [B,T,N] f32 {0,1}: same-video targets (loss.py:73-76 or the self-labelled ones, loss.py:227);
+ * col_invalid [Mp] bytes: padded texts (dropped columns, loss.py:233,241); row_leak [R] bytes or NULL: frames whose
+ * same-video logits read -6e4 (reference in-place quirk for model='init' + learn_agreement, loss.py:96-101).
+ *
+ * tan_nce_fwd: symmetric multi-positive NCE terms of loss.py:240-253 (and 262-274):
+ *   v_terms[s,r] = LSE_cols(all) - LSE_cols(pos), t_terms[s,c] = LSE_rows(all) - LSE_rows(pos); the row/column sums of
+ *   exp(l/0.07 - 1/0.07) are saved (rowsum [S,R], colsum [S,Mp], possum_v [S,R], possum_t [S,Mp]) for tan_nce_bwd, which
+ *   turns upstream g_v [S,R], g_t [S,Mp] into dlogits [S,R,Mp] (out_dtype).  ws: tan_nce_ws_floats() f32 scratch.   */
+long tan_nce_ws_floats(int S, int B, int T, int N);
+int tan_nce_fwd(const float* logits, const float* tgt, const unsigned char* col_invalid, const unsigned char* row_leak,
+                float* rowsum, float* colsum, float* possum_v, float* possum_t, float* v_terms, float* t_terms, float* ws,
+                int S, int B, int T, int N, int n_valid_cols, void* stream);
+int tan_nce_bwd(const float* logits, const float* tgt, const unsigned char* col_invalid, const unsigned char* row_leak,
+                const float* rowsum, const float* colsum, const float* possum_v, const float* possum_t, const float* g_v,
+                const float* g_t, void* dlogits, int out_dtype, int S, int B, int T, int N, void* stream);
+/* self-labelling scan, loss.py:88-143 (joint) / 146-179 (dual): two-way softmax (over texts, /0.07, over time) of the
+ * last-stage same-video logits, sliding-window mean with window length dur[b,n] (0 = padded text), first-index argmax.
+ * Outputs max_pos [B,N] int32, max_prob/max_logit [B,N] f32, self_tgt [B,N,T] bytes (the chosen window).            */
+int tan_selflabel(const float* logits, const unsigned char* video_pad, const unsigned char* text_pad, const float* dur,
+                  int* max_pos, float* max_prob, float* max_logit, unsigned char* self_tgt, int S, int B, int T, int N,
+                  void* stream);
+/* out[b,n] = max_t logits[S-1,(b,t),(b,n)] / 0.07   (loss.py:280,283) */
+int tan_diag_max(const float* logits, const unsigned char* row_leak, float* out, int S, int B, int T, int N, void* stream);
+/* IoU of the two self-labelled windows, confidence, target policy kind (0 'i', 1 'u', 2 'keep', 3 'keep-joint') and the
+ * per-frame first-text de-duplication with restore, loss.py:181-226.  q_joint/q_dual: device scalars (0.3-quantiles of
+ * the max logits).  tgt_out [B,T,N] f32, iou [B,N] f32, conf [B,N] bytes.  N <= 64.                                 */
+int tan_agreement(const unsigned char* joint_tgt, const unsigned char* dual_tgt, const unsigned char* youtube_tgt,
+                  const float* max_logit_joint, const float* max_logit_dual, const float* q_joint, const float* q_dual,
+                  int kind, float* tgt_out, float* iou, unsigned char* conf, int B, int T, int N, void* stream);
+/* torch.quantile(x[~invalid], q) ('linear' interpolation, at::lerp rounding) without a host sync; n <= 8192 */
+int tan_masked_quantile(const float* x, const unsigned char* invalid, int n, float q, float* out, void* stream);
+
+/* ---- fused AdamW (+ EMA twin, + bf16 shadow weights) over one flat f32 parameter buffer ---------------------
+ * torch.optim.AdamW single-tensor arithmetic (train/main.py:397, groups of main.py:330-356) followed by
+ * TwinTemporalAligner._momentum_update (tan_model.py:339-344).  mode[i]: 0 no decay, 1 decay, 2 parameter never
+ * receives a gradient (skipped like a .grad-is-None parameter); NULL = all decay.  step >= 1 is the 1-based count. */
+int tan_adamw_step(float* p, const float* g, float* m, float* v, const unsigned char* mode, long n, double lr,
+                   double beta1, double beta2, double eps, double weight_decay, int step, float grad_scale, void* p_bf16,
+                   float* ema, float ema_m, void* ema_bf16, void* stream);
+/* target = m*target + (1-m)*online  (TwinTemporalAligner._momentum_update, tan_model.py:339-344) */
+int tan_ema_update(float* target, const float* online, long n, float m, void* target_bf16, void* stream);
+
+/* ---- one TemporalEncoder stack (tfm_model.py:41-55), forward and backward in one call each -----------------
+ * Weights are `dtype` (f32, or the bf16 shadow copies); biases / LayerNorm affine / all gradients are f32 and
+ * gradients are ACCUMULATED.  Layouts: w_qkv [3C,C] (in_proj_weight, q|k|v), w_out [C,C], w_fc [4C,C], w_proj [C,4C]. */
+typedef struct tan_layer_params {
+    const void *w_qkv, *w_out, *w_fc, *w_proj;
+    const float *b_qkv, *b_out, *b_fc, *b_proj;
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    float *g_w_qkv, *g_w_out, *g_w_fc, *g_w_proj;
+    float *g_b_qkv, *g_b_out, *g_b_fc, *g_b_proj;
+    float *g_ln1_g, *g_ln1_b, *g_ln2_g, *g_ln2_b;
+} tan_layer_params;
+
+/* per-layer saved activations, rows R = B*L */
+typedef struct tan_layer_bufs {
+    void *xn1, *qkv, *attn_o, *x_mid, *xn2, *h_pre, *h_act, *x_out; /* dtype: [R,C] [R,3C] [R,C] [R,C] [R,C] [R,4C] [R,4C] [R,C] */
+    float *mean1, *rstd1, *mean2, *rstd2;                            /* [R] */
+    float* lse;                                                      /* [B,H,L] */
+} tan_layer_bufs;
+
+typedef struct tan_encoder_desc {
+    int dtype, B, L, C, H, layers;
+    const unsigned char* key_padding_mask; /* [B,L] bytes, 1 = ignore, or NULL */
+    const void* x0;                        /* [R,C] stack input */
+    const tan_layer_params* params;        /* HOST array [layers] of device pointers */
+    const tan_layer_bufs* bufs;            /* HOST array [layers] */
+    const float *post_g, *post_b;          /* ln_video_post_enc / ln_joint_post_enc (tan_model.py:174,206) */
+    float *g_post_g, *g_post_b;
+    void* post_out;                        /* [R,C] last stage = LN_post(x_out[last]); NULL to skip */
+    float *post_mean, *post_rstd;
+    /* backward only */
+    void *scr_dx, *scr_dx2, *scr_do, *scr_dxn; /* [R,C] */
+    void* scr_dh;                               /* [R,4C] */
+    void* scr_dqkv;                             /* [R,3C] */
+    float* ln_ws;                               /* tan_layernorm_bwd_ws_floats(C) */
+    const void* const* d_stage;                 /* HOST array [layers]: grad w.r.t. stage s ([R,C] dtype) or NULL */
+    void* d_x0;                                 /* [R,C] out: grad w.r.t. x0 */
+} tan_encoder_desc;
+int tan_encoder_fwd(const tan_encoder_desc* e, void* stream);
+int tan_encoder_bwd(const tan_encoder_desc* e, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

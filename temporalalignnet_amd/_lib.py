@@ -62,3 +62,28 @@ def lib() -> C.CDLL:
 def check(code: int, what: str):
     if code != 0:
         raise TanHipError(f"{what} failed with code {code}" + (" (bad argument)" if code == -1 else " (hipError_t)"))
+
+
+class LayerParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "w_qkv", "w_out", "w_fc", "w_proj", "b_qkv", "b_out", "b_fc", "b_proj", "ln1_g", "ln1_b", "ln2_g", "ln2_b",
+        "g_w_qkv", "g_w_out", "g_w_fc", "g_w_proj", "g_b_qkv", "g_b_out", "g_b_fc", "g_b_proj",
+        "g_ln1_g", "g_ln1_b", "g_ln2_g", "g_ln2_b")]
+
+
+class LayerBufs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "xn1", "qkv", "attn_o", "x_mid", "xn2", "h_pre", "h_act", "x_out", "mean1", "rstd1", "mean2", "rstd2", "lse")]
+
+
+class EncoderDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("B", C.c_int), ("L", C.c_int), ("C", C.c_int), ("H", C.c_int), ("layers", C.c_int),
+        ("key_padding_mask", C.c_void_p), ("x0", C.c_void_p),
+        ("params", C.POINTER(LayerParams)), ("bufs", C.POINTER(LayerBufs)),
+        ("post_g", C.c_void_p), ("post_b", C.c_void_p), ("g_post_g", C.c_void_p), ("g_post_b", C.c_void_p),
+        ("post_out", C.c_void_p), ("post_mean", C.c_void_p), ("post_rstd", C.c_void_p),
+        ("scr_dx", C.c_void_p), ("scr_dx2", C.c_void_p), ("scr_do", C.c_void_p), ("scr_dxn", C.c_void_p),
+        ("scr_dh", C.c_void_p), ("scr_dqkv", C.c_void_p), ("ln_ws", C.c_void_p),
+        ("d_stage", C.POINTER(C.c_void_p)), ("d_x0", C.c_void_p),
+    ]

@@ -1,0 +1,135 @@
+// Host-side runner for one TemporalEncoder stack (model/tfm_model.py:41-55): S pre-LN residual attention blocks
+// (tfm_model.py:17-38) forward and backward as a fixed sequence of kernel launches on one stream -- one C call per
+// stack instead of ~25 Python->C transitions per layer.  No allocation, no synchronisation: every buffer is passed in.
+//
+// forward, per layer (rows R = B*L):
+//   xn1 = LN1(x_in)                      tan_layernorm_fwd
+//   qkv = xn1 W_in^T + b_in              tan_gemm
+//   o   = attention(qkv, key_padding)    tan_attn_fwd
+//   x_mid = x_in + o W_out^T + b_out     tan_gemm (+bias +residual epilogue)
+//   xn2 = LN2(x_mid)                     tan_layernorm_fwd
+//   h   = quickgelu(xn2 W_fc^T + b_fc)   tan_gemm (activation epilogue, pre-activation kept for backward)
+//   x_out = x_mid + h W_proj^T + b_proj  tan_gemm (+bias +residual epilogue)
+// deep-supervision stage s < S-1 is layer s+1's xn1 (TemporalEncoder.forward drops the first ln_1 output and appends
+// the final residual stream); the last stage is post-LN'ed by the caller-provided ln_*_post_enc (tan_model.py:174,206).
+#include "tan_common.h"
+
+using namespace tal;
+
+namespace {
+
+int linear_fwd(int dt, const void* x, const void* w, const float* b, void* y, long M, int N, int K, int act, void* aux,
+               const void* residual, void* st) {
+    tan_gemm_desc d{};
+    d.dtype = dt; d.out_dtype = dt;
+    d.M = (int)M; d.N = N; d.K = K;
+    d.a_kc = 1; d.b_kc = 1;
+    d.A = x; d.lda = K; d.B = w; d.ldb = K; d.C = y; d.ldc = N;
+    d.bias = b; d.residual = residual; d.ldr = N; d.act = act; d.aux = aux; d.ldaux = N;
+    d.accumulate = 0; d.split_k = 1; d.alpha = 1.0f; d.batch = 1;
+    return tan_gemm(&d, st);
+}
+
+// dx[M,K] = dy[M,N] W[N,K]  (optionally * gelu'(aux) and + residual)
+int linear_bwd_x(int dt, const void* dy, const void* w, void* dx, long M, int N, int K, int act, void* aux, const void* residual,
+                 void* st) {
+    tan_gemm_desc d{};
+    d.dtype = dt; d.out_dtype = dt;
+    d.M = (int)M; d.N = K; d.K = N;
+    d.a_kc = 1; d.b_kc = 0;               // B = W stored [N(contract), K(out)]
+    d.A = dy; d.lda = N; d.B = w; d.ldb = K; d.C = dx; d.ldc = K;
+    d.residual = residual; d.ldr = K; d.act = act; d.aux = aux; d.ldaux = K;
+    d.split_k = 1; d.alpha = 1.0f; d.batch = 1;
+    return tan_gemm(&d, st);
+}
+
+// gw[N,K] += dy[M,N]^T x[M,K]   (f32 accumulate, split over the long M contraction)
+int linear_bwd_w(int dt, const void* dy, const void* x, float* gw, long M, int N, int K, void* st) {
+    tan_gemm_desc d{};
+    d.dtype = dt; d.out_dtype = TAN_F32;
+    d.M = N; d.N = K; d.K = (int)M;
+    d.a_kc = 0; d.b_kc = 0;
+    d.A = dy; d.lda = N; d.B = x; d.ldb = K; d.C = gw; d.ldc = K;
+    d.accumulate = 1; d.alpha = 1.0f; d.batch = 1;
+    const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
+    long split = (512 + tiles - 1) / tiles;
+    const long max_split = (M + 255) / 256;
+    if (split > max_split) split = max_split;
+    if (split > 32) split = 32;
+    if (split < 1) split = 1;
+    d.split_k = (int)split;
+    return tan_gemm(&d, st);
+}
+
+#define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+}  // namespace
+
+extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
+    TAN_REQUIRE(e && e->layers > 0 && e->params && e->bufs && e->x0);
+    const int dt = e->dtype, C = e->C, H = e->H;
+    const long R = (long)e->B * e->L;
+    const void* x_in = e->x0;
+    for (int i = 0; i < e->layers; ++i) {
+        const tan_layer_params& p = e->params[i];
+        const tan_layer_bufs& b = e->bufs[i];
+        CK(tan_layernorm_fwd(x_in, p.ln1_g, p.ln1_b, b.xn1, b.mean1, b.rstd1, nullptr, 0, R, C, 1e-5f, dt, st));
+        CK(linear_fwd(dt, b.xn1, p.w_qkv, p.b_qkv, b.qkv, R, 3 * C, C, TAN_ACT_NONE, nullptr, nullptr, st));
+        CK(tan_attn_fwd(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->B, e->L, H, dt, st));
+        CK(linear_fwd(dt, b.attn_o, p.w_out, p.b_out, b.x_mid, R, C, C, TAN_ACT_NONE, nullptr, x_in, st));
+        CK(tan_layernorm_fwd(b.x_mid, p.ln2_g, p.ln2_b, b.xn2, b.mean2, b.rstd2, nullptr, 0, R, C, 1e-5f, dt, st));
+        CK(linear_fwd(dt, b.xn2, p.w_fc, p.b_fc, b.h_act, R, 4 * C, C, TAN_ACT_QUICKGELU, b.h_pre, nullptr, st));
+        CK(linear_fwd(dt, b.h_act, p.w_proj, p.b_proj, b.x_out, R, C, 4 * C, TAN_ACT_NONE, nullptr, b.x_mid, st));
+        x_in = b.x_out;
+    }
+    if (e->post_out)
+        CK(tan_layernorm_fwd(x_in, e->post_g, e->post_b, e->post_out, e->post_mean, e->post_rstd, nullptr, 0, R, C, 1e-5f, dt, st));
+    return 0;
+}
+
+// d_stage[s] (may be NULL = no gradient) is the gradient w.r.t. deep-supervision stage s; parameter gradients are
+// ACCUMULATED into the g_* pointers of params[] (f32).  d_x0 receives the gradient w.r.t. the stack input.
+extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
+    TAN_REQUIRE(e && e->layers > 0 && e->params && e->bufs && e->x0 && e->d_stage && e->d_x0);
+    TAN_REQUIRE(e->scr_dx && e->scr_dx2 && e->scr_dh && e->scr_dqkv && e->scr_do && e->scr_dxn && e->ln_ws);
+    const int dt = e->dtype, C = e->C, H = e->H, S = e->layers;
+    const long R = (long)e->B * e->L;
+    const size_t esz = dt == TAN_F32 ? 4 : 2;
+    void* dx = e->scr_dx;      // gradient w.r.t. the residual stream leaving the current layer
+    void* dx2 = e->scr_dx2;
+    const void* x_last = e->bufs[S - 1].x_out;
+    if (e->d_stage[S - 1]) {
+        TAN_REQUIRE(e->post_out);
+        CK(tan_layernorm_bwd(e->d_stage[S - 1], x_last, e->post_g, e->post_mean, e->post_rstd, nullptr, dx, e->g_post_g,
+                             e->g_post_b, e->ln_ws, R, C, dt, st));
+    } else {
+        hipError_t err = hipMemsetAsync(dx, 0, (size_t)R * C * esz, (hipStream_t)st);
+        if (err != hipSuccess) return (int)err;
+    }
+    for (int i = S - 1; i >= 0; --i) {
+        const tan_layer_params& p = e->params[i];
+        const tan_layer_bufs& b = e->bufs[i];
+        const void* x_in = i == 0 ? e->x0 : e->bufs[i - 1].x_out;
+        // ---- MLP branch: x_out = x_mid + c_proj(quickgelu(c_fc(LN2(x_mid))))
+        CK(tan_colsum_acc(dx, p.g_b_proj, R, C, dt, st));
+        CK(linear_bwd_w(dt, dx, b.h_act, p.g_w_proj, R, C, 4 * C, st));
+        CK(linear_bwd_x(dt, dx, p.w_proj, e->scr_dh, R, C, 4 * C, TAN_ACT_QUICKGELU_GRAD, b.h_pre, nullptr, st));
+        CK(tan_colsum_acc(e->scr_dh, p.g_b_fc, R, 4 * C, dt, st));
+        CK(linear_bwd_w(dt, e->scr_dh, b.xn2, p.g_w_fc, R, 4 * C, C, st));
+        CK(linear_bwd_x(dt, e->scr_dh, p.w_fc, e->scr_dxn, R, 4 * C, C, TAN_ACT_NONE, nullptr, nullptr, st));
+        CK(tan_layernorm_bwd(e->scr_dxn, b.x_mid, p.ln2_g, b.mean2, b.rstd2, dx, dx2, p.g_ln2_g, p.g_ln2_b, e->ln_ws, R, C, dt, st));
+        // ---- attention branch: x_mid = x_in + out_proj(attn(LN1(x_in)))
+        CK(tan_colsum_acc(dx2, p.g_b_out, R, C, dt, st));
+        CK(linear_bwd_w(dt, dx2, b.attn_o, p.g_w_out, R, C, C, st));
+        CK(linear_bwd_x(dt, dx2, p.w_out, e->scr_do, R, C, C, TAN_ACT_NONE, nullptr, nullptr, st));
+        CK(tan_attn_bwd(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->scr_do, e->scr_dqkv, e->B, e->L, H, dt, st));
+        CK(tan_colsum_acc(e->scr_dqkv, p.g_b_qkv, R, 3 * C, dt, st));
+        CK(linear_bwd_w(dt, e->scr_dqkv, b.xn1, p.g_w_qkv, R, 3 * C, C, st));
+        // stage i-1 IS this layer's xn1: its gradient joins here
+        const void* dstage = i >= 1 ? e->d_stage[i - 1] : nullptr;
+        CK(linear_bwd_x(dt, e->scr_dqkv, p.w_qkv, e->scr_dxn, R, 3 * C, C, TAN_ACT_NONE, nullptr, dstage, st));
+        void* dx_in = i == 0 ? e->d_x0 : dx;
+        CK(tan_layernorm_bwd(e->scr_dxn, x_in, p.ln1_g, b.mean1, b.rstd1, dx2, dx_in, p.g_ln1_g, p.g_ln1_b, e->ln_ws, R, C, dt, st));
+    }
+    return 0;
+}

@@ -1,0 +1,409 @@
+// Loss-side kernels for train/loss.py:get_loss (gfx950): the symmetric multi-positive NCE over materialised
+// logits, the self-labelling scan ("softmax over time" + sliding-window argmax), agreement / de-duplication of the
+// self-labelled targets and a masked quantile.  Logits are raw cosines [S, R = B*T, Mp = B*N] f32 (stage-major);
+// the temperature 0.07 is applied here exactly as the reference does (a true division).
+#include "tan_common.h"
+
+namespace tal {
+
+constexpr float TAU = 0.07f;
+constexpr float FILL = -6e4f;
+
+// ------------------------------------------------------------------------------------------------------
+// NCE "all" sums (loss.py:246-247,251-252): rowsum[s,r] = sum_{valid c} e, colsum[s,c] = sum_r e,
+// e = exp(l/0.07 - 1/0.07)  (|l| <= 1 so e <= ~1: no running max needed; the shift is added back in nce_terms).
+// Block = 64 rows of one stage; each wave owns 16 rows, lanes stride the columns; column partials accumulate in
+// LDS (ds_add_f32) and leave as colpart[row_chunk][s][Mp].
+__global__ __launch_bounds__(256) void nce_stats_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ col_invalid,
+                                                        const unsigned char* __restrict__ row_leak, float* __restrict__ rowsum,
+                                                        float* __restrict__ colpart, int R, int Mp, int T, int N) {
+    extern __shared__ float cs[];
+    const int s = blockIdx.y, rc = blockIdx.x, S = gridDim.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < Mp; c += 256) cs[c] = 0.f;
+    __syncthreads();
+    const float shift = 1.0f / TAU;
+    for (int i = 0; i < 16; ++i) {
+        const int r = rc * 64 + wave * 16 + i;
+        if (r >= R) break;
+        const float* row = logits + ((long)s * R + r) * Mp;
+        float acc = 0.f;
+        // reference quirk (loss.py:96-101 in place on the online logits, model='init' + learn_agreement): same-video
+        // entries of padded frames read -6e4, i.e. contribute nothing
+        const int leak_b = (row_leak && row_leak[r]) ? r / T : -1;
+        for (int c = lane; c < Mp; c += 64) {
+            const float e = (c / N == leak_b) ? 0.f : expf(row[c] / TAU - shift);
+            if (!col_invalid[c]) acc += e;
+            atomicAdd(&cs[c], e);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) rowsum[(long)s * R + r] = acc;
+    }
+    __syncthreads();
+    float* out = colpart + ((long)rc * S + s) * Mp;
+    for (int c = threadIdx.x; c < Mp; c += 256) out[c] = cs[c];
+}
+
+__global__ void nce_colsum_finalize(const float* __restrict__ colpart, float* __restrict__ colsum, int nchunk, long SM) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= SM) return;
+    float s = 0.f;
+    for (int k = 0; k < nchunk; ++k) s += colpart[(long)k * SM + i];
+    colsum[i] = s;
+}
+
+// positives live on the same-video blocks only (loss.py:73-76): possum_v[s,(b,t)] = sum_k tgt[b,t,k] e,
+// possum_t[s,(b,k)] = sum_t tgt[b,t,k] e.  One block per (video, stage).
+__global__ __launch_bounds__(256) void nce_pos_kernel(const float* __restrict__ logits, const float* __restrict__ tgt,
+                                                      const unsigned char* __restrict__ col_invalid,
+                                                      const unsigned char* __restrict__ row_leak, float* __restrict__ possum_v,
+                                                      float* __restrict__ possum_t, int B, int T, int N) {
+    const int b = blockIdx.x, s = blockIdx.y;
+    const int R = B * T, Mp = B * N;
+    const float shift = 1.0f / TAU;
+    const float* blk = logits + ((long)s * R + (long)b * T) * Mp + (long)b * N;
+    const float* tg = tgt + (long)b * T * N;
+    for (int t = threadIdx.x; t < T; t += 256) {
+        float acc = 0.f;
+        for (int k = 0; k < N; ++k)
+            if (tg[t * N + k] != 0.f && !col_invalid[b * N + k] && !(row_leak && row_leak[b * T + t]))
+                acc += expf(blk[(long)t * Mp + k] / TAU - shift);
+        possum_v[(long)s * R + b * T + t] = acc;
+    }
+    for (int k = threadIdx.x; k < N; k += 256) {
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t)
+            if (tg[t * N + k] != 0.f && !(row_leak && row_leak[b * T + t])) acc += expf(blk[(long)t * Mp + k] / TAU - shift);
+        possum_t[(long)s * Mp + b * N + k] = acc;
+    }
+}
+
+// v_terms[s,r] = LSE_all - LSE_pos (loss.py:246-248), t_terms[s,c] likewise (loss.py:250-253).  LSE over an empty positive
+// set reproduces the reference's -6e4 fill: log(sum_valid exp(-6e4)) = -6e4 + log(#cols).
+__global__ void nce_terms_kernel(const float* __restrict__ allsum, const float* __restrict__ possum, float* __restrict__ terms,
+                                 long n, float log_count) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float shift = 1.0f / TAU;
+    const float den = logf(allsum[i]) + shift;
+    const float num = possum[i] > 0.f ? logf(possum[i]) + shift : FILL + log_count;
+    terms[i] = den - num;
+}
+
+// d logits (loss.py:240-275 backward): dl = (1/0.07) * [ gv[s,r] (e/rowsum - pos e/possum_v) + gt[s,c] (e/colsum - pos e/possum_t) ]
+template <typename TO>
+__global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ tgt,
+                                                      const unsigned char* __restrict__ col_invalid,
+                                                      const unsigned char* __restrict__ row_leak,
+                                                      const float* __restrict__ rowsum, const float* __restrict__ colsum,
+                                                      const float* __restrict__ possum_v, const float* __restrict__ possum_t,
+                                                      const float* __restrict__ gv, const float* __restrict__ gt,
+                                                      TO* __restrict__ dl, int S, int B, int T, int N) {
+    const int R = B * T, Mp = B * N;
+    const long total = (long)S * R * Mp;
+    const float shift = 1.0f / TAU, inv_tau = 1.0f / TAU;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % Mp);
+        const long sr = i / Mp;
+        const int r = (int)(sr % R), s = (int)(sr / R);
+        float g = 0.f;
+        const int b = r / T, bc = c / N;
+        const float e = (b == bc && row_leak && row_leak[r]) ? 0.f : expf(logits[i] / TAU - shift);
+        const float gvr = gv[sr], gtc = gt[(long)s * Mp + c];
+        if (!col_invalid[c]) g += gvr * e / rowsum[sr];
+        g += gtc * e / colsum[(long)s * Mp + c];
+        if (b == bc && tgt[((long)b * T + (r - b * T)) * N + (c - bc * N)] != 0.f) {
+            if (!col_invalid[c] && possum_v[sr] > 0.f) g -= gvr * e / possum_v[sr];
+            if (possum_t[(long)s * Mp + c] > 0.f) g -= gtc * e / possum_t[(long)s * Mp + c];
+        }
+        st_f(dl + i, g * inv_tau);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Self-labelling scan (loss.py:88-143 / 146-179), one block per video:
+//   z[t,n]  = logits[S-1, (b,t), (b,n)] / 0.07, -6e4 where frame t or text n is padding          (loss.py:91-101)
+//   p1      = softmax_n z ; prob = softmax_t (p1 / 0.07)                                           (loss.py:104)
+//   window i of text n covers [i, i+dur_n) if it fits in [0,T), minus frames 0 and T-1, uniform     (loss.py:112-131)
+//   scan[i] = mean of prob over the window ; max_pos = first argmax_i ; max_logit = window mean of z (loss.py:133-141)
+__global__ __launch_bounds__(256) void selflabel_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ vpad,
+                                                        const unsigned char* __restrict__ tpad, const float* __restrict__ dur,
+                                                        int* __restrict__ max_pos, float* __restrict__ max_prob,
+                                                        float* __restrict__ max_logit, unsigned char* __restrict__ self_tgt,
+                                                        int S, int B, int T, int N) {
+    extern __shared__ float sm[];
+    float* z = sm;               // [T][N]
+    float* p = z + T * N;        // [T][N]
+    const int b = blockIdx.x, R = B * T, Mp = B * N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* blk = logits + ((long)(S - 1) * R + (long)b * T) * Mp + (long)b * N;
+    for (int i = threadIdx.x; i < T * N; i += 256) {
+        const int t = i / N, n = i % N;
+        float v = blk[(long)t * Mp + n] / TAU;
+        if (vpad && vpad[b * T + t]) v = FILL;
+        if (tpad[b * N + n]) v = FILL;
+        z[i] = v;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {  // softmax over texts
+        float m = -INFINITY;
+        for (int n = 0; n < N; ++n) m = fmaxf(m, z[t * N + n]);
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) { const float e = expf(z[t * N + n] - m); p[t * N + n] = e; s += e; }
+        for (int n = 0; n < N; ++n) p[t * N + n] = (p[t * N + n] / s) / TAU;
+    }
+    __syncthreads();
+    for (int n = wave; n < N; n += 4) {  // softmax over time, one wave per text
+        float m = -INFINITY;
+        for (int t = lane; t < T; t += 64) m = fmaxf(m, p[t * N + n]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int t = lane; t < T; t += 64) { const float e = expf(p[t * N + n] - m); p[t * N + n] = e; s += e; }
+        s = wave_sum(s);
+        for (int t = lane; t < T; t += 64) p[t * N + n] = p[t * N + n] / s;
+    }
+    __syncthreads();
+    for (int n = wave; n < N; n += 4) {
+        const int d = (int)dur[b * N + n];
+        float best = -INFINITY;
+        int best_i = 0x7fffffff;
+        for (int i = lane; i < T; i += 64) {
+            float v = 0.f;
+            if (d > 0 && i + d <= T) {
+                const int lo = max(i, 1), hi = min(i + d, T - 1);  // members j in [lo, hi)
+                const int cnt = hi - lo;
+                if (cnt > 0) {
+                    const float w = 1.0f / (float)cnt;
+                    for (int j = lo; j < hi; ++j) v += p[j * N + n] * w;
+                }
+            }
+            if (v > best) { best = v; best_i = i; }   // lane visits i in increasing order: keeps its first max
+        }
+        // wave arg-max, ties to the smallest index (torch.max returns the first maximal index)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(best_i, o, 64);
+            if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+        }
+        const int i = best_i;
+        int lo = 0, hi = 0;
+        if (d > 0 && i + d <= T) { lo = max(i, 1); hi = min(i + d, T - 1); }
+        const int cnt = max(hi - lo, 0);
+        float ml = 0.f;
+        if (cnt > 0) {
+            const float w = 1.0f / (float)cnt;
+            for (int j = lo + lane; j < hi; j += 64) ml += z[j * N + n] * w;
+        }
+        ml = wave_sum(ml);
+        for (int t = lane; t < T; t += 64) self_tgt[((long)b * N + n) * T + t] = (t >= lo && t < hi) ? 1 : 0;
+        if (lane == 0) {
+            max_pos[b * N + n] = i;
+            max_prob[b * N + n] = best;
+            max_logit[b * N + n] = ml;
+        }
+    }
+}
+
+// per-text max over time of the last-stage same-video logits / 0.07 (loss.py:280,283)
+__global__ void diag_max_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ row_leak,
+                                float* __restrict__ out, int S, int B, int T, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * N) return;
+    const int b = i / N, n = i % N, R = B * T, Mp = B * N;
+    const float* col = logits + ((long)(S - 1) * R + (long)b * T) * Mp + (long)b * N + n;
+    float m = -INFINITY;
+    for (int t = 0; t < T; ++t) m = fmaxf(m, (row_leak && row_leak[b * T + t]) ? FILL : col[(long)t * Mp] / TAU);
+    out[i] = m;
+}
+
+// Agreement of the two self-labelled windows + exclusion principle (loss.py:181-226), one block per video.
+//   kind 0 'i', 1 'u', 2 'keep', 3 'keep-joint'.  Writes tgt_out [B,T,N] f32, iou [B,N], conf [B,N].
+__global__ __launch_bounds__(256) void agreement_kernel(const unsigned char* __restrict__ jt, const unsigned char* __restrict__ dt,
+                                                        const unsigned char* __restrict__ yt, const float* __restrict__ ml_j,
+                                                        const float* __restrict__ ml_d, const float* __restrict__ q_j,
+                                                        const float* __restrict__ q_d, int kind, float* __restrict__ tgt_out,
+                                                        float* __restrict__ iou_out, unsigned char* __restrict__ conf_out,
+                                                        int B, int T, int N) {
+    extern __shared__ unsigned char smb[];
+    unsigned char* agree = smb;          // [N][T]
+    unsigned char* dedup = agree + N * T;  // [N][T]
+    __shared__ int conf_iou_s[64], lost_s[64];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int n = wave; n < N; n += 4) {
+        const long base = ((long)b * N + n) * T;
+        int inter = 0, uni = 0;
+        for (int t = lane; t < T; t += 64) {
+            inter += (jt[base + t] & dt[base + t]) ? 1 : 0;
+            uni += (jt[base + t] | dt[base + t]) ? 1 : 0;
+        }
+        inter = (int)wave_sum((float)inter);
+        uni = (int)wave_sum((float)uni);
+        const float iou = (float)inter / fmaxf((float)uni, 1e-5f);
+        const bool c_iou = iou >= 0.5f;
+        const bool conf = c_iou && (ml_d[b * N + n] >= q_d[0]) && (ml_j[b * N + n] >= q_j[0]);
+        if (lane == 0) {
+            iou_out[b * N + n] = iou;
+            conf_out[b * N + n] = conf ? 1 : 0;
+            conf_iou_s[n] = c_iou;
+        }
+        for (int t = lane; t < T; t += 64) {
+            const unsigned char j = jt[base + t], d = dt[base + t], y = yt[base + t];
+            unsigned char a;
+            if (kind == 0) a = conf ? (j & d) : 0;
+            else if (kind == 1) a = conf ? (j | d) : 0;
+            else if (kind == 2) a = c_iou ? (j | d) : y;
+            else a = c_iou ? j : y;
+            agree[n * T + t] = a ? 1 : 0;
+            dedup[n * T + t] = 0;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {  // first text at every frame (argmax over n; 0 when none)
+        int first = 0;
+        for (int n = 0; n < N; ++n) if (agree[n * T + t]) { first = n; break; }
+        dedup[first * T + t] = 1;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) dedup[t] = agree[t];  // text 0 keeps its own row
+    __syncthreads();
+    for (int n = wave; n < N; n += 4) {
+        int any = 0;
+        for (int t = lane; t < T; t += 64) any += dedup[n * T + t];
+        any = (int)wave_sum((float)any);
+        if (lane == 0) lost_s[n] = (any == 0);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N * T; i += 256) {
+        const int n = i / T, t = i % T;
+        const unsigned char v = lost_s[n] ? yt[((long)b * N + n) * T + t] : dedup[i];
+        tgt_out[((long)b * T + t) * N + n] = v ? 1.0f : 0.0f;
+    }
+}
+
+// quantile (torch.quantile, 'linear') of the valid entries of x[n]; single block, bitonic sort in LDS.
+__global__ __launch_bounds__(1024) void masked_quantile_kernel(const float* __restrict__ x, const unsigned char* __restrict__ invalid,
+                                                               int n, float q, float* __restrict__ out, int npow2) {
+    extern __shared__ float v[];
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+        float val = INFINITY;
+        if (i < n && !(invalid && invalid[i])) { val = x[i]; atomicAdd(&cnt, 1); }
+        v[i] = val;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool up = ((i & k) == 0);
+                    const float a = v[i], b2 = v[ixj];
+                    if ((a > b2) == up) { v[i] = b2; v[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    if (threadIdx.x == 0) {
+        const int m = cnt;
+        if (m == 0) { out[0] = NAN; return; }
+        const float rank = q * (float)(m - 1);
+        const float lo = floorf(rank);
+        const int il = (int)lo, ih = min(il + 1, m - 1);
+        const float w = rank - lo, a = v[il], b2 = v[ih];
+        out[0] = (w < 0.5f) ? a + w * (b2 - a) : b2 - (b2 - a) * (1.0f - w);  // at::lerp
+    }
+}
+
+}  // namespace tal
+
+using namespace tal;
+
+extern "C" long tan_nce_ws_floats(int S, int B, int T, int N) {
+    const long R = (long)B * T, Mp = (long)B * N;
+    return (long)cdiv(R, 64) * S * Mp;
+}
+
+extern "C" int tan_nce_fwd(const float* logits, const float* tgt, const unsigned char* col_invalid, const unsigned char* row_leak,
+                           float* rowsum, float* colsum,
+                           float* possum_v, float* possum_t, float* v_terms, float* t_terms, float* ws, int S, int B, int T,
+                           int N, int n_valid_cols, void* stream) {
+    TAN_REQUIRE(logits && tgt && col_invalid && rowsum && colsum && possum_v && possum_t && v_terms && t_terms && ws);
+    TAN_REQUIRE(S > 0 && B > 0 && T > 0 && N > 0);
+    const int R = B * T, Mp = B * N;
+    TAN_REQUIRE((size_t)Mp * 4 <= 64 * 1024);
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = cdiv(R, 64);
+    hipLaunchKernelGGL(nce_stats_kernel, dim3(nchunk, S), dim3(256), (size_t)Mp * 4, st, logits, col_invalid, row_leak, rowsum, ws, R, Mp, T, N);
+    TAN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nce_colsum_finalize, dim3(cdiv((long)S * Mp, 256)), dim3(256), 0, st, ws, colsum, nchunk, (long)S * Mp);
+    TAN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nce_pos_kernel, dim3(B, S), dim3(256), 0, st, logits, tgt, col_invalid, row_leak, possum_v, possum_t, B, T, N);
+    TAN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nce_terms_kernel, dim3(cdiv((long)S * R, 256)), dim3(256), 0, st, rowsum, possum_v, v_terms, (long)S * R,
+                       logf((float)n_valid_cols));
+    hipLaunchKernelGGL(nce_terms_kernel, dim3(cdiv((long)S * Mp, 256)), dim3(256), 0, st, colsum, possum_t, t_terms,
+                       (long)S * Mp, logf((float)R));
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_nce_bwd(const float* logits, const float* tgt, const unsigned char* col_invalid, const unsigned char* row_leak,
+                           const float* rowsum,
+                           const float* colsum, const float* possum_v, const float* possum_t, const float* g_v, const float* g_t,
+                           void* dlogits, int out_dtype, int S, int B, int T, int N, void* stream) {
+    TAN_REQUIRE(logits && tgt && col_invalid && rowsum && colsum && possum_v && possum_t && g_v && g_t && dlogits);
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)S * B * T * B * N;
+    const unsigned grid = (unsigned)min((long)8192, (long)cdiv(total, 256));
+    if (out_dtype == TAN_F32)
+        hipLaunchKernelGGL((nce_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, logits, tgt, col_invalid, row_leak, rowsum, colsum, possum_v,
+                           possum_t, g_v, g_t, (float*)dlogits, S, B, T, N);
+    else if (out_dtype == TAN_BF16)
+        hipLaunchKernelGGL((nce_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, logits, tgt, col_invalid, row_leak, rowsum, colsum,
+                           possum_v, possum_t, g_v, g_t, (bf16_t*)dlogits, S, B, T, N);
+    else return TAN_ERR_BAD_ARG;
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_selflabel(const float* logits, const unsigned char* video_pad, const unsigned char* text_pad, const float* dur,
+                             int* max_pos, float* max_prob, float* max_logit, unsigned char* self_tgt, int S, int B, int T, int N,
+                             void* stream) {
+    TAN_REQUIRE(logits && text_pad && dur && max_pos && max_prob && max_logit && self_tgt && S > 0 && B > 0 && T > 0 && N > 0);
+    const size_t sm = (size_t)2 * T * N * 4;
+    TAN_REQUIRE(sm <= 64 * 1024);
+    hipLaunchKernelGGL(selflabel_kernel, dim3(B), dim3(256), sm, (hipStream_t)stream, logits, video_pad, text_pad, dur, max_pos,
+                       max_prob, max_logit, self_tgt, S, B, T, N);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_diag_max(const float* logits, const unsigned char* row_leak, float* out, int S, int B, int T, int N, void* stream) {
+    TAN_REQUIRE(logits && out && S > 0 && B > 0 && T > 0 && N > 0);
+    hipLaunchKernelGGL(diag_max_kernel, dim3(cdiv((long)B * N, 128)), dim3(128), 0, (hipStream_t)stream, logits, row_leak, out, S, B, T, N);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_agreement(const unsigned char* joint_tgt, const unsigned char* dual_tgt, const unsigned char* youtube_tgt,
+                             const float* max_logit_joint, const float* max_logit_dual, const float* q_joint, const float* q_dual,
+                             int kind, float* tgt_out, float* iou, unsigned char* conf, int B, int T, int N, void* stream) {
+    TAN_REQUIRE(joint_tgt && dual_tgt && youtube_tgt && max_logit_joint && max_logit_dual && q_joint && q_dual && tgt_out && iou && conf);
+    TAN_REQUIRE(kind >= 0 && kind <= 3 && N <= 64 && (size_t)2 * N * T <= 64 * 1024);
+    hipLaunchKernelGGL(agreement_kernel, dim3(B), dim3(256), (size_t)2 * N * T, (hipStream_t)stream, joint_tgt, dual_tgt, youtube_tgt,
+                       max_logit_joint, max_logit_dual, q_joint, q_dual, kind, tgt_out, iou, conf, B, T, N);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_masked_quantile(const float* x, const unsigned char* invalid, int n, float q, float* out, void* stream) {
+    TAN_REQUIRE(x && out && n > 0 && n <= 8192);
+    int p2 = 1;
+    while (p2 < n) p2 <<= 1;
+    hipLaunchKernelGGL(masked_quantile_kernel, dim3(1), dim3(1024), (size_t)p2 * 4, (hipStream_t)stream, x, invalid, n, q, out, p2);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,852 @@
+"""MI355X-native TemporalAligner / TwinTemporalAligner with the reference's Python surface.
+
+Drop-in boundary: same constructor arguments, `forward` signature and returned dict keys,
+`get_visual_feature / get_joint_feature / get_textual_feature(_with_time) / get_text_visual_sim_{joint,dual} /
+get_alignability`, `TwinTemporalAligner.{forward, forward_from_ema, _momentum_update, _copy_param}` and `state_dict`
+keys as reference model/tan_model.py.  The interface drift of the released reference is resolved as a superset:
+`lang_model` is an alias of `bert`, `abs_text_pos=` is accepted (and ignored, as nothing in the model reads it),
+`get_text_visual_sim` aliases `get_text_visual_sim_joint`.
+
+Underneath there is no ATen arithmetic: parameters live in one flat f32 buffer (+ flat f32 gradient, + bf16 shadow in
+throughput mode) and every op is a hand-written HIP kernel of libtan_hip.so (include/tan_hip.h).  The whole forward is
+ONE autograd node; its backward runs the HIP backward and accumulates parameter gradients straight into the flat
+gradient buffer that `p.grad` views alias (one RCCL all-reduce bucket, one fused AdamW launch).
+
+compute_dtype: 'fp32' = parity mode (exact-f32 MFMA, matches the reference CPU path to ~1e-6);
+               'bf16' = throughput mode (bf16 operands / activations, f32 accumulation, statistics and logits).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib, ops
+from .tfm_model import TemporalEncoder, _LayerNormParams, _LinearParams, get_position_embedding_sine
+
+WIDTH, HEADS = 512, 8
+_ALIGN = 8  # flat offsets are multiples of 8 elements (16-byte aligned bf16 / 32-byte f32 views)
+
+
+def _vp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class _Flat:
+    """Flat storage behind the aligner's own parameters (language model excluded)."""
+
+    def __init__(self, owner: nn.Module, named):
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]
+        self.off, total = {}, 0
+        for n, p in named:
+            self.off[n] = (total, p.numel(), tuple(p.shape))
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.total = total
+        self.flat = self.grad = self.shadow = None
+        self.shadow_version = -1
+        self.device = None
+
+    def bound(self):
+        p0, pl = self.params[0], self.params[-1]
+        return (self.flat is not None and p0.device == self.flat.device
+                and p0.data_ptr() == self.flat.data_ptr()
+                and pl.data_ptr() == self.flat.data_ptr() + 4 * self.off[self.names[-1]][0])
+
+    def bind(self, want_shadow: bool):
+        """(Re)build the flat buffers from the current parameter values and alias every parameter to its slice."""
+        dev = self.params[0].device
+        flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        for n, p in zip(self.names, self.params):
+            o, k, shp = self.off[n]
+            flat[o:o + k].view(shp).copy_(p.data)
+        old_grads = [p.grad for p in self.params]
+        self.flat, self.grad, self.device = flat, torch.zeros_like(flat), dev
+        for n, p, g in zip(self.names, self.params, old_grads):
+            o, k, shp = self.off[n]
+            p.data = flat[o:o + k].view(shp)
+            if g is not None:
+                self.grad[o:o + k].view(shp).copy_(g)
+                p.grad = self.grad[o:o + k].view(shp)
+        self.shadow = torch.empty(self.total, dtype=torch.bfloat16, device=dev) if want_shadow else None
+        self.shadow_version = -1
+
+    def sync_shadow(self):
+        if self.shadow is not None and self.shadow_version != self.flat._version:
+            ops.cast(self.flat, self.shadow)
+            self.shadow_version = self.flat._version
+
+    def view(self, buf, name):
+        o, k, shp = self.off[name]
+        return buf[o:o + k].view(shp)
+
+
+class _Blocks:
+    """Contiguous activation blocks carved out of one allocation."""
+
+    def __init__(self, dtype, device, sizes: dict):
+        self.off, total = {}, 0
+        for k, n in sizes.items():
+            self.off[k] = (total, n)
+            total += (n + 63) // 64 * 64
+        self.buf = torch.empty(total, dtype=dtype, device=device)
+
+    def __getitem__(self, k):
+        o, n = self.off[k]
+        return self.buf[o:o + n]
+
+
+class _EncRun:
+    """Saved activations of one encoder stack + its ctypes descriptor."""
+
+    def __init__(self, model, prefix, layers, B, L, cd, dev):
+        R, Cw = B * L, WIDTH
+        self.prefix, self.layers, self.B, self.L, self.R = prefix, layers, B, L, R
+        per = {"xn1": R * Cw, "qkv": R * 3 * Cw, "attn_o": R * Cw, "x_mid": R * Cw, "xn2": R * Cw, "h_pre": R * 4 * Cw,
+               "h_act": R * 4 * Cw, "x_out": R * Cw}
+        self.act = _Blocks(cd, dev, {f"{i}.{k}": n for i in range(layers) for k, n in per.items()} | {"post": R * Cw})
+        st = {"mean1": R, "rstd1": R, "mean2": R, "rstd2": R, "lse": B * HEADS * L}
+        self.stat = _Blocks(torch.float32, dev, {f"{i}.{k}": n for i in range(layers) for k, n in st.items()}
+                            | {"post_mean": R, "post_rstd": R})
+        self.bufs = (_lib.LayerBufs * layers)()
+        for i in range(layers):
+            for k in per:
+                setattr(self.bufs[i], k, self.act[f"{i}.{k}"].data_ptr())
+            for k in st:
+                setattr(self.bufs[i], k, self.stat[f"{i}.{k}"].data_ptr())
+
+    def stage(self, s):
+        """[R, C] deep-supervision output s (tfm_model.py:48-55)."""
+        if s < self.layers - 1:
+            return self.act[f"{s + 1}.xn1"].view(self.R, WIDTH)
+        return self.act["post"].view(self.R, WIDTH)
+
+
+class _AlignerFn(torch.autograd.Function):
+    """The whole TemporalAligner.forward as one autograd node (HIP forward, HIP backward)."""
+
+    @staticmethod
+    def forward(ctx, model, video, lang, vmask_u8, tmask_u8, opts, *params):
+        ctx.set_materialize_grads(False)      # unused outputs must not materialise 100s of MB of zero gradients
+        run = model._run_forward(video, lang, vmask_u8, tmask_u8, opts)
+        ctx.model, ctx.run = model, run
+        ctx.lang_requires_grad = lang.requires_grad
+        return tuple(run["outputs"])
+
+    @staticmethod
+    def backward(ctx, *grads):
+        model = ctx.model
+        d_lang = model._run_backward(ctx.run, grads, ctx.lang_requires_grad)
+        return (None, None, d_lang, None, None, None) + (None,) * len(model._flat.params)
+
+
+class TemporalAligner(nn.Module):
+    def __init__(self, num_encoder_layers=2, num_decoder_layers=2, sim="cos", language_model="word2vec",
+                 pos_enc="learned", use_text_pos_enc=0, return_dual_feature=1, random_pos_start=1,
+                 use_alignability_head=0, *, compute_dtype="fp32", d_video=1024):
+        super().__init__()
+        self.num_encoder_layers = num_encoder_layers
+        self.num_decoder_layers = num_decoder_layers
+        self.sim = sim
+        self.pos_enc = pos_enc
+        self.language_model = language_model
+        self.use_text_pos_enc = use_text_pos_enc
+        self.return_dual_feature = return_dual_feature
+        self.random_pos_start = random_pos_start
+        self.use_alignability_head = use_alignability_head
+        self.compute_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16, torch.float32: torch.float32,
+                              torch.bfloat16: torch.bfloat16}[compute_dtype]
+        if num_encoder_layers < 1 or num_decoder_layers < 1:
+            raise NotImplementedError("the HIP path needs >= 1 layer per stack (reference edge case tan_model.py:177-179)")
+
+        if language_model == "word2vec":
+            from .word2vec_model import Word2VecModel
+            self.bert = Word2VecModel()
+        elif language_model in (None, "none"):
+            self.bert = None
+        else:
+            raise NotImplementedError(f"language_model={language_model!r}: only 'word2vec' (tan_model.py:39-40) or None")
+        text_embed_dim = 512
+
+        self.video_temporal_encoder = TemporalEncoder(width=WIDTH, layers=num_encoder_layers, heads=HEADS)
+        self.joint_temporal_encoder = TemporalEncoder(width=WIDTH, layers=num_decoder_layers, heads=HEADS)
+        self.video_pre_proj = _LinearParams(d_video, WIDTH, bias=False)
+        self.text_pre_proj = _LinearParams(text_embed_dim, WIDTH, bias=False)
+        self.ln_text_init = _LayerNormParams(WIDTH)
+        self.ln_video_init = _LayerNormParams(WIDTH)
+        self.ln_position_init = _LayerNormParams(WIDTH)
+        self.ln_video_post_enc = _LayerNormParams(WIDTH)
+        self.ln_joint_post_enc = _LayerNormParams(WIDTH)
+        if pos_enc == "learned":
+            self.temporal_pos_embed = nn.Parameter(torch.empty(1024, WIDTH))
+            nn.init.normal_(self.temporal_pos_embed, std=0.01)
+        elif pos_enc == "sine":
+            self.register_buffer("temporal_pos_embed", get_position_embedding_sine(WIDTH, 1024))
+        else:
+            raise ValueError(pos_enc)
+        self.text_temporal_pos_embed = nn.Parameter(torch.empty(1024, WIDTH))
+        nn.init.normal_(self.text_temporal_pos_embed, std=0.01)
+        self.mlp = _LinearParams(WIDTH, WIDTH)      # never used in any forward (tan_model.py:68)
+        if use_alignability_head:
+            self.binary_head = _LinearParams(WIDTH, 1)
+            nn.init.normal_(self.binary_head.weight, std=0.01)
+            nn.init.zeros_(self.binary_head.bias)
+        self.initialize_parameters()
+        # reference registration order differs from construction order only for the two pos-embeds, which the
+        # reference registers before the encoders' parameters appear in state_dict(); key *names* are what matter.
+        self._flat = _Flat(self, [(n, p) for n, p in self.named_parameters() if not n.startswith("bert.")])
+        self._ln_ws = None
+
+    # ------------------------------------------------------------------ init (tan_model.py:76-97)
+    def initialize_parameters(self):
+        nn.init.normal_(self.video_pre_proj.weight, std=0.01)
+        nn.init.normal_(self.text_pre_proj.weight, std=0.01)
+        nn.init.normal_(self.mlp.weight, std=0.01)
+        nn.init.zeros_(self.mlp.bias)
+        w, layers = self.joint_temporal_encoder.width, self.joint_temporal_encoder.layers
+        proj_std = (w ** -0.5) * ((2 * layers) ** -0.5)
+        attn_std = w ** -0.5
+        fc_std = (2 * w) ** -0.5
+        for enc in (self.video_temporal_encoder, self.joint_temporal_encoder):
+            for blk in enc.resblocks:
+                nn.init.normal_(blk.attn.in_proj_weight, std=attn_std)
+                nn.init.normal_(blk.attn.out_proj.weight, std=proj_std)
+                nn.init.normal_(blk.mlp.c_fc.weight, std=fc_std)
+                nn.init.normal_(blk.mlp.c_proj.weight, std=proj_std)
+
+    @property
+    def lang_model(self):          # train/main.py:58,174,202 spelling
+        return self.bert
+
+    # ------------------------------------------------------------------ flat-buffer plumbing
+    def _ensure_flat(self):
+        f = self._flat
+        if not f.bound():
+            if not f.params[0].is_cuda:
+                raise _lib.TanHipError("TemporalAligner parameters are on the CPU: the HIP path has no CPU fallback; "
+                                       "call .cuda() first")
+            f.bind(want_shadow=self.compute_dtype == torch.bfloat16)
+        f.sync_shadow()
+        return f
+
+    def flat_parameters(self):
+        return self._ensure_flat().flat
+
+    def flat_grad(self):
+        return self._ensure_flat().grad
+
+    def _w(self, name):
+        """weight in compute dtype (bf16 shadow or the f32 master)"""
+        f = self._flat
+        return f.view(f.shadow if self.compute_dtype == torch.bfloat16 else f.flat, name)
+
+    def _f(self, name):
+        return self._flat.view(self._flat.flat, name)
+
+    def _g(self, name):
+        return self._flat.view(self._flat.grad, name)
+
+    def _bind_grads(self):
+        """Make every p.grad alias its slice of the flat gradient (zeroing the buffer if grads were None)."""
+        f = self._flat
+        fresh = all(p.grad is None for p in f.params if p.requires_grad)
+        if fresh:
+            f.grad.zero_()
+        for n, p in zip(f.names, f.params):
+            if not p.requires_grad:
+                continue
+            gv = f.view(f.grad, n)
+            if p.grad is None:
+                p.grad = gv
+            elif p.grad.data_ptr() != gv.data_ptr():
+                gv.copy_(p.grad)
+                p.grad = gv
+
+    def param_modes(self, name_prefix=""):
+        """u8 per-element optimizer mode for tan_adamw_step: 1 decay / 0 no decay by the reference's substring rule on the
+        FULL parameter name (train/main.py:332,340-343) / 2 never receives a gradient (torch skips .grad-is-None params)."""
+        f = self._flat
+        mode = torch.zeros(f.total, dtype=torch.uint8)
+        unused = {"mlp.weight", "mlp.bias"}
+        if not self.use_text_pos_enc:
+            unused.add("text_temporal_pos_embed")
+        for n in f.names:
+            o, k, _ = f.off[n]
+            full = name_prefix + n
+            if n in unused:
+                mode[o:o + k] = 2
+            elif any(tok in full for tok in (".ln_", ".bias", ".logit_scale", ".entropy_scale")):
+                mode[o:o + k] = 0
+            else:
+                mode[o:o + k] = 1
+        return mode
+
+    # ------------------------------------------------------------------ encoder descriptors
+    def _layer_params(self, prefix, layers):
+        arr = (_lib.LayerParams * layers)()
+        m = {"w_qkv": "attn.in_proj_weight", "w_out": "attn.out_proj.weight", "w_fc": "mlp.c_fc.weight",
+             "w_proj": "mlp.c_proj.weight"}
+        fm = {"b_qkv": "attn.in_proj_bias", "b_out": "attn.out_proj.bias", "b_fc": "mlp.c_fc.bias",
+              "b_proj": "mlp.c_proj.bias", "ln1_g": "ln_1.weight", "ln1_b": "ln_1.bias", "ln2_g": "ln_2.weight",
+              "ln2_b": "ln_2.bias"}
+        for i in range(layers):
+            base = f"{prefix}.resblocks.{i}."
+            for k, v in m.items():
+                setattr(arr[i], k, self._w(base + v).data_ptr())
+                setattr(arr[i], "g_" + k, self._g(base + v).data_ptr())
+            for k, v in fm.items():
+                setattr(arr[i], k, self._f(base + v).data_ptr())
+                setattr(arr[i], "g_" + k, self._g(base + v).data_ptr())
+        return arr
+
+    def _enc_desc(self, er: _EncRun, x0, keypad, post_name):
+        d = _lib.EncoderDesc()
+        d.dtype = ops._dt(x0)
+        d.B, d.L, d.C, d.H, d.layers = er.B, er.L, WIDTH, HEADS, er.layers
+        d.key_padding_mask = _vp(keypad)
+        d.x0 = _vp(x0)
+        er.params = self._layer_params(er.prefix, er.layers)
+        d.params = er.params
+        d.bufs = er.bufs
+        d.post_g, d.post_b = _vp(self._f(post_name + ".weight")), _vp(self._f(post_name + ".bias"))
+        d.g_post_g, d.g_post_b = _vp(self._g(post_name + ".weight")), _vp(self._g(post_name + ".bias"))
+        d.post_out = _vp(er.act["post"])
+        d.post_mean, d.post_rstd = _vp(er.stat["post_mean"]), _vp(er.stat["post_rstd"])
+        return d
+
+    def _encoder_fwd(self, er, x0, keypad, post_name):
+        d = self._enc_desc(er, x0, keypad, post_name)
+        _lib.check(_lib.lib().tan_encoder_fwd(C.byref(d), ops._stream()), "tan_encoder_fwd")
+
+    def _encoder_bwd(self, er, x0, keypad, post_name, d_stage, d_x0):
+        cd, dev, R = x0.dtype, x0.device, er.R
+        d = self._enc_desc(er, x0, keypad, post_name)
+        scr = _Blocks(cd, dev, {"dx": R * WIDTH, "dx2": R * WIDTH, "do": R * WIDTH, "dxn": R * WIDTH,
+                                "dh": R * 4 * WIDTH, "dqkv": R * 3 * WIDTH})
+        d.scr_dx, d.scr_dx2, d.scr_do, d.scr_dxn = (_vp(scr[k]) for k in ("dx", "dx2", "do", "dxn"))
+        d.scr_dh, d.scr_dqkv = _vp(scr["dh"]), _vp(scr["dqkv"])
+        n_ws = _lib.lib().tan_layernorm_bwd_ws_floats(C.c_int(WIDTH))
+        ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+        d.ln_ws = _vp(ws)
+        arr = (C.c_void_p * er.layers)(*[(t.data_ptr() if t is not None else None) for t in d_stage])
+        d.d_stage = arr
+        d.d_x0 = _vp(d_x0)
+        _lib.check(_lib.lib().tan_encoder_bwd(C.byref(d), ops._stream()), "tan_encoder_bwd")
+
+    # ------------------------------------------------------------------ embedding front-ends
+    def _pos_table(self, which):
+        return self._f(which) if (which != "temporal_pos_embed" or self.pos_enc == "learned") else self.temporal_pos_embed
+
+    def _pos_ln(self, which, n, start, interpolate_from, cd, keep):
+        """ln_position_init(pos[start:start+n]) (or the linearly interpolated table) as [n, C] in compute dtype; f32 inside."""
+        dev = self._flat.flat.device
+        table = self._pos_table(which)
+        if interpolate_from:
+            src = table[0:interpolate_from].contiguous()
+            pos = torch.empty(n, WIDTH, device=dev)
+            ops.interp_linear(src, pos, interpolate_from, n, WIDTH)
+        else:
+            pos = table[start:start + n]
+        out = torch.empty(n, WIDTH, device=dev)
+        mean, rstd = torch.empty(n, device=dev), torch.empty(n, device=dev)
+        ops.layernorm_fwd(pos, self._f("ln_position_init.weight"), self._f("ln_position_init.bias"), out, mean, rstd)
+        out_c = out if cd == torch.float32 else ops.cast(out, torch.empty(n, WIDTH, device=dev, dtype=cd))
+        saved = {"which": which, "n": n, "start": start, "interp": interpolate_from, "pos": pos, "mean": mean, "rstd": rstd}
+        return out_c, saved
+
+    def _pos_ln_bwd(self, saved, d_out_c):
+        """backward of _pos_ln: d_out_c [n, C] compute dtype -> accumulate into the table / ln_position_init grads."""
+        n, dev = saved["n"], d_out_c.device
+        d_out = d_out_c if d_out_c.dtype == torch.float32 else ops.cast(d_out_c, torch.empty(n, WIDTH, device=dev))
+        d_pos = torch.empty(n, WIDTH, device=dev)
+        ops.layernorm_bwd(d_out, saved["pos"], self._f("ln_position_init.weight"), saved["mean"], saved["rstd"], d_pos,
+                          self._g("ln_position_init.weight"), self._g("ln_position_init.bias"))
+        which = saved["which"]
+        if which == "temporal_pos_embed" and self.pos_enc != "learned":
+            return
+        g = self._g(which)
+        if saved["interp"]:
+            ops.interp_linear_bwd(d_pos, g, saved["interp"], n, WIDTH)
+        else:
+            ops.rows_copy(d_pos, g[saved["start"]:saved["start"] + n], 1, n, WIDTH, n, 0, n, 0, accumulate=True)
+
+    def _draw(self, n, interpolate_from):
+        """np.random draw of the position offset, in the reference's order and from its global RNG (tan_model.py:163,195,224)."""
+        if interpolate_from or not self.random_pos_start:
+            return 0
+        return int(np.random.randint(0, int(n / 2)))
+
+    # ------------------------------------------------------------------ the HIP forward
+    def _prep(self, x):
+        """input features -> contiguous compute-dtype device tensor"""
+        cd = self.compute_dtype
+        if not x.is_cuda:
+            raise _lib.TanHipError("TemporalAligner needs device tensors: the HIP path has no CPU fallback")
+        x = x.detach().float().contiguous()
+        if cd != torch.float32:
+            x = ops.cast(x, torch.empty(x.shape, dtype=cd, device=x.device))
+        return x
+
+    def _prep_inputs(self, video, lang):
+        return self._prep(video), (self._prep(lang) if lang is not None else None)
+
+    def _video_embed(self, video_c, pos_start, interpolate_from, keep):
+        """x0 = ln_video_init(video_pre_proj(video)) + ln_position_init(pos)  (tan_model.py:155-167); computed ONCE and shared
+        by the dual and joint paths (the reference evaluates it twice, bit-identically)."""
+        B, T, Dv = video_c.shape
+        cd, dev = video_c.dtype, video_c.device
+        R = B * T
+        proj = torch.empty(R, WIDTH, dtype=cd, device=dev)
+        ops.gemm(video_c, self._w("video_pre_proj.weight"), proj, M=R, N=WIDTH, K=Dv)
+        pos_c, pos_saved = self._pos_ln("temporal_pos_embed", T, pos_start, interpolate_from, cd, keep)
+        x0 = torch.empty(R, WIDTH, dtype=cd, device=dev)
+        mean, rstd = torch.empty(R, device=dev), torch.empty(R, device=dev)
+        ops.layernorm_fwd(proj, self._f("ln_video_init.weight"), self._f("ln_video_init.bias"), x0, mean, rstd, pos_c, T)
+        return x0, {"proj": proj, "mean": mean, "rstd": rstd, "pos": pos_saved, "video_c": video_c}
+
+    def _video_embed_bwd(self, sv, d_x0):
+        video_c = sv["video_c"]
+        B, T, Dv = video_c.shape
+        R, cd, dev = B * T, d_x0.dtype, d_x0.device
+        d_proj = torch.empty(R, WIDTH, dtype=cd, device=dev)
+        ops.layernorm_bwd(d_x0, sv["proj"], self._f("ln_video_init.weight"), sv["mean"], sv["rstd"], d_proj,
+                          self._g("ln_video_init.weight"), self._g("ln_video_init.bias"))
+        ops.gemm(d_proj, video_c, self._g("video_pre_proj.weight"), M=WIDTH, N=Dv, K=R, a_kc=False, b_kc=False,
+                 lda=WIDTH, ldb=Dv, accumulate=True, split_k=max(1, min(32, R // 256)))
+        d_pos = torch.empty(T, WIDTH, dtype=cd, device=dev)
+        ops.group_sum(d_x0, d_pos, B, T, WIDTH)
+        self._pos_ln_bwd(sv["pos"], d_pos)
+
+    def _text_embed(self, lang_c, with_time, pos_start, interpolate_from, keep):
+        """ln_text_init(text_pre_proj(lang)) (+ ln_position_init(text_pos))  (tan_model.py:231-234 / 212-228)."""
+        B, N, Dt = lang_c.shape
+        cd, dev = lang_c.dtype, lang_c.device
+        R = B * N
+        proj = torch.empty(R, WIDTH, dtype=cd, device=dev)
+        ops.gemm(lang_c, self._w("text_pre_proj.weight"), proj, M=R, N=WIDTH, K=Dt)
+        pos_c = pos_saved = None
+        if with_time:
+            pos_c, pos_saved = self._pos_ln("text_temporal_pos_embed", N, pos_start, interpolate_from, cd, keep)
+        out = torch.empty(R, WIDTH, dtype=cd, device=dev)
+        mean, rstd = torch.empty(R, device=dev), torch.empty(R, device=dev)
+        ops.layernorm_fwd(proj, self._f("ln_text_init.weight"), self._f("ln_text_init.bias"), out, mean, rstd, pos_c, N if with_time else 0)
+        return out, {"proj": proj, "mean": mean, "rstd": rstd, "pos": pos_saved, "lang_c": lang_c}
+
+    def _text_embed_bwd(self, sv, d_out, need_d_lang):
+        lang_c = sv["lang_c"]
+        B, N, Dt = lang_c.shape
+        R, cd, dev = B * N, d_out.dtype, d_out.device
+        d_proj = torch.empty(R, WIDTH, dtype=cd, device=dev)
+        ops.layernorm_bwd(d_out, sv["proj"], self._f("ln_text_init.weight"), sv["mean"], sv["rstd"], d_proj,
+                          self._g("ln_text_init.weight"), self._g("ln_text_init.bias"))
+        ops.gemm(d_proj, lang_c, self._g("text_pre_proj.weight"), M=WIDTH, N=Dt, K=R, a_kc=False, b_kc=False,
+                 lda=WIDTH, ldb=Dt, accumulate=True, split_k=max(1, min(16, R // 256)))
+        if sv["pos"] is not None:
+            d_pos = torch.empty(N, WIDTH, dtype=cd, device=dev)
+            ops.group_sum(d_out, d_pos, B, N, WIDTH)
+            self._pos_ln_bwd(sv["pos"], d_pos)
+        if need_d_lang:
+            d_lang = torch.empty(R, Dt, dtype=cd, device=dev)
+            ops.gemm(d_proj, self._w("text_pre_proj.weight"), d_lang, M=R, N=Dt, K=WIDTH, a_kc=True, b_kc=False, ldb=Dt)
+            return d_lang.float().view(B, N, Dt)
+        return None
+
+    def _run_video_stack(self, x0, vmask_u8, B, T):
+        er = _EncRun(self, "video_temporal_encoder", self.num_encoder_layers, B, T, x0.dtype, x0.device)
+        self._encoder_fwd(er, x0, vmask_u8, "ln_video_post_enc")
+        return er
+
+    def _run_joint_stack(self, x0, text_t, vmask_u8, tmask_u8, B, T, N):
+        cd, dev = x0.dtype, x0.device
+        L = T + N
+        xj = torch.empty(B * L, WIDTH, dtype=cd, device=dev)
+        ops.rows_copy(x0, xj, B, T, WIDTH, T, 0, L, 0)
+        ops.rows_copy(text_t, xj, B, N, WIDTH, N, 0, L, T)
+        if vmask_u8 is None and tmask_u8 is None:
+            keypad = None
+        else:
+            vm = vmask_u8 if vmask_u8 is not None else torch.zeros(B, T, dtype=torch.uint8, device=dev)
+            tm = tmask_u8 if tmask_u8 is not None else torch.zeros(B, N, dtype=torch.uint8, device=dev)
+            keypad = torch.cat([vm, tm], dim=1).contiguous()
+        er = _EncRun(self, "joint_temporal_encoder", self.num_decoder_layers, B, L, cd, dev)
+        self._encoder_fwd(er, xj, keypad, "ln_joint_post_enc")
+        er.xj, er.keypad = xj, keypad
+        return er
+
+    def _run_forward(self, video, lang, vmask_u8, tmask_u8, opts, keep=True):  # noqa: C901
+        """HIP forward of TemporalAligner.forward (tan_model.py:100-149).  Returns the run record used by backward."""
+        self._ensure_flat()
+        B, T, _ = video.shape
+        N = lang.shape[1]
+        cd, dev = self.compute_dtype, video.device
+        Se, Sd, Cw = self.num_encoder_layers, self.num_decoder_layers, WIDTH
+        itp = opts.get("interpolate_from")
+        video_c, lang_c = self._prep_inputs(video, lang)
+        # reference RNG order: visual, [text-with-time], joint
+        p_v = self._draw(T, itp)
+        p_t = self._draw(N, itp) if self.use_text_pos_enc else 0
+        p_j = self._draw(T, itp)
+        x0, sv_video = self._video_embed(video_c, p_v, itp, keep)
+        if p_j != p_v:      # random_pos_start=1 draws independent offsets for the dual and joint paths
+            x0j, sv_video_j = self._video_embed(video_c, p_j, itp, keep)
+        else:
+            x0j, sv_video_j = x0, None
+        lang_raw, sv_text = self._text_embed(lang_c, False, 0, None, keep)
+        if self.use_text_pos_enc:
+            lang_t, sv_text_t = self._text_embed(lang_c, True, p_t, itp, keep)
+        else:
+            lang_t, sv_text_t = lang_raw, None
+        ev = self._run_video_stack(x0, vmask_u8, B, T)
+        ej = self._run_joint_stack(x0j, lang_t, vmask_u8, tmask_u8, B, T, N)
+        R, Mp, L = B * T, B * N, T + N
+        # L2-normalised features (tan_model.py:116-117,136-137)
+        vn_d = torch.empty(Se, R, Cw, dtype=cd, device=dev)
+        vn_j = torch.empty(Sd, R, Cw, dtype=cd, device=dev)
+        tn_d = torch.empty(Mp, Cw, dtype=cd, device=dev)
+        tn_j = torch.empty(Sd, Mp, Cw, dtype=cd, device=dev)
+        inv = _Blocks(torch.float32, dev, {"vd": Se * R, "vj": Sd * R, "td": Mp, "tj": Sd * Mp})
+        for s in range(Se):
+            ops.l2norm_fwd(ev.stage(s), vn_d[s], inv["vd"][s * R:(s + 1) * R], R, Cw)
+        ops.l2norm_fwd(lang_raw, tn_d, inv["td"], Mp, Cw)
+        for s in range(Sd):
+            ops.l2norm_fwd(ej.stage(s), vn_j[s], inv["vj"][s * R:(s + 1) * R], R, Cw, T, L, 0)
+            ops.l2norm_fwd(ej.stage(s), tn_j[s], inv["tj"][s * Mp:(s + 1) * Mp], Mp, Cw, N, L, T)
+        # cosine logits, stage-major [S, R, Mp] f32; the reference layout [B,S,T,B,N] is a permuted view (tan_model.py:118,138)
+        lg_d = torch.empty(Se, R, Mp, device=dev)
+        lg_j = torch.empty(Sd, R, Mp, device=dev)
+        ops.gemm(vn_d, tn_d, lg_d, M=R, N=Mp, K=Cw, batch=Se, sA=R * Cw, sB=0, sC=R * Mp)
+        ops.gemm(vn_j, tn_j, lg_j, M=R, N=Mp, K=Cw, batch=Sd, sA=R * Cw, sB=Mp * Cw, sC=R * Mp)
+        outputs = [lg_d.view(Se, B, T, B, N).permute(1, 0, 2, 3, 4), lg_j.view(Sd, B, T, B, N).permute(1, 0, 2, 3, 4),
+                   vn_d.view(Se, B, T, Cw).permute(1, 0, 2, 3), tn_d.view(B, N, Cw)]
+        run = {"B": B, "T": T, "N": N, "ev": ev, "ej": ej, "x0": x0, "x0j": x0j, "sv_video": sv_video,
+               "sv_video_j": sv_video_j, "sv_text": sv_text, "sv_text_t": sv_text_t, "lang_raw": lang_raw, "lang_t": lang_t,
+               "vn_d": vn_d, "vn_j": vn_j, "tn_d": tn_d, "tn_j": tn_j, "inv": inv, "vmask": vmask_u8, "tmask": tmask_u8}
+        if self.use_alignability_head:
+            w, b = self._f("binary_head.weight").view(-1), self._f("binary_head.bias")
+            a_d = torch.empty(Mp, device=dev)
+            ops.head_fwd(lang_raw, w, b, a_d, Mp, Cw)
+            jt_raw = torch.empty(Sd, Mp, Cw, dtype=cd, device=dev)
+            a_j = torch.empty(Sd, Mp, device=dev)
+            for s in range(Sd):
+                ops.rows_copy(ej.stage(s), jt_raw[s], B, N, Cw, L, T, N, 0)
+            ops.head_fwd(jt_raw, w, b, a_j, Sd * Mp, Cw)
+            run["jt_raw"] = jt_raw
+            outputs += [a_d.view(B, N, 1), a_j.view(Sd, B, N, 1).permute(1, 0, 2, 3)]
+        run["outputs"] = outputs
+        return run
+
+    # ------------------------------------------------------------------ the HIP backward
+    def _run_backward(self, run, grads, need_d_lang):
+        self._bind_grads()
+        B, T, N = run["B"], run["T"], run["N"]
+        ev, ej = run["ev"], run["ej"]
+        cd, dev = self.compute_dtype, run["x0"].device
+        Se, Sd, Cw = self.num_encoder_layers, self.num_decoder_layers, WIDTH
+        R, Mp, L = B * T, B * N, T + N
+        g_ld, g_lj, g_vn, g_tn = grads[0], grads[1], grads[2], grads[3]
+        g_ad = grads[4] if self.use_alignability_head else None
+        g_aj = grads[5] if self.use_alignability_head else None
+
+        def stage_major(g, S):
+            """[B,S,T,B,N] grad -> contiguous [S,R,Mp] in compute dtype (zero-copy when it is our own permuted buffer)."""
+            g = g.permute(1, 0, 2, 3, 4)
+            g = g if g.is_contiguous() else g.contiguous()
+            g = g.view(S, R, Mp)
+            if g.dtype != cd:
+                g = ops.cast(g.float().contiguous() if g.dtype != torch.float32 else g, torch.empty(S, R, Mp, dtype=cd, device=dev))
+            return g
+
+        inv = run["inv"]
+        dst_v = [None] * Se           # d stage outputs of the video stack
+        dst_j = [None] * Sd
+        d_lang_raw = torch.zeros(Mp, Cw, dtype=cd, device=dev)
+        have_lang_raw = False
+        # ---- dual similarity: logits_d[s] = vn_d[s] tn_d^T
+        d_vn_d = None
+        if g_ld is not None:
+            dl = stage_major(g_ld, Se)
+            d_vn_d = torch.empty(Se, R, Cw, dtype=cd, device=dev)
+            ops.gemm(dl, run["tn_d"], d_vn_d, M=R, N=Cw, K=Mp, a_kc=True, b_kc=False, lda=Mp, ldb=Cw, batch=Se,
+                     sA=R * Mp, sB=0, sC=R * Cw)
+            acc = torch.zeros(Mp, Cw, device=dev)
+            ops.gemm(dl, run["vn_d"], acc, M=Mp, N=Cw, K=Se * R, a_kc=False, b_kc=False, lda=Mp, ldb=Cw, accumulate=True,
+                     split_k=max(1, min(32, Se * R // 512)))
+            d_tn_d = acc if cd == torch.float32 else ops.cast(acc, torch.empty(Mp, Cw, dtype=cd, device=dev))
+        else:
+            d_tn_d = None
+        if g_vn is not None:          # dual_feature_video is an output too
+            gv = g_vn.permute(1, 0, 2, 3).contiguous().view(Se, R, Cw).to(cd)
+            d_vn_d = gv if d_vn_d is None else d_vn_d + gv
+        if g_tn is not None:
+            gt = g_tn.contiguous().view(Mp, Cw).to(cd)
+            d_tn_d = gt if d_tn_d is None else d_tn_d + gt
+        if d_vn_d is not None:
+            for s in range(Se):
+                dst_v[s] = torch.empty(R, Cw, dtype=cd, device=dev)
+                ops.l2norm_bwd(d_vn_d[s], run["vn_d"][s], inv["vd"][s * R:(s + 1) * R], dst_v[s], R, Cw)
+        if d_tn_d is not None:
+            ops.l2norm_bwd(d_tn_d, run["tn_d"], inv["td"], d_lang_raw, Mp, Cw)
+            have_lang_raw = True
+        # ---- joint similarity: logits_j[s] = vn_j[s] tn_j[s]^T
+        if g_lj is not None:
+            dl = stage_major(g_lj, Sd)
+            d_vn_j = torch.empty(Sd, R, Cw, dtype=cd, device=dev)
+            d_tn_j = torch.empty(Sd, Mp, Cw, dtype=cd, device=dev)
+            ops.gemm(dl, run["tn_j"], d_vn_j, M=R, N=Cw, K=Mp, a_kc=True, b_kc=False, lda=Mp, ldb=Cw, batch=Sd,
+                     sA=R * Mp, sB=Mp * Cw, sC=R * Cw)
+            ops.gemm(dl, run["vn_j"], d_tn_j, M=Mp, N=Cw, K=R, a_kc=False, b_kc=False, lda=Mp, ldb=Cw, batch=Sd,
+                     sA=R * Mp, sB=R * Cw, sC=Mp * Cw)
+            for s in range(Sd):
+                dst_j[s] = torch.empty(B * L, Cw, dtype=cd, device=dev)
+                ops.l2norm_bwd(d_vn_j[s], run["vn_j"][s], inv["vj"][s * R:(s + 1) * R], dst_j[s], R, Cw, T, L, 0)
+                ops.l2norm_bwd(d_tn_j[s], run["tn_j"][s], inv["tj"][s * Mp:(s + 1) * Mp], dst_j[s], Mp, Cw, N, L, T)
+        # ---- alignability heads (tan_model.py:147-148)
+        if self.use_alignability_head and (g_ad is not None or g_aj is not None):
+            w = self._f("binary_head.weight").view(-1)
+            gw, gb = self._g("binary_head.weight").view(-1), self._g("binary_head.bias")
+            if g_ad is not None:
+                ops.head_bwd(g_ad.contiguous().view(Mp).float(), run["lang_raw"], w, d_lang_raw, gw, gb, Mp, Cw, accumulate_dx=True)
+                have_lang_raw = True
+            if g_aj is not None:
+                gaj = g_aj.permute(1, 0, 2, 3).contiguous().view(Sd * Mp).float()
+                d_jt = torch.empty(Sd, Mp, Cw, dtype=cd, device=dev)
+                ops.head_bwd(gaj, run["jt_raw"], w, d_jt, gw, gb, Sd * Mp, Cw)
+                for s in range(Sd):
+                    if dst_j[s] is None:
+                        dst_j[s] = torch.zeros(B * L, Cw, dtype=cd, device=dev)
+                    ops.rows_copy(d_jt[s], dst_j[s], B, N, Cw, N, 0, L, T, accumulate=True)
+        # ---- encoder stacks
+        d_x0 = torch.zeros(R, Cw, dtype=cd, device=dev)
+        d_x0j = d_x0
+        any_v = any(t is not None for t in dst_v)
+        any_j = any(t is not None for t in dst_j)
+        if any_v:
+            self._encoder_bwd(ev, run["x0"], run["vmask"], "ln_video_post_enc", dst_v, d_x0)
+        d_lang_t = None
+        if any_j:
+            d_xj = torch.empty(B * L, Cw, dtype=cd, device=dev)
+            self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dst_j, d_xj)
+            if run["sv_video_j"] is not None:
+                d_x0j = torch.empty(R, Cw, dtype=cd, device=dev)
+                ops.rows_copy(d_xj, d_x0j, B, T, Cw, L, 0, T, 0)
+            else:
+                ops.rows_copy(d_xj, d_x0, B, T, Cw, L, 0, T, 0, accumulate=any_v)
+            if run["sv_text_t"] is None:
+                ops.rows_copy(d_xj, d_lang_raw, B, N, Cw, L, T, N, 0, accumulate=have_lang_raw)
+                have_lang_raw = True
+            else:
+                d_lang_t = torch.empty(Mp, Cw, dtype=cd, device=dev)
+                ops.rows_copy(d_xj, d_lang_t, B, N, Cw, L, T, N, 0)
+        # ---- embeddings
+        d_lang = None
+        if any_v or (any_j and run["sv_video_j"] is None):
+            self._video_embed_bwd(run["sv_video"], d_x0)
+        if any_j and run["sv_video_j"] is not None:
+            self._video_embed_bwd(run["sv_video_j"], d_x0j)
+        if have_lang_raw:
+            d_lang = self._text_embed_bwd(run["sv_text"], d_lang_raw, need_d_lang)
+        if d_lang_t is not None:
+            d2 = self._text_embed_bwd(run["sv_text_t"], d_lang_t, need_d_lang)
+            d_lang = d2 if d_lang is None else (d_lang + d2 if d2 is not None else d_lang)
+        return d_lang
+
+    # ------------------------------------------------------------------ public surface (tan_model.py:100-312)
+    @staticmethod
+    def _mask_u8(m):
+        if m is None:
+            return None
+        return m.to(torch.uint8).contiguous()
+
+    def forward(self, video_embed, lang_embed, video_padding_mask, lang_padding_mask, text_timestamp=None,
+                interpolate_from=None, abs_text_pos=None):
+        self._ensure_flat()
+        f = self._flat
+        outs = _AlignerFn.apply(self, video_embed, lang_embed, self._mask_u8(video_padding_mask),
+                                self._mask_u8(lang_padding_mask), {"interpolate_from": interpolate_from}, *f.params)
+        out = {"logits_dual": outs[0], "logits_joint": outs[1]}
+        if self.return_dual_feature:
+            out["dual_feature_video"], out["dual_feature_text"] = outs[2], outs[3]
+        if self.use_alignability_head:
+            out["dual_logits_alignability"], out["joint_logits_alignability"] = outs[4], outs[5]
+        return out
+
+    @torch.no_grad()
+    def get_visual_feature(self, video_embed, video_padding_mask, interpolate_from=None):
+        """[B,S,T,C] deep-supervision video features of the dual encoder (tan_model.py:152-179).  Inference entry point
+        (retrieval, eval_zeroshot_retrieval.py:180-184): gradients flow through forward(), not through this method."""
+        self._ensure_flat()
+        B, T, _ = video_embed.shape
+        video_c, _ = self._prep_inputs(video_embed, None)
+        x0, _ = self._video_embed(video_c, self._draw(T, interpolate_from), interpolate_from, False)
+        ev = self._run_video_stack(x0, self._mask_u8(video_padding_mask), B, T)
+        S = self.num_encoder_layers
+        return torch.stack([ev.stage(s).view(B, T, WIDTH) for s in range(S)], dim=1).float()
+
+    @torch.no_grad()
+    def get_textual_feature(self, lang_embed):
+        """ln_text_init(text_pre_proj(lang)) [B,N,C] (tan_model.py:231-234)."""
+        self._ensure_flat()
+        lang_c = self._prep(lang_embed)
+        out, _ = self._text_embed(lang_c, False, 0, None, False)
+        return out.view(*lang_embed.shape[:2], WIDTH).float()
+
+    @torch.no_grad()
+    def get_textual_feature_with_time(self, lang_embed, text_timestamp=None, interpolate_from=None):
+        """tan_model.py:212-228."""
+        self._ensure_flat()
+        lang_c = self._prep(lang_embed)
+        N = lang_embed.shape[1]
+        out, _ = self._text_embed(lang_c, True, self._draw(N, interpolate_from), interpolate_from, False)
+        return out.view(*lang_embed.shape[:2], WIDTH).float()
+
+    @torch.no_grad()
+    def get_joint_feature(self, video_embed, video_padding_mask, lang_embed_with_time, lang_padding_mask,
+                          interpolate_from=None):
+        """([B,S,T,C], [B,S,N,C]) from the joint encoder (tan_model.py:182-209); `lang_embed_with_time` is the
+        already-projected text feature, as in the reference."""
+        self._ensure_flat()
+        B, T, _ = video_embed.shape
+        N = lang_embed_with_time.shape[1]
+        video_c, _ = self._prep_inputs(video_embed, None)
+        x0, _ = self._video_embed(video_c, self._draw(T, interpolate_from), interpolate_from, False)
+        lt = lang_embed_with_time.detach().to(self.compute_dtype).contiguous().view(B * N, WIDTH)
+        ej = self._run_joint_stack(x0, lt, self._mask_u8(video_padding_mask), self._mask_u8(lang_padding_mask), B, T, N)
+        S, L = self.num_decoder_layers, T + N
+        out = torch.stack([ej.stage(s).view(B, L, WIDTH) for s in range(S)], dim=1).float()
+        return out[:, :, :T], out[:, :, T:]
+
+    @staticmethod
+    def _split_interp(interpolate_from):
+        if isinstance(interpolate_from, (list, tuple)):
+            assert len(interpolate_from) == 2
+            return interpolate_from[0], interpolate_from[1]
+        return interpolate_from, None
+
+    def _eval_joint(self, video_embed, lang_embed, interpolate_from):
+        """shared by get_text_visual_sim_joint / get_alignability: zero masks, joint stack on (video, text)."""
+        vi, ti = self._split_interp(interpolate_from)
+        self._ensure_flat()
+        B, T, _ = video_embed.shape
+        N = lang_embed.shape[1]
+        video_c, lang_c = self._prep_inputs(video_embed, lang_embed)
+        if self.use_text_pos_enc:   # reference order: text offset first, then video (tan_model.py:245-259)
+            lang_t, _ = self._text_embed(lang_c, True, self._draw(N, ti), ti, False)
+        else:
+            lang_t, _ = self._text_embed(lang_c, False, 0, None, False)
+        x0, _ = self._video_embed(video_c, self._draw(T, vi), vi, False)
+        ej = self._run_joint_stack(x0, lang_t, None, None, B, T, N)
+        return ej, lang_c, B, T, N
+
+    def _within_sample_sim(self, vn, tn, S, B, T, N, t_stage_stride):
+        """einsum 'bstc,b(s)kc->bstk' as a batched GEMM over (s, b)."""
+        out = torch.empty(S, B, T, N, device=vn.device)
+        for s in range(S):
+            ops.gemm(vn[s], tn[s] if t_stage_stride else tn, out[s], M=T, N=N, K=WIDTH, batch=B, sA=T * WIDTH,
+                     sB=N * WIDTH, sC=T * N)
+        return out.permute(1, 0, 2, 3)
+
+    @torch.no_grad()
+    def get_text_visual_sim_joint(self, video_embed, lang_embed, interpolate_from=None):
+        """[B,S,T,K] within-sample cosine similarities from the joint encoder (tan_model.py:237-264)."""
+        ej, _, B, T, N = self._eval_joint(video_embed, lang_embed, interpolate_from)
+        S, L, cd, dev = self.num_decoder_layers, T + N, self.compute_dtype, video_embed.device
+        vn = torch.empty(S, B * T, WIDTH, dtype=cd, device=dev)
+        tn = torch.empty(S, B * N, WIDTH, dtype=cd, device=dev)
+        for s in range(S):
+            ops.l2norm_fwd(ej.stage(s), vn[s], None, B * T, WIDTH, T, L, 0)
+            ops.l2norm_fwd(ej.stage(s), tn[s], None, B * N, WIDTH, N, L, T)
+        return self._within_sample_sim(vn, tn, S, B, T, N, True)
+
+    get_text_visual_sim = get_text_visual_sim_joint   # alias needed by the released Twin constructor (tan_model.py:328)
+
+    @torch.no_grad()
+    def get_text_visual_sim_dual(self, video_embed, lang_embed, interpolate_from=None):
+        """[B,S,T,K] within-sample cosine similarities from the dual encoder (tan_model.py:267-283)."""
+        self._ensure_flat()
+        B, T, _ = video_embed.shape
+        N = lang_embed.shape[1]
+        cd, dev, S = self.compute_dtype, video_embed.device, self.num_encoder_layers
+        video_c, lang_c = self._prep_inputs(video_embed, lang_embed)
+        lang_raw, _ = self._text_embed(lang_c, False, 0, None, False)
+        x0, _ = self._video_embed(video_c, self._draw(T, interpolate_from), interpolate_from, False)
+        ev = self._run_video_stack(x0, None, B, T)
+        vn = torch.empty(S, B * T, WIDTH, dtype=cd, device=dev)
+        tn = torch.empty(B * N, WIDTH, dtype=cd, device=dev)
+        for s in range(S):
+            ops.l2norm_fwd(ev.stage(s), vn[s], None, B * T, WIDTH)
+        ops.l2norm_fwd(lang_raw, tn, None, B * N, WIDTH)
+        return self._within_sample_sim(vn, tn, S, B, T, N, False)
+
+    @torch.no_grad()
+    def get_alignability(self, video_embed, lang_embed, interpolate_from=None, abs_text_pos=None):
+        """{'alignability-dual' [B,K,1], 'alignability-joint' [B,S,K,1]} (tan_model.py:286-312)."""
+        ej, lang_c, B, T, N = self._eval_joint(video_embed, lang_embed, interpolate_from)
+        S, L, cd, dev = self.num_decoder_layers, T + N, self.compute_dtype, video_embed.device
+        w, b = self._f("binary_head.weight").view(-1), self._f("binary_head.bias")
+        lang_raw, _ = self._text_embed(lang_c, False, 0, None, False)
+        a_d = torch.empty(B * N, device=dev)
+        ops.head_fwd(lang_raw, w, b, a_d, B * N, WIDTH)
+        jt = torch.empty(S, B * N, WIDTH, dtype=cd, device=dev)
+        for s in range(S):
+            ops.rows_copy(ej.stage(s), jt[s], B, N, WIDTH, L, T, N, 0)
+        a_j = torch.empty(S, B * N, device=dev)
+        ops.head_fwd(jt, w, b, a_j, S * B * N, WIDTH)
+        return {"alignability-dual": a_d.view(B, N, 1), "alignability-joint": a_j.view(S, B, N, 1).permute(1, 0, 2, 3)}
+
+    # checkpoint compatibility: the released checkpoint spells the language model `lang_model.` (train/main.py:467-469)
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for k in list(state_dict.keys()):
+            if k.startswith(prefix + "lang_model."):
+                state_dict[prefix + "bert." + k[len(prefix + "lang_model."):]] = state_dict.pop(k)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+class TwinTemporalAligner(nn.Module):
+    """Online + EMA target copy (model/tan_model.py:315-351)."""
+
+    def __init__(self, m=0.999, *args, **kwargs):
+        super().__init__()
+        self.m = m
+        self.online = TemporalAligner(*args, **kwargs)
+        self.target = TemporalAligner(*args, **kwargs)
+        self._copy_param()
+        self.bert = self.online.bert
+        self.get_visual_feature = self.online.get_visual_feature
+        self.get_joint_feature = self.online.get_joint_feature
+        self.get_textual_feature_with_time = self.online.get_textual_feature_with_time
+        self.get_textual_feature = self.online.get_textual_feature
+        self.get_text_visual_sim = self.online.get_text_visual_sim
+        self.get_text_visual_sim_joint = self.online.get_text_visual_sim_joint
+        self.get_text_visual_sim_dual = self.online.get_text_visual_sim_dual
+        self.get_alignability = self.online.get_alignability
+        self.target.random_pos_start = 0
+
+    @property
+    def lang_model(self):
+        return self.bert
+
+    def _copy_param(self):
+        for po, pt in zip(self.online.parameters(), self.target.parameters()):
+            pt.data.copy_(po.data)
+            pt.requires_grad = False
+
+    @torch.no_grad()
+    def _momentum_update(self):
+        """target = m * target + (1 - m) * online (tan_model.py:339-344): one HIP launch over the flat buffers."""
+        fo, ft = self.online._ensure_flat(), self.target._ensure_flat()
+        _lib.check(_lib.lib().tan_ema_update(_vp(ft.flat), _vp(fo.flat), C.c_long(fo.total), C.c_float(self.m),
+                                             _vp(ft.shadow), ops._stream()), "tan_ema_update")
+        if ft.shadow is not None:
+            ft.shadow_version = ft.flat._version
+        if self.online.bert is not None:     # language-model parameters live outside the flat buffers
+            for po, pt in zip(self.online.bert.parameters(), self.target.bert.parameters()):
+                pt.data.mul_(self.m).add_(po.data, alpha=1.0 - self.m)
+
+    def forward(self, *args, **kwargs):
+        return self.online(*args, **kwargs)
+
+    @torch.no_grad()
+    def forward_from_ema(self, *args, **kwargs):
+        return self.target(*args, **kwargs)
