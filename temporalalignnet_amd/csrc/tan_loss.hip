@@ -4,6 +4,11 @@
 // the temperature 0.07 is applied here exactly as the reference does (a true division).
 #include "tan_common.h"
 
+// The self-labelling indices and threshold masks must match the reference bit for bit, so this file is compiled
+// without cross-statement FMA contraction (hipcc's default -ffp-contract=fast fused `q*(n-1) - floor(q*(n-1))` into an
+// exact fma and turned a zero interpolation weight into 3.6e-7, flipping a `>= quantile` comparison).
+#pragma clang fp contract(off)
+
 namespace tal {
 
 constexpr float TAU = 0.07f;

@@ -1,0 +1,246 @@
+"""MI355X-native `get_loss` with the reference's signature and returned dict (train/loss.py:55-422), plus
+`get_mask_from_time`, `get_text_pos`, `circulant`.
+
+Everything O(B*T*B*N) or O(B*T*N) runs in hand-written HIP kernels (include/tan_hip.h: tan_nce_fwd/bwd, tan_selflabel,
+tan_agreement, tan_diag_max, tan_masked_quantile); what remains in torch are O(B*N) vector reductions (masked means,
+z-scores, the BCE over <= B*N texts) on device tensors.  Unlike the reference (boolean-mask indexing, torch.quantile on
+compacted tensors, np.array of all sentences -- ~40 hidden device->host syncs per call) this version never synchronises:
+padded texts are handled by masks/weights instead of compaction, which is the same arithmetic over the same elements.
+
+Known, documented differences from the reference:
+  * only sim='cos' (the reference model only produces cosine logits, tan_model.py:116-119);
+  * loss.py:296,301 index a [#texts-with-positives] tensor with a [#texts] mask and raise IndexError if some
+    non-padded text has no positive frame; here such a text is simply averaged like the others.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+from torch.nn.utils.rnn import pad_sequence
+
+from . import _lib, ops
+
+_KIND = {"i": 0, "u": 1, "keep": 2, "keep-joint": 3}
+
+
+def circulant(tensor, dim):
+    """All cyclic shifts along `dim`, new axis last: circulant([0,1,2]) -> [[0,1,2],[2,0,1],[1,2,0]] (loss.py:16-23).
+    Kept for API parity; the HIP self-labelling kernel builds its windows by index arithmetic instead."""
+    S = tensor.shape[dim]
+    x = tensor.movedim(dim, -1)
+    j = torch.arange(S, device=tensor.device)
+    out = x[..., (j[None, :] - j[:, None]) % S]
+    return out if dim in (-1, tensor.dim() - 1) else out.movedim(-2, dim)
+
+
+def get_mask_from_time(start_list, end_list, num_timestamp, num_text, device="cuda"):
+    """[B, N, T] bool mask `start <= t < end` from ragged lists; padded starts T+100 / ends -100 (loss.py:26-41)."""
+    B = len(start_list)
+    start = pad_sequence([torch.FloatTensor(i) for i in start_list], batch_first=True, padding_value=num_timestamp + 1e2)
+    end = pad_sequence([torch.FloatTensor(i) for i in end_list], batch_first=True, padding_value=-1e2)
+    start, end = start.to(device, non_blocking=True), end.to(device, non_blocking=True)
+    steps = torch.arange(num_timestamp, device=device)[None, None, :].expand(B, num_text, -1)
+    mask = (start[:, :, None] <= steps) & (steps < end[:, :, None])
+    return mask, start, end
+
+
+def get_text_pos(start_list, end_list, device="cuda"):
+    """zero-padded [B, N, 2] (loss.py:44-52)."""
+    start = pad_sequence([torch.FloatTensor(i) for i in start_list], batch_first=True, padding_value=0)
+    end = pad_sequence([torch.FloatTensor(i) for i in end_list], batch_first=True, padding_value=0)
+    return torch.stack((start.to(device, non_blocking=True), end.to(device, non_blocking=True)), dim=-1)
+
+
+def _stage_major(logits):
+    """[B,S,T,B,N] -> contiguous f32 [S, B*T, B*N]; zero-copy for tensors produced by our TemporalAligner."""
+    B, S, T, B2, N = logits.shape
+    x = logits.permute(1, 0, 2, 3, 4)
+    if not x.is_contiguous() or x.dtype != torch.float32:
+        x = x.float().contiguous()
+    return x.view(S, B * T, B * N)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class _NCEFn(torch.autograd.Function):
+    """v_terms [S,R], t_terms [S,Mp] of the symmetric multi-positive NCE (loss.py:240-253) on HIP."""
+
+    @staticmethod
+    def forward(ctx, lg, tgt, col_invalid, row_leak, B, T, N):
+        S, R, Mp = lg.shape
+        dev = lg.device
+        stats = torch.empty(2 * S * R + 2 * S * Mp, device=dev)
+        rowsum, possum_v = stats[:S * R], stats[S * R:2 * S * R]
+        colsum, possum_t = stats[2 * S * R:2 * S * R + S * Mp], stats[2 * S * R + S * Mp:]
+        v_terms, t_terms = torch.empty(S, R, device=dev), torch.empty(S, Mp, device=dev)
+        L = _lib.lib()
+        ws = torch.empty(L.tan_nce_ws_floats(C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N)), device=dev)
+        _lib.check(L.tan_nce_fwd(_p(lg), _p(tgt), _p(col_invalid), _p(row_leak), _p(rowsum), _p(colsum), _p(possum_v),
+                                 _p(possum_t), _p(v_terms), _p(t_terms), _p(ws), C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N),
+                                 C.c_int(Mp), ops._stream()), "tan_nce_fwd")
+        ctx.saved = (lg, tgt, col_invalid, row_leak, rowsum, colsum, possum_v, possum_t)
+        ctx.dims = (S, B, T, N)
+        return v_terms, t_terms
+
+    @staticmethod
+    def backward(ctx, g_v, g_t):
+        lg, tgt, col_invalid, row_leak, rowsum, colsum, possum_v, possum_t = ctx.saved
+        S, B, T, N = ctx.dims
+        g_v = torch.zeros_like(rowsum).view(S, -1) if g_v is None else g_v.contiguous()
+        g_t = torch.zeros_like(colsum).view(S, -1) if g_t is None else g_t.contiguous()
+        dl = torch.empty_like(lg)
+        _lib.check(_lib.lib().tan_nce_bwd(_p(lg), _p(tgt), _p(col_invalid), _p(row_leak), _p(rowsum), _p(colsum), _p(possum_v),
+                                          _p(possum_t), _p(g_v), _p(g_t), _p(dl), _lib.TAN_F32, C.c_int(S), C.c_int(B),
+                                          C.c_int(T), C.c_int(N), ops._stream()), "tan_nce_bwd")
+        return dl, None, None, None, None, None, None
+
+
+def _selflabel(lg, vpad_u8, tpad_u8, dur, B, T, N):
+    S, dev = lg.shape[0], lg.device
+    max_pos = torch.empty(B, N, dtype=torch.int32, device=dev)
+    max_prob, max_logit = torch.empty(B, N, device=dev), torch.empty(B, N, device=dev)
+    self_tgt = torch.empty(B, N, T, dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().tan_selflabel(_p(lg), _p(vpad_u8), _p(tpad_u8), _p(dur), _p(max_pos), _p(max_prob), _p(max_logit),
+                                        _p(self_tgt), C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N), ops._stream()),
+               "tan_selflabel")
+    return {"max_pos": max_pos, "max_prob": max_prob, "max_logit": max_logit, "tgt": self_tgt}
+
+
+def _quantile(x, invalid_u8, q):
+    out = torch.empty(1, device=x.device)
+    _lib.check(_lib.lib().tan_masked_quantile(_p(x), _p(invalid_u8), C.c_int(x.numel()), C.c_float(q), _p(out), ops._stream()),
+               "tan_masked_quantile")
+    return out
+
+
+def _diag_max(lg, row_leak, B, T, N):
+    out = torch.empty(B * N, device=lg.device)
+    _lib.check(_lib.lib().tan_diag_max(_p(lg), _p(row_leak), _p(out), C.c_int(lg.shape[0]), C.c_int(B), C.c_int(T), C.c_int(N),
+                                       ops._stream()), "tan_diag_max")
+    return out
+
+
+def _masked_mean(x, mask_f):
+    """mean of x[:, mask] for x [S, K], mask [K] -- (sum x*mask) / (S * sum mask); 0/0 = nan like an empty .mean()."""
+    return (x * mask_f[None]).sum() / (x.shape[0] * mask_f.sum())
+
+
+def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding_mask, logits, args, abs_text_pos=None,
+             return_aux=False):
+    """Reference signature (train/loss.py:55-57); returns the reference's loss_dict ('loss' carries the graph)."""
+    if args.sim != "cos":
+        raise NotImplementedError("HIP get_loss supports sim='cos' only (the model only emits cosine logits)")
+    cotrain = args.model == "cotrain"
+    dev = logits["logits_dual"].device
+    if dev.type != "cuda":
+        raise _lib.TanHipError("get_loss needs device tensors: the HIP path has no CPU fallback")
+    B, T, _ = video_seq.shape
+    N = text_embed.shape[1]
+    R, Mp = B * T, B * N
+    lg_d, lg_j = _stage_major(logits["logits_dual"]), _stage_major(logits["logits_joint"])
+    tpad = text_padding_mask.to(dev).bool()
+    tpad_u8 = tpad.to(torch.uint8).contiguous()
+    vpad = video_padding_mask.to(dev).bool()
+    vpad_u8 = vpad.to(torch.uint8).contiguous()
+    valid = (~tpad).view(Mp)
+    valid_f = valid.float()
+    out, aux = {}, {}
+
+    tgt_raw = input_data.get("_tgt_raw") if isinstance(input_data, dict) else None
+    if tgt_raw is None:
+        tgt_raw, _, _ = get_mask_from_time(input_data["start"], input_data["end"], T, N, device=dev)   # [B,N,T] bool
+    row_leak = None
+    if args.learn_agreement:
+        with torch.no_grad():
+            src_j = _stage_major(logits["ema-logits_joint"]) if cotrain else lg_j.detach()
+            src_d = _stage_major(logits["ema-logits_dual"]) if cotrain else lg_d.detach()
+            dur = tgt_raw.sum(-1).float().clamp(min=1.0).masked_fill(tpad, 0.0).contiguous()         # loss.py:113-115
+            J = _selflabel(src_j, vpad_u8, tpad_u8, dur, B, T, N)
+            D = _selflabel(src_d, vpad_u8, tpad_u8, dur, B, T, N)
+            q_j = _quantile(J["max_logit"].view(-1), tpad_u8.view(-1), 0.3)                           # loss.py:191-194
+            q_d = _quantile(D["max_logit"].view(-1), tpad_u8.view(-1), 0.3)
+            tgt = torch.empty(B, T, N, device=dev)
+            iou = torch.empty(B, N, device=dev)
+            conf = torch.empty(B, N, dtype=torch.uint8, device=dev)
+            yt = tgt_raw.to(torch.uint8).contiguous()
+            _lib.check(_lib.lib().tan_agreement(_p(J["tgt"]), _p(D["tgt"]), _p(yt), _p(J["max_logit"]), _p(D["max_logit"]),
+                                                _p(q_j), _p(q_d), C.c_int(_KIND[args.temporal_agreement_type]), _p(tgt),
+                                                _p(iou), _p(conf), C.c_int(B), C.c_int(T), C.c_int(N), ops._stream()),
+                       "tan_agreement")
+            out["confidence-ratio"] = (conf.view(Mp).float() * valid_f).sum() / valid_f.sum()
+            out["iou-threshold"] = torch.tensor(0.5, device=dev)
+            if not cotrain:      # reference in-place quirk: the -6e4 fills leak into the online logits (loss.py:96-101)
+                row_leak = vpad_u8.view(R)
+            aux.update(max_position_joint=J["max_pos"], max_position_dual=D["max_pos"], max_logits_joint=J["max_logit"],
+                       max_logits_dual=D["max_logit"], joint_self_tgt=J["tgt"], dual_self_tgt=D["tgt"], iou=iou,
+                       confidence_mask=conf, agreement_tgt=tgt)
+    else:
+        tgt = tgt_raw.permute(0, 2, 1).float().contiguous()                                           # [B,T,N]
+
+    tgt_valid = tgt * (~tpad)[:, None, :].float()
+    rows_pos = (tgt_valid.sum(-1) > 0).view(R).float()                                                # loss.py:236
+    cols_pos = ((tgt.sum(1) > 0).view(Mp) & valid).float()                                            # loss.py:237
+
+    v_d, t_d = _NCEFn.apply(lg_d, tgt, tpad_u8.view(Mp), row_leak, B, T, N)
+    v_j, t_j = _NCEFn.apply(lg_j, tgt, tpad_u8.view(Mp), row_leak, B, T, N)
+    loss_dual = (_masked_mean(v_d, rows_pos) + _masked_mean(t_d, cols_pos)) / 2
+    loss_joint = (_masked_mean(v_j, rows_pos) + _masked_mean(t_j, cols_pos)) / 2
+    out["loss-dual"], out["loss-joint"] = loss_dual.detach(), loss_joint.detach()
+
+    if args.loss_threshold > 0 or args.use_alignability_head:
+        with torch.no_grad():
+            md = _diag_max(lg_d.detach(), row_leak, B, T, N)                                          # loss.py:280
+            mj = _diag_max(lg_j.detach(), row_leak, B, T, N)                                          # loss.py:283
+            n_valid = valid_f.sum()
+
+            def zscore(x):
+                mean = (x * valid_f).sum() / n_valid
+                var = (((x - mean) ** 2) * valid_f).sum() / (n_valid - 1)
+                return (x - mean) / var.sqrt()
+
+            metric = -(zscore(md) + zscore(mj))
+            th = _quantile(metric, tpad_u8.view(-1), float(args.loss_threshold))                      # loss.py:286
+            th_mask = (metric <= th) & valid
+            th_f = th_mask.float()
+            rows_pos_th = ((tgt_valid * th_f.view(B, 1, N)).sum(-1) > 0).view(R).float()              # loss.py:288-290
+            aux.update(t_th_mask=th_mask, max_logits_dual_per_text=md, max_logits_joint_per_text=mj)
+        if args.loss_threshold > 0:
+            out["loss-dual-all"], out["loss-joint-all"] = loss_dual.detach(), loss_joint.detach()
+            loss_dual_th = (_masked_mean(v_d, rows_pos_th) + _masked_mean(t_d, th_f)) / 2
+            loss_joint_th = (_masked_mean(v_j, rows_pos_th) + _masked_mean(t_j, th_f)) / 2
+            out["loss-dual"], out["loss-joint"] = loss_dual_th.detach(), loss_joint_th.detach()
+        if args.use_alignability_head:
+            with torch.no_grad():
+                med_d = _quantile(md, tpad_u8.view(-1), 0.5)                                          # loss.py:315-320
+                med_j = _quantile(mj, tpad_u8.view(-1), 0.5)
+                lab = torch.full_like(metric, 2.0)
+                lab = lab.masked_fill((md > med_d) & (mj > med_j), 1.0)
+                lab = lab.masked_fill((md < med_d) & (mj < med_j), 0.0)
+                if abs_text_pos is not None:                                                          # loss.py:325-328
+                    centre = abs_text_pos.to(dev).mean(-1).view(Mp)
+                    lab = lab.masked_fill((centre < 0.2) | (centre > 0.8), 0.0)
+                sel = ((lab != 2) & valid).float()
+                y = lab * sel
+                n_sel = sel.sum()
+                pos_weight = n_sel / y.sum() - 1.0                                                    # 1/mean(y) - 1
+                aux["t_align_th_mask"] = torch.where(valid, lab, torch.full_like(lab, float("nan")))
+            a_joint = logits["joint_logits_alignability"][:, 2, :, 0].reshape(Mp)                     # stage index 2 (loss.py:341)
+            bce = F.binary_cross_entropy_with_logits(a_joint, y, pos_weight=pos_weight.expand(Mp), reduction="none")
+            bce_joint = (bce * sel).sum() / n_sel
+            out["loss-joint-bce"] = bce_joint.detach()
+            out["alignability_top1"] = ((((a_joint.detach() > 0).float() == y).float()) * sel).sum() / n_sel
+
+    nce_w = 0 if args.optim_policy == "bce" else 1
+    if args.loss_threshold > 0:
+        out["loss-total"] = ((loss_dual + loss_joint) / 2).detach()
+        loss = (loss_dual_th + loss_joint_th) / 2
+    else:
+        loss = (loss_dual + loss_joint) / 2
+    if args.use_alignability_head:
+        loss = loss * nce_w + bce_joint
+    out["loss"] = loss
+    return (out, aux) if return_aux else out

@@ -1,0 +1,115 @@
+"""HIP get_loss vs reference-generated goldens (G3, G4) and the CPU oracle: scalars, d loss/d logits, and the
+integer / boolean self-labelling tensors bit-exactly."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_ref, tan_ref, train_ref
+from temporalalignnet_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def P(seed, E, D, head):
+    return {k: torch.from_numpy(v) for k, v in synth.make_params(seed, E, D, head).items()}
+
+
+def oracle_logits(p, b, E, D):
+    t = train_ref.to_torch_batch(b)
+    with torch.no_grad():
+        return tan_ref.forward(p, t["video"], t["text_embed"], t["padding_mask"], t["text_padding_mask"].bool(), E=E, D=D,
+                               use_alignability_head=True)
+
+
+def to_dev(out, grad_keys=()):
+    d = {}
+    for k, v in out.items():
+        d[k] = v.cuda().contiguous()
+        if k in grad_keys:
+            d[k].requires_grad_(True)
+    return d
+
+
+def run_hip(b, logits, args):
+    from temporalalignnet_amd.loss import get_loss
+    t = train_ref.to_torch_batch(b)
+    return get_loss(b, t["video"].cuda(), t["text_embed"].cuda(), t["padding_mask"].cuda(), t["text_padding_mask"].cuda(),
+                    logits, args, t["abs_text_pos"].cuda(), return_aux=True)
+
+
+@pytest.mark.parametrize("tag,kw", [("default", {}), ("agree", {"learn_agreement": 1}), ("th", {"loss_threshold": 0.5})])
+def test_g3_loss_init(golden, tag, kw):
+    g = golden("g3_loss_init")
+    b = synth.make_batch(11, B=4, T=16, n_min=2, n_max=5, video_pad_tail=3)
+    lg = to_dev(oracle_logits(P(101, 1, 1, True), b, 1, 1), ("logits_dual", "logits_joint"))
+    ld, aux = run_hip(b, lg, loss_ref.default_args(**kw))
+    ld["loss"].backward()
+    for k in ld:
+        np.testing.assert_allclose(ld[k].detach().cpu().numpy(), g[f"{tag}/{k}"], rtol=2e-5, atol=2e-6, err_msg=k)
+    np.testing.assert_allclose(lg["logits_dual"].grad.cpu().numpy(), g[f"{tag}/dlogits_dual"], rtol=2e-4, atol=2e-7)
+    np.testing.assert_allclose(lg["logits_joint"].grad.cpu().numpy(), g[f"{tag}/dlogits_joint"], rtol=2e-4, atol=2e-7)
+    if tag == "agree":
+        assert (aux["max_position_dual"].cpu().numpy() == g["agree/dual_max_position"]).all()
+        B, T, N = 4, 16, aux["agreement_tgt"].shape[-1]
+        full = g["agree/agreement_self_tgt"]                      # [B,T,B,N] uint8
+        diag = np.stack([full[i, :, i, :] for i in range(B)])
+        assert (aux["agreement_tgt"].cpu().numpy().astype(np.uint8) == diag).all()
+        jt = np.stack([g["agree/joint_self_tgt"][i, :, i, :] for i in range(B)])          # [B,T,N]
+        assert (aux["joint_self_tgt"].cpu().numpy().transpose(0, 2, 1) == jt).all()
+
+
+@pytest.mark.parametrize("kind", ["keep", "keep-joint", "i", "u"])
+def test_g4_loss_cotrain(golden, kind):
+    g = golden("g4_loss_cotrain")
+    b = synth.make_batch(14, B=6, T=32, n_min=3, n_max=7)
+    B = 6
+    on = to_dev(oracle_logits(P(104, 3, 3, True), b, 3, 3), ("logits_dual", "logits_joint", "joint_logits_alignability"))
+    ema = to_dev(oracle_logits(P(204, 3, 3, True), b, 3, 3))
+    args = loss_ref.default_args(model="cotrain", loss_threshold=0.5, temporal_agreement_type=kind)
+    ld, aux = run_hip(b, {**on, **{f"ema-{k}": v for k, v in ema.items()}}, args)
+    ld["loss"].backward()
+    # integer / boolean tensors: bit-exact against the reference
+    assert (aux["max_position_dual"].cpu().numpy() == g[f"{kind}/dual_max_position"]).all()
+    diag = lambda full: np.stack([full[i, :, i, :] for i in range(B)])
+    assert (aux["agreement_tgt"].cpu().numpy().astype(np.uint8) == diag(g[f"{kind}/agreement_self_tgt"])).all()
+    assert (aux["dual_self_tgt"].cpu().numpy().transpose(0, 2, 1) == diag(g[f"{kind}/dual_self_tgt"])).all()
+    assert (aux["joint_self_tgt"].cpu().numpy().transpose(0, 2, 1) == diag(g[f"{kind}/joint_self_tgt"])).all()
+    valid = ~torch.as_tensor(b["text_padding_mask"]).bool().view(-1).numpy()
+    assert (aux["t_th_mask"].cpu().numpy()[valid] == g[f"{kind}/t_th_mask"]).all()
+    assert (aux["t_align_th_mask"].cpu().numpy()[valid] == g[f"{kind}/t_align_th_mask"]).all()
+    assert (aux["confidence_mask"].cpu().numpy().astype(bool) == g[f"{kind}/confidence_mask"]).all()
+    np.testing.assert_allclose(aux["iou"].cpu().numpy(), g[f"{kind}/self_tgt_iou"], rtol=1e-6)
+    np.testing.assert_allclose(aux["max_logits_joint"].cpu().numpy(), g[f"{kind}/joint_max_logits_per_text"], rtol=1e-4, atol=1e-4)
+    scalars = ["loss", "loss-dual", "loss-joint", "loss-dual-all", "loss-joint-all", "loss-total", "loss-joint-bce",
+               "alignability_top1", "confidence-ratio", "iou-threshold"]
+    assert set(scalars) == set(ld)
+    for k in scalars:
+        np.testing.assert_allclose(ld[k].detach().cpu().numpy(), g[f"{kind}/{k}"], rtol=3e-5, atol=2e-6, err_msg=k)
+    np.testing.assert_allclose(on["logits_dual"].grad.cpu().numpy(), g[f"{kind}/dlogits_dual"], rtol=2e-4, atol=2e-7)
+    np.testing.assert_allclose(on["logits_joint"].grad.cpu().numpy(), g[f"{kind}/dlogits_joint"], rtol=2e-4, atol=2e-7)
+    np.testing.assert_allclose(on["joint_logits_alignability"].grad.cpu().numpy(), g[f"{kind}/dalign_joint"], rtol=2e-4, atol=1e-7)
+
+
+def test_masked_quantile_matches_torch():
+    from temporalalignnet_amd.loss import _quantile
+    gen = torch.Generator().manual_seed(0)
+    for n in (1, 2, 7, 100, 1280, 2048):
+        x = torch.randn(n, generator=gen)
+        inv = (torch.rand(n, generator=gen) < 0.3)
+        if inv.all():
+            inv[0] = False
+        for q in (0.0, 0.3, 0.5, 0.77, 1.0):
+            got = _quantile(x.cuda(), inv.to(torch.uint8).cuda(), q).item()
+            want = torch.quantile(x[~inv], q).item()
+            assert abs(got - want) <= 1e-6 * max(1.0, abs(want)), (n, q, got, want)
+
+
+def test_api_helpers_match_oracle():
+    from temporalalignnet_amd.loss import circulant, get_mask_from_time, get_text_pos
+    assert circulant(torch.tensor([0, 1, 2]), 0).tolist() == [[0, 1, 2], [2, 0, 1], [1, 2, 0]]
+    b = synth.make_batch(3, B=5, T=16, n_min=2, n_max=6)
+    N = b["text_embed"].shape[1]
+    m, s, e = get_mask_from_time(b["start"], b["end"], 16, N, device="cuda")
+    mr, sr, er = loss_ref.mask_from_time(b["start"], b["end"], 16, N)
+    assert torch.equal(m.cpu(), mr) and torch.equal(s.cpu(), sr) and torch.equal(e.cpu(), er)
+    assert torch.equal(get_text_pos(b["start"], b["end"], device="cuda").cpu(), loss_ref.text_pos(b["start"], b["end"]))
