@@ -1,0 +1,141 @@
+"""Training-step driver: the MI355X counterpart of train/main.py:train() (reference lines 33-162).
+
+One step = zero_grad -> forward (-> EMA forward for 'cotrain') -> get_loss -> backward -> [all-reduce of the flat
+gradient] -> AdamW on both parameter groups -> EMA update, in that order (main.py:81-122).  The optimizer is ONE fused
+HIP launch over the flat parameter buffer (tan_adamw_step) that also refreshes the bf16 shadow weights and the EMA
+target; parameter grouping follows optim_policy (main.py:330-356) including its substring rule on full parameter names.
+
+The reference's GradScaler is not reproduced: throughput mode is bf16 (f32 exponent range), so no loss scaling.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import types
+
+import numpy as np
+import torch
+
+from . import _lib, dist, ops
+from .loss import get_loss, get_mask_from_time
+from .tan_model import TemporalAligner, TwinTemporalAligner, _vp
+
+
+def default_args(**kw):
+    """The flags of train/config.py:6-53 that the hot path reads, with the reference's defaults."""
+    a = dict(model="init", sim="cos", learn_agreement=0, temporal_agreement_type="keep", loss_threshold=0.0,
+             use_alignability_head=0, optim_policy="default", seq_len=64, lr=1e-4, wd=1e-5, clip_grad=0.0,
+             momentum_m=0.999, num_encoder_layers=6, num_decoder_layers=6, epochs=10, backprop_freq=1)
+    a.update(kw)
+    if a["model"] == "cotrain":            # train/main.py:361-363
+        a["learn_agreement"] = 1
+        a["use_alignability_head"] = 1
+    return types.SimpleNamespace(**a)
+
+
+def build_model(args, compute_dtype="fp32", language_model=None, **kw):
+    """Model construction of train/main.py:370-390."""
+    common = dict(num_encoder_layers=args.num_encoder_layers, num_decoder_layers=args.num_decoder_layers, sim=args.sim,
+                  language_model=language_model, use_alignability_head=args.use_alignability_head,
+                  compute_dtype=compute_dtype, **kw)
+    if args.model == "init":
+        return TemporalAligner(**common)
+    return TwinTemporalAligner(m=args.momentum_m, random_pos_start=0, **common)
+
+
+def lr_multiplier(iteration, iter_per_epoch, epochs, warmup=1000):
+    """Linear warm-up then cosine (train/main.py:488-494)."""
+    if iteration < warmup:
+        return iteration / warmup
+    return 0.5 * (1.0 + math.cos(math.pi * (iteration - warmup) / (epochs * iter_per_epoch - warmup)))
+
+
+def to_device_batch(batch: dict, device="cuda") -> dict:
+    """numpy batch (temporalalignnet_amd.synth.make_batch / loader collate schema) -> device tensors, plus the
+    [B,N,T] timestamp mask of train/main.py:71 computed once."""
+    out = dict(batch)
+    for k in ("video", "text_embed", "text_padding_mask", "abs_text_pos"):
+        if k in batch and batch[k] is not None:
+            out[k] = torch.as_tensor(batch[k]).to(device, non_blocking=True)
+    out["padding_mask"] = torch.as_tensor(batch["padding_mask"]).bool().to(device, non_blocking=True)
+    T, N = out["video"].shape[1], out["text_embed"].shape[1]
+    out["_tgt_raw"], _, _ = get_mask_from_time(batch["start"], batch["end"], T, N, device=device)
+    return out
+
+
+class Trainer:
+    def __init__(self, model, args, *, betas=(0.9, 0.999), eps=1e-8, iter_per_epoch=None, warmup=1000):
+        self.model, self.args = model, args
+        self.twin = isinstance(model, TwinTemporalAligner)
+        self.online = model.online if self.twin else model
+        self.betas, self.eps = betas, eps
+        self.iteration = 0
+        self.iter_per_epoch, self.warmup = iter_per_epoch, warmup
+        self._state = None
+
+    # -------------------------------------------------------------- optimizer state
+    def _ensure_state(self):
+        f = self.online._ensure_flat()
+        if self._state is None or self._state["m"].device != f.flat.device:
+            mode = self.online.param_modes("online." if self.twin else "")
+            if self.args.optim_policy == "bce":        # only binary_head trains (main.py:345-352)
+                for n in f.names:
+                    if "binary_head" not in n:
+                        o, k, _ = f.off[n]
+                        mode[o:o + k] = 2
+            self._state = {"m": torch.zeros_like(f.flat), "v": torch.zeros_like(f.flat), "mode": mode.to(f.flat.device)}
+        return f, self._state
+
+    def current_lr(self):
+        """The reference steps its LambdaLR with the pre-increment iteration AFTER the optimizer step
+        (main.py:137-139), so the k-th optimizer step (0-based) runs at lambda(max(k-1, 0)); self.iteration == k+1 here."""
+        if self.iter_per_epoch is None:
+            return self.args.lr
+        return self.args.lr * lr_multiplier(max(self.iteration - 2, 0), self.iter_per_epoch, self.args.epochs, self.warmup)
+
+    def zero_grad(self):
+        f = self.online._ensure_flat()
+        f.grad.zero_()
+        self.online._bind_grads()
+
+    def forward_backward(self, batch):
+        a, m = self.args, self.model
+        logits = m(batch["video"], batch["text_embed"], video_padding_mask=batch["padding_mask"],
+                   lang_padding_mask=batch["text_padding_mask"].bool(), text_timestamp=batch.get("_tgt_raw"),
+                   abs_text_pos=batch.get("abs_text_pos"))
+        if a.model == "cotrain":
+            ema = m.forward_from_ema(batch["video"], batch["text_embed"], video_padding_mask=batch["padding_mask"],
+                                     lang_padding_mask=batch["text_padding_mask"].bool(),
+                                     text_timestamp=batch.get("_tgt_raw"), abs_text_pos=batch.get("abs_text_pos"))
+            logits = {**logits, **{f"ema-{k}": v for k, v in ema.items()}}
+        loss_dict = get_loss(batch, batch["video"], batch["text_embed"], batch["padding_mask"], batch["text_padding_mask"],
+                             logits, a, batch.get("abs_text_pos"))
+        loss_dict["loss"].backward()
+        return loss_dict
+
+    def optimizer_step(self, grad_scale=1.0):
+        f, st = self._ensure_state()
+        a = self.args
+        if a.clip_grad > 0:                            # per-parameter L2 clip, utils/train_utils.py:3-13
+            for p in f.params:
+                if p.grad is not None:
+                    coef = a.clip_grad / (p.grad.norm(2) * grad_scale + 1e-6)
+                    p.grad.mul_(torch.clamp(coef, max=1.0))
+        ema = self.model.target._ensure_flat() if self.twin else None
+        self.iteration += 1
+        _lib.check(_lib.lib().tan_adamw_step(
+            _vp(f.flat), _vp(f.grad), _vp(st["m"]), _vp(st["v"]), _vp(st["mode"]), C.c_long(f.total),
+            C.c_double(self.current_lr()), C.c_double(self.betas[0]), C.c_double(self.betas[1]), C.c_double(self.eps),
+            C.c_double(a.wd), C.c_int(self.iteration), C.c_float(grad_scale), _vp(f.shadow),
+            _vp(ema.flat) if ema is not None else None, C.c_float(self.model.m if self.twin else 0.0),
+            _vp(ema.shadow) if ema is not None else None, ops._stream()), "tan_adamw_step")
+
+    def step(self, batch):
+        """One optimizer step on an already device-resident batch (see to_device_batch)."""
+        self.zero_grad()
+        loss_dict = self.forward_backward(batch)
+        world = dist.world_size()
+        if world > 1:
+            dist.allreduce_sum_(self.online.flat_grad())
+        self.optimizer_step(grad_scale=1.0 / world)
+        return loss_dict
