@@ -1,0 +1,157 @@
+#!/usr/bin/env python
+"""Headline benchmark: video-seq/s of the TemporalAlignNet training step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype bf16|fp32] [--stage 1|2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): E6D6, T=64, bf16, stage-1 ('init': NCE only), B=128 videos per GPU
+(train/readme.md:10), N ~ U[4,16] sentences per video, synthetic HTM-370K-shaped features (random S3D-like 1024-d
+clip features and 512-d sentence embeddings), random-init weights.  One step = zero_grad + forward + get_loss +
+backward + (gradient all-reduce over RCCL when N>1) + fused AdamW, inputs already resident in HBM.  Multi-GPU shards
+by video (weak scaling: every rank its own 128 videos), one all-reduce of the flat gradient per step.
+
+Prints ONE JSON line (rank 0): value = whole-job video-seq/s; `roofline` = the dominant kernel (the MFMA GEMM family)
+timed live with HIP events on its own stream inside the timed steps; `cpu_baseline` = the CPU oracle (oracle/, a PyTorch
+CPU restatement of the reference pinned to reference-generated goldens) on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+F32_MFMA_PEAK_TFLOPS = 157.3
+GEMM_KIND_NAMES = {0: "gemm_bf16<A:K-contig,B:K-contig> (Linear fwd, similarity)", 1: "gemm_bf16<A:K-contig,B:K-strided> (dX)",
+                   2: "gemm_bf16<A:K-strided,B:K-contig>", 3: "gemm_bf16<A:K-strided,B:K-strided> (dW)",
+                   4: "gemm_f32<kc,kc>", 5: "gemm_f32<kc,ks>", 6: "gemm_f32<ks,kc>", 7: "gemm_f32<ks,ks>",
+                   8: "attn_fwd", 9: "attn_bwd"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="videos per GPU per step")
+    ap.add_argument("--seq-len", type=int, default=64)
+    ap.add_argument("--layers", type=int, default=6)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--stage", type=int, default=1, choices=[1, 2], help="1 = 'init' NCE only; 2 = 'cotrain'")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(a, args_ns):
+    """The CPU oracle's train step on a bounded sample (same E/D/T/N distribution, fewer videos), host cores of this box."""
+    from oracle import train_ref
+    from temporalalignnet_amd import synth
+    torch.set_num_threads(os.cpu_count())
+    E = D = a.layers
+    head = bool(args_ns.use_alignability_head)
+    tr = train_ref.RefTrainer(synth.make_params(1, E, D, head, randomize_affine=False), E=E, D=D, args=args_ns, lr=1e-4, wd=1e-5,
+                              random_pos_start=False)
+    b = train_ref.to_torch_batch(synth.make_batch(888, B=a.cpu_batch, T=a.seq_len, n_min=4, n_max=16))
+    tr.step(b)                                   # warm-up
+    t0 = time.perf_counter()
+    for _ in range(a.cpu_steps):
+        tr.step(b)
+    dt = (time.perf_counter() - t0) / a.cpu_steps
+    return {"value": round(a.cpu_batch / dt, 2), "unit": "video-seq/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"CPU oracle (PyTorch CPU fp32 restatement of the reference) E{E}D{D} T={a.seq_len} N~U[4,16] "
+                      f"stage-{a.stage} train step on {a.cpu_batch} videos, {a.cpu_steps} timed steps after 1 warm-up "
+                      f"({dt:.2f} s/step)"}
+
+
+def main():
+    a = parse()
+    from temporalalignnet_amd import _lib, dist, synth
+    from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
+    world, rank, local = dist.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    args_ns = default_args(model="init" if a.stage == 1 else "cotrain", num_encoder_layers=a.layers, num_decoder_layers=a.layers,
+                           loss_threshold=0.0 if a.stage == 1 else 0.5, seq_len=a.seq_len)
+    torch.manual_seed(888)
+    model = build_model(args_ns, compute_dtype=a.dtype).to(dev)
+    if a.stage == 1:
+        model.random_pos_start = 1
+    trainer = Trainer(model, args_ns, iter_per_epoch=2890, warmup=1000)   # 370k videos / 128
+    trainer.iteration = 1000                                             # past warm-up: non-zero learning rate
+    dist.broadcast_(trainer.online.flat_parameters())
+    if a.stage == 2:
+        model._copy_param()
+    batch = to_device_batch(synth.make_batch(888 + rank, B=a.batch, T=a.seq_len, n_min=4, n_max=16), device=dev)
+
+    for _ in range(a.warmup):
+        trainer.step(batch)
+    L = _lib.lib()
+    use_timer = not a.no_kernel_timer
+    if use_timer:
+        _lib.check(L.tan_prof_enable(1, 1200 * max(a.steps, 1)), "tan_prof_enable")
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = trainer.step(batch)
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = dist.max_over_ranks(elapsed, dev)
+    final_loss = float(loss["loss"].item())
+
+    roof = None
+    if use_timer:
+        nk = 10
+        ms, work, cnt = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_long * nk)()
+        L.tan_prof_collect(ms, work, cnt, nk)
+        L.tan_prof_enable(0, 0)
+        kinds = [{"kernel": GEMM_KIND_NAMES[k], "ms_per_step": ms[k] / a.steps, "launches_per_step": cnt[k] / a.steps,
+                  "tflops": (work[k] / (ms[k] * 1e-3) / 1e12) if ms[k] > 0 else 0.0} for k in range(nk) if cnt[k] > 0]
+        gemm = [k for k in range(8) if cnt[k] > 0]
+        if gemm:
+            peak = BF16_MFMA_PEAK_TFLOPS if a.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
+            tms, twork, tcnt = sum(ms[k] for k in gemm), sum(work[k] for k in gemm), sum(cnt[k] for k in gemm)
+            ach = twork / (tms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "tal::gemm_kernel (all operand layouts)", "achieved": round(ach, 1),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "avg_launch_us": round(tms * 1e3 / tcnt, 2), "launches_per_step": tcnt / a.steps,
+                    "gemm_ms_per_step": round(tms / a.steps, 3), "algorithmic_gflop_per_step": round(twork / a.steps / 1e9, 1),
+                    "by_kernel": [{**x, "ms_per_step": round(x["ms_per_step"], 3), "tflops": round(x["tflops"], 1)} for x in kinds]}
+
+    if rank == 0:
+        out = {
+            "metric": "video-seq/sec (len=64, E6D6) at 1/2/4/8 MI355X; HTM-Align ROC-AUC parity",
+            "value": round(a.batch * world * a.steps / elapsed, 1), "unit": "video-seq/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"E{a.layers}D{a.layers} len={a.seq_len} {a.dtype} stage-{a.stage} "
+                                   f"({'init: multi-positive NCE only' if a.stage == 1 else 'cotrain: EMA + alignability + NCE'}) "
+                                   f"train step (fwd+loss+bwd+AdamW), synthetic HTM-370K-shaped features, N~U[4,16] sentences/video",
+                       "global_batch": a.batch * world, "per_gpu_batch": a.batch, "seq_len": a.seq_len,
+                       "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
+            "roofline": roof,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a, args_ns)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

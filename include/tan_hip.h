@@ -32,6 +32,18 @@ extern "C" {
 
 int tan_version(void);
 
+/* Optional in-stream kernel timer (bench.py's `roofline` line): while enabled every tan_gemm / tan_attn_* launch is
+ * bracketed by hipEvents on its own stream.  tan_prof_collect synchronises and returns per kind the summed duration
+ * [ms], the summed ALGORITHMIC work [flop] (2*M*N*K per GEMM; 4*B*H*L*L*64 attention fwd, 14*... bwd incl. recompute)
+ * and the launch count; returns 1 if the record buffer overflowed.  GEMM kinds: base + 2*(A K-strided) + (B K-strided). */
+#define TAN_PROF_GEMM_BF16 0
+#define TAN_PROF_GEMM_F32 4
+#define TAN_PROF_ATTN_FWD 8
+#define TAN_PROF_ATTN_BWD 9
+#define TAN_PROF_NKINDS 10
+int tan_prof_enable(int on, int max_records);
+int tan_prof_collect(double* ms_by_kind, double* work_by_kind, long* count_by_kind, int nkinds);
+
 /* ---- GEMM (nn.Linear fwd/bwd: tfm_model.py:21-27, tan_model.py:48-49,70; einsum tan_model.py:118,138) ----
  * C[M,N] (=|+=) alpha * opA(A)[M,K] * opB(B)[K,N]  (+ bias[N]) (activation) (+ residual[M,N])
  *   a_kc=1: A stored [M,K] (lda = row stride)   a_kc=0: A stored [K,M] (lda = stride between k)

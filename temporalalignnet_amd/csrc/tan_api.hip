@@ -1,4 +1,74 @@
-// Library-level entry points.
+// Library-level entry points: version and the optional in-stream kernel timer used by bench.py's roofline line.
+#include <vector>
+
 #include "tan_common.h"
 
+namespace tal {
+
+struct ProfState {
+    bool on = false;
+    int cap = 0, n = 0;
+    std::vector<hipEvent_t> ev;      // 2 per record
+    std::vector<int> kind;
+    std::vector<double> work;
+};
+static ProfState g_prof;
+
+int prof_begin(hipStream_t st, int kind, double work) {
+    ProfState& p = g_prof;
+    if (!p.on || p.n >= p.cap) return -1;
+    const int i = p.n++;
+    p.kind[i] = kind;
+    p.work[i] = work;
+    (void)hipEventRecord(p.ev[2 * i], st);
+    return i;
+}
+void prof_end(hipStream_t st, int rec) {
+    if (rec >= 0) (void)hipEventRecord(g_prof.ev[2 * rec + 1], st);
+}
+
+}  // namespace tal
+
+using namespace tal;
+
 extern "C" int tan_version(void) { return 100; }
+
+// Profiling hook (the library's only process-global state; off by default).  While enabled, every tan_gemm /
+// tan_attn_* launch is bracketed by hipEvents on ITS OWN stream; tan_prof_collect synchronises those events and
+// returns, per kernel kind, the summed duration [ms], the summed algorithmic work [flop] and the launch count.
+extern "C" int tan_prof_enable(int on, int max_records) {
+    ProfState& p = g_prof;
+    if (on) {
+        if ((int)p.ev.size() < 2 * max_records) {
+            const size_t old = p.ev.size();
+            p.ev.resize(2 * (size_t)max_records);
+            for (size_t i = old; i < p.ev.size(); ++i) {
+                hipError_t e = hipEventCreate(&p.ev[i]);
+                if (e != hipSuccess) return (int)e;
+            }
+        }
+        p.kind.assign(max_records, 0);
+        p.work.assign(max_records, 0.0);
+        p.cap = max_records;
+        p.n = 0;
+    }
+    p.on = on != 0;
+    return 0;
+}
+
+extern "C" int tan_prof_collect(double* ms_by_kind, double* work_by_kind, long* count_by_kind, int nkinds) {
+    ProfState& p = g_prof;
+    for (int k = 0; k < nkinds; ++k) { ms_by_kind[k] = 0; work_by_kind[k] = 0; count_by_kind[k] = 0; }
+    for (int i = 0; i < p.n; ++i) {
+        hipError_t e = hipEventSynchronize(p.ev[2 * i + 1]);
+        if (e != hipSuccess) return (int)e;
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]);
+        if (e != hipSuccess) return (int)e;
+        const int k = p.kind[i];
+        if (k >= 0 && k < nkinds) { ms_by_kind[k] += ms; work_by_kind[k] += p.work[i]; count_by_kind[k] += 1; }
+    }
+    const int dropped = p.n >= p.cap ? 1 : 0;
+    p.n = 0;
+    return dropped ? 1 : 0;   // 1 = record buffer filled up (later launches were not timed)
+}

@@ -323,6 +323,7 @@ extern "C" int tan_attn_fwd(const void* qkv, const unsigned char* key_padding_ma
     dim3 grid(a.Lpad / 64, H, B);
     hipStream_t st = (hipStream_t)stream;
     int rc;
+    const int rec = prof_begin(st, TAN_PROF_ATTN_FWD, 4.0 * B * H * (double)L * L * DH);
     if (dtype == TAN_F32) {
         size_t sm = fwd_smem<float>(a.Lpad);
         if ((rc = set_smem(attn_fwd_kernel<float>, sm))) return rc;
@@ -332,6 +333,7 @@ extern "C" int tan_attn_fwd(const void* qkv, const unsigned char* key_padding_ma
         if ((rc = set_smem(attn_fwd_kernel<bf16_t>, sm))) return rc;
         hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), grid, dim3(256), sm, st, a);
     } else return TAN_ERR_BAD_ARG;
+    prof_end(st, rec);
     TAN_LAUNCH_CHECK();
     return 0;
 }
@@ -345,6 +347,7 @@ extern "C" int tan_attn_bwd(const void* qkv, const unsigned char* key_padding_ma
     dim3 grid(a.Lpad / 64, H, B);
     hipStream_t st = (hipStream_t)stream;
     int rc;
+    const int rec = prof_begin(st, TAN_PROF_ATTN_BWD, 14.0 * B * H * (double)L * L * DH);
     if (dtype == TAN_F32) {
         if ((rc = set_smem(attn_bwd_dq_kernel<float>, bwd_smem<float>(5)))) return rc;
         if ((rc = set_smem(attn_bwd_dkv_kernel<float>, bwd_smem<float>(6)))) return rc;
@@ -356,6 +359,7 @@ extern "C" int tan_attn_bwd(const void* qkv, const unsigned char* key_padding_ma
         hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t>), grid, dim3(256), bwd_smem<bf16_t>(5), st, a);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16_t>), grid, dim3(256), bwd_smem<bf16_t>(6), st, a);
     } else return TAN_ERR_BAD_ARG;
+    prof_end(st, rec);
     TAN_LAUNCH_CHECK();
     return 0;
 }

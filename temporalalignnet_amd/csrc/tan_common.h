@@ -72,6 +72,10 @@ inline int hip_ok(hipError_t e) { return (int)e; }
 #define TAN_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
 #define TAN_REQUIRE(cond) do { if (!(cond)) return TAN_ERR_BAD_ARG; } while (0)
 
+// optional in-stream kernel timer (tan_api.hip); kinds: see TAN_PROF_* in tan_hip.h
+int prof_begin(hipStream_t st, int kind, double work);
+void prof_end(hipStream_t st, int rec);
+
 inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
 
 }  // namespace tal

@@ -228,10 +228,13 @@ extern "C" int tan_gemm(const tan_gemm_desc* d, void* stream) {
     a.vecB = vec_ok(d->B, d->ldb, d->sB) && (a.kchunk % ve == 0);
     dim3 grid(cdiv(d->N, BN), cdiv(d->M, BM), d->batch * d->split_k);
     hipStream_t st = (hipStream_t)stream;
-    if (d->dtype == TAN_F32) {
-        TAN_REQUIRE(d->out_dtype == TAN_F32);
-        return launch_gemm<float, float>(d, a, grid, st);
-    }
-    if (d->out_dtype == TAN_F32) return launch_gemm<bf16_t, float>(d, a, grid, st);
-    return launch_gemm<bf16_t, bf16_t>(d, a, grid, st);
+    if (d->dtype == TAN_F32) TAN_REQUIRE(d->out_dtype == TAN_F32);
+    const int kind = (d->dtype == TAN_BF16 ? TAN_PROF_GEMM_BF16 : TAN_PROF_GEMM_F32) + (d->a_kc ? 0 : 2) + (d->b_kc ? 0 : 1);
+    const int rec = prof_begin(st, kind, 2.0 * d->M * d->N * (double)d->K * d->batch);
+    int rc;
+    if (d->dtype == TAN_F32) rc = launch_gemm<float, float>(d, a, grid, st);
+    else if (d->out_dtype == TAN_F32) rc = launch_gemm<bf16_t, float>(d, a, grid, st);
+    else rc = launch_gemm<bf16_t, bf16_t>(d, a, grid, st);
+    prof_end(st, rec);
+    return rc;
 }
