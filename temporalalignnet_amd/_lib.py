@@ -53,6 +53,10 @@ def lib() -> C.CDLL:
             raise TanHipError(
                 f"{LIB_PATH} not found: build it with `python -m temporalalignnet_amd.build` "
                 "(the HIP path has no CPU fallback)")
+        # torch bundles its own ROCm runtime (torch/lib/libamdhip64.so); it must be the one already loaded when our
+        # library's DT_NEEDED libamdhip64.so.7 is resolved, otherwise two HIP runtimes end up in one process
+        # (observed: every launch fails with hipErrorNoDevice).  PyTorch is the memory/stream plumbing anyway.
+        import torch  # noqa: F401
         _lib = C.CDLL(LIB_PATH)
         for name in declared_symbols():
             getattr(_lib, name).restype = C.c_long if name.endswith("_floats") or name.endswith("_bytes") else C.c_int

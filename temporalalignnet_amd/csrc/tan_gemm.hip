@@ -37,7 +37,7 @@ struct GemmArgs {
     long sA, sB, sC;
     int M, N, K;
     int act, accumulate, split_k, kchunk;
-    int vecA, vecB;
+    int vecA, vecB, fast;
     float alpha;
 };
 
@@ -66,6 +66,30 @@ __device__ __forceinline__ Vec16 load_vec(const T* __restrict__ P, long ld, int 
 #pragma unroll
         for (int e = 0; e < VE; ++e) if (o + e < OUT) { if (sizeof(T) == 4) r.f[e] = ((const float*)p)[e]; else r.h[e] = ((const bf16_t*)p)[e]; }
     }
+    return r;
+}
+
+// Branch-free variant for aligned operands (16-byte aligned base / leading dim / batch stride, K % VE == 0 and, for a
+// K-strided operand, OUT % VE == 0): the address is clamped in bounds, the load is unconditional and out-of-range
+// vectors are zeroed with selects -- so all staging loads of a K-step issue back to back.  (hipcc wraps a conditional
+// load in a branch + s_waitcnt vmcnt(0), which serialised the 8 loads per thread of the generic path.)
+template <typename T, bool KC>
+__device__ __forceinline__ Vec16 load_vec_fast(const T* __restrict__ P, long ld, int outer0, int k0, int v, int OUT, int kend) {
+    constexpr int VE = GemmCfg<T>::VE, BK = GemmCfg<T>::BK;
+    int o, k;
+    if (KC) {
+        constexpr int VPR = BK / VE;
+        o = outer0 + v / VPR; k = k0 + (v % VPR) * VE;
+    } else {
+        constexpr int VPR = BM / VE;
+        k = k0 + v / VPR; o = outer0 + (v % VPR) * VE;
+    }
+    const bool ok = (o < OUT) && (k < kend);
+    const int oc = min(o, OUT - (KC ? 1 : VE)), kc = min(k, kend - (KC ? VE : 1));
+    const T* p = KC ? P + (long)oc * ld + kc : P + (long)kc * ld + oc;
+    Vec16 r;
+    r.u = *reinterpret_cast<const uint4*>(p);
+    r.u.x = ok ? r.u.x : 0u; r.u.y = ok ? r.u.y : 0u; r.u.z = ok ? r.u.z : 0u; r.u.w = ok ? r.u.w : 0u;
     return r;
 }
 
@@ -99,7 +123,36 @@ __device__ __forceinline__ void store_vec(T* lds, int v, const Vec16& r) {
     }
 }
 
-template <typename T, typename TC, bool A_KC, bool B_KC>
+template <typename TC, bool GUARD>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], TC* C, const TC* R, TC* AUX, int m0, int n0,
+                                              int wm, int wn, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + acc_col(lane);
+            if (GUARD && col >= g.N) continue;
+            const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+                if (GUARD && row >= g.M) continue;
+                float v = acc[i][j][r] * g.alpha + bv;
+                if (g.act == TAN_ACT_QUICKGELU) {
+                    if (AUX) st_f(AUX + (long)row * g.ldaux + col, v);
+                    v = quick_gelu(v);
+                } else if (g.act == TAN_ACT_QUICKGELU_GRAD) {
+                    v *= quick_gelu_grad(ld_f(AUX + (long)row * g.ldaux + col));
+                }
+                if (R) v += ld_f(R + (long)row * g.ldr + col);
+                TC* cp = C + (long)row * g.ldc + col;
+                if (g.accumulate) unsafeAtomicAdd((float*)cp, v);
+                else st_f(cp, v);
+            }
+        }
+}
+
+template <typename T, typename TC, bool A_KC, bool B_KC, bool FAST>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     typedef GemmCfg<T> Cfg;
     constexpr int BK = Cfg::BK;
@@ -132,8 +185,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            ra[i] = load_vec<T, A_KC>(A, g.lda, m0, k0, tid + 256 * i, g.M, g.K, kend, g.vecA);
-            rb[i] = load_vec<T, B_KC>(B, g.ldb, n0, k0, tid + 256 * i, g.N, g.K, kend, g.vecB);
+            if (FAST) {
+                ra[i] = load_vec_fast<T, A_KC>(A, g.lda, m0, k0, tid + 256 * i, g.M, kend);
+                rb[i] = load_vec_fast<T, B_KC>(B, g.ldb, n0, k0, tid + 256 * i, g.N, kend);
+            } else {
+                ra[i] = load_vec<T, A_KC>(A, g.lda, m0, k0, tid + 256 * i, g.M, g.K, kend, g.vecA);
+                rb[i] = load_vec<T, B_KC>(B, g.ldb, n0, k0, tid + 256 * i, g.N, g.K, kend, g.vecB);
+            }
         }
     };
     if (kbeg < kend) gload(kbeg);
@@ -164,41 +222,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     TC* C = (TC*)g.C + (long)batch * g.sC;
     const TC* R = g.residual ? (const TC*)g.residual + (long)batch * g.sC : nullptr;
     TC* AUX = g.aux ? (TC*)g.aux + (long)batch * g.sC : nullptr;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + acc_col(lane);
-            if (col >= g.N) continue;
-            const float bv = g.bias ? g.bias[col] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
-                if (row >= g.M) continue;
-                float v = acc[i][j][r] * g.alpha + bv;
-                if (g.act == TAN_ACT_QUICKGELU) {
-                    if (AUX) st_f(AUX + (long)row * g.ldaux + col, v);
-                    v = quick_gelu(v);
-                } else if (g.act == TAN_ACT_QUICKGELU_GRAD) {
-                    v *= quick_gelu_grad(ld_f(AUX + (long)row * g.ldaux + col));
-                }
-                if (R) v += ld_f(R + (long)row * g.ldr + col);
-                TC* cp = C + (long)row * g.ldc + col;
-                if (g.accumulate) unsafeAtomicAdd((float*)cp, v);
-                else st_f(cp, v);
-            }
-        }
+    if (m0 + BM <= g.M && n0 + BN <= g.N) gemm_epilogue<TC, false>(g, acc, C, R, AUX, m0, n0, wm, wn, lane);
+    else gemm_epilogue<TC, true>(g, acc, C, R, AUX, m0, n0, wm, wn, lane);
 }
 
 template <typename T, typename TC>
 static int launch_gemm(const tan_gemm_desc* d, const GemmArgs& a, dim3 grid, hipStream_t st) {
-    if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_kernel<T, TC, true, true>), grid, dim3(256), 0, st, a);
-    else if (d->a_kc && !d->b_kc) hipLaunchKernelGGL((gemm_kernel<T, TC, true, false>), grid, dim3(256), 0, st, a);
-    else if (!d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_kernel<T, TC, false, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_kernel<T, TC, false, false>), grid, dim3(256), 0, st, a);
+    const bool fast = a.fast != 0;
+#define TAN_GEMM_LAUNCH(AK, BK_, F) hipLaunchKernelGGL((gemm_kernel<T, TC, AK, BK_, F>), grid, dim3(256), 0, st, a)
+    if (d->a_kc && d->b_kc) { if (fast) TAN_GEMM_LAUNCH(true, true, true); else TAN_GEMM_LAUNCH(true, true, false); }
+    else if (d->a_kc && !d->b_kc) { if (fast) TAN_GEMM_LAUNCH(true, false, true); else TAN_GEMM_LAUNCH(true, false, false); }
+    else if (!d->a_kc && d->b_kc) { if (fast) TAN_GEMM_LAUNCH(false, true, true); else TAN_GEMM_LAUNCH(false, true, false); }
+    else { if (fast) TAN_GEMM_LAUNCH(false, false, true); else TAN_GEMM_LAUNCH(false, false, false); }
+#undef TAN_GEMM_LAUNCH
     TAN_LAUNCH_CHECK();
     return 0;
 }
+
+int gemm_glds_try(const tan_gemm_desc* d, hipStream_t st);   // tan_gemm_glds.hip
 
 }  // namespace tal
 
@@ -226,12 +267,15 @@ extern "C" int tan_gemm(const tan_gemm_desc* d, void* stream) {
     };
     a.vecA = vec_ok(d->A, d->lda, d->sA) && (a.kchunk % ve == 0);
     a.vecB = vec_ok(d->B, d->ldb, d->sB) && (a.kchunk % ve == 0);
+    // branch-free staging needs vectors that never straddle an edge
+    a.fast = a.vecA && a.vecB && (d->K % ve == 0) && (d->a_kc || d->M % ve == 0) && (d->b_kc || d->N % ve == 0);
     dim3 grid(cdiv(d->N, BN), cdiv(d->M, BM), d->batch * d->split_k);
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == TAN_F32) TAN_REQUIRE(d->out_dtype == TAN_F32);
     const int kind = (d->dtype == TAN_BF16 ? TAN_PROF_GEMM_BF16 : TAN_PROF_GEMM_F32) + (d->a_kc ? 0 : 2) + (d->b_kc ? 0 : 1);
     const int rec = prof_begin(st, kind, 2.0 * d->M * d->N * (double)d->K * d->batch);
-    int rc;
+    int rc = gemm_glds_try(d, st);            // aligned bf16: direct-to-LDS kernel
+    if (rc != -2) { prof_end(st, rec); return rc; }
     if (d->dtype == TAN_F32) rc = launch_gemm<float, float>(d, a, grid, st);
     else if (d->out_dtype == TAN_F32) rc = launch_gemm<bf16_t, float>(d, a, grid, st);
     else rc = launch_gemm<bf16_t, bf16_t>(d, a, grid, st);

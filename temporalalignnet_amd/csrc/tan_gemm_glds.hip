@@ -1,0 +1,205 @@
+// bf16 MFMA GEMM, direct-to-LDS edition (gfx950).  Fast path of tan_gemm for aligned bf16 problems whose contraction
+// length is a multiple of 64; everything else stays on the register-staged kernel in tan_gemm.hip.
+//
+//   * 128x128 block tile, 256 threads = 4 waves (2x2), 64x64 per wave = 2x2 v_mfma_f32_32x32x16_bf16 accumulators.
+//   * operands stream HBM -> LDS with global_load_lds_dwordx4 (16 B per lane, no VGPR round trip, no ds_write pass),
+//     two LDS buffers, ONE barrier per 64-deep K-step: the DMA of tile t+1 is in flight while tile t is multiplied.
+//   * the LDS destination of a DMA is lane-linear (wave base + lane*16), so bank conflicts are removed by permuting the
+//     per-lane SOURCE address and applying the same XOR when reading (cdna_hip_programming.md rule 21):
+//       K-contiguous operand  image [128 rows][8 x 16-B slots]   slot = chunk ^ ((row >> 1) & 7), read with ds_read_b128
+//       K-strided operand     image [64 k][16 x 16-B slots]      slot = chunk ^ ((k & 3) << 2),   read with
+//                             ds_read_b64_tr_b16 (hardware 4x16 transpose: 4 consecutive k of one column per lane)
+//     both read patterns are conflict-free (each 16/32-lane service group touches every bank once).
+//   * rows / columns past the edge of the problem are CLAMPED to a valid address instead of masked: they only feed
+//     accumulator rows / columns that the guarded epilogue never stores.
+#include <type_traits>
+
+#include "tan_mma.h"
+
+namespace tal {
+
+constexpr int GBM = 128, GBN = 128, GBK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;   // one operand tile, either orientation: 16 KiB
+
+struct GemmArgs2 {
+    const bf16_t* A; const bf16_t* B; void* C;
+    const float* bias; const void* residual; void* aux;
+    long lda, ldb, ldc, ldr, ldaux;
+    long sA, sB, sC;
+    int M, N, K;
+    int act, accumulate, split_k, kchunk;
+    float alpha;
+};
+
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+
+// DMA one operand tile (16 KiB = 16 wave-instructions of 1 KiB; each of the 4 waves issues 4)
+template <bool KC>
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ P, long ld, int outer0, int OUT, int k0, char* lds_tile,
+                                           int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave * 4 + i;             // 1-KiB piece index, wave-uniform
+        const bf16_t* src;
+        if (KC) {
+            const int row = piece * 8 + (lane >> 3), slot = lane & 7;
+            const int chunk = slot ^ ((row >> 1) & 7);
+            const int gr = min(outer0 + row, OUT - 1);
+            src = P + (long)gr * ld + k0 + chunk * 8;
+        } else {
+            const int k = piece * 4 + (lane >> 4), slot = lane & 15;
+            const int chunk = slot ^ ((k & 3) << 2);
+            const int go = min(outer0 + chunk * 8, OUT - 8);
+            src = P + (long)(k0 + k) * ld + go;
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + piece * 1024), 16, 0, 0);
+    }
+}
+
+// A- or B-operand fragment (lane: outer index o0 + (lane & 31), k = ks + 8 * (lane >> 5) .. + 7)
+template <bool KC>
+__device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int o0, int ks, int lane) {
+    if (KC) {
+        const int row = o0 + (lane & 31), chunk = (ks >> 3) + (lane >> 5);
+        const int slot = chunk ^ ((row >> 1) & 7);
+        return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + slot * 16);
+    } else {
+        const int g = lane >> 4, p = lane & 15, r = p >> 2, q = p & 3;
+        const int col = o0 + 16 * (g & 1) + 4 * q;           // first of the 4 columns this lane's 8 bytes cover
+        const int k = ks + 8 * (g >> 1) + r;                  // k & 3 == r
+        const int slot = (col >> 3) ^ (r << 2);
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4* lds_v4;
+        const char* p0 = lds_tile + k * 256 + slot * 16 + (q & 1) * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)p0);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p0 + 1024));   // +4 k-rows; (k+4)&3 == r: same slot
+        union { bf16x8 v; s16x4 h[2]; } u;
+        u.h[0] = lo; u.h[1] = hi;
+        return u.v;
+    }
+}
+
+template <typename TC, bool GUARD>
+__device__ __forceinline__ void epilogue2(const GemmArgs2& g, f32x16 (&acc)[2][2], TC* C, const TC* R, TC* AUX, int m0, int n0,
+                                          int wm, int wn, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + acc_col(lane);
+            if (GUARD && col >= g.N) continue;
+            const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+                if (GUARD && row >= g.M) continue;
+                float v = acc[i][j][r] * g.alpha + bv;
+                if (g.act == TAN_ACT_QUICKGELU) {
+                    if (AUX) st_f(AUX + (long)row * g.ldaux + col, v);
+                    v = quick_gelu(v);
+                } else if (g.act == TAN_ACT_QUICKGELU_GRAD) {
+                    v *= quick_gelu_grad(ld_f(AUX + (long)row * g.ldaux + col));
+                }
+                if (R) v += ld_f(R + (long)row * g.ldr + col);
+                TC* cp = C + (long)row * g.ldc + col;
+                if (g.accumulate) unsafeAtomicAdd((float*)cp, v);
+                else st_f(cp, v);
+            }
+        }
+}
+
+template <typename TC, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs2 g) {
+    __shared__ __attribute__((aligned(1024))) char lds[4 * TILE_BYTES];   // [buf][A|B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * GBN, m0 = blockIdx.y * GBM;
+    const int z = blockIdx.z, batch = z / g.split_k, split = z % g.split_k;
+    const bf16_t* A = g.A + (long)batch * g.sA;
+    const bf16_t* B = g.B + (long)batch * g.sB;
+    const int kbeg = split * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nt = (kend - kbeg) / GBK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
+
+    // One K-step: start the DMA of tile t+1 into the OTHER buffer, multiply tile t, then wait + barrier.  The two buffers
+    // are addressed with compile-time offsets (loop unrolled by two) so that the compiler can tell the DMA destination
+    // from the fragment reads; with a runtime buffer index it drains the DMA (s_waitcnt vmcnt(0)) before the first ds_read.
+    auto kstep = [&](int t, auto cur_c, auto nxt_c) {
+        constexpr int CUR = decltype(cur_c)::value, NXT = decltype(nxt_c)::value;
+        if (t + 1 < nt) {
+            const int k0 = kbeg + (t + 1) * GBK;
+            stage_tile<A_KC>(A, g.lda, m0, g.M, k0, lds + NXT * 2 * TILE_BYTES, wave, lane);
+            stage_tile<B_KC>(B, g.ldb, n0, g.N, k0, lds + NXT * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < GBK; ks += 16) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = load_frag<A_KC>(lds + CUR * 2 * TILE_BYTES, wm * 64 + i * 32, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = load_frag<B_KC>(lds + CUR * 2 * TILE_BYTES + TILE_BYTES, wn * 64 + j * 32, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    if (nt > 0) {
+        stage_tile<A_KC>(A, g.lda, m0, g.M, kbeg, lds, wave, lane);
+        stage_tile<B_KC>(B, g.ldb, n0, g.N, kbeg, lds + TILE_BYTES, wave, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nt; t += 2) {
+        kstep(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        if (t + 1 < nt) kstep(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    }
+
+    TC* C = (TC*)g.C + (long)batch * g.sC;
+    const TC* R = g.residual ? (const TC*)g.residual + (long)batch * g.sC : nullptr;
+    TC* AUX = g.aux ? (TC*)g.aux + (long)batch * g.sC : nullptr;
+    if (m0 + GBM <= g.M && n0 + GBN <= g.N) epilogue2<TC, false>(g, acc, C, R, AUX, m0, n0, wm, wn, lane);
+    else epilogue2<TC, true>(g, acc, C, R, AUX, m0, n0, wm, wn, lane);
+}
+
+template <typename TC>
+static int launch2(const tan_gemm_desc* d, const GemmArgs2& a, dim3 grid, hipStream_t st) {
+    if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_glds_kernel<TC, true, true>), grid, dim3(256), 0, st, a);
+    else if (d->a_kc && !d->b_kc) hipLaunchKernelGGL((gemm_glds_kernel<TC, true, false>), grid, dim3(256), 0, st, a);
+    else if (!d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_glds_kernel<TC, false, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_glds_kernel<TC, false, false>), grid, dim3(256), 0, st, a);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+// returns -2 when the problem is not eligible (caller falls back to the register-staged kernel)
+int gemm_glds_try(const tan_gemm_desc* d, hipStream_t st) {
+    if (d->dtype != TAN_BF16) return -2;
+    auto al = [](const void* p, long ld, long bs) { return ((uintptr_t)p % 16 == 0) && (ld % 8 == 0) && (bs % 8 == 0); };
+    if (!al(d->A, d->lda, d->sA) || !al(d->B, d->ldb, d->sB)) return -2;
+    if (d->K % GBK != 0) return -2;
+    if (!d->a_kc && (d->M % 8 != 0 || d->M < 8)) return -2;
+    if (!d->b_kc && (d->N % 8 != 0 || d->N < 8)) return -2;
+    GemmArgs2 a;
+    a.A = (const bf16_t*)d->A; a.B = (const bf16_t*)d->B; a.C = d->C; a.bias = d->bias; a.residual = d->residual; a.aux = d->aux;
+    a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.ldr = d->ldr; a.ldaux = d->ldaux;
+    a.sA = d->sA; a.sB = d->sB; a.sC = d->sC;
+    a.M = d->M; a.N = d->N; a.K = d->K;
+    a.act = d->act; a.accumulate = d->accumulate; a.split_k = d->split_k; a.alpha = d->alpha;
+    a.kchunk = (int)(((long)cdiv(cdiv(d->K, d->split_k), GBK)) * GBK);
+    dim3 grid(cdiv(d->N, GBN), cdiv(d->M, GBM), d->batch * d->split_k);
+    if (d->out_dtype == TAN_F32) return launch2<float>(d, a, grid, st);
+    return launch2<bf16_t>(d, a, grid, st);
+}
+
+}  // namespace tal

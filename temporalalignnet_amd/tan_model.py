@@ -197,7 +197,7 @@ class TemporalAligner(nn.Module):
         # reference registration order differs from construction order only for the two pos-embeds, which the
         # reference registers before the encoders' parameters appear in state_dict(); key *names* are what matter.
         self._flat = _Flat(self, [(n, p) for n, p in self.named_parameters() if not n.startswith("bert.")])
-        self._ln_ws = None
+        self._ws_pool = {}
 
     # ------------------------------------------------------------------ init (tan_model.py:76-97)
     def initialize_parameters(self):
@@ -323,13 +323,10 @@ class TemporalAligner(nn.Module):
     def _encoder_bwd(self, er, x0, keypad, post_name, d_stage, d_x0):
         cd, dev, R = x0.dtype, x0.device, er.R
         d = self._enc_desc(er, x0, keypad, post_name)
-        scr = _Blocks(cd, dev, {"dx": R * WIDTH, "dx2": R * WIDTH, "do": R * WIDTH, "dxn": R * WIDTH,
-                                "dh": R * 4 * WIDTH, "dqkv": R * 3 * WIDTH})
+        scr = self._take_scratch(R, cd, dev)       # stream-ordered reuse: one backward at a time per model
         d.scr_dx, d.scr_dx2, d.scr_do, d.scr_dxn = (_vp(scr[k]) for k in ("dx", "dx2", "do", "dxn"))
         d.scr_dh, d.scr_dqkv = _vp(scr["dh"]), _vp(scr["dqkv"])
-        n_ws = _lib.lib().tan_layernorm_bwd_ws_floats(C.c_int(WIDTH))
-        ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
-        d.ln_ws = _vp(ws)
+        d.ln_ws = _vp(scr.ln_ws)
         arr = (C.c_void_p * er.layers)(*[(t.data_ptr() if t is not None else None) for t in d_stage])
         d.d_stage = arr
         d.d_x0 = _vp(d_x0)
@@ -453,8 +450,36 @@ class TemporalAligner(nn.Module):
             return d_lang.float().view(B, N, Dt)
         return None
 
+    # Activation workspaces (~1 GB per stack at B=128) are pooled per shape: allocating them afresh every step costs
+    # tens of ms of hipMalloc/hipFree on the host.  A workspace is taken at forward and handed back after backward
+    # (or right after a no-grad forward, whose outputs never alias it).
+    def _take_ws(self, prefix, layers, B, L, cd, dev):
+        key = (prefix, layers, B, L, cd, dev)
+        pool = self._ws_pool.setdefault(key, [])
+        er = pool.pop() if pool else _EncRun(self, prefix, layers, B, L, cd, dev)
+        er.pool_key = key
+        return er
+
+    def _release_ws(self, er):
+        if er is not None and getattr(er, "pool_key", None) is not None:
+            pool = self._ws_pool.setdefault(er.pool_key, [])
+            if len(pool) < 2:
+                pool.append(er)
+            er.pool_key = None
+
+    def _take_scratch(self, R, cd, dev):
+        key = ("scr", R, cd, dev)
+        scr = self._ws_pool.get(key)
+        if scr is None:
+            scr = _Blocks(cd, dev, {"dx": R * WIDTH, "dx2": R * WIDTH, "do": R * WIDTH, "dxn": R * WIDTH,
+                                    "dh": R * 4 * WIDTH, "dqkv": R * 3 * WIDTH})
+            n_ws = _lib.lib().tan_layernorm_bwd_ws_floats(C.c_int(WIDTH))
+            scr.ln_ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+            self._ws_pool[key] = scr
+        return scr
+
     def _run_video_stack(self, x0, vmask_u8, B, T):
-        er = _EncRun(self, "video_temporal_encoder", self.num_encoder_layers, B, T, x0.dtype, x0.device)
+        er = self._take_ws("video_temporal_encoder", self.num_encoder_layers, B, T, x0.dtype, x0.device)
         self._encoder_fwd(er, x0, vmask_u8, "ln_video_post_enc")
         return er
 
@@ -470,7 +495,7 @@ class TemporalAligner(nn.Module):
             vm = vmask_u8 if vmask_u8 is not None else torch.zeros(B, T, dtype=torch.uint8, device=dev)
             tm = tmask_u8 if tmask_u8 is not None else torch.zeros(B, N, dtype=torch.uint8, device=dev)
             keypad = torch.cat([vm, tm], dim=1).contiguous()
-        er = _EncRun(self, "joint_temporal_encoder", self.num_decoder_layers, B, L, cd, dev)
+        er = self._take_ws("joint_temporal_encoder", self.num_decoder_layers, B, L, cd, dev)
         self._encoder_fwd(er, xj, keypad, "ln_joint_post_enc")
         er.xj, er.keypad = xj, keypad
         return er
@@ -535,6 +560,9 @@ class TemporalAligner(nn.Module):
             run["jt_raw"] = jt_raw
             outputs += [a_d.view(B, N, 1), a_j.view(Sd, B, N, 1).permute(1, 0, 2, 3)]
         run["outputs"] = outputs
+        if not opts.get("needs_grad", True):       # nothing will call backward: the stacks' workspaces are free again
+            self._release_ws(ev)
+            self._release_ws(ej)
         return run
 
     # ------------------------------------------------------------------ the HIP backward
@@ -650,6 +678,8 @@ class TemporalAligner(nn.Module):
         if d_lang_t is not None:
             d2 = self._text_embed_bwd(run["sv_text_t"], d_lang_t, need_d_lang)
             d_lang = d2 if d_lang is None else (d_lang + d2 if d2 is not None else d_lang)
+        self._release_ws(ev)
+        self._release_ws(ej)
         return d_lang
 
     # ------------------------------------------------------------------ public surface (tan_model.py:100-312)
@@ -663,8 +693,10 @@ class TemporalAligner(nn.Module):
                 interpolate_from=None, abs_text_pos=None):
         self._ensure_flat()
         f = self._flat
+        needs_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in f.params) or lang_embed.requires_grad)
         outs = _AlignerFn.apply(self, video_embed, lang_embed, self._mask_u8(video_padding_mask),
-                                self._mask_u8(lang_padding_mask), {"interpolate_from": interpolate_from}, *f.params)
+                                self._mask_u8(lang_padding_mask),
+                                {"interpolate_from": interpolate_from, "needs_grad": needs_grad}, *f.params)
         out = {"logits_dual": outs[0], "logits_joint": outs[1]}
         if self.return_dual_feature:
             out["dual_feature_video"], out["dual_feature_text"] = outs[2], outs[3]
@@ -682,7 +714,9 @@ class TemporalAligner(nn.Module):
         x0, _ = self._video_embed(video_c, self._draw(T, interpolate_from), interpolate_from, False)
         ev = self._run_video_stack(x0, self._mask_u8(video_padding_mask), B, T)
         S = self.num_encoder_layers
-        return torch.stack([ev.stage(s).view(B, T, WIDTH) for s in range(S)], dim=1).float()
+        out = torch.stack([ev.stage(s).view(B, T, WIDTH) for s in range(S)], dim=1).float()
+        self._release_ws(ev)
+        return out
 
     @torch.no_grad()
     def get_textual_feature(self, lang_embed):
@@ -715,6 +749,7 @@ class TemporalAligner(nn.Module):
         ej = self._run_joint_stack(x0, lt, self._mask_u8(video_padding_mask), self._mask_u8(lang_padding_mask), B, T, N)
         S, L = self.num_decoder_layers, T + N
         out = torch.stack([ej.stage(s).view(B, L, WIDTH) for s in range(S)], dim=1).float()
+        self._release_ws(ej)
         return out[:, :, :T], out[:, :, T:]
 
     @staticmethod
@@ -757,6 +792,7 @@ class TemporalAligner(nn.Module):
         for s in range(S):
             ops.l2norm_fwd(ej.stage(s), vn[s], None, B * T, WIDTH, T, L, 0)
             ops.l2norm_fwd(ej.stage(s), tn[s], None, B * N, WIDTH, N, L, T)
+        self._release_ws(ej)
         return self._within_sample_sim(vn, tn, S, B, T, N, True)
 
     get_text_visual_sim = get_text_visual_sim_joint   # alias needed by the released Twin constructor (tan_model.py:328)
@@ -777,6 +813,7 @@ class TemporalAligner(nn.Module):
         for s in range(S):
             ops.l2norm_fwd(ev.stage(s), vn[s], None, B * T, WIDTH)
         ops.l2norm_fwd(lang_raw, tn, None, B * N, WIDTH)
+        self._release_ws(ev)
         return self._within_sample_sim(vn, tn, S, B, T, N, False)
 
     @torch.no_grad()
@@ -791,6 +828,7 @@ class TemporalAligner(nn.Module):
         jt = torch.empty(S, B * N, WIDTH, dtype=cd, device=dev)
         for s in range(S):
             ops.rows_copy(ej.stage(s), jt[s], B, N, WIDTH, L, T, N, 0)
+        self._release_ws(ej)
         a_j = torch.empty(S, B * N, device=dev)
         ops.head_fwd(jt, w, b, a_j, S * B * N, WIDTH)
         return {"alignability-dual": a_d.view(B, N, 1), "alignability-joint": a_j.view(S, B, N, 1).permute(1, 0, 2, 3)}

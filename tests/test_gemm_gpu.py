@@ -76,3 +76,26 @@ def test_gemm_splitk_accumulate_and_batch(dtype):
     ops.gemm(V, T_, out, M=R, N=Mp, K=Cc, batch=S, sA=R * Cc, sB=Mp * Cc, sC=R * Mp)
     ref = torch.einsum("src,smc->srm", V.double(), T_.double())
     assert (out.double() - ref).abs().max().item() < (1e-3 if dtype == torch.float32 else 0.5)
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("M,N,K", [(8192, 512, 512), (1000, 1536, 512), (520, 2048, 2048), (512, 512, 10240), (136, 40, 64)])
+def test_gemm_direct_to_lds_path(a_kc, b_kc, M, N, K):
+    """aligned bf16 problems (K % 64 == 0) take the global_load_lds kernel: check every operand orientation, edge tiles,
+    split-K accumulation and the fused epilogues against an fp64 reference on asymmetric random data."""
+    from temporalalignnet_amd import ops
+    dtype = torch.bfloat16
+    A = _mk((M, K) if a_kc else (K, M), dtype, 11)
+    B = _mk((N, K) if b_kc else (K, N), dtype, 12)
+    ref = (A if a_kc else A.t()).double() @ (B.t() if b_kc else B).double()
+    tol = 2e-2 * max(1.0, (K / 512) ** 0.5) * (ref.abs().max().item() + 1.0)
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=dtype)
+    ops.gemm(A, B, out, M=M, N=N, K=K, a_kc=a_kc, b_kc=b_kc)
+    assert (out.double() - ref).abs().max().item() < tol
+    acc = torch.ones(M, N, device="cuda", dtype=torch.float32)
+    ops.gemm(A, B, acc, M=M, N=N, K=K, a_kc=a_kc, b_kc=b_kc, accumulate=True, split_k=2 if K >= 128 else 1)
+    assert (acc.double() - ref - 1).abs().max().item() < 2e-3 * (ref.abs().max().item() + 1.0)
+    bias = _mk((N,), torch.float32, 13)
+    res = _mk((M, N), dtype, 14)
+    ops.gemm(A, B, out, M=M, N=N, K=K, a_kc=a_kc, b_kc=b_kc, bias=bias, residual=res)
+    assert (out.double() - (ref + bias.double() + res.double())).abs().max().item() < tol
