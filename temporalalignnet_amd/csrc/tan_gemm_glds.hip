@@ -27,7 +27,7 @@ struct GemmArgs2 {
     long lda, ldb, ldc, ldr, ldaux;
     long sA, sB, sC;
     int M, N, K;
-    int act, accumulate, split_k, kchunk;
+    int act, accumulate, split_k, kchunk, vec_epi;
     float alpha;
 };
 
@@ -109,6 +109,79 @@ __device__ __forceinline__ void epilogue2(const GemmArgs2& g, f32x16 (&acc)[2][2
         }
 }
 
+// Vectorised epilogue: the 128x128 f32 tile is parked in the (now idle) 64 KiB of LDS, then every thread finishes 8 rows x
+// 8 adjacent columns with 16-byte loads of aux / residual and 16-byte stores -- instead of 64 scattered 2-byte accesses
+// per lane, each behind its own branch and wait.  Needs N % 8 == 0 and 16-byte aligned C / residual / aux rows.
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+    uint4 u;
+    u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = u;
+}
+__device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+template <typename TC>
+__device__ __forceinline__ void epilogue_vec(const GemmArgs2& g, f32x16 (&acc)[2][2], float* tile, TC* C, const TC* R, TC* AUX,
+                                             int m0, int n0, int wm, int wn, int lane, int tid) {
+    // phase 1: accumulators (+ alpha, bias) -> LDS tile [128][128] f32
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int lc = wn * 64 + j * 32 + acc_col(lane);
+            const int gc = min(n0 + lc, g.N - 1);
+            const float bv = g.bias ? g.bias[gc] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[(wm * 64 + i * 32 + acc_row(r, lane)) * 128 + lc] = acc[i][j][r] * g.alpha + bv;
+        }
+    __syncthreads();
+    // phase 2: 8 rows x 8 columns per thread, 16-byte global accesses
+    const int cv = (tid & 15) * 8, col = n0 + cv;
+    if (col >= g.N) return;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int lr = (tid >> 4) + 16 * p, row = m0 + lr;
+        if (row >= g.M) break;
+        float v[8];
+        {
+            const float4 a = *reinterpret_cast<const float4*>(tile + lr * 128 + cv);
+            const float4 b = *reinterpret_cast<const float4*>(tile + lr * 128 + cv + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        }
+        if (g.act == TAN_ACT_QUICKGELU) {
+            if (AUX) st8(AUX + (long)row * g.ldaux + col, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = quick_gelu(v[e]);
+        } else if (g.act == TAN_ACT_QUICKGELU_GRAD) {
+            float x[8];
+            ld8(AUX + (long)row * g.ldaux + col, x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= quick_gelu_grad(x[e]);
+        }
+        if (R) {
+            float x[8];
+            ld8(R + (long)row * g.ldr + col, x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += x[e];
+        }
+        st8(C + (long)row * g.ldc + col, v);
+    }
+}
+
 template <typename TC, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs2 g) {
     __shared__ __attribute__((aligned(1024))) char lds[4 * TILE_BYTES];   // [buf][A|B]
@@ -168,7 +241,8 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs2 g) {
     TC* C = (TC*)g.C + (long)batch * g.sC;
     const TC* R = g.residual ? (const TC*)g.residual + (long)batch * g.sC : nullptr;
     TC* AUX = g.aux ? (TC*)g.aux + (long)batch * g.sC : nullptr;
-    if (m0 + GBM <= g.M && n0 + GBN <= g.N) epilogue2<TC, false>(g, acc, C, R, AUX, m0, n0, wm, wn, lane);
+    if (g.vec_epi) epilogue_vec<TC>(g, acc, reinterpret_cast<float*>(lds), C, R, AUX, m0, n0, wm, wn, lane, tid);
+    else if (m0 + GBM <= g.M && n0 + GBN <= g.N) epilogue2<TC, false>(g, acc, C, R, AUX, m0, n0, wm, wn, lane);
     else epilogue2<TC, true>(g, acc, C, R, AUX, m0, n0, wm, wn, lane);
 }
 
@@ -197,6 +271,10 @@ int gemm_glds_try(const tan_gemm_desc* d, hipStream_t st) {
     a.M = d->M; a.N = d->N; a.K = d->K;
     a.act = d->act; a.accumulate = d->accumulate; a.split_k = d->split_k; a.alpha = d->alpha;
     a.kchunk = (int)(((long)cdiv(cdiv(d->K, d->split_k), GBK)) * GBK);
+    const int oe = d->out_dtype == TAN_F32 ? 4 : 2;
+    auto al16 = [&](const void* p, long ld) { return !p || (((uintptr_t)p % 16 == 0) && ((ld * oe) % 16 == 0)); };
+    a.vec_epi = !d->accumulate && d->N % 8 == 0 && al16(d->C, d->ldc) && al16(d->residual, d->ldr) && al16(d->aux, d->ldaux) &&
+                ((d->sC * oe) % 16 == 0);
     dim3 grid(cdiv(d->N, GBN), cdiv(d->M, GBM), d->batch * d->split_k);
     if (d->out_dtype == TAN_F32) return launch2<float>(d, a, grid, st);
     return launch2<bf16_t>(d, a, grid, st);
