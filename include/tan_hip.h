@@ -31,6 +31,8 @@ extern "C" {
 #define TAN_ACT_QUICKGELU_GRAD 2 /* C = acc * d/dx quickgelu(x), x read from aux */
 
 int tan_version(void);
+/* sizeof(tan_gemm_desc | tan_layer_params | tan_layer_bufs | tan_encoder_desc) for which = 0..3 (binding self-check) */
+int tan_abi_sizeof(int which);
 
 /* Optional in-stream kernel timer (bench.py's `roofline` line): while enabled every tan_gemm / tan_attn_* launch is
  * bracketed by hipEvents on its own stream.  tan_prof_collect synchronises and returns per kind the summed duration

@@ -33,6 +33,17 @@ using namespace tal;
 
 extern "C" int tan_version(void) { return 100; }
 
+// sizeof of the ABI structs, so that a binding (ctypes, cgo, JNI ...) can assert its mirror has the same layout
+extern "C" int tan_abi_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(tan_gemm_desc);
+        case 1: return (int)sizeof(tan_layer_params);
+        case 2: return (int)sizeof(tan_layer_bufs);
+        case 3: return (int)sizeof(tan_encoder_desc);
+        default: return TAN_ERR_BAD_ARG;
+    }
+}
+
 // Profiling hook (the library's only process-global state; off by default).  While enabled, every tan_gemm /
 // tan_attn_* launch is bracketed by hipEvents on ITS OWN stream; tan_prof_collect synchronises those events and
 // returns, per kernel kind, the summed duration [ms], the summed algorithmic work [flop] and the launch count.

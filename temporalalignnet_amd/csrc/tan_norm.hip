@@ -116,19 +116,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
 }
 
-// 256 threads = 64 columns x 4 row-slices; each block owns 64 consecutive entries of the [2][C] partial tables
+// 256 threads = 16 columns x 16 slices of the partial list; each block owns 16 consecutive entries of the [2][C] tables
 __global__ __launch_bounds__(256) void ln_bwd_finalize(const float* __restrict__ ws, int nblk, int C, float* __restrict__ dgamma,
                                                        float* __restrict__ dbeta) {
-    __shared__ float red[4][64];
-    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + col;          // index into [2][C]
+    __shared__ float red[16][17];
+    const int col = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + col;          // index into [2][C]
     float s = 0.f;
     if (idx < 2 * C)
-        for (int b = part; b < nblk; b += 4) s += ws[(long)b * 2 * C + idx];
+        for (int b = part; b < nblk; b += 16) s += ws[(long)b * 2 * C + idx];
     red[part][col] = s;
     __syncthreads();
     if (part == 0 && idx < 2 * C) {
-        s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        s = 0.f;
+#pragma unroll
+        for (int y = 0; y < 16; ++y) s += red[y][col];
         const int which = idx / C, c = idx % C;
         float* out = which == 0 ? dgamma : dbeta;
         if (out) out[c] += s;
@@ -188,32 +190,37 @@ __global__ __launch_bounds__(256) void l2n_bwd_kernel(const T* __restrict__ dy, 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// column sum (bias gradients): out[c] += sum_r x[r][c].  Each thread owns 4 adjacent columns (one 8/16-byte load per
-// row), a block covers 256 columns x rows_per_block rows, 4 row loads in flight per thread; one atomic per column/block.
+// column sum (bias gradients): out[c] += sum_r x[r][c].  A 256-thread block covers `rows_per_block` rows: TPR = C/8
+// threads span one row with 16-byte loads (8 bf16 / 2x4 f32), the remaining 256/TPR thread groups take alternate rows;
+// partial sums meet in LDS and leave as one atomic per column per block.
 template <typename T>
-__global__ __launch_bounds__(64) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long rows, int C,
-                                                    int rows_per_block) {
-    const int c = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long rows, int C,
+                                                     int rows_per_block, int tpr) {
+    __shared__ float red[256 * 8];
+    const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr, ny = 256 / tpr;
     const long r0 = (long)blockIdx.y * rows_per_block;
     const long r1 = min(rows, r0 + rows_per_block);
-    float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0;
-    long r = r0;
-    for (; r + 4 <= r1; r += 4) {
-        const float4 a = ld4(x + r * C + c), b = ld4(x + (r + 1) * C + c), d = ld4(x + (r + 2) * C + c), e = ld4(x + (r + 3) * C + c);
-        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-        s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
-        s2.x += d.x; s2.y += d.y; s2.z += d.z; s2.w += d.w;
-        s3.x += e.x; s3.y += e.y; s3.z += e.z; s3.w += e.w;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const int c = (blockIdx.x * tpr + tx) * 8;
+    if (c < C && ty < ny) {
+        for (long r = r0 + ty; r < r1; r += ny) {
+            const float4 a = ld4(x + r * C + c), b = ld4(x + r * C + c + 4);
+            acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+            acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+        }
     }
-    for (; r < r1; ++r) {
-        const float4 a = ld4(x + r * C + c);
-        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = acc[e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < tpr * 8; i += 256) {
+        const int cx = i / 8, e = i % 8, col = (blockIdx.x * tpr + cx) * 8 + e;
+        if (col >= C) continue;
+        float s = 0.f;
+        for (int y = 0; y < ny; ++y) s += red[(y * tpr + cx) * 8 + e];
+        unsafeAtomicAdd(out + col, s);
     }
-    unsafeAtomicAdd(out + c + 0, (s0.x + s1.x) + (s2.x + s3.x));
-    unsafeAtomicAdd(out + c + 1, (s0.y + s1.y) + (s2.y + s3.y));
-    unsafeAtomicAdd(out + c + 2, (s0.z + s1.z) + (s2.z + s3.z));
-    unsafeAtomicAdd(out + c + 3, (s0.w + s1.w) + (s2.w + s3.w));
 }
 
 // grouped row copy / add: dst[(g*dgs + doff + r)*C + c] (=|+=) src[(g*sgs + soff + r)*C + c]
@@ -380,7 +387,7 @@ extern "C" int tan_layernorm_bwd(const void* dy, const void* x, const float* gam
                                                          (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, ws, rows)));
     TAN_LAUNCH_CHECK();
     if (dgamma || dbeta) {
-        hipLaunchKernelGGL(ln_bwd_finalize, dim3(cdiv(2 * C, 64)), dim3(256), 0, st, ws, nblk, C, dgamma, dbeta);
+        hipLaunchKernelGGL(ln_bwd_finalize, dim3(cdiv(2 * C, 16)), dim3(256), 0, st, ws, nblk, C, dgamma, dbeta);
         TAN_LAUNCH_CHECK();
     }
     return 0;
@@ -408,11 +415,14 @@ extern "C" int tan_l2norm_bwd(const void* dy, const void* y, const float* inv_no
 }
 
 extern "C" int tan_colsum_acc(const void* x, float* out, long rows, int C, int dtype, void* stream) {
-    TAN_REQUIRE(x && out && rows > 0 && C > 0 && C % 4 == 0);
+    TAN_REQUIRE(x && out && rows > 0 && C > 0 && C % 8 == 0);
     hipStream_t st = (hipStream_t)stream;
-    const int rpb = 32;
-    dim3 grid(cdiv(C, 256), cdiv(rows, rpb));
-    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(64), 0, st, (const T*)x, out, rows, C, rpb));
+    int tpr = C / 8;                      // threads spanning one row
+    if (tpr > 256) tpr = 256;
+    while (256 % tpr) --tpr;              // must divide the block
+    const int rpb = 16 * (256 / tpr);     // 16 rows per thread group
+    dim3 grid(cdiv(C, tpr * 8), cdiv(rows, rpb));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, st, (const T*)x, out, rows, C, rpb, tpr));
     TAN_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,61 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/tan_hip.h declares (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+from temporalalignnet_amd import _lib
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _lib.declared_symbols()
+    assert len(names) >= 30 and "tan_gemm" in names and "tan_encoder_bwd" in names
+    L = _lib.lib()
+    for n in names:
+        assert getattr(L, n) is not None, n
+    assert L.tan_version() >= 100
+
+
+def test_ctypes_mirrors_have_the_c_layout():
+    L = _lib.lib()
+    assert L.tan_abi_sizeof(0) == C.sizeof(_lib.GemmDesc)
+    assert L.tan_abi_sizeof(1) == C.sizeof(_lib.LayerParams)
+    assert L.tan_abi_sizeof(2) == C.sizeof(_lib.LayerBufs)
+    assert L.tan_abi_sizeof(3) == C.sizeof(_lib.EncoderDesc)
+
+
+def test_bad_arguments_are_rejected_without_touching_a_device():
+    L = _lib.lib()
+    d = _lib.GemmDesc()            # all-null descriptor
+    assert L.tan_gemm(C.byref(d), None) == -1
+    assert L.tan_layernorm_fwd(None, None, None, None, None, None, None, 0, C.c_long(4), 512, C.c_float(1e-5), 0, None) == -1
+    assert L.tan_masked_quantile(None, None, 5, C.c_float(0.3), None, None) == -1
+
+
+def test_header_cites_reference_lines_and_has_no_torch_types():
+    src = open(os.path.join(ROOT, "include", "tan_hip.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)          # declarations only
+    assert "torch" not in code.lower() and "at::" not in code and "Tensor" not in code
+    assert len(re.findall(r"(tan_model|tfm_model|loss|main)\.py:\d+", src)) >= 15
+
+
+def test_product_has_no_cpu_fallback():
+    """The HIP path must fail loudly on CPU tensors instead of silently computing elsewhere."""
+    import pytest
+    import torch
+    from temporalalignnet_amd.tan_model import TemporalAligner
+    m = TemporalAligner(1, 1, language_model=None)
+    with pytest.raises(_lib.TanHipError):
+        m(torch.zeros(1, 4, 1024), torch.zeros(1, 2, 512), torch.zeros(1, 4).bool(), torch.zeros(1, 2).bool(), None)
+    from temporalalignnet_amd import ops
+    with pytest.raises(_lib.TanHipError):
+        ops.layernorm_fwd(torch.zeros(4, 512), torch.ones(512), torch.zeros(512), torch.zeros(4, 512))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "temporalalignnet_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
