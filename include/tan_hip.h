@@ -42,7 +42,8 @@ int tan_abi_sizeof(int which);
 #define TAN_PROF_GEMM_F32 4
 #define TAN_PROF_ATTN_FWD 8
 #define TAN_PROF_ATTN_BWD 9
-#define TAN_PROF_NKINDS 10
+#define TAN_PROF_SIMNCE 10
+#define TAN_PROF_NKINDS 11
 int tan_prof_enable(int on, int max_records);
 int tan_prof_collect(double* ms_by_kind, double* work_by_kind, long* count_by_kind, int nkinds);
 
@@ -138,14 +139,18 @@ int tan_nce_fwd(const float* logits, const float* tgt, const unsigned char* col_
 int tan_nce_bwd(const float* logits, const float* tgt, const unsigned char* col_invalid, const unsigned char* row_leak,
                 const float* rowsum, const float* colsum, const float* possum_v, const float* possum_t, const float* g_v,
                 const float* g_t, void* dlogits, int out_dtype, int S, int B, int T, int N, void* stream);
-/* self-labelling scan, loss.py:88-143 (joint) / 146-179 (dual): two-way softmax (over texts, /0.07, over time) of the
+/* `blocks`: the last-stage same-video logit blocks; element (b,t,n) at blocks[b*block_stride + t*row_stride + n].  For
+ * materialised stage-major logits: blocks = logits + (S-1)*R*Mp, block_stride = T*Mp + N, row_stride = Mp; for a compact
+ * [B,T,N] tensor: T*N and N.
+ * self-labelling scan, loss.py:88-143 (joint) / 146-179 (dual): two-way softmax (over texts, /0.07, over time) of the
  * last-stage same-video logits, sliding-window mean with window length dur[b,n] (0 = padded text), first-index argmax.
  * Outputs max_pos [B,N] int32, max_prob/max_logit [B,N] f32, self_tgt [B,N,T] bytes (the chosen window).            */
-int tan_selflabel(const float* logits, const unsigned char* video_pad, const unsigned char* text_pad, const float* dur,
-                  int* max_pos, float* max_prob, float* max_logit, unsigned char* self_tgt, int S, int B, int T, int N,
-                  void* stream);
-/* out[b,n] = max_t logits[S-1,(b,t),(b,n)] / 0.07   (loss.py:280,283) */
-int tan_diag_max(const float* logits, const unsigned char* row_leak, float* out, int S, int B, int T, int N, void* stream);
+int tan_selflabel(const float* blocks, long block_stride, long row_stride, const unsigned char* video_pad,
+                  const unsigned char* text_pad, const float* dur, int* max_pos, float* max_prob, float* max_logit,
+                  unsigned char* self_tgt, int B, int T, int N, void* stream);
+/* out[b,n] = max_t block(b,t,n) / 0.07   (loss.py:280,283) */
+int tan_diag_max(const float* blocks, long block_stride, long row_stride, const unsigned char* row_leak, float* out, int B, int T,
+                 int N, void* stream);
 /* IoU of the two self-labelled windows, confidence, target policy kind (0 'i', 1 'u', 2 'keep', 3 'keep-joint') and the
  * per-frame first-text de-duplication with restore, loss.py:181-226.  q_joint/q_dual: device scalars (0.3-quantiles of
  * the max logits).  tgt_out [B,T,N] f32, iou [B,N] f32, conf [B,N] bytes.  N <= 64.                                 */
@@ -154,6 +159,21 @@ int tan_agreement(const unsigned char* joint_tgt, const unsigned char* dual_tgt,
                   int kind, float* tgt_out, float* iou, unsigned char* conf, int B, int T, int N, void* stream);
 /* torch.quantile(x[~invalid], q) ('linear' interpolation, at::lerp rounding) without a host sync; n <= 8192 */
 int tan_masked_quantile(const float* x, const unsigned char* invalid, int n, float q, float* out, void* stream);
+
+/* ---- logits-free similarity + NCE (bf16 features) ---------------------------------------------------------------
+ * Fused replacement of einsum (tan_model.py:118,138) + NCE terms (loss.py:240-253): vn [S,R,C], tn [S or 1,Mp,C] unit
+ * features (t_stage_stride = Mp*C, or 0 when the text features are shared by all stages), other arguments as tan_nce_fwd.
+ * One workgroup sweeps a 128-row panel of one stage over all text columns; logits only ever exist as MFMA accumulators.
+ * tan_simnce_bwd_dl recomputes them and writes d loss/d logits [S,R,Mp] in bf16 for the two follow-up tan_gemm calls.
+ * ws: tan_simnce_ws_floats() f32 scratch.  Requires C % 64 == 0, B*N <= 2048.                                           */
+long tan_simnce_ws_floats(int S, int B, int T, int N);
+int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
+                   const unsigned char* row_leak, float* rowsum, float* colsum, float* possum_v, float* possum_t,
+                   float* v_terms, float* t_terms, float* ws, int S, int B, int T, int N, int C, void* stream);
+int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
+                      const unsigned char* row_leak, const float* rowsum, const float* colsum, const float* possum_v,
+                      const float* possum_t, const float* g_v, const float* g_t, void* dl, float* ws, int S, int B, int T, int N,
+                      int C, void* stream);
 
 /* ---- fused AdamW (+ EMA twin, + bf16 shadow weights) over one flat f32 parameter buffer ---------------------
  * torch.optim.AdamW single-tensor arithmetic (train/main.py:397, groups of main.py:330-356) followed by

@@ -131,20 +131,20 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ 
 //   p1      = softmax_n z ; prob = softmax_t (p1 / 0.07)                                           (loss.py:104)
 //   window i of text n covers [i, i+dur_n) if it fits in [0,T), minus frames 0 and T-1, uniform     (loss.py:112-131)
 //   scan[i] = mean of prob over the window ; max_pos = first argmax_i ; max_logit = window mean of z (loss.py:133-141)
-__global__ __launch_bounds__(256) void selflabel_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ vpad,
+__global__ __launch_bounds__(256) void selflabel_kernel(const float* __restrict__ blocks, long sb, long st, const unsigned char* __restrict__ vpad,
                                                         const unsigned char* __restrict__ tpad, const float* __restrict__ dur,
                                                         int* __restrict__ max_pos, float* __restrict__ max_prob,
                                                         float* __restrict__ max_logit, unsigned char* __restrict__ self_tgt,
-                                                        int S, int B, int T, int N) {
+                                                        int B, int T, int N) {
     extern __shared__ float sm[];
     float* z = sm;               // [T][N]
     float* p = z + T * N;        // [T][N]
-    const int b = blockIdx.x, R = B * T, Mp = B * N;
+    const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* blk = logits + ((long)(S - 1) * R + (long)b * T) * Mp + (long)b * N;
+    const float* blk = blocks + (long)b * sb;            // same-video block of the last stage: element (t, n) at blk[t*st + n]
     for (int i = threadIdx.x; i < T * N; i += 256) {
         const int t = i / N, n = i % N;
-        float v = blk[(long)t * Mp + n] / TAU;
+        float v = blk[(long)t * st + n] / TAU;
         if (vpad && vpad[b * T + t]) v = FILL;
         if (tpad[b * N + n]) v = FILL;
         z[i] = v;
@@ -211,14 +211,14 @@ __global__ __launch_bounds__(256) void selflabel_kernel(const float* __restrict_
 }
 
 // per-text max over time of the last-stage same-video logits / 0.07 (loss.py:280,283)
-__global__ void diag_max_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ row_leak,
-                                float* __restrict__ out, int S, int B, int T, int N) {
+__global__ void diag_max_kernel(const float* __restrict__ blocks, long sb, long st, const unsigned char* __restrict__ row_leak,
+                                float* __restrict__ out, int B, int T, int N) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * N) return;
-    const int b = i / N, n = i % N, R = B * T, Mp = B * N;
-    const float* col = logits + ((long)(S - 1) * R + (long)b * T) * Mp + (long)b * N + n;
+    const int b = i / N, n = i % N;
+    const float* col = blocks + (long)b * sb + n;
     float m = -INFINITY;
-    for (int t = 0; t < T; ++t) m = fmaxf(m, (row_leak && row_leak[b * T + t]) ? FILL : col[(long)t * Mp] / TAU);
+    for (int t = 0; t < T; ++t) m = fmaxf(m, (row_leak && row_leak[b * T + t]) ? FILL : col[(long)t * st] / TAU);
     out[i] = m;
 }
 
@@ -374,21 +374,23 @@ extern "C" int tan_nce_bwd(const float* logits, const float* tgt, const unsigned
     return 0;
 }
 
-extern "C" int tan_selflabel(const float* logits, const unsigned char* video_pad, const unsigned char* text_pad, const float* dur,
-                             int* max_pos, float* max_prob, float* max_logit, unsigned char* self_tgt, int S, int B, int T, int N,
-                             void* stream) {
-    TAN_REQUIRE(logits && text_pad && dur && max_pos && max_prob && max_logit && self_tgt && S > 0 && B > 0 && T > 0 && N > 0);
+extern "C" int tan_selflabel(const float* blocks, long block_stride, long row_stride, const unsigned char* video_pad,
+                             const unsigned char* text_pad, const float* dur, int* max_pos, float* max_prob, float* max_logit,
+                             unsigned char* self_tgt, int B, int T, int N, void* stream) {
+    TAN_REQUIRE(blocks && text_pad && dur && max_pos && max_prob && max_logit && self_tgt && B > 0 && T > 0 && N > 0);
     const size_t sm = (size_t)2 * T * N * 4;
     TAN_REQUIRE(sm <= 64 * 1024);
-    hipLaunchKernelGGL(selflabel_kernel, dim3(B), dim3(256), sm, (hipStream_t)stream, logits, video_pad, text_pad, dur, max_pos,
-                       max_prob, max_logit, self_tgt, S, B, T, N);
+    hipLaunchKernelGGL(selflabel_kernel, dim3(B), dim3(256), sm, (hipStream_t)stream, blocks, block_stride, row_stride, video_pad, text_pad, dur,
+                       max_pos, max_prob, max_logit, self_tgt, B, T, N);
     TAN_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int tan_diag_max(const float* logits, const unsigned char* row_leak, float* out, int S, int B, int T, int N, void* stream) {
-    TAN_REQUIRE(logits && out && S > 0 && B > 0 && T > 0 && N > 0);
-    hipLaunchKernelGGL(diag_max_kernel, dim3(cdiv((long)B * N, 128)), dim3(128), 0, (hipStream_t)stream, logits, row_leak, out, S, B, T, N);
+extern "C" int tan_diag_max(const float* blocks, long block_stride, long row_stride, const unsigned char* row_leak, float* out, int B,
+                            int T, int N, void* stream) {
+    TAN_REQUIRE(blocks && out && B > 0 && T > 0 && N > 0);
+    hipLaunchKernelGGL(diag_max_kernel, dim3(cdiv((long)B * N, 128)), dim3(128), 0, (hipStream_t)stream, blocks, block_stride, row_stride, row_leak,
+                       out, B, T, N);
     TAN_LAUNCH_CHECK();
     return 0;
 }

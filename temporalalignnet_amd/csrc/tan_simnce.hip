@@ -1,0 +1,358 @@
+// Logits-free similarity + multi-positive NCE (gfx950, bf16 features).
+//
+// The reference materialises cosine logits [B,S,T,B,N] (tan_model.py:118,138; 403 MB f32 per tensor at B=128,N=16) and then
+// makes several passes over them (clone / masked fill / two logsumexp per direction, loss.py:240-275).  Here one workgroup
+// owns a 128-row panel of one stage and sweeps ALL text columns: every 128x128 logit tile is produced by the direct-to-LDS
+// MFMA pipeline of tan_gemm_glds.hip and consumed in registers.
+//
+//   MODE_STATS : e = exp(l/0.07 - 1/0.07); row sums (valid columns) stay in registers across the sweep, column sums go to LDS
+//                atomics, positives (same-video entries with tgt=1) likewise  ->  rowsum, possum_v, colpart, pospart
+//   MODE_DL    : recomputes the tile and writes d loss / d logit (bf16) for the two follow-up GEMMs (d v_hat, d t_hat)
+//
+// so the forward never writes logits, and the backward writes them once in bf16 instead of f32 + cast.
+#include <type_traits>
+
+#include "tan_mma.h"
+
+namespace tal {
+
+constexpr float S_TAU = 0.07f;
+constexpr int S_TILE = 128 * 64 * 2;  // 16 KiB operand tile
+constexpr int S_MAXCOLS = 2048;       // B*N limit of the fused path (LDS column accumulators)
+
+typedef const void __attribute__((address_space(1)))* sgptr_t;
+typedef void __attribute__((address_space(3)))* slptr_t;
+
+struct SimArgs {
+    const bf16_t* V;      // [S, R, C] unit video features
+    const bf16_t* Tt;     // [S or 1, Mp, C] unit text features
+    long t_stage_stride;  // Mp*C or 0
+    const float* tgt;     // [B, T, N] {0,1}
+    const unsigned char* col_invalid;  // [Mp]
+    const unsigned char* row_leak;     // [R] or null
+    float *rowsum, *possum_v;          // [S, R]
+    float *colpart, *pospart;          // [panels, S, Mp]   (MODE_STATS out)
+    const float *colsum, *possum_t;    // [S, Mp]           (MODE_DL in)
+    const float *g_v, *g_t;            // [S, R], [S, Mp]   (MODE_DL in)
+    bf16_t* dl;                        // [S, R, Mp]        (MODE_DL out)
+    int S, B, T, N, C, R, Mp;
+};
+
+// K-contiguous 128-row operand tile, same image as tan_gemm_glds.hip (slot = chunk ^ ((row >> 1) & 7))
+__device__ __forceinline__ void s_stage(const bf16_t* __restrict__ P, long ld, int outer0, int OUT, int k0, char* lds_tile,
+                                        int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave * 4 + i;
+        const int row = piece * 8 + (lane >> 3), slot = lane & 7;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        const int gr = min(outer0 + row, OUT - 1);
+        __builtin_amdgcn_global_load_lds((sgptr_t)(P + (long)gr * ld + k0 + chunk * 8), (slptr_t)(lds_tile + piece * 1024), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ bf16x8 s_frag(const char* lds_tile, int o0, int ks, int lane) {
+    const int row = o0 + (lane & 31), chunk = (ks >> 3) + (lane >> 5);
+    return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + (chunk ^ ((row >> 1) & 7)) * 16);
+}
+
+struct TileCtx {
+    const unsigned char* col_invalid;
+    const float* colsum; const float* g_t; bf16_t* dl;
+    int R, Mp, s, m0, wm, wn, lane;
+    float inv_tau;
+};
+
+// consume one finished 128x128 logit tile (column tile ct) straight from the accumulators.  Positives and the padded-frame
+// quirk only touch the same-video blocks and are handled by simnce_diag_kernel on separately computed [S,B,T,N] blocks, so
+// this hot loop carries no target lookups.
+template <int MODE>
+__device__ __forceinline__ void tile_done(const TileCtx& c, f32x16 (&acc)[2][2], float (&rowacc)[2][16], float* colacc, int ct) {
+    const int c0 = ct * 128, R = c.R, Mp = c.Mp, lane = c.lane;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = c0 + c.wn * 64 + j * 32 + acc_col(lane);
+        const bool col_ok = col < Mp;
+        const bool col_valid = col_ok && !c.col_invalid[min(col, Mp - 1)];
+        float csum = 0.f, bc = 0.f;
+        if (MODE == 1) {
+            const long idx = (long)c.s * Mp + min(col, Mp - 1);
+            const float gt = c.g_t[idx], cs = c.colsum[idx];
+            bc = col_ok ? gt / cs * c.inv_tau : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c.m0 + c.wm * 64 + i * 32 + acc_row(r, lane);
+                float e = __expf((acc[i][j][r] - 1.0f) * c.inv_tau);
+                if (!col_ok || row >= R) e = 0.f;
+                if (MODE == 0) {
+                    if (col_valid) rowacc[i][r] += e;
+                    csum += e;
+                } else {
+                    const float g = e * ((col_valid ? rowacc[i][r] : 0.f) + bc);
+                    if (col_ok && row < R) c.dl[((long)c.s * R + row) * Mp + col] = f2bf(g);
+                }
+            }
+        if (MODE == 0 && col_ok) atomicAdd(&colacc[col], csum);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void simnce_kernel(SimArgs a) {
+    // ONE static LDS object (4 operand tiles, then colacc[S_MAXCOLS], posacc[S_MAXCOLS]): with a dynamic (extern) array hipcc
+    // cannot tell the DMA destination from the fragment reads and drains the DMA before every ds_read.
+    __shared__ __attribute__((aligned(1024))) char lds[4 * S_TILE + (MODE == 0 ? S_MAXCOLS * 4 : 0)];
+    float* colacc = reinterpret_cast<float*>(lds + 4 * S_TILE);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int panel = blockIdx.x, s = blockIdx.y, m0 = panel * 128;
+    const int R = a.R, Mp = a.Mp, Cw = a.C, nS = a.S;
+    const bf16_t* V = a.V + (long)s * R * Cw;
+    const bf16_t* Tt = a.Tt + (long)s * a.t_stage_stride;
+    const int nk = Cw / 64, nct = (Mp + 127) / 128, nsteps = nct * nk;
+    const float inv_tau = 1.0f / S_TAU;
+
+    if (MODE == 0) {
+        for (int c = tid; c < S_MAXCOLS; c += 256) colacc[c] = 0.f;
+    }
+    // per-lane row bookkeeping: this lane's 32 rows are m0 + wm*64 + i*32 + acc_row(r, lane)
+    float rowacc[2][16];      // MODE_STATS: running row sums; MODE_DL: gv/rowsum/tau
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            rowacc[i][r] = 0.f;
+            if (MODE == 1) {      // clamped, unconditional loads (a conditional load costs a branch + s_waitcnt each)
+                const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+                const long idx = (long)s * R + min(row, R - 1);
+                const float gv = a.g_v[idx], rs = a.rowsum[idx];
+                rowacc[i][r] = row < R ? gv / rs * inv_tau : 0.f;
+            }
+        }
+    TileCtx c;
+    c.col_invalid = a.col_invalid; c.colsum = a.colsum; c.g_t = a.g_t; c.dl = a.dl;
+    c.R = R; c.Mp = Mp; c.s = s; c.m0 = m0; c.wm = wm; c.wn = wn; c.lane = lane; c.inv_tau = inv_tau;
+
+    f32x16 acc[2][2];
+    // One K-step of the flattened (column tile, k) sweep.  Buffer offsets are compile-time (two copies of the body).
+#define SIM_KSTEP(STEP, CUR, NXT)                                                                                          \
+    {                                                                                                                      \
+        const int step_ = (STEP);                                                                                          \
+        const int ct_ = step_ / nk, kt_ = step_ - ct_ * nk;                                                                \
+        if (step_ + 1 < nsteps) {                                                                                          \
+            const int ct2 = (step_ + 1) / nk, kt2 = (step_ + 1) - ct2 * nk;                                                \
+            s_stage(V, Cw, m0, R, kt2 * 64, lds + (NXT) * 2 * S_TILE, wave, lane);                                         \
+            s_stage(Tt, Cw, ct2 * 128, Mp, kt2 * 64, lds + (NXT) * 2 * S_TILE + S_TILE, wave, lane);                       \
+        }                                                                                                                  \
+        if (kt_ == 0) {                                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]); \
+        }                                                                                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 64; ks += 16) {                                                            \
+            bf16x8 af[2], bfr[2];                                                                                          \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) af[i] = s_frag(lds + (CUR) * 2 * S_TILE, wm * 64 + i * 32, ks, lane); \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                  \
+                bfr[j] = s_frag(lds + (CUR) * 2 * S_TILE + S_TILE, wn * 64 + j * 32, ks, lane);                            \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                    \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);                    \
+        }                                                                                                                  \
+        if (kt_ == nk - 1) tile_done<MODE>(c, acc, rowacc, colacc, ct_);                                   \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                   \
+        __syncthreads();                                                                                                   \
+    }
+
+    s_stage(V, Cw, m0, R, 0, lds, wave, lane);
+    s_stage(Tt, Cw, 0, Mp, 0, lds + S_TILE, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int step = 0; step < nsteps; step += 2) {
+        SIM_KSTEP(step, 0, 1)
+        if (step + 1 < nsteps) SIM_KSTEP(step + 1, 1, 0)
+    }
+#undef SIM_KSTEP
+
+    if (MODE == 0) {
+        // row sums: reduce over the 32 lanes that share a row (same lane >> 5), then over the two column waves via atomics
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = rowacc[i][r];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+                if ((lane & 31) == 0 && row < R) unsafeAtomicAdd(a.rowsum + (long)s * R + row, v);
+            }
+        __syncthreads();
+        float* cp = a.colpart + ((long)panel * nS + s) * Mp;
+        for (int cc = tid; cc < Mp; cc += 256) cp[cc] = colacc[cc];
+    }
+}
+
+// colsum[s,c] = sum over row panels of colpart
+__global__ void simnce_col_finalize(const float* __restrict__ colpart, float* __restrict__ colsum, int npanel, long SM) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= SM) return;
+    float s = 0.f;
+    for (int k = 0; k < npanel; ++k) s += colpart[(long)k * SM + i];
+    colsum[i] = s;
+}
+
+// Same-video blocks diag[s,b,t,n] (separately computed cosines): positives (loss.py:73-76) and the padded-frame quirk
+// (loss.py:96-101: those entries read -6e4, i.e. e = 0).  One block per (video, stage).
+//   DL = false: possum_v / possum_t, and the leaked e's are taken back out of rowsum / colsum
+//   DL = true : dl -= e (gv/possum_v [valid col] + gt/possum_t) / tau on positives; dl = 0 on leaked entries
+template <bool DL>
+__global__ __launch_bounds__(256) void simnce_diag_kernel(const float* __restrict__ diag, const float* __restrict__ tgt,
+                                                          const unsigned char* __restrict__ col_invalid,
+                                                          const unsigned char* __restrict__ row_leak, float* __restrict__ rowsum,
+                                                          float* __restrict__ colsum, float* __restrict__ possum_v,
+                                                          float* __restrict__ possum_t, const float* __restrict__ g_v,
+                                                          const float* __restrict__ g_t, bf16_t* __restrict__ dl, int B, int T, int N) {
+    const int b = blockIdx.x, s = blockIdx.y;
+    const int R = B * T, Mp = B * N;
+    const float inv_tau = 1.0f / S_TAU;
+    const float* blk = diag + ((long)s * B + b) * T * N;
+    const float* tg = tgt + (long)b * T * N;
+    if (!DL) {
+        for (int t = threadIdx.x; t < T; t += 256) {
+            const bool leak = row_leak && row_leak[b * T + t];
+            float acc = 0.f, lost = 0.f;
+            for (int k = 0; k < N; ++k) {
+                const float e = __expf((blk[t * N + k] - 1.0f) * inv_tau);
+                const bool valid = !col_invalid[b * N + k];
+                if (leak) { if (valid) lost += e; }
+                else if (tg[t * N + k] != 0.f && valid) acc += e;
+            }
+            possum_v[(long)s * R + b * T + t] = acc;
+            if (leak) rowsum[(long)s * R + b * T + t] -= lost;
+        }
+        for (int k = threadIdx.x; k < N; k += 256) {
+            float acc = 0.f, lost = 0.f;
+            for (int t = 0; t < T; ++t) {
+                const float e = __expf((blk[t * N + k] - 1.0f) * inv_tau);
+                if (row_leak && row_leak[b * T + t]) lost += e;
+                else if (tg[t * N + k] != 0.f) acc += e;
+            }
+            possum_t[(long)s * Mp + b * N + k] = acc;
+            if (lost != 0.f) colsum[(long)s * Mp + b * N + k] -= lost;
+        }
+    } else {
+        for (int i = threadIdx.x; i < T * N; i += 256) {
+            const int t = i / N, k = i - t * N;
+            const long r = (long)s * R + b * T + t, c = (long)s * Mp + b * N + k;
+            bf16_t* out = dl + r * Mp + b * N + k;
+            if (row_leak && row_leak[b * T + t]) { *out = 0; continue; }
+            if (tg[i] == 0.f) continue;
+            const float e = __expf((blk[i] - 1.0f) * inv_tau);
+            const bool valid = !col_invalid[b * N + k];
+            float corr = 0.f;
+            if (valid && possum_v[r] > 0.f) corr += g_v[r] / possum_v[r];
+            if (possum_t[c] > 0.f) corr += g_t[c] / possum_t[c];
+            *out = f2bf(bf2f(*out) - e * corr * inv_tau);
+        }
+    }
+}
+
+__global__ void simnce_terms(const float* __restrict__ allsum, const float* __restrict__ possum, float* __restrict__ terms, long n,
+                             float log_count) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float shift = 1.0f / S_TAU;
+    const float den = logf(allsum[i]) + shift;
+    const float num = possum[i] > 0.f ? logf(possum[i]) + shift : -6e4f + log_count;
+    terms[i] = den - num;
+}
+
+}  // namespace tal
+
+using namespace tal;
+
+extern "C" long tan_simnce_ws_floats(int S, int B, int T, int N) {
+    const long R = (long)B * T, Mp = (long)B * N;
+    return (long)cdiv(R, 128) * S * Mp + (long)S * B * T * N;     // column partials + same-video blocks
+}
+
+static int simnce_common(SimArgs& a, int S, int B, int T, int N, int C) {
+    a.S = S; a.B = B; a.T = T; a.N = N; a.C = C; a.R = B * T; a.Mp = B * N;
+    if (S <= 0 || B <= 0 || T <= 0 || N <= 0 || C <= 0 || C % 64 != 0) return TAN_ERR_BAD_ARG;
+    if (((uintptr_t)a.V % 16) || ((uintptr_t)a.Tt % 16)) return TAN_ERR_BAD_ARG;
+    if (a.Mp > S_MAXCOLS) return TAN_ERR_BAD_ARG;
+    return 0;
+}
+
+// same-video cosine blocks diag[s,b,t,n] = <vn[s,b*T+t], tn[s,b*N+n]> through the ordinary GEMM (batch = S*B... per stage)
+static int simnce_diag_blocks(const SimArgs& a, float* diag, hipStream_t st) {
+    for (int s = 0; s < a.S; ++s) {
+        tan_gemm_desc d{};
+        d.dtype = TAN_BF16; d.out_dtype = TAN_F32;
+        d.M = a.T; d.N = a.N; d.K = a.C; d.a_kc = 1; d.b_kc = 1;
+        d.A = a.V + (long)s * a.R * a.C; d.lda = a.C;
+        d.B = a.Tt + (long)s * a.t_stage_stride; d.ldb = a.C;
+        d.C = diag + (long)s * a.B * a.T * a.N; d.ldc = a.N;
+        d.split_k = 1; d.alpha = 1.0f;
+        d.batch = a.B; d.sA = (long)a.T * a.C; d.sB = (long)a.N * a.C; d.sC = (long)a.T * a.N;
+        int rc = tan_gemm(&d, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// v_terms / t_terms of loss.py:240-253 straight from unit features (no logits); sums are kept for tan_simnce_bwd_dl.
+extern "C" int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
+                              const unsigned char* row_leak, float* rowsum, float* colsum, float* possum_v, float* possum_t,
+                              float* v_terms, float* t_terms, float* ws, int S, int B, int T, int N, int C, void* stream) {
+    TAN_REQUIRE(vn && tn && tgt && col_invalid && rowsum && colsum && possum_v && possum_t && v_terms && t_terms && ws);
+    SimArgs a{};
+    a.V = (const bf16_t*)vn; a.Tt = (const bf16_t*)tn; a.t_stage_stride = t_stage_stride;
+    a.tgt = tgt; a.col_invalid = col_invalid; a.row_leak = row_leak;
+    a.rowsum = rowsum; a.possum_v = possum_v;
+    int rc = simnce_common(a, S, B, T, N, C);
+    if (rc) return rc;
+    const int npanel = cdiv(a.R, 128);
+    a.colpart = ws;
+    float* diag = ws + (long)npanel * S * a.Mp;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(rowsum, 0, sizeof(float) * (size_t)S * a.R, st);
+    if (e != hipSuccess) return (int)e;
+    const int prec = prof_begin(st, TAN_PROF_SIMNCE, 2.0 * S * a.R * (double)a.Mp * C);
+    hipLaunchKernelGGL((simnce_kernel<0>), dim3(npanel, S), dim3(256), 0, st, a);
+    prof_end(st, prec);
+    TAN_LAUNCH_CHECK();
+    const long SM = (long)S * a.Mp, SR = (long)S * a.R;
+    hipLaunchKernelGGL(simnce_col_finalize, dim3(cdiv(SM, 256)), dim3(256), 0, st, a.colpart, colsum, npanel, SM);
+    if ((rc = simnce_diag_blocks(a, diag, st))) return rc;
+    hipLaunchKernelGGL((simnce_diag_kernel<false>), dim3(B, S), dim3(256), 0, st, diag, tgt, col_invalid, row_leak, rowsum, colsum,
+                       possum_v, possum_t, (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, B, T, N);
+    hipLaunchKernelGGL(simnce_terms, dim3(cdiv(SR, 256)), dim3(256), 0, st, rowsum, possum_v, v_terms, SR, logf((float)a.Mp));
+    hipLaunchKernelGGL(simnce_terms, dim3(cdiv(SM, 256)), dim3(256), 0, st, colsum, possum_t, t_terms, SM, logf((float)a.R));
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+// d loss / d logits [S, R, Mp] in bf16 from upstream g_v [S,R], g_t [S,Mp] (recomputes every logit tile); ws as in fwd
+extern "C" int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_stride, const float* tgt,
+                                 const unsigned char* col_invalid, const unsigned char* row_leak, const float* rowsum,
+                                 const float* colsum, const float* possum_v, const float* possum_t, const float* g_v, const float* g_t,
+                                 void* dl, float* ws, int S, int B, int T, int N, int C, void* stream) {
+    TAN_REQUIRE(vn && tn && tgt && col_invalid && rowsum && colsum && possum_v && possum_t && g_v && g_t && dl && ws);
+    SimArgs a{};
+    a.V = (const bf16_t*)vn; a.Tt = (const bf16_t*)tn; a.t_stage_stride = t_stage_stride;
+    a.tgt = tgt; a.col_invalid = col_invalid; a.row_leak = row_leak;
+    a.rowsum = (float*)rowsum; a.possum_v = (float*)possum_v; a.colsum = colsum; a.possum_t = possum_t;
+    a.g_v = g_v; a.g_t = g_t; a.dl = (bf16_t*)dl;
+    int rc = simnce_common(a, S, B, T, N, C);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    float* diag = ws + (long)cdiv(a.R, 128) * S * a.Mp;
+    const int prec = prof_begin(st, TAN_PROF_SIMNCE, 2.0 * S * a.R * (double)a.Mp * C);
+    hipLaunchKernelGGL((simnce_kernel<1>), dim3(cdiv(a.R, 128), S), dim3(256), 0, st, a);
+    prof_end(st, prec);
+    TAN_LAUNCH_CHECK();
+    if ((rc = simnce_diag_blocks(a, diag, st))) return rc;
+    hipLaunchKernelGGL((simnce_diag_kernel<true>), dim3(B, S), dim3(256), 0, st, diag, tgt, col_invalid, row_leak, (float*)rowsum,
+                       (float*)colsum, (float*)possum_v, (float*)possum_t, g_v, g_t, (bf16_t*)dl, B, T, N);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}

@@ -99,14 +99,31 @@ class _NCEFn(torch.autograd.Function):
         return dl, None, None, None, None, None, None
 
 
-def _selflabel(lg, vpad_u8, tpad_u8, dur, B, T, N):
-    S, dev = lg.shape[0], lg.device
+class _Blocks:
+    """Last-stage same-video logit blocks: element (b,t,n) at base[b*sb + t*st + n] (see include/tan_hip.h)."""
+
+    def __init__(self, tensor, offset_elems, sb, st):
+        self.tensor, self.ptr, self.sb, self.st = tensor, C.c_void_p(tensor.data_ptr() + 4 * offset_elems), sb, st
+
+    @staticmethod
+    def of_logits(lg, B, T, N):           # stage-major [S, R, Mp]
+        S, R, Mp = lg.shape
+        return _Blocks(lg, (S - 1) * R * Mp, T * Mp + N, Mp)
+
+    @staticmethod
+    def of_diag(diag):                    # compact [B, T, N]
+        B, T, N = diag.shape
+        return _Blocks(diag, 0, T * N, N)
+
+
+def _selflabel(blk, vpad_u8, tpad_u8, dur, B, T, N):
+    dev = blk.tensor.device
     max_pos = torch.empty(B, N, dtype=torch.int32, device=dev)
     max_prob, max_logit = torch.empty(B, N, device=dev), torch.empty(B, N, device=dev)
     self_tgt = torch.empty(B, N, T, dtype=torch.uint8, device=dev)
-    _lib.check(_lib.lib().tan_selflabel(_p(lg), _p(vpad_u8), _p(tpad_u8), _p(dur), _p(max_pos), _p(max_prob), _p(max_logit),
-                                        _p(self_tgt), C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N), ops._stream()),
-               "tan_selflabel")
+    _lib.check(_lib.lib().tan_selflabel(blk.ptr, C.c_long(blk.sb), C.c_long(blk.st), _p(vpad_u8), _p(tpad_u8), _p(dur),
+                                        _p(max_pos), _p(max_prob), _p(max_logit), _p(self_tgt), C.c_int(B), C.c_int(T),
+                                        C.c_int(N), ops._stream()), "tan_selflabel")
     return {"max_pos": max_pos, "max_prob": max_prob, "max_logit": max_logit, "tgt": self_tgt}
 
 
@@ -117,11 +134,75 @@ def _quantile(x, invalid_u8, q):
     return out
 
 
-def _diag_max(lg, row_leak, B, T, N):
-    out = torch.empty(B * N, device=lg.device)
-    _lib.check(_lib.lib().tan_diag_max(_p(lg), _p(row_leak), _p(out), C.c_int(lg.shape[0]), C.c_int(B), C.c_int(T), C.c_int(N),
-                                       ops._stream()), "tan_diag_max")
+def _diag_max(blk, row_leak, B, T, N):
+    out = torch.empty(B * N, device=blk.tensor.device)
+    _lib.check(_lib.lib().tan_diag_max(blk.ptr, C.c_long(blk.sb), C.c_long(blk.st), _p(row_leak), _p(out), C.c_int(B), C.c_int(T),
+                                       C.c_int(N), ops._stream()), "tan_diag_max")
     return out
+
+
+class FusedSim:
+    """What a fused forward hands to get_loss instead of materialised logits: unit features (autograd-connected) of the
+    dual and joint paths, stage-major.  vn [S,R,C], tn [1 or S, Mp, C] in the model's compute dtype (bf16)."""
+
+    def __init__(self, vn_d, tn_d, vn_j, tn_j, B, T, N):
+        self.vn_d, self.tn_d, self.vn_j, self.tn_j, self.B, self.T, self.N = vn_d, tn_d, vn_j, tn_j, B, T, N
+
+    def diag_blocks(self, which):
+        """[B,T,N] f32 last-stage same-video cosine logits (all that self-labelling / thresholding read of the B^2 tensor)."""
+        vn, tn = (self.vn_d, self.tn_d) if which == "dual" else (self.vn_j, self.tn_j)
+        B, T, N, Cw = self.B, self.T, self.N, vn.shape[-1]
+        out = torch.empty(B, T, N, device=vn.device)
+        ops.gemm(vn.detach()[-1], tn.detach()[-1], out, M=T, N=N, K=Cw, batch=B, sA=T * Cw, sB=N * Cw, sC=T * N)
+        return out
+
+
+class _FusedNCEFn(torch.autograd.Function):
+    """_NCEFn without the logits: tan_simnce_fwd / tan_simnce_bwd_dl + the two d-feature GEMMs."""
+
+    @staticmethod
+    def forward(ctx, vn, tn, tgt, col_invalid, row_leak, B, T, N):
+        S, R, Cw = vn.shape
+        Mp, dev = B * N, vn.device
+        shared = tn.shape[0] == 1
+        stats = torch.empty(2 * S * R + 2 * S * Mp, device=dev)
+        rowsum, possum_v = stats[:S * R], stats[S * R:2 * S * R]
+        colsum, possum_t = stats[2 * S * R:2 * S * R + S * Mp], stats[2 * S * R + S * Mp:]
+        v_terms, t_terms = torch.empty(S, R, device=dev), torch.empty(S, Mp, device=dev)
+        L = _lib.lib()
+        ws = torch.empty(L.tan_simnce_ws_floats(C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N)), device=dev)
+        _lib.check(L.tan_simnce_fwd(_p(vn), _p(tn), C.c_long(0 if shared else Mp * Cw), _p(tgt), _p(col_invalid), _p(row_leak),
+                                    _p(rowsum), _p(colsum), _p(possum_v), _p(possum_t), _p(v_terms), _p(t_terms), _p(ws),
+                                    C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N), C.c_int(Cw), ops._stream()), "tan_simnce_fwd")
+        ctx.saved = (vn, tn, tgt, col_invalid, row_leak, rowsum, colsum, possum_v, possum_t, ws)
+        ctx.dims = (S, B, T, N, Cw, shared)
+        return v_terms, t_terms
+
+    @staticmethod
+    def backward(ctx, g_v, g_t):
+        vn, tn, tgt, col_invalid, row_leak, rowsum, colsum, possum_v, possum_t, ws = ctx.saved
+        S, B, T, N, Cw, shared = ctx.dims
+        R, Mp, dev = B * T, B * N, vn.device
+        g_v = torch.zeros(S, R, device=dev) if g_v is None else g_v.contiguous()
+        g_t = torch.zeros(S, Mp, device=dev) if g_t is None else g_t.contiguous()
+        dl = torch.empty(S, R, Mp, dtype=torch.bfloat16, device=dev)
+        _lib.check(_lib.lib().tan_simnce_bwd_dl(_p(vn), _p(tn), C.c_long(0 if shared else Mp * Cw), _p(tgt), _p(col_invalid),
+                                                _p(row_leak), _p(rowsum), _p(colsum), _p(possum_v), _p(possum_t), _p(g_v),
+                                                _p(g_t), _p(dl), _p(ws), C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N),
+                                                C.c_int(Cw), ops._stream()), "tan_simnce_bwd_dl")
+        d_vn = torch.empty_like(vn)
+        ops.gemm(dl, tn, d_vn, M=R, N=Cw, K=Mp, a_kc=True, b_kc=False, lda=Mp, ldb=Cw, batch=S, sA=R * Mp,
+                 sB=0 if shared else Mp * Cw, sC=R * Cw)
+        if shared:       # one text feature for every stage: contract over (stage, row) in a single split-K GEMM
+            acc = torch.zeros(Mp, Cw, device=dev)
+            ops.gemm(dl, vn, acc, M=Mp, N=Cw, K=S * R, a_kc=False, b_kc=False, lda=Mp, ldb=Cw, accumulate=True,
+                     split_k=max(1, min(32, S * R // 512)))
+            d_tn = ops.cast(acc, torch.empty(1, Mp, Cw, dtype=tn.dtype, device=dev))
+        else:
+            d_tn = torch.empty_like(tn)
+            ops.gemm(dl, vn, d_tn, M=Mp, N=Cw, K=R, a_kc=False, b_kc=False, lda=Mp, ldb=Cw, batch=S, sA=R * Mp, sB=R * Cw,
+                     sC=Mp * Cw)
+        return d_vn, d_tn, None, None, None, None, None, None
 
 
 def _masked_mean(x, mask_f):
@@ -135,13 +216,18 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
     if args.sim != "cos":
         raise NotImplementedError("HIP get_loss supports sim='cos' only (the model only emits cosine logits)")
     cotrain = args.model == "cotrain"
-    dev = logits["logits_dual"].device
+    fused = logits.get("_fused")                    # FusedSim from TemporalAligner.forward(..., fused=True)
+    dev = fused.vn_d.device if fused is not None else logits["logits_dual"].device
     if dev.type != "cuda":
         raise _lib.TanHipError("get_loss needs device tensors: the HIP path has no CPU fallback")
     B, T, _ = video_seq.shape
     N = text_embed.shape[1]
     R, Mp = B * T, B * N
-    lg_d, lg_j = _stage_major(logits["logits_dual"]), _stage_major(logits["logits_joint"])
+    if fused is None:
+        lg_d, lg_j = _stage_major(logits["logits_dual"]), _stage_major(logits["logits_joint"])
+        blk_d, blk_j = _Blocks.of_logits(lg_d.detach(), B, T, N), _Blocks.of_logits(lg_j.detach(), B, T, N)
+    else:
+        blk_d = blk_j = None                        # built lazily from the features below
     tpad = text_padding_mask.to(dev).bool()
     tpad_u8 = tpad.to(torch.uint8).contiguous()
     vpad = video_padding_mask.to(dev).bool()
@@ -156,8 +242,17 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
     row_leak = None
     if args.learn_agreement:
         with torch.no_grad():
-            src_j = _stage_major(logits["ema-logits_joint"]) if cotrain else lg_j.detach()
-            src_d = _stage_major(logits["ema-logits_dual"]) if cotrain else lg_d.detach()
+            ema_fused = logits.get("ema-_fused") if cotrain else None
+            if cotrain and ema_fused is not None:
+                src_j, src_d = _Blocks.of_diag(ema_fused.diag_blocks("joint")), _Blocks.of_diag(ema_fused.diag_blocks("dual"))
+            elif cotrain:
+                src_j = _Blocks.of_logits(_stage_major(logits["ema-logits_joint"]), B, T, N)
+                src_d = _Blocks.of_logits(_stage_major(logits["ema-logits_dual"]), B, T, N)
+            elif fused is not None:
+                blk_j, blk_d = _Blocks.of_diag(fused.diag_blocks("joint")), _Blocks.of_diag(fused.diag_blocks("dual"))
+                src_j, src_d = blk_j, blk_d
+            else:
+                src_j, src_d = blk_j, blk_d
             dur = tgt_raw.sum(-1).float().clamp(min=1.0).masked_fill(tpad, 0.0).contiguous()         # loss.py:113-115
             J = _selflabel(src_j, vpad_u8, tpad_u8, dur, B, T, N)
             D = _selflabel(src_d, vpad_u8, tpad_u8, dur, B, T, N)
@@ -185,16 +280,22 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
     rows_pos = (tgt_valid.sum(-1) > 0).view(R).float()                                                # loss.py:236
     cols_pos = ((tgt.sum(1) > 0).view(Mp) & valid).float()                                            # loss.py:237
 
-    v_d, t_d = _NCEFn.apply(lg_d, tgt, tpad_u8.view(Mp), row_leak, B, T, N)
-    v_j, t_j = _NCEFn.apply(lg_j, tgt, tpad_u8.view(Mp), row_leak, B, T, N)
+    if fused is None:
+        v_d, t_d = _NCEFn.apply(lg_d, tgt, tpad_u8.view(Mp), row_leak, B, T, N)
+        v_j, t_j = _NCEFn.apply(lg_j, tgt, tpad_u8.view(Mp), row_leak, B, T, N)
+    else:
+        v_d, t_d = _FusedNCEFn.apply(fused.vn_d, fused.tn_d, tgt, tpad_u8.view(Mp), row_leak, B, T, N)
+        v_j, t_j = _FusedNCEFn.apply(fused.vn_j, fused.tn_j, tgt, tpad_u8.view(Mp), row_leak, B, T, N)
     loss_dual = (_masked_mean(v_d, rows_pos) + _masked_mean(t_d, cols_pos)) / 2
     loss_joint = (_masked_mean(v_j, rows_pos) + _masked_mean(t_j, cols_pos)) / 2
     out["loss-dual"], out["loss-joint"] = loss_dual.detach(), loss_joint.detach()
 
     if args.loss_threshold > 0 or args.use_alignability_head:
         with torch.no_grad():
-            md = _diag_max(lg_d.detach(), row_leak, B, T, N)                                          # loss.py:280
-            mj = _diag_max(lg_j.detach(), row_leak, B, T, N)                                          # loss.py:283
+            if blk_d is None:
+                blk_j, blk_d = _Blocks.of_diag(fused.diag_blocks("joint")), _Blocks.of_diag(fused.diag_blocks("dual"))
+            md = _diag_max(blk_d, row_leak, B, T, N)                                                  # loss.py:280
+            mj = _diag_max(blk_j, row_leak, B, T, N)                                                  # loss.py:283
             n_valid = valid_f.sum()
 
             def zscore(x):

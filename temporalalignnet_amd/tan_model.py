@@ -538,13 +538,19 @@ class TemporalAligner(nn.Module):
         for s in range(Sd):
             ops.l2norm_fwd(ej.stage(s), vn_j[s], inv["vj"][s * R:(s + 1) * R], R, Cw, T, L, 0)
             ops.l2norm_fwd(ej.stage(s), tn_j[s], inv["tj"][s * Mp:(s + 1) * Mp], Mp, Cw, N, L, T)
-        # cosine logits, stage-major [S, R, Mp] f32; the reference layout [B,S,T,B,N] is a permuted view (tan_model.py:118,138)
-        lg_d = torch.empty(Se, R, Mp, device=dev)
-        lg_j = torch.empty(Sd, R, Mp, device=dev)
-        ops.gemm(vn_d, tn_d, lg_d, M=R, N=Mp, K=Cw, batch=Se, sA=R * Cw, sB=0, sC=R * Mp)
-        ops.gemm(vn_j, tn_j, lg_j, M=R, N=Mp, K=Cw, batch=Sd, sA=R * Cw, sB=Mp * Cw, sC=R * Mp)
-        outputs = [lg_d.view(Se, B, T, B, N).permute(1, 0, 2, 3, 4), lg_j.view(Sd, B, T, B, N).permute(1, 0, 2, 3, 4),
-                   vn_d.view(Se, B, T, Cw).permute(1, 0, 2, 3), tn_d.view(B, N, Cw)]
+        if opts.get("fused"):
+            # logits-free mode: hand the unit features to get_loss (tan_simnce_* never materialises [S,R,Mp])
+            outputs = [vn_d.view(Se, B, T, Cw).permute(1, 0, 2, 3), tn_d.view(B, N, Cw), vn_j, tn_j]
+            names = ["vn_d", "tn_d", "vn_j", "tn_j"]
+        else:
+            # cosine logits, stage-major [S, R, Mp] f32; the reference layout [B,S,T,B,N] is a permuted view (tan_model.py:118,138)
+            lg_d = torch.empty(Se, R, Mp, device=dev)
+            lg_j = torch.empty(Sd, R, Mp, device=dev)
+            ops.gemm(vn_d, tn_d, lg_d, M=R, N=Mp, K=Cw, batch=Se, sA=R * Cw, sB=0, sC=R * Mp)
+            ops.gemm(vn_j, tn_j, lg_j, M=R, N=Mp, K=Cw, batch=Sd, sA=R * Cw, sB=Mp * Cw, sC=R * Mp)
+            outputs = [lg_d.view(Se, B, T, B, N).permute(1, 0, 2, 3, 4), lg_j.view(Sd, B, T, B, N).permute(1, 0, 2, 3, 4),
+                       vn_d.view(Se, B, T, Cw).permute(1, 0, 2, 3), tn_d.view(B, N, Cw)]
+            names = ["lg_d", "lg_j", "vn_d", "tn_d"]
         run = {"B": B, "T": T, "N": N, "ev": ev, "ej": ej, "x0": x0, "x0j": x0j, "sv_video": sv_video,
                "sv_video_j": sv_video_j, "sv_text": sv_text, "sv_text_t": sv_text_t, "lang_raw": lang_raw, "lang_t": lang_t,
                "vn_d": vn_d, "vn_j": vn_j, "tn_d": tn_d, "tn_j": tn_j, "inv": inv, "vmask": vmask_u8, "tmask": tmask_u8}
@@ -559,7 +565,8 @@ class TemporalAligner(nn.Module):
             ops.head_fwd(jt_raw, w, b, a_j, Sd * Mp, Cw)
             run["jt_raw"] = jt_raw
             outputs += [a_d.view(B, N, 1), a_j.view(Sd, B, N, 1).permute(1, 0, 2, 3)]
-        run["outputs"] = outputs
+            names += ["a_d", "a_j"]
+        run["outputs"], run["names"] = outputs, names
         if not opts.get("needs_grad", True):       # nothing will call backward: the stacks' workspaces are free again
             self._release_ws(ev)
             self._release_ws(ej)
@@ -573,9 +580,10 @@ class TemporalAligner(nn.Module):
         cd, dev = self.compute_dtype, run["x0"].device
         Se, Sd, Cw = self.num_encoder_layers, self.num_decoder_layers, WIDTH
         R, Mp, L = B * T, B * N, T + N
-        g_ld, g_lj, g_vn, g_tn = grads[0], grads[1], grads[2], grads[3]
-        g_ad = grads[4] if self.use_alignability_head else None
-        g_aj = grads[5] if self.use_alignability_head else None
+        gd = dict(zip(run["names"], grads))
+        g_ld, g_lj, g_vn, g_tn = gd.get("lg_d"), gd.get("lg_j"), gd.get("vn_d"), gd.get("tn_d")
+        g_vnj, g_tnj = gd.get("vn_j"), gd.get("tn_j")
+        g_ad, g_aj = gd.get("a_d"), gd.get("a_j")
 
         def stage_major(g, S):
             """[B,S,T,B,N] grad -> contiguous [S,R,Mp] in compute dtype (zero-copy when it is our own permuted buffer)."""
@@ -618,6 +626,7 @@ class TemporalAligner(nn.Module):
             ops.l2norm_bwd(d_tn_d, run["tn_d"], inv["td"], d_lang_raw, Mp, Cw)
             have_lang_raw = True
         # ---- joint similarity: logits_j[s] = vn_j[s] tn_j[s]^T
+        d_vn_j = d_tn_j = None
         if g_lj is not None:
             dl = stage_major(g_lj, Sd)
             d_vn_j = torch.empty(Sd, R, Cw, dtype=cd, device=dev)
@@ -626,6 +635,10 @@ class TemporalAligner(nn.Module):
                      sA=R * Mp, sB=Mp * Cw, sC=R * Cw)
             ops.gemm(dl, run["vn_j"], d_tn_j, M=Mp, N=Cw, K=R, a_kc=False, b_kc=False, lda=Mp, ldb=Cw, batch=Sd,
                      sA=R * Mp, sB=R * Cw, sC=Mp * Cw)
+        if g_vnj is not None or g_tnj is not None:       # fused mode: feature gradients arrive directly from _FusedNCEFn
+            d_vn_j = g_vnj.contiguous().to(cd) if g_vnj is not None else torch.zeros(Sd, R, Cw, dtype=cd, device=dev)
+            d_tn_j = g_tnj.contiguous().to(cd) if g_tnj is not None else torch.zeros(Sd, Mp, Cw, dtype=cd, device=dev)
+        if d_vn_j is not None:
             for s in range(Sd):
                 dst_j[s] = torch.empty(B * L, Cw, dtype=cd, device=dev)
                 ops.l2norm_bwd(d_vn_j[s], run["vn_j"][s], inv["vj"][s * R:(s + 1) * R], dst_j[s], R, Cw, T, L, 0)
@@ -690,18 +703,33 @@ class TemporalAligner(nn.Module):
         return m.to(torch.uint8).contiguous()
 
     def forward(self, video_embed, lang_embed, video_padding_mask, lang_padding_mask, text_timestamp=None,
-                interpolate_from=None, abs_text_pos=None):
+                interpolate_from=None, abs_text_pos=None, fused=False):
+        """Reference signature (tan_model.py:100-103).  `fused=True` (bf16 mode only, not in the reference) skips the
+        [B,S,T,B,N] logits: the dict then carries '_fused' (unit features) for temporalalignnet_amd.loss.get_loss, which
+        runs the logits-free similarity+NCE kernels; 'logits_dual' / 'logits_joint' are absent."""
         self._ensure_flat()
         f = self._flat
+        fused = bool(fused) and self.compute_dtype == torch.bfloat16
         needs_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in f.params) or lang_embed.requires_grad)
         outs = _AlignerFn.apply(self, video_embed, lang_embed, self._mask_u8(video_padding_mask),
                                 self._mask_u8(lang_padding_mask),
-                                {"interpolate_from": interpolate_from, "needs_grad": needs_grad}, *f.params)
-        out = {"logits_dual": outs[0], "logits_joint": outs[1]}
-        if self.return_dual_feature:
-            out["dual_feature_video"], out["dual_feature_text"] = outs[2], outs[3]
+                                {"interpolate_from": interpolate_from, "needs_grad": needs_grad, "fused": fused}, *f.params)
+        B, T, N = video_embed.shape[0], video_embed.shape[1], lang_embed.shape[1]
+        if fused:
+            from .loss import FusedSim
+            Se = self.num_encoder_layers
+            out = {"_fused": FusedSim(outs[0].permute(1, 0, 2, 3).reshape(Se, B * T, WIDTH), outs[1].reshape(1, B * N, WIDTH),
+                                      outs[2], outs[3], B, T, N)}
+            nxt = 4
+            if self.return_dual_feature:
+                out["dual_feature_video"], out["dual_feature_text"] = outs[0], outs[1]
+        else:
+            out = {"logits_dual": outs[0], "logits_joint": outs[1]}
+            nxt = 4
+            if self.return_dual_feature:
+                out["dual_feature_video"], out["dual_feature_text"] = outs[2], outs[3]
         if self.use_alignability_head:
-            out["dual_logits_alignability"], out["joint_logits_alignability"] = outs[4], outs[5]
+            out["dual_logits_alignability"], out["joint_logits_alignability"] = outs[nxt], outs[nxt + 1]
         return out
 
     @torch.no_grad()

@@ -40,7 +40,8 @@ def build_model(args, compute_dtype="fp32", language_model=None, **kw):
                   compute_dtype=compute_dtype, **kw)
     if args.model == "init":
         return TemporalAligner(**common)
-    return TwinTemporalAligner(m=args.momentum_m, random_pos_start=0, **common)
+    common.setdefault("random_pos_start", 0)       # train/main.py:389
+    return TwinTemporalAligner(m=args.momentum_m, **common)
 
 
 def lr_multiplier(iteration, iter_per_epoch, epochs, warmup=1000):
@@ -64,8 +65,11 @@ def to_device_batch(batch: dict, device="cuda") -> dict:
 
 
 class Trainer:
-    def __init__(self, model, args, *, betas=(0.9, 0.999), eps=1e-8, iter_per_epoch=None, warmup=1000):
+    def __init__(self, model, args, *, betas=(0.9, 0.999), eps=1e-8, iter_per_epoch=None, warmup=1000, fused_loss=None):
         self.model, self.args = model, args
+        online = model.online if isinstance(model, TwinTemporalAligner) else model
+        # logits-free similarity+NCE whenever the model runs in bf16 (the fused kernels are bf16-only)
+        self.fused_loss = (online.compute_dtype == torch.bfloat16) if fused_loss is None else bool(fused_loss)
         self.twin = isinstance(model, TwinTemporalAligner)
         self.online = model.online if self.twin else model
         self.betas, self.eps = betas, eps
@@ -102,11 +106,12 @@ class Trainer:
         a, m = self.args, self.model
         logits = m(batch["video"], batch["text_embed"], video_padding_mask=batch["padding_mask"],
                    lang_padding_mask=batch["text_padding_mask"].bool(), text_timestamp=batch.get("_tgt_raw"),
-                   abs_text_pos=batch.get("abs_text_pos"))
+                   abs_text_pos=batch.get("abs_text_pos"), fused=self.fused_loss)
         if a.model == "cotrain":
             ema = m.forward_from_ema(batch["video"], batch["text_embed"], video_padding_mask=batch["padding_mask"],
                                      lang_padding_mask=batch["text_padding_mask"].bool(),
-                                     text_timestamp=batch.get("_tgt_raw"), abs_text_pos=batch.get("abs_text_pos"))
+                                     text_timestamp=batch.get("_tgt_raw"), abs_text_pos=batch.get("abs_text_pos"),
+                                     fused=self.fused_loss)
             logits = {**logits, **{f"ema-{k}": v for k, v in ema.items()}}
         loss_dict = get_loss(batch, batch["video"], batch["text_embed"], batch["padding_mask"], batch["text_padding_mask"],
                              logits, a, batch.get("abs_text_pos"))
