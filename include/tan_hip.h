@@ -104,6 +104,8 @@ int tan_rows_copy(const void* src, void* dst, int G, int R, int C, long src_grp_
 /* out[r][c] = sum_g x[g*R + r][c]  (backward of the broadcast position add) */
 int tan_group_sum(const void* x, void* out, int G, int R, int C, int dtype, void* stream);
 int tan_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
+/* out[i] += sum_s parts[s*n + i]  (folds split-K partial tiles into an f32 gradient); n % 4 == 0 */
+int tan_reduce_add(const float* parts, float* out, int nparts, long n, void* stream);
 /* binary_head = nn.Linear(512,1) (tan_model.py:70,147-148): out[r] = <x[r],w> + b (f32 out); bwd accumulates dw, db */
 int tan_head_fwd(const void* x, const float* w, const float* b, float* out, long rows, int C, int dtype, void* stream);
 int tan_head_bwd(const float* dout, const void* x, const float* w, void* dx, float* dw, float* db, long rows, int C,
@@ -219,6 +221,8 @@ typedef struct tan_encoder_desc {
     void* scr_dh;                               /* [R,4C] */
     void* scr_dqkv;                             /* [R,3C] */
     float* ln_ws;                               /* tan_layernorm_bwd_ws_floats(C) */
+    float* dw_ws;                               /* split-K partial tiles for the dW GEMMs, or NULL (then f32 atomics) */
+    long dw_ws_floats;                          /* >= 32 * 4*C*C to cover every layer shape */
     const void* const* d_stage;                 /* HOST array [layers]: grad w.r.t. stage s ([R,C] dtype) or NULL */
     void* d_x0;                                 /* [R,C] out: grad w.r.t. x0 */
 } tan_encoder_desc;

@@ -89,5 +89,6 @@ class EncoderDesc(C.Structure):
         ("post_out", C.c_void_p), ("post_mean", C.c_void_p), ("post_rstd", C.c_void_p),
         ("scr_dx", C.c_void_p), ("scr_dx2", C.c_void_p), ("scr_do", C.c_void_p), ("scr_dxn", C.c_void_p),
         ("scr_dh", C.c_void_p), ("scr_dqkv", C.c_void_p), ("ln_ws", C.c_void_p),
+        ("dw_ws", C.c_void_p), ("dw_ws_floats", C.c_long),
         ("d_stage", C.POINTER(C.c_void_p)), ("d_x0", C.c_void_p),
     ]

@@ -43,21 +43,33 @@ int linear_bwd_x(int dt, const void* dy, const void* w, void* dx, long M, int N,
     return tan_gemm(&d, st);
 }
 
-// gw[N,K] += dy[M,N]^T x[M,K]   (f32 accumulate, split over the long M contraction)
-int linear_bwd_w(int dt, const void* dy, const void* x, float* gw, long M, int N, int K, void* st) {
+// gw[N,K] += dy[M,N]^T x[M,K]: the long M contraction is cut into `split` slices.  With a workspace the slices are written
+// as plain f32 partial tiles (batched GEMM, 16-byte stores) and folded into the gradient by one streaming kernel -- measured
+// 37 us vs 47 us for f32 atomics on the c_fc shape; without a workspace (or for ragged M) the slices accumulate with atomics.
+int linear_bwd_w(int dt, const void* dy, const void* x, float* gw, long M, int N, int K, float* ws, long ws_floats, void* st) {
     tan_gemm_desc d{};
     d.dtype = dt; d.out_dtype = TAN_F32;
-    d.M = N; d.N = K; d.K = (int)M;
+    d.M = N; d.N = K;
     d.a_kc = 0; d.b_kc = 0;
-    d.A = dy; d.lda = N; d.B = x; d.ldb = K; d.C = gw; d.ldc = K;
-    d.accumulate = 1; d.alpha = 1.0f; d.batch = 1;
+    d.A = dy; d.lda = N; d.B = x; d.ldb = K; d.ldc = K;
+    d.alpha = 1.0f;
     const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
-    long split = (512 + tiles - 1) / tiles;
+    long want = (512 + tiles - 1) / tiles;                 // enough workgroups to fill 256 CUs twice over
     const long max_split = (M + 255) / 256;
-    if (split > max_split) split = max_split;
-    if (split > 32) split = 32;
-    if (split < 1) split = 1;
-    d.split_k = (int)split;
+    if (want > max_split) want = max_split;
+    if (want > 32) want = 32;
+    if (want < 1) want = 1;
+    long split = want;
+    while (split > 1 && (M % split != 0 || (M / split) % 64 != 0)) --split;      // equal slices, multiples of the K-step
+    if (ws && split > 1 && (long)split * N * K <= ws_floats) {
+        const long kc = M / split;
+        d.K = (int)kc; d.C = ws; d.accumulate = 0; d.split_k = 1;
+        d.batch = (int)split; d.sA = kc * N; d.sB = kc * K; d.sC = (long)N * K;
+        int rc = tan_gemm(&d, st);
+        if (rc) return rc;
+        return tan_reduce_add(ws, gw, (int)split, (long)N * K, st);
+    }
+    d.K = (int)M; d.C = gw; d.accumulate = 1; d.batch = 1; d.split_k = (int)want;
     return tan_gemm(&d, st);
 }
 
@@ -112,19 +124,19 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         const void* x_in = i == 0 ? e->x0 : e->bufs[i - 1].x_out;
         // ---- MLP branch: x_out = x_mid + c_proj(quickgelu(c_fc(LN2(x_mid))))
         CK(tan_colsum_acc(dx, p.g_b_proj, R, C, dt, st));
-        CK(linear_bwd_w(dt, dx, b.h_act, p.g_w_proj, R, C, 4 * C, st));
+        CK(linear_bwd_w(dt, dx, b.h_act, p.g_w_proj, R, C, 4 * C, e->dw_ws, e->dw_ws_floats, st));
         CK(linear_bwd_x(dt, dx, p.w_proj, e->scr_dh, R, C, 4 * C, TAN_ACT_QUICKGELU_GRAD, b.h_pre, nullptr, st));
         CK(tan_colsum_acc(e->scr_dh, p.g_b_fc, R, 4 * C, dt, st));
-        CK(linear_bwd_w(dt, e->scr_dh, b.xn2, p.g_w_fc, R, 4 * C, C, st));
+        CK(linear_bwd_w(dt, e->scr_dh, b.xn2, p.g_w_fc, R, 4 * C, C, e->dw_ws, e->dw_ws_floats, st));
         CK(linear_bwd_x(dt, e->scr_dh, p.w_fc, e->scr_dxn, R, 4 * C, C, TAN_ACT_NONE, nullptr, nullptr, st));
         CK(tan_layernorm_bwd(e->scr_dxn, b.x_mid, p.ln2_g, b.mean2, b.rstd2, dx, dx2, p.g_ln2_g, p.g_ln2_b, e->ln_ws, R, C, dt, st));
         // ---- attention branch: x_mid = x_in + out_proj(attn(LN1(x_in)))
         CK(tan_colsum_acc(dx2, p.g_b_out, R, C, dt, st));
-        CK(linear_bwd_w(dt, dx2, b.attn_o, p.g_w_out, R, C, C, st));
+        CK(linear_bwd_w(dt, dx2, b.attn_o, p.g_w_out, R, C, C, e->dw_ws, e->dw_ws_floats, st));
         CK(linear_bwd_x(dt, dx2, p.w_out, e->scr_do, R, C, C, TAN_ACT_NONE, nullptr, nullptr, st));
         CK(tan_attn_bwd(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->scr_do, e->scr_dqkv, e->B, e->L, H, dt, st));
         CK(tan_colsum_acc(e->scr_dqkv, p.g_b_qkv, R, 3 * C, dt, st));
-        CK(linear_bwd_w(dt, e->scr_dqkv, b.xn1, p.g_w_qkv, R, 3 * C, C, st));
+        CK(linear_bwd_w(dt, e->scr_dqkv, b.xn1, p.g_w_qkv, R, 3 * C, C, e->dw_ws, e->dw_ws_floats, st));
         // stage i-1 IS this layer's xn1: its gradient joins here
         const void* dstage = i >= 1 ? e->d_stage[i - 1] : nullptr;
         CK(linear_bwd_x(dt, e->scr_dqkv, p.w_qkv, e->scr_dxn, R, 3 * C, C, TAN_ACT_NONE, nullptr, dstage, st));

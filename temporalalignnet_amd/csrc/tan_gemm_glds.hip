@@ -188,7 +188,16 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs2 g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * GBN, m0 = blockIdx.y * GBM;
+    // XCD-aware tile order: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (private L2 each), so
+    // id -> (id % 8) * ceil(n/8) + id / 8 (bijective form for any n) hands each XCD a CONTIGUOUS run of tiles; with the
+    // column tile varying fastest, the tiles that share an A row-panel then hit the same L2 instead of eight.
+    const int ntn = gridDim.x, nwg = gridDim.x * gridDim.y;
+    int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const int xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    }
+    const int n0 = (wg % ntn) * GBN, m0 = (wg / ntn) * GBM;
     const int z = blockIdx.z, batch = z / g.split_k, split = z % g.split_k;
     const bf16_t* A = g.A + (long)batch * g.sA;
     const bf16_t* B = g.B + (long)batch * g.sB;

@@ -255,6 +255,18 @@ __global__ __launch_bounds__(256) void group_sum_kernel(const T* __restrict__ x,
     st_f(out + i, s);
 }
 
+// out[i] += sum_s parts[s][i]   (split-K partial tiles -> f32 gradient)
+__global__ __launch_bounds__(256) void reduce_add_kernel(const float* __restrict__ parts, float* __restrict__ out, int nparts, long n) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        float4 a = *reinterpret_cast<const float4*>(out + i);
+        for (int s = 0; s < nparts; ++s) {
+            const float4 p = *reinterpret_cast<const float4*>(parts + (long)s * n + i);
+            a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+        }
+        *reinterpret_cast<float4*>(out + i) = a;
+    }
+}
+
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, long n) {
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
@@ -375,14 +387,14 @@ extern "C" int tan_layernorm_fwd(const void* x, const float* gamma, const float*
     return 0;
 }
 
-extern "C" long tan_layernorm_bwd_ws_floats(int C) { return 256L * 2 * C; }
+extern "C" long tan_layernorm_bwd_ws_floats(int C) { return 512L * 2 * C; }
 
 extern "C" int tan_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                  const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, long rows, int C,
                                  int dtype, void* stream) {
     TAN_REQUIRE(dy && x && gamma && mean && rstd && dx && ws && rows > 0);
     hipStream_t st = (hipStream_t)stream;
-    const int nblk = (int)min((long)256, (long)cdiv(rows, ROWS_PER_BLOCK));
+    const int nblk = (int)min((long)512, (long)cdiv(rows, ROWS_PER_BLOCK));
     DISPATCH_T(dtype, DISPATCH_NCH(C, hipLaunchKernelGGL((ln_bwd_kernel<T, NCH>), dim3(nblk), dim3(256), 0, st, (const T*)dy,
                                                          (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, ws, rows)));
     TAN_LAUNCH_CHECK();
@@ -420,7 +432,7 @@ extern "C" int tan_colsum_acc(const void* x, float* out, long rows, int C, int d
     int tpr = C / 8;                      // threads spanning one row
     if (tpr > 256) tpr = 256;
     while (256 % tpr) --tpr;              // must divide the block
-    const int rpb = 16 * (256 / tpr);     // 16 rows per thread group
+    const int rpb = 8 * (256 / tpr);      // 8 rows per thread group
     dim3 grid(cdiv(C, tpr * 8), cdiv(rows, rpb));
     DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, st, (const T*)x, out, rows, C, rpb, tpr));
     TAN_LAUNCH_CHECK();
@@ -444,6 +456,14 @@ extern "C" int tan_group_sum(const void* x, void* out, int G, int R, int C, int 
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype, hipLaunchKernelGGL((group_sum_kernel<T>), dim3(cdiv((long)R * C, 256)), dim3(256), 0, st, (const T*)x,
                                          (T*)out, G, R, C));
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_reduce_add(const float* parts, float* out, int nparts, long n, void* stream) {
+    TAN_REQUIRE(parts && out && nparts > 0 && n > 0 && n % 4 == 0);
+    const unsigned grid = (unsigned)min((long)2048, (long)cdiv(n, 1024));
+    hipLaunchKernelGGL(reduce_add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, parts, out, nparts, n);
     TAN_LAUNCH_CHECK();
     return 0;
 }

@@ -327,6 +327,7 @@ class TemporalAligner(nn.Module):
         d.scr_dx, d.scr_dx2, d.scr_do, d.scr_dxn = (_vp(scr[k]) for k in ("dx", "dx2", "do", "dxn"))
         d.scr_dh, d.scr_dqkv = _vp(scr["dh"]), _vp(scr["dqkv"])
         d.ln_ws = _vp(scr.ln_ws)
+        d.dw_ws, d.dw_ws_floats = _vp(scr.dw_ws), scr.dw_ws.numel()
         arr = (C.c_void_p * er.layers)(*[(t.data_ptr() if t is not None else None) for t in d_stage])
         d.d_stage = arr
         d.d_x0 = _vp(d_x0)
@@ -475,6 +476,7 @@ class TemporalAligner(nn.Module):
                                     "dh": R * 4 * WIDTH, "dqkv": R * 3 * WIDTH})
             n_ws = _lib.lib().tan_layernorm_bwd_ws_floats(C.c_int(WIDTH))
             scr.ln_ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+            scr.dw_ws = torch.empty(32 * 4 * WIDTH * WIDTH, dtype=torch.float32, device=dev)     # split-K partial tiles
             self._ws_pool[key] = scr
         return scr
 
