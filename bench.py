@@ -133,8 +133,13 @@ def main():
             peak = BF16_MFMA_PEAK_TFLOPS if a.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
             tms, twork, tcnt = sum(ms[k] for k in gemm), sum(work[k] for k in gemm), sum(cnt[k] for k in gemm)
             ach = twork / (tms * 1e-3) / 1e12
+            traffic = None      # HBM bytes per launch from the committed PMC passes of this same command (profiles/README.md)
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(pmc) and a.dtype == "bf16" and a.stage == 1 and a.batch == 128 and a.seq_len == 64:
+                fam = json.load(open(pmc))["mfma_gemm_family"]
+                traffic = round(fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch"])
             roof = {"bound": "mfma", "kernel": "tal::gemm_glds_kernel + tal::simnce_kernel (one direct-to-LDS MFMA pipeline, all operand layouts)", "achieved": round(ach, 1),
-                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "avg_launch_us": round(tms * 1e3 / tcnt, 2), "launches_per_step": tcnt / a.steps,
                     "gemm_ms_per_step": round(tms / a.steps, 3), "algorithmic_gflop_per_step": round(twork / a.steps / 1e9, 1),
                     "by_kernel": [{**x, "ms_per_step": round(x["ms_per_step"], 3), "tflops": round(x["tflops"], 1)} for x in kinds]}

@@ -107,7 +107,11 @@ __global__ __launch_bounds__(256, 2) void simnce_kernel(SimArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int panel = blockIdx.x, s = blockIdx.y, m0 = panel * 128;
+    // Workgroup order: consecutive ids go round-robin to the 8 XCDs, so each group of 64 consecutive ids is one stage (its
+    // 2 MB of text features then stay resident in every XCD's L2 instead of six stages thrashing it).
+    const int npanel = gridDim.x;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    const int s = wg / npanel, panel = wg - s * npanel, m0 = panel * 128;
     const int R = a.R, Mp = a.Mp, Cw = a.C, nS = a.S;
     const bf16_t* V = a.V + (long)s * R * Cw;
     const bf16_t* Tt = a.Tt + (long)s * a.t_stage_stride;

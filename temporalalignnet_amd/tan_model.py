@@ -198,6 +198,7 @@ class TemporalAligner(nn.Module):
         # reference registers before the encoders' parameters appear in state_dict(); key *names* are what matter.
         self._flat = _Flat(self, [(n, p) for n, p in self.named_parameters() if not n.startswith("bert.")])
         self._ws_pool = {}
+        self._grad_ready_hook = None      # callable(tag) fired inside backward when a slice of the flat gradient is final
 
     # ------------------------------------------------------------------ init (tan_model.py:76-97)
     def initialize_parameters(self):
@@ -236,6 +237,17 @@ class TemporalAligner(nn.Module):
 
     def flat_grad(self):
         return self._ensure_flat().grad
+
+    def flat_range(self, prefix):
+        """[lo, hi) of the flat buffers covered by the parameters whose names start with `prefix` (contiguous by
+        construction: registration order groups each encoder stack)."""
+        f = self._flat
+        spans = [(f.off[n][0], f.off[n][0] + f.off[n][1]) for n in f.names if n.startswith(prefix)]
+        lo, hi = min(s[0] for s in spans), max(s[1] for s in spans)
+        hi = (hi + _ALIGN - 1) // _ALIGN * _ALIGN
+        inside = [n for n in f.names if lo <= f.off[n][0] < hi]
+        assert all(n.startswith(prefix) for n in inside), "parameters of this prefix are not contiguous in the flat buffer"
+        return lo, min(hi, f.total)
 
     def _w(self, name):
         """weight in compute dtype (bf16 shadow or the f32 master)"""
@@ -671,6 +683,8 @@ class TemporalAligner(nn.Module):
         if any_j:
             d_xj = torch.empty(B * L, Cw, dtype=cd, device=dev)
             self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dst_j, d_xj)
+            if self._grad_ready_hook is not None:        # joint-stack gradients are final: DDP starts reducing them now
+                self._grad_ready_hook("joint")
             if run["sv_video_j"] is not None:
                 d_x0j = torch.empty(R, Cw, dtype=cd, device=dev)
                 ops.rows_copy(d_xj, d_x0j, B, T, Cw, L, 0, T, 0)

@@ -136,11 +136,27 @@ class Trainer:
             _vp(ema.shadow) if ema is not None else None, ops._stream()), "tan_adamw_step")
 
     def step(self, batch):
-        """One optimizer step on an already device-resident batch (see to_device_batch)."""
+        """One optimizer step on an already device-resident batch (see to_device_batch).  With N>1 ranks the flat gradient
+        is summed over RCCL in two pieces: the joint stack's slice (47% of the bytes) is launched asynchronously from inside
+        backward as soon as it is final and overlaps the video stack's backward; the rest follows at the end."""
         self.zero_grad()
-        loss_dict = self.forward_backward(batch)
         world = dist.world_size()
+        pending = []
         if world > 1:
-            dist.allreduce_sum_(self.online.flat_grad())
+            flat = self.online.flat_grad()
+            lo, hi = self.online.flat_range("joint_temporal_encoder.")
+            self.online._grad_ready_hook = lambda tag: pending.append(dist.allreduce_sum_(flat[lo:hi], async_op=True))
+        try:
+            loss_dict = self.forward_backward(batch)
+        finally:
+            self.online._grad_ready_hook = None
+        if world > 1:
+            if pending:
+                dist.allreduce_sum_(flat[:lo])
+                dist.allreduce_sum_(flat[hi:])
+                for w in pending:
+                    w.wait()
+            else:
+                dist.allreduce_sum_(flat)
         self.optimizer_step(grad_scale=1.0 / world)
         return loss_dict
