@@ -69,6 +69,7 @@ typedef struct tan_gemm_desc {
     int split_k;
     float alpha;
     int batch; long sA, sB, sC;
+    float* colsum; /* optional [N] f32: += column sums of the stored output (fused bias gradient); batch must be 1 */
 } tan_gemm_desc;
 int tan_gemm(const tan_gemm_desc* d, void* stream);
 
@@ -76,14 +77,15 @@ int tan_gemm(const tan_gemm_desc* d, void* stream);
  * fwd: y = (x-mean)*rstd*gamma+beta (+ add[row % add_period], the broadcast position term of
  *      tan_model.py:167,199).  reference: tfm_model.py:22,28,35,37; tan_model.py:50-54,155,174,206.
  *      mean/rstd [rows] f32 are saved for backward (may be NULL).
- * bwd: dx = (dres +) LN'(dy); dgamma/dbeta (f32, may be NULL) are ACCUMULATED (+=).  ws: f32 scratch of
- *      tan_layernorm_bwd_ws_floats(C) elements.                                                            */
+ * bwd: dx = (dres +) LN'(dy); dgamma/dbeta (f32, may be NULL) are ACCUMULATED (+=); dx_colsum (may be NULL) += column
+ *      sums of the OUTPUT dx, i.e. the bias gradient of the Linear that wrote the stream this LN normalises (saves a
+ *      separate pass).  ws: f32 scratch of tan_layernorm_bwd_ws_floats(C) elements.                           */
 int tan_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                       const void* add, int add_period, long rows, int C, float eps, int dtype, void* stream);
 long tan_layernorm_bwd_ws_floats(int C);
 int tan_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                      const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, long rows, int C, int dtype,
-                      void* stream);
+                      const void* dres, void* dx, float* dgamma, float* dbeta, float* dx_colsum, float* ws, long rows, int C,
+                      int dtype, void* stream);
 
 /* ---- L2 normalisation over channels, no epsilon (tan_model.py:116-117,136-137) ---------------------------
  * Output rows r = 0..rows-1 are gathered from x row (r/grp)*src_grp_rows + src_off + r%grp, which extracts the

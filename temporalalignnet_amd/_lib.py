@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("aux", C.c_void_p), ("ldaux", C.c_long),
         ("accumulate", C.c_int), ("split_k", C.c_int), ("alpha", C.c_float),
         ("batch", C.c_int), ("sA", C.c_long), ("sB", C.c_long), ("sC", C.c_long),
+        ("colsum", C.c_void_p),
     ]
 
 

@@ -32,7 +32,7 @@ int linear_fwd(int dt, const void* x, const void* w, const float* b, void* y, lo
 
 // dx[M,K] = dy[M,N] W[N,K]  (optionally * gelu'(aux) and + residual)
 int linear_bwd_x(int dt, const void* dy, const void* w, void* dx, long M, int N, int K, int act, void* aux, const void* residual,
-                 void* st) {
+                 float* colsum, void* st) {
     tan_gemm_desc d{};
     d.dtype = dt; d.out_dtype = dt;
     d.M = (int)M; d.N = K; d.K = N;
@@ -40,6 +40,7 @@ int linear_bwd_x(int dt, const void* dy, const void* w, void* dx, long M, int N,
     d.A = dy; d.lda = N; d.B = w; d.ldb = K; d.C = dx; d.ldc = K;
     d.residual = residual; d.ldr = K; d.act = act; d.aux = aux; d.ldaux = K;
     d.split_k = 1; d.alpha = 1.0f; d.batch = 1;
+    d.colsum = colsum;
     return tan_gemm(&d, st);
 }
 
@@ -112,36 +113,40 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
     const void* x_last = e->bufs[S - 1].x_out;
     if (e->d_stage[S - 1]) {
         TAN_REQUIRE(e->post_out);
+        // dx = grad of the last layer's x_out: its column sums are that layer's c_proj bias gradient
         CK(tan_layernorm_bwd(e->d_stage[S - 1], x_last, e->post_g, e->post_mean, e->post_rstd, nullptr, dx, e->g_post_g,
-                             e->g_post_b, e->ln_ws, R, C, dt, st));
+                             e->g_post_b, e->params[S - 1].g_b_proj, e->ln_ws, R, C, dt, st));
     } else {
         hipError_t err = hipMemsetAsync(dx, 0, (size_t)R * C * esz, (hipStream_t)st);
         if (err != hipSuccess) return (int)err;
     }
+    // bias gradients that are column sums of a LayerNorm-backward OUTPUT are accumulated inside that kernel:
+    //   g_b_proj[i] <- colsum(dx entering layer i)   = output of layer i+1's LN1 backward (or of the post-LN backward)
+    //   g_b_out[i]  <- colsum(dx2)                   = output of layer i's LN2 backward
     for (int i = S - 1; i >= 0; --i) {
         const tan_layer_params& p = e->params[i];
         const tan_layer_bufs& b = e->bufs[i];
         const void* x_in = i == 0 ? e->x0 : e->bufs[i - 1].x_out;
         // ---- MLP branch: x_out = x_mid + c_proj(quickgelu(c_fc(LN2(x_mid))))
-        CK(tan_colsum_acc(dx, p.g_b_proj, R, C, dt, st));
         CK(linear_bwd_w(dt, dx, b.h_act, p.g_w_proj, R, C, 4 * C, e->dw_ws, e->dw_ws_floats, st));
-        CK(linear_bwd_x(dt, dx, p.w_proj, e->scr_dh, R, C, 4 * C, TAN_ACT_QUICKGELU_GRAD, b.h_pre, nullptr, st));
-        CK(tan_colsum_acc(e->scr_dh, p.g_b_fc, R, 4 * C, dt, st));
+        CK(linear_bwd_x(dt, dx, p.w_proj, e->scr_dh, R, C, 4 * C, TAN_ACT_QUICKGELU_GRAD, b.h_pre, nullptr, p.g_b_fc, st));
         CK(linear_bwd_w(dt, e->scr_dh, b.xn2, p.g_w_fc, R, 4 * C, C, e->dw_ws, e->dw_ws_floats, st));
-        CK(linear_bwd_x(dt, e->scr_dh, p.w_fc, e->scr_dxn, R, 4 * C, C, TAN_ACT_NONE, nullptr, nullptr, st));
-        CK(tan_layernorm_bwd(e->scr_dxn, b.x_mid, p.ln2_g, b.mean2, b.rstd2, dx, dx2, p.g_ln2_g, p.g_ln2_b, e->ln_ws, R, C, dt, st));
+        CK(linear_bwd_x(dt, e->scr_dh, p.w_fc, e->scr_dxn, R, 4 * C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
+        CK(tan_layernorm_bwd(e->scr_dxn, b.x_mid, p.ln2_g, b.mean2, b.rstd2, dx, dx2, p.g_ln2_g, p.g_ln2_b, p.g_b_out, e->ln_ws, R, C,
+                             dt, st));
         // ---- attention branch: x_mid = x_in + out_proj(attn(LN1(x_in)))
-        CK(tan_colsum_acc(dx2, p.g_b_out, R, C, dt, st));
         CK(linear_bwd_w(dt, dx2, b.attn_o, p.g_w_out, R, C, C, e->dw_ws, e->dw_ws_floats, st));
-        CK(linear_bwd_x(dt, dx2, p.w_out, e->scr_do, R, C, C, TAN_ACT_NONE, nullptr, nullptr, st));
+        CK(linear_bwd_x(dt, dx2, p.w_out, e->scr_do, R, C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
         CK(tan_attn_bwd(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->scr_do, e->scr_dqkv, e->B, e->L, H, dt, st));
         CK(tan_colsum_acc(e->scr_dqkv, p.g_b_qkv, R, 3 * C, dt, st));
         CK(linear_bwd_w(dt, e->scr_dqkv, b.xn1, p.g_w_qkv, R, 3 * C, C, e->dw_ws, e->dw_ws_floats, st));
         // stage i-1 IS this layer's xn1: its gradient joins here
         const void* dstage = i >= 1 ? e->d_stage[i - 1] : nullptr;
-        CK(linear_bwd_x(dt, e->scr_dqkv, p.w_qkv, e->scr_dxn, R, 3 * C, C, TAN_ACT_NONE, nullptr, dstage, st));
+        CK(linear_bwd_x(dt, e->scr_dqkv, p.w_qkv, e->scr_dxn, R, 3 * C, C, TAN_ACT_NONE, nullptr, dstage, nullptr, st));
         void* dx_in = i == 0 ? e->d_x0 : dx;
-        CK(tan_layernorm_bwd(e->scr_dxn, x_in, p.ln1_g, b.mean1, b.rstd1, dx2, dx_in, p.g_ln1_g, p.g_ln1_b, e->ln_ws, R, C, dt, st));
+        float* next_b_proj = i > 0 ? e->params[i - 1].g_b_proj : nullptr;       // dx_in is layer i-1's x_out gradient
+        CK(tan_layernorm_bwd(e->scr_dxn, x_in, p.ln1_g, b.mean1, b.rstd1, dx2, dx_in, p.g_ln1_g, p.g_ln1_b, next_b_proj, e->ln_ws, R,
+                             C, dt, st));
     }
     return 0;
 }

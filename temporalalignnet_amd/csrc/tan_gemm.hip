@@ -274,11 +274,14 @@ extern "C" int tan_gemm(const tan_gemm_desc* d, void* stream) {
     if (d->dtype == TAN_F32) TAN_REQUIRE(d->out_dtype == TAN_F32);
     const int kind = (d->dtype == TAN_BF16 ? TAN_PROF_GEMM_BF16 : TAN_PROF_GEMM_F32) + (d->a_kc ? 0 : 2) + (d->b_kc ? 0 : 1);
     const int rec = prof_begin(st, kind, 2.0 * d->M * d->N * (double)d->K * d->batch);
-    int rc = gemm_glds_try(d, st);            // aligned bf16: direct-to-LDS kernel
+    if (d->colsum) TAN_REQUIRE(d->batch == 1 && !d->accumulate);
+    int rc = gemm_glds_try(d, st);            // aligned bf16: direct-to-LDS kernel (fuses colsum when its epilogue is vectorised)
+    if (rc == -3) { prof_end(st, rec); return tan_colsum_acc(d->C, d->colsum, d->M, d->N, d->out_dtype, stream); }
     if (rc != -2) { prof_end(st, rec); return rc; }
     if (d->dtype == TAN_F32) rc = launch_gemm<float, float>(d, a, grid, st);
     else if (d->out_dtype == TAN_F32) rc = launch_gemm<bf16_t, float>(d, a, grid, st);
     else rc = launch_gemm<bf16_t, bf16_t>(d, a, grid, st);
     prof_end(st, rec);
+    if (rc == 0 && d->colsum) rc = tan_colsum_acc(d->C, d->colsum, d->M, d->N, d->out_dtype, stream);
     return rc;
 }

@@ -29,6 +29,7 @@ struct GemmArgs2 {
     int M, N, K;
     int act, accumulate, split_k, kchunk, vec_epi;
     float alpha;
+    float* colsum;
 };
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
@@ -151,11 +152,13 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs2& g, f32x16 (&acc)[2
     __syncthreads();
     // phase 2: 8 rows x 8 columns per thread, 16-byte global accesses
     const int cv = (tid & 15) * 8, col = n0 + cv;
-    if (col >= g.N) return;
+    float cs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = 0.f;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int lr = (tid >> 4) + 16 * p, row = m0 + lr;
-        if (row >= g.M) break;
+        if (row >= g.M || col >= g.N) break;
         float v[8];
         {
             const float4 a = *reinterpret_cast<const float4*>(tile + lr * 128 + cv);
@@ -179,6 +182,20 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs2& g, f32x16 (&acc)[2
             for (int e = 0; e < 8; ++e) v[e] += x[e];
         }
         st8(C + (long)row * g.ldc + col, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] += v[e];
+    }
+    if (g.colsum) {      // fused bias gradient: column sums of this tile -> one atomic per column
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[(tid >> 4) * 128 + cv + e] = cs[e];
+        __syncthreads();
+        if (tid < 128 && n0 + tid < g.N) {
+            float s = 0.f;
+#pragma unroll
+            for (int y = 0; y < 16; ++y) s += tile[y * 128 + tid];
+            unsafeAtomicAdd(g.colsum + n0 + tid, s);
+        }
     }
 }
 
@@ -284,7 +301,12 @@ int gemm_glds_try(const tan_gemm_desc* d, hipStream_t st) {
     auto al16 = [&](const void* p, long ld) { return !p || (((uintptr_t)p % 16 == 0) && ((ld * oe) % 16 == 0)); };
     a.vec_epi = !d->accumulate && d->N % 8 == 0 && al16(d->C, d->ldc) && al16(d->residual, d->ldr) && al16(d->aux, d->ldaux) &&
                 ((d->sC * oe) % 16 == 0);
+    a.colsum = a.vec_epi ? d->colsum : nullptr;
     dim3 grid(cdiv(d->N, GBN), cdiv(d->M, GBM), d->batch * d->split_k);
+    if (d->colsum && !a.vec_epi) {            // cannot fuse: run the GEMM, caller adds a separate column-sum pass
+        int rc = d->out_dtype == TAN_F32 ? launch2<float>(d, a, grid, st) : launch2<bf16_t>(d, a, grid, st);
+        return rc ? rc : -3;
+    }
     if (d->out_dtype == TAN_F32) return launch2<float>(d, a, grid, st);
     return launch2<bf16_t>(d, a, grid, st);
 }

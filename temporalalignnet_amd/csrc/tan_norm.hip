@@ -64,12 +64,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ rstd_i, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ ws, long rows) {
     constexpr int C = NCH * 256;
-    __shared__ float red[ROWS_PER_BLOCK][2][C];
+    __shared__ float red[ROWS_PER_BLOCK][3][C];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float4 dg[NCH], db[NCH], gm[NCH];
+    float4 dg[NCH], db[NCH], gm[NCH], ds[NCH];      // ds: column sums of the OUTPUT dx (a fused tan_colsum_acc)
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        dg[i] = make_float4(0, 0, 0, 0); db[i] = make_float4(0, 0, 0, 0);
+        dg[i] = make_float4(0, 0, 0, 0); db[i] = make_float4(0, 0, 0, 0); ds[i] = make_float4(0, 0, 0, 0);
         gm[i] = *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 4);
     }
     for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + w; row < rows; row += (long)gridDim.x * ROWS_PER_BLOCK) {
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
             st4(dx + row * C + c, o);
+            ds[i].x += o.x; ds[i].y += o.y; ds[i].z += o.z; ds[i].w += o.w;
         }
     }
 #pragma unroll
@@ -105,34 +106,35 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         const int c = (i * 64 + lane) * 4;
         *reinterpret_cast<float4*>(&red[w][0][c]) = dg[i];
         *reinterpret_cast<float4*>(&red[w][1][c]) = db[i];
+        *reinterpret_cast<float4*>(&red[w][2][c]) = ds[i];
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 2 * C; idx += 256) {
+    for (int idx = threadIdx.x; idx < 3 * C; idx += 256) {
         const int which = idx / C, c = idx % C;
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < ROWS_PER_BLOCK; ++r) s += red[r][which][c];
-        ws[((long)blockIdx.x * 2 + which) * C + c] = s;
+        ws[((long)blockIdx.x * 3 + which) * C + c] = s;
     }
 }
 
-// 256 threads = 16 columns x 16 slices of the partial list; each block owns 16 consecutive entries of the [2][C] tables
+// 256 threads = 16 columns x 16 slices of the partial list; each block owns 16 consecutive entries of the [3][C] tables
 __global__ __launch_bounds__(256) void ln_bwd_finalize(const float* __restrict__ ws, int nblk, int C, float* __restrict__ dgamma,
-                                                       float* __restrict__ dbeta) {
+                                                       float* __restrict__ dbeta, float* __restrict__ dx_colsum) {
     __shared__ float red[16][17];
     const int col = threadIdx.x & 15, part = threadIdx.x >> 4;
-    const int idx = blockIdx.x * 16 + col;          // index into [2][C]
+    const int idx = blockIdx.x * 16 + col;          // index into [3][C]
     float s = 0.f;
-    if (idx < 2 * C)
-        for (int b = part; b < nblk; b += 16) s += ws[(long)b * 2 * C + idx];
+    if (idx < 3 * C)
+        for (int b = part; b < nblk; b += 16) s += ws[(long)b * 3 * C + idx];
     red[part][col] = s;
     __syncthreads();
-    if (part == 0 && idx < 2 * C) {
+    if (part == 0 && idx < 3 * C) {
         s = 0.f;
 #pragma unroll
         for (int y = 0; y < 16; ++y) s += red[y][col];
         const int which = idx / C, c = idx % C;
-        float* out = which == 0 ? dgamma : dbeta;
+        float* out = which == 0 ? dgamma : (which == 1 ? dbeta : dx_colsum);
         if (out) out[c] += s;
     }
 }
@@ -221,6 +223,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
         for (int y = 0; y < ny; ++y) s += red[(y * tpr + cx) * 8 + e];
         unsafeAtomicAdd(out + col, s);
     }
+}
+
+// generic fallback (any C): one thread per column, 64 rows per block
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_generic_kernel(const T* __restrict__ x, float* __restrict__ out, long rows, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long r0 = (long)blockIdx.y * 64, r1 = min(rows, r0 + 64);
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += ld_f(x + r * C + c);
+    unsafeAtomicAdd(out + c, s);
 }
 
 // grouped row copy / add: dst[(g*dgs + doff + r)*C + c] (=|+=) src[(g*sgs + soff + r)*C + c]
@@ -387,19 +400,19 @@ extern "C" int tan_layernorm_fwd(const void* x, const float* gamma, const float*
     return 0;
 }
 
-extern "C" long tan_layernorm_bwd_ws_floats(int C) { return 512L * 2 * C; }
+extern "C" long tan_layernorm_bwd_ws_floats(int C) { return 512L * 3 * C; }
 
 extern "C" int tan_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                                 const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, long rows, int C,
-                                 int dtype, void* stream) {
+                                 const void* dres, void* dx, float* dgamma, float* dbeta, float* dx_colsum, float* ws, long rows,
+                                 int C, int dtype, void* stream) {
     TAN_REQUIRE(dy && x && gamma && mean && rstd && dx && ws && rows > 0);
     hipStream_t st = (hipStream_t)stream;
     const int nblk = (int)min((long)512, (long)cdiv(rows, ROWS_PER_BLOCK));
     DISPATCH_T(dtype, DISPATCH_NCH(C, hipLaunchKernelGGL((ln_bwd_kernel<T, NCH>), dim3(nblk), dim3(256), 0, st, (const T*)dy,
                                                          (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, ws, rows)));
     TAN_LAUNCH_CHECK();
-    if (dgamma || dbeta) {
-        hipLaunchKernelGGL(ln_bwd_finalize, dim3(cdiv(2 * C, 16)), dim3(256), 0, st, ws, nblk, C, dgamma, dbeta);
+    if (dgamma || dbeta || dx_colsum) {
+        hipLaunchKernelGGL(ln_bwd_finalize, dim3(cdiv(3 * C, 16)), dim3(256), 0, st, ws, nblk, C, dgamma, dbeta, dx_colsum);
         TAN_LAUNCH_CHECK();
     }
     return 0;
@@ -427,8 +440,14 @@ extern "C" int tan_l2norm_bwd(const void* dy, const void* y, const float* inv_no
 }
 
 extern "C" int tan_colsum_acc(const void* x, float* out, long rows, int C, int dtype, void* stream) {
-    TAN_REQUIRE(x && out && rows > 0 && C > 0 && C % 8 == 0);
+    TAN_REQUIRE(x && out && rows > 0 && C > 0);
     hipStream_t st = (hipStream_t)stream;
+    if (C % 8 != 0 || ((uintptr_t)x % 16) != 0) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_generic_kernel<T>), dim3(cdiv(C, 256), cdiv(rows, 64)), dim3(256), 0, st,
+                                             (const T*)x, out, rows, C));
+        TAN_LAUNCH_CHECK();
+        return 0;
+    }
     int tpr = C / 8;                      // threads spanning one row
     if (tpr > 256) tpr = 256;
     while (256 % tpr) --tpr;              // must divide the block

@@ -35,7 +35,7 @@ def _stream():
 
 def gemm(A, B, C_out, *, M, N, K, a_kc=True, b_kc=True, lda=None, ldb=None, ldc=None, bias=None, residual=None,
          ldr=None, act=ACT_NONE, aux=None, ldaux=None, accumulate=False, split_k=1, alpha=1.0, batch=1,
-         sA=0, sB=0, sC=0):
+         sA=0, sB=0, sC=0, colsum=None):
     """C[M,N] (=|+=) alpha * opA(A) @ opB(B) (+bias)(act)(+residual); see include/tan_hip.h:tan_gemm."""
     d = _lib.GemmDesc()
     d.dtype, d.out_dtype = _dt(A), _dt(C_out)
@@ -51,6 +51,7 @@ def gemm(A, B, C_out, *, M, N, K, a_kc=True, b_kc=True, lda=None, ldb=None, ldc=
     d.aux, d.ldaux = _ptr(aux), ldaux if ldaux is not None else N
     d.accumulate, d.split_k, d.alpha = int(accumulate), split_k, alpha
     d.batch, d.sA, d.sB, d.sC = batch, sA, sB, sC
+    d.colsum = _ptr(colsum)
     _lib.check(_lib.lib().tan_gemm(C.byref(d), _stream()), "tan_gemm")
     return C_out
 
@@ -80,12 +81,13 @@ def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, add=None, add_period=
     return y
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma=None, dbeta=None, dres=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma=None, dbeta=None, dres=None, dx_colsum=None):
     rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
     L = _lib.lib()
     ws = _ws_f32(L.tan_layernorm_bwd_ws_floats(C.c_int(Cc)), x.device)
     _lib.check(L.tan_layernorm_bwd(_ptr(dy), _ptr(x), _f32(gamma), _f32(mean), _f32(rstd), _ptr(dres), _ptr(dx),
-                                   _f32(dgamma), _f32(dbeta), _ptr(ws), C.c_long(rows), C.c_int(Cc), _dt(x), _stream()),
+                                   _f32(dgamma), _f32(dbeta), _f32(dx_colsum), _ptr(ws), C.c_long(rows), C.c_int(Cc), _dt(x),
+                                   _stream()),
                "tan_layernorm_bwd")
     return dx
 

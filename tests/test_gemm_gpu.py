@@ -99,3 +99,18 @@ def test_gemm_direct_to_lds_path(a_kc, b_kc, M, N, K):
     res = _mk((M, N), dtype, 14)
     ops.gemm(A, B, out, M=M, N=N, K=K, a_kc=a_kc, b_kc=b_kc, bias=bias, residual=res)
     assert (out.double() - (ref + bias.double() + res.double())).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(1000, 2048, 512), (300, 520, 128), (64, 20, 24)])
+def test_gemm_fused_colsum(dtype, M, N, K):
+    """bias-gradient column sums fused into the epilogue (direct-to-LDS path) or appended as a pass (other paths)"""
+    from temporalalignnet_amd import ops
+    A, B = _mk((M, K), dtype, 21), _mk((N, K), dtype, 22)
+    out = torch.empty(M, N, device="cuda", dtype=dtype)
+    cs = torch.ones(N, device="cuda")
+    ops.gemm(A, B, out, M=M, N=N, K=K, colsum=cs)
+    ref = A.double() @ B.double().t()
+    assert (out.double() - ref).abs().max().item() < _tol(dtype, K) * (ref.abs().max().item() + 1)
+    err = (cs.double() - ref.sum(0) - 1).abs().max().item()
+    assert err < (1e-5 * M * K ** 0.5 if dtype == torch.float32 else 0.05 * M ** 0.5 + 0.5), err

@@ -43,8 +43,10 @@ def test_layernorm_fwd_bwd(dtype, rows, period):
     dx = torch.empty_like(x)
     dg = torch.ones(C, device="cuda")
     db = torch.ones(C, device="cuda")
-    ops.layernorm_bwd(dy, x, g, mean, rstd, dx, dg, db, dres)
+    cs = torch.ones(C, device="cuda")
+    ops.layernorm_bwd(dy, x, g, mean, rstd, dx, dg, db, dres, dx_colsum=cs)
     close(dx, xr.grad + dres.double(), 1e-4 if dtype == torch.float32 else 8e-2)
+    close(cs, (xr.grad + dres.double()).sum(0) + 1, 1e-3 if dtype == torch.float32 else 0.5)
     close(dg, gr.grad + 1, 1e-3 if dtype == torch.float32 else 0.3)
     close(db, br.grad + 1, 1e-3 if dtype == torch.float32 else 0.3)
 
