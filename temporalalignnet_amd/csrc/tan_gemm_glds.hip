@@ -12,6 +12,7 @@
 //     both read patterns are conflict-free (each 16/32-lane service group touches every bank once).
 //   * rows / columns past the edge of the problem are CLAMPED to a valid address instead of masked: they only feed
 //     accumulator rows / columns that the guarded epilogue never stores.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "tan_mma.h"
@@ -272,8 +273,140 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs2 g) {
     else epilogue2<TC, true>(g, acc, C, R, AUX, m0, n0, wm, wn, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 4-stage variant: K-step 32, four 16-KiB LDS stages, THREE tiles in flight per workgroup (counted s_waitcnt vmcnt(8),
+// raw s_barrier) instead of one 32-KiB tile.  Used where it measured faster (see use_four_stage).
+constexpr int T4_BYTES = 128 * 32 * 2;    // 8 KiB operand tile
+
+template <bool KC>
+__device__ __forceinline__ void stage_tile4(const bf16_t* __restrict__ P, long ld, int outer0, int OUT, int k0, char* lds_tile,
+                                            int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int piece = wave * 2 + i;             // 8 pieces of 1 KiB
+        const bf16_t* src;
+        if (KC) {                                   // [128 rows][4 x 16-B slots], slot = chunk ^ ((row >> 2) & 3)
+            const int row = piece * 16 + (lane >> 2), slot = lane & 3;
+            const int chunk = slot ^ ((row >> 2) & 3);
+            const int gr = min(outer0 + row, OUT - 1);
+            src = P + (long)gr * ld + k0 + chunk * 8;
+        } else {                                    // [32 k][16 x 16-B slots], slot = chunk ^ ((k & 3) << 2)
+            const int k = piece * 4 + (lane >> 4), slot = lane & 15;
+            const int chunk = slot ^ ((k & 3) << 2);
+            const int go = min(outer0 + chunk * 8, OUT - 8);
+            src = P + (long)(k0 + k) * ld + go;
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + piece * 1024), 16, 0, 0);
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ bf16x8 load_frag4(const char* lds_tile, int o0, int ks, int lane) {
+    if (KC) {
+        const int row = o0 + (lane & 31), chunk = (ks >> 3) + (lane >> 5);
+        return *reinterpret_cast<const bf16x8*>(lds_tile + row * 64 + (chunk ^ ((row >> 2) & 3)) * 16);
+    } else {
+        return load_frag<false>(lds_tile, o0, ks, lane);      // same [k][256 B] image as the 64-deep tile
+    }
+}
+
+template <typename TC, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_glds4_kernel(GemmArgs2 g) {
+    __shared__ __attribute__((aligned(1024))) char lds[8 * T4_BYTES];   // [stage][A|B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = gridDim.x, nwg = gridDim.x * gridDim.y;
+    int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const int xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    }
+    const int n0 = (wg % ntn) * GBN, m0 = (wg / ntn) * GBM;
+    const int z = blockIdx.z, batch = z / g.split_k, split = z % g.split_k;
+    const bf16_t* A = g.A + (long)batch * g.sA;
+    const bf16_t* B = g.B + (long)batch * g.sB;
+    const int kbeg = split * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nt = (kend - kbeg) / 32;
+    const long lda = g.lda, ldb = g.ldb;
+    const int M = g.M, N = g.N;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
+
+#define G4_STAGE(T_, S_)                                                                                    \
+    {                                                                                                       \
+        stage_tile4<A_KC>(A, lda, m0, M, kbeg + (T_) * 32, lds + (S_) * 2 * T4_BYTES, wave, lane);          \
+        stage_tile4<B_KC>(B, ldb, n0, N, kbeg + (T_) * 32, lds + (S_) * 2 * T4_BYTES + T4_BYTES, wave, lane); \
+    }
+    // every step issues exactly 4 DMA instructions per wave (a dummy re-load of the last tile past the end keeps the count
+    // uniform), so "tile t+1 has landed" is always vmcnt(8): the two younger tiles may still be in flight
+#define G4_STEP(T_, CUR, PRE)                                                                               \
+    {                                                                                                       \
+        const int t_ = (T_);                                                                                \
+        G4_STAGE(min(t_ + 3, nt - 1), PRE)                                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 32; ks += 16) {                                             \
+            bf16x8 a[2], b[2];                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) a[i] = load_frag4<A_KC>(lds + (CUR) * 2 * T4_BYTES, wm * 64 + i * 32, ks, lane); \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
+                b[j] = load_frag4<B_KC>(lds + (CUR) * 2 * T4_BYTES + T4_BYTES, wn * 64 + j * 32, ks, lane); \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);        \
+        }                                                                                                   \
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                         \
+        __builtin_amdgcn_s_barrier();                                                                       \
+    }
+
+    if (nt > 0) {
+        G4_STAGE(0, 0)
+        G4_STAGE(min(1, nt - 1), 1)
+        G4_STAGE(min(2, nt - 1), 2)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nt; t += 4) {
+            G4_STEP(t, 0, 3)
+            if (t + 1 < nt) G4_STEP(t + 1, 1, 0)
+            if (t + 2 < nt) G4_STEP(t + 2, 2, 1)
+            if (t + 3 < nt) G4_STEP(t + 3, 3, 2)
+        }
+    }
+#undef G4_STEP
+#undef G4_STAGE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // dummy tail DMAs must land before the LDS is reused
+    __syncthreads();
+
+    TC* C = (TC*)g.C + (long)batch * g.sC;
+    const TC* R = g.residual ? (const TC*)g.residual + (long)batch * g.sC : nullptr;
+    TC* AUX = g.aux ? (TC*)g.aux + (long)batch * g.sC : nullptr;
+    if (g.vec_epi) epilogue_vec<TC>(g, acc, reinterpret_cast<float*>(lds), C, R, AUX, m0, n0, wm, wn, lane, tid);
+    else if (m0 + GBM <= g.M && n0 + GBN <= g.N) epilogue2<TC, false>(g, acc, C, R, AUX, m0, n0, wm, wn, lane);
+    else epilogue2<TC, true>(g, acc, C, R, AUX, m0, n0, wm, wn, lane);
+}
+
+static int use_four_stage(const tan_gemm_desc* d, const GemmArgs2& a) {
+    static int forced = -2;
+    if (forced == -2) { const char* e = getenv("TAN_GEMM_STAGES"); forced = e ? atoi(e) : -1; }
+    if (forced == 2) return 0;
+    if (forced == 4) return 1;
+    // measured (tools/gemm_bench.py): +10 % on K-contiguous x K-contiguous with K >= 1024 (c_proj forward), but -10..20 % on
+    // the K-strided (tr-read) operand layouts, where the extra barrier per 8 MFMAs costs more than the deeper prefetch gains
+    return d->a_kc && d->b_kc && a.kchunk >= 1024;
+}
+
 template <typename TC>
 static int launch2(const tan_gemm_desc* d, const GemmArgs2& a, dim3 grid, hipStream_t st) {
+    if (use_four_stage(d, a)) {
+        if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_glds4_kernel<TC, true, true>), grid, dim3(256), 0, st, a);
+        else if (d->a_kc && !d->b_kc) hipLaunchKernelGGL((gemm_glds4_kernel<TC, true, false>), grid, dim3(256), 0, st, a);
+        else if (!d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_glds4_kernel<TC, false, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_glds4_kernel<TC, false, false>), grid, dim3(256), 0, st, a);
+        TAN_LAUNCH_CHECK();
+        return 0;
+    }
     if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_glds_kernel<TC, true, true>), grid, dim3(256), 0, st, a);
     else if (d->a_kc && !d->b_kc) hipLaunchKernelGGL((gemm_glds_kernel<TC, true, false>), grid, dim3(256), 0, st, a);
     else if (!d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_glds_kernel<TC, false, true>), grid, dim3(256), 0, st, a);
