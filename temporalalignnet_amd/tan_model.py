@@ -198,6 +198,8 @@ class TemporalAligner(nn.Module):
         # reference registers before the encoders' parameters appear in state_dict(); key *names* are what matter.
         self._flat = _Flat(self, [(n, p) for n, p in self.named_parameters() if not n.startswith("bert.")])
         self._ws_pool = {}
+        self.overlap_stacks = True        # run the video and joint stacks on two HIP streams
+        self._side = None
         self._grad_ready_hook = None      # callable(tag) fired inside backward when a slice of the flat gradient is final
 
     # ------------------------------------------------------------------ init (tan_model.py:76-97)
@@ -480,6 +482,13 @@ class TemporalAligner(nn.Module):
                 pool.append(er)
             er.pool_key = None
 
+    def _side_stream(self, dev):
+        if not self.overlap_stacks:
+            return None
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
+
     def _take_scratch(self, R, cd, dev):
         key = ("scr", R, cd, dev)
         scr = self._ws_pool.get(key)
@@ -537,8 +546,18 @@ class TemporalAligner(nn.Module):
             lang_t, sv_text_t = self._text_embed(lang_c, True, p_t, itp, keep)
         else:
             lang_t, sv_text_t = lang_raw, None
-        ev = self._run_video_stack(x0, vmask_u8, B, T)
-        ej = self._run_joint_stack(x0j, lang_t, vmask_u8, tmask_u8, B, T, N)
+        # the two stacks are independent (tan_model.py:108-134): the joint stack runs on a side HIP stream next to the video
+        # stack, which fills the CUs left idle by each other's small kernels (attention, LayerNorm) and launch gaps
+        main, side = torch.cuda.current_stream(), self._side_stream(dev)
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ej = self._run_joint_stack(x0j, lang_t, vmask_u8, tmask_u8, B, T, N)
+            ev = self._run_video_stack(x0, vmask_u8, B, T)
+            main.wait_stream(side)
+        else:
+            ev = self._run_video_stack(x0, vmask_u8, B, T)
+            ej = self._run_joint_stack(x0j, lang_t, vmask_u8, tmask_u8, B, T, N)
         R, Mp, L = B * T, B * N, T + N
         # L2-normalised features (tan_model.py:116-117,136-137)
         vn_d = torch.empty(Se, R, Cw, dtype=cd, device=dev)
@@ -677,14 +696,27 @@ class TemporalAligner(nn.Module):
         d_x0j = d_x0
         any_v = any(t is not None for t in dst_v)
         any_j = any(t is not None for t in dst_j)
-        if any_v:
-            self._encoder_bwd(ev, run["x0"], run["vmask"], "ln_video_post_enc", dst_v, d_x0)
         d_lang_t = None
+        d_xj = torch.empty(B * L, Cw, dtype=cd, device=dev) if any_j else None
+        main, side = torch.cuda.current_stream(), self._side_stream(dev)
+        if any_j and any_v and side is not None:
+            # joint stack backward on the side stream (its gradient slice is final first: DDP starts reducing it while
+            # the video stack is still in backward), video stack backward on the main stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dst_j, d_xj)
+                if self._grad_ready_hook is not None:
+                    self._grad_ready_hook("joint")
+            self._encoder_bwd(ev, run["x0"], run["vmask"], "ln_video_post_enc", dst_v, d_x0)
+            main.wait_stream(side)
+        else:
+            if any_j:
+                self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dst_j, d_xj)
+                if self._grad_ready_hook is not None:    # joint-stack gradients are final: DDP starts reducing them now
+                    self._grad_ready_hook("joint")
+            if any_v:
+                self._encoder_bwd(ev, run["x0"], run["vmask"], "ln_video_post_enc", dst_v, d_x0)
         if any_j:
-            d_xj = torch.empty(B * L, Cw, dtype=cd, device=dev)
-            self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dst_j, d_xj)
-            if self._grad_ready_hook is not None:        # joint-stack gradients are final: DDP starts reducing them now
-                self._grad_ready_hook("joint")
             if run["sv_video_j"] is not None:
                 d_x0j = torch.empty(R, Cw, dtype=cd, device=dev)
                 ops.rows_copy(d_xj, d_x0j, B, T, Cw, L, 0, T, 0)
