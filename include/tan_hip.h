@@ -29,6 +29,7 @@ extern "C" {
 #define TAN_ACT_NONE 0
 #define TAN_ACT_QUICKGELU 1      /* C = x*sigmoid(1.702x), x = acc+bias; x itself optionally stored to aux */
 #define TAN_ACT_QUICKGELU_GRAD 2 /* C = acc * d/dx quickgelu(x), x read from aux */
+#define TAN_ACT_RELU 3           /* C = max(acc+bias, 0)  (Word2VecModel fc1, model/word2vec_model.py:86) */
 
 int tan_version(void);
 /* sizeof(tan_gemm_desc | tan_layer_params | tan_layer_bufs | tan_encoder_desc) for which = 0..3 (binding self-check) */
@@ -178,6 +179,20 @@ int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_stride, const
                       const unsigned char* row_leak, const float* rowsum, const float* colsum, const float* possum_v,
                       const float* possum_t, const float* g_v, const float* g_t, void* dl, float* ws, int S, int B, int T, int N,
                       int C, void* stream);
+
+/* ---- sentence embedder (model/word2vec_model.py:76-102) ----------------------------------------
+ * tan_embed_gather: out[r, 0:D] = table[ids[r], :] cast to `dtype`, out[r, D:Dpad] = 0 (ids NULL = identity: a padded
+ *   cast of a [rows, D] f32 matrix).  Pads the 300-d word vectors / fc1 weight rows to a multiple of 64 for the MFMA GEMM.
+ * tan_unpad_add: dst[r, 0:D] += src[r, 0:D] for src [rows, Dpad] f32 (the padded dW1 back into the 300-wide gradient).
+ * tan_wordpool_fwd: pooled[m,j] = max_w (mask[m,w] ? h[m,w,j] : -6e4), argmax[m,j] = first maximising w
+ *   (masked_fill + torch.max, word2vec_model.py:94-96); tan_wordpool_bwd: dh[m,w,j] = (w == argmax && pooled > 0) ? d_pooled : 0,
+ *   i.e. the max routing followed by the in-place ReLU's gradient; db1 (optional, f32 [H]) += column sums of dh.            */
+int tan_embed_gather(const long* ids, const float* table, void* out, long rows, int D, int Dpad, long V, int dtype, void* stream);
+int tan_unpad_add(const float* src, float* dst, long rows, int D, int Dpad, void* stream);
+int tan_wordpool_fwd(const void* h, const unsigned char* mask, void* pooled, int* argmax, long M, int W, int H, int dtype,
+                     void* stream);
+int tan_wordpool_bwd(const void* d_pooled, const void* pooled, const int* argmax, void* dh, float* db, long M, int W, int H,
+                     int dtype, void* stream);
 
 /* ---- fused AdamW (+ EMA twin, + bf16 shadow weights) over one flat f32 parameter buffer ---------------------
  * torch.optim.AdamW single-tensor arithmetic (train/main.py:397, groups of main.py:330-356) followed by

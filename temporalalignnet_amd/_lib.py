@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libtan_hip.so")
 HEADER = os.path.join(HERE, "..", "include", "tan_hip.h")
 
 TAN_F32, TAN_BF16 = 0, 1
-ACT_NONE, ACT_QUICKGELU, ACT_QUICKGELU_GRAD = 0, 1, 2
+ACT_NONE, ACT_QUICKGELU, ACT_QUICKGELU_GRAD, ACT_RELU = 0, 1, 2, 3
 
 
 class TanHipError(RuntimeError):

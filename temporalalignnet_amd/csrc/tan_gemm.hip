@@ -143,6 +143,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                     v = quick_gelu(v);
                 } else if (g.act == TAN_ACT_QUICKGELU_GRAD) {
                     v *= quick_gelu_grad(ld_f(AUX + (long)row * g.ldaux + col));
+                } else if (g.act == TAN_ACT_RELU) {
+                    v = fmaxf(v, 0.0f);
                 }
                 if (R) v += ld_f(R + (long)row * g.ldr + col);
                 TC* cp = C + (long)row * g.ldc + col;

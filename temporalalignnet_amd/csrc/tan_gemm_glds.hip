@@ -102,6 +102,8 @@ __device__ __forceinline__ void epilogue2(const GemmArgs2& g, f32x16 (&acc)[2][2
                     v = quick_gelu(v);
                 } else if (g.act == TAN_ACT_QUICKGELU_GRAD) {
                     v *= quick_gelu_grad(ld_f(AUX + (long)row * g.ldaux + col));
+                } else if (g.act == TAN_ACT_RELU) {
+                    v = fmaxf(v, 0.0f);
                 }
                 if (R) v += ld_f(R + (long)row * g.ldr + col);
                 TC* cp = C + (long)row * g.ldc + col;
@@ -175,6 +177,9 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs2& g, f32x16 (&acc)[2
             ld8(AUX + (long)row * g.ldaux + col, x);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= quick_gelu_grad(x[e]);
+        } else if (g.act == TAN_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
         }
         if (R) {
             float x[8];

@@ -215,3 +215,33 @@ def align_videos(seed=18, n_videos=3):
             "emb": normal(seed, f"emb{i}", (K, 512)),
         })
     return vids
+
+
+# --------------------------------------------------------------------------------------
+# sentence embedder (row f1)
+# --------------------------------------------------------------------------------------
+def w2v_params(seed: int, V: int) -> dict:
+    """Word2VecModel parameters (model/word2vec_model.py:76-82): word table, fc1 300->2048, fc2 2048->512."""
+    return {"word_embd.weight": normal(seed, "word_embd", (V, 300), 0.3),
+            "fc1.weight": normal(seed, "fc1.w", (2048, 300), 300 ** -0.5), "fc1.bias": normal(seed, "fc1.b", (2048,), 0.05),
+            "fc2.weight": normal(seed, "fc2.w", (512, 2048), 2048 ** -0.5), "fc2.bias": normal(seed, "fc2.b", (512,), 0.05)}
+
+
+def w2v_tokens(seed: int, M: int, V: int, W: int = 32):
+    """[M, W] token ids (0 = padding / unknown) with ragged lengths, one all-zero sentence, and the attention mask."""
+    ids = randint(seed, "ids", 1, V - 1, M * W).reshape(M, W)
+    lens = randint(seed, "len", 1, W, M)
+    for m in range(M):
+        ids[m, lens[m]:] = 0
+    if M > 2:
+        ids[2, :] = 0                     # "all stop words" sentence (word2vec_model.py:92-93)
+        ids[1, 3] = 0                     # an unknown word in the middle
+    return ids.astype(np.int64), (ids != 0).astype(np.uint8)
+
+
+def w2v_vocab(n: int):
+    return np.array([f"w{i}" for i in range(n)] + ["don't", "stir", "the", "eggs"])
+
+
+def w2v_sentences():
+    return ["Stir the eggs, don't stop!", "w3 W7 unknownword w11", "", "w1 " * 12, "the THE the's eggs_w2"]

@@ -163,7 +163,7 @@ class TemporalAligner(nn.Module):
 
         if language_model == "word2vec":
             from .word2vec_model import Word2VecModel
-            self.bert = Word2VecModel()
+            self.bert = Word2VecModel(compute_dtype=compute_dtype)
         elif language_model in (None, "none"):
             self.bert = None
         else:

@@ -64,6 +64,26 @@ def to_device_batch(batch: dict, device="cuda") -> dict:
     return out
 
 
+def pad_sequence_by_last(sequences):
+    """Stack ragged [n_b, C] tensors to [B, max n_b, C], padding each with copies of its last row
+    (data/loader_htm.py:13-23, used at train/main.py:61)."""
+    n_max = max(s.shape[0] for s in sequences)
+    return torch.stack([torch.cat([s, s[-1:].expand(n_max - s.shape[0], -1)], 0) if s.shape[0] < n_max else s
+                        for s in sequences], 0)
+
+
+def embed_sentences(model, token_list):
+    """train/main.py:55-65: concatenate every video's [n_b, 32] token ids, run the language model, split per video and
+    pad -> (text_embed [B, N, 512], text_padding_mask [B, N] float 0/1)."""
+    n_per = [t.shape[0] for t in token_list]
+    flat = torch.cat(token_list, 0).long()
+    emb = model.lang_model(input_ids=flat, attention_mask=flat != 0)["pooler_output"]
+    text_embed = pad_sequence_by_last(torch.split(emb, n_per, dim=0))
+    N = text_embed.shape[1]
+    pad = torch.stack([(torch.arange(N, device=flat.device) >= n).float() for n in n_per], 0)
+    return text_embed, pad
+
+
 class Trainer:
     def __init__(self, model, args, *, betas=(0.9, 0.999), eps=1e-8, iter_per_epoch=None, warmup=1000, fused_loss=None):
         self.model, self.args = model, args
@@ -97,13 +117,46 @@ class Trainer:
             return self.args.lr
         return self.args.lr * lr_multiplier(max(self.iteration - 2, 0), self.iter_per_epoch, self.args.epochs, self.warmup)
 
+    def _lm_params(self):
+        lm = self.online.bert
+        return [] if lm is None else [(n, p) for n, p in lm.named_parameters() if p.requires_grad]
+
     def zero_grad(self):
         f = self.online._ensure_flat()
         f.grad.zero_()
         self.online._bind_grads()
+        for _, p in self._lm_params():
+            p.grad = None
+
+    def _lm_step(self, grad_scale):
+        """AdamW (+EMA) for the language model's fc1/fc2, which live outside the aligner's flat buffer: one fused launch per
+        tensor with the same decay rule (train/main.py:332: '.bias' -> no decay; names are `bert.fc1.weight`, ...)."""
+        named = self._lm_params()
+        if not named:
+            return
+        if "lm" not in self._state:
+            self._state["lm"] = {n: (torch.zeros_like(p), torch.zeros_like(p)) for n, p in named}
+        tgt = dict(self.model.target.bert.named_parameters()) if self.twin and self.model.target.bert is not None else {}
+        a = self.args
+        for n, p in named:
+            if p.grad is None:
+                continue
+            if dist.world_size() > 1:
+                dist.allreduce_sum_(p.grad)
+            m, v = self._state["lm"][n]
+            wd = 0.0 if n.endswith(".bias") else a.wd
+            ema = tgt.get(n)
+            _lib.check(_lib.lib().tan_adamw_step(
+                _vp(p.data), _vp(p.grad.contiguous()), _vp(m), _vp(v), None, C.c_long(p.numel()), C.c_double(self.current_lr()),
+                C.c_double(self.betas[0]), C.c_double(self.betas[1]), C.c_double(self.eps), C.c_double(wd), C.c_int(self.iteration),
+                C.c_float(grad_scale), None, _vp(ema.data) if ema is not None else None,
+                C.c_float(self.model.m if self.twin else 0.0), None, ops._stream()), "tan_adamw_step")
 
     def forward_backward(self, batch):
         a, m = self.args, self.model
+        if "token" in batch and self.online.bert is not None:      # sentence embeddings from the language model (main.py:55-65)
+            batch = dict(batch)
+            batch["text_embed"], batch["text_padding_mask"] = embed_sentences(m, batch["token"])
         logits = m(batch["video"], batch["text_embed"], video_padding_mask=batch["padding_mask"],
                    lang_padding_mask=batch["text_padding_mask"].bool(), text_timestamp=batch.get("_tgt_raw"),
                    abs_text_pos=batch.get("abs_text_pos"), fused=self.fused_loss)
@@ -134,6 +187,7 @@ class Trainer:
             C.c_double(a.wd), C.c_int(self.iteration), C.c_float(grad_scale), _vp(f.shadow),
             _vp(ema.flat) if ema is not None else None, C.c_float(self.model.m if self.twin else 0.0),
             _vp(ema.shadow) if ema is not None else None, ops._stream()), "tan_adamw_step")
+        self._lm_step(grad_scale)
 
     def step(self, batch):
         """One optimizer step on an already device-resident batch (see to_device_batch).  With N>1 ranks the flat gradient

@@ -354,9 +354,41 @@ def g6_eval_harness():
     save("g6_eval_harness", **arrs)
 
 
+def g8_word2vec():
+    """G8 (row f1): the reference's Word2VecModel.forward and Word2VecTokenizer on a synthetic vocabulary.  Both classes load
+    MIL-NCE asset files in __init__ (absent here), so instances are made with __new__ and given the same attributes
+    __init__ would set; forward / __call__ are the reference's own code."""
+    sys.path.insert(0, f"{REF}/model")
+    import word2vec_model as ref_w2v
+    V = 500
+    p = synth.w2v_params(31, V)
+    m = ref_w2v.Word2VecModel.__new__(ref_w2v.Word2VecModel)
+    torch.nn.Module.__init__(m)
+    m.word_embd = torch.nn.Embedding(V, 300)
+    m.fc1, m.fc2 = torch.nn.Linear(300, 2048), torch.nn.Linear(2048, 512)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    ids, mask = synth.w2v_tokens(32, M=9, V=V)
+    ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask).bool()
+    out = m(ids_t, mask_t.clone())
+    w = torch.from_numpy(synth.normal(33, "w", (9, 512)))
+    (out["pooler_output"] * w).sum().backward()
+    arrs = {"pooler_output": out["pooler_output"].detach().numpy(), "last_hidden_state": out["last_hidden_state"].detach().numpy(),
+            "pooler_nomask": m(ids_t)["pooler_output"].detach().numpy()}
+    for k, v in grad_stats((n, q.grad) for n, q in m.named_parameters() if q.grad is not None).items():
+        arrs["grad/" + k] = v
+    tok = ref_w2v.Word2VecTokenizer.__new__(ref_w2v.Word2VecTokenizer)
+    vocab = synth.w2v_vocab(40)
+    tok.word_to_token = {w_: i + 1 for i, w_ in enumerate(vocab)}
+    tok.max_words = 8
+    sents = synth.w2v_sentences()
+    t = tok(sents, return_tensors="pt")
+    arrs["tok_ids"], arrs["tok_mask"] = t["input_ids"].numpy(), t["attention_mask"].numpy()
+    save("g8_word2vec", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     table = {"g1": g1_forward_small, "g2": g2_forward_e6d6, "g3": g3_loss_init, "g4": g4_loss_cotrain,
-             "g5": g5_train_steps, "g6": g6_eval_harness, "g7": g7_long_and_interp}
+             "g5": g5_train_steps, "g6": g6_eval_harness, "g7": g7_long_and_interp, "g8": g8_word2vec}
     for w in which:
         table[w]()
