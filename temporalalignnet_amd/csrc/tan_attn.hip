@@ -12,6 +12,7 @@
 // backward: P is recomputed from lse.  dq kernel: workgroup per query tile, loops key tiles.
 //           dk/dv kernel: workgroup per key tile, loops query tiles.  No atomics, deterministic.
 #include "tan_mma.h"
+#include <cstdlib>
 
 namespace tal {
 
@@ -310,9 +311,307 @@ template <typename K> static int set_smem(K kernel, size_t bytes) {
     return 0;
 }
 
+
+// ======================================================================================================
+// Short-sequence bf16 path (L <= 128: the len=64 video stack and the 64+N joint stack of the headline config).
+// One workgroup per (video, head); wave w owns the 32 queries (and, in the backward, the 32 keys) 32w..32w+31, so the
+// workgroup has ceil(L/32) waves.  q, k, v (and dO) head slices go HBM -> LDS once with direct-to-LDS loads into
+// [row][64] images (128-B rows, 16-B chunk index XOR-swizzled by the row so that both the row-wise ds_read_b128 and the
+// transposing ds_read_b64_tr_b16 gathers spread over the banks).  Everything after the single barrier is wave-private:
+//   scores are computed TRANSPOSED (S^T = K Q^T), so a lane holds one query column: the softmax reductions are a
+//   register loop plus one lane^32 exchange, and the 32x32 accumulator tile is, register for register, the B-operand
+//   fragment of the next MFMA (O^T = V^T P^T) once the contraction index is permuted the same way on the A side --
+//   which the transposing LDS read does for free.  No score panel in LDS, no workgroup barrier inside the math.
+// The backward recomputes P in both orientations instead of exchanging it: phase A (wave owns queries) gives dq and
+// delta_i = sum_j P_ij dP_ij (== rowsum(dO*O)), phase B (wave owns keys) gives dk, dv.  Deterministic, no atomics.
+typedef const __attribute__((address_space(1))) void* attn_gptr_t;
+typedef __attribute__((address_space(3))) void* attn_lptr_t;
+typedef short attn_s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int img_swz(int row) { const int t = (row >> 1) & 7; return t ^ ((t & 1) << 2); }
+
+// lane: outer index = row, k = 8 * chunk .. + 7   (image rows are the outer index)
+__device__ __forceinline__ bf16x8 img_frag_kc(const char* img, int row, int chunk) {
+    return *reinterpret_cast<const bf16x8*>(img + row * 128 + ((chunk ^ img_swz(row)) << 4));
+}
+// lane: outer index = col0 + (lane & 31), contraction slots e = 0..7 <-> image rows rbase + 4*(lane>>5) + (e&3) + 8*(e>>2)
+// (the order in which a 32x32 accumulator tile holds its rows, see acc_frag)
+__device__ __forceinline__ bf16x8 img_frag_tr(const char* img, int rbase, int col0, int lane) {
+    const int g = lane >> 4, p = lane & 15, r = p >> 2, q = p & 3;
+    const int row = rbase + 4 * (g >> 1) + r;
+    const int chunk = (col0 + 16 * (g & 1) + 4 * q) >> 3;
+    typedef __attribute__((address_space(3))) attn_s16x4* lds_v4;
+    const char* p0 = img + row * 128 + ((chunk ^ img_swz(row)) << 4) + (q & 1) * 8;
+    const char* p1 = img + (row + 8) * 128 + ((chunk ^ img_swz(row + 8)) << 4) + (q & 1) * 8;
+    union { bf16x8 v; attn_s16x4 h[2]; } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)p0);
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)p1);
+    return u.v;
+}
+// registers 8j..8j+7 of an accumulator tile as an operand fragment (contraction = the tile's row index)
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int j) {
+    union { bf16x8 v; bf16_t s[8]; } u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) u.s[e] = f2bf(a[8 * j + e]);
+    return u.v;
+}
+// stage `nimg` [LP][64] head slices (image i from src + i * img_stride, row stride ld) into consecutive LDS images
+template <int NKB>
+__device__ __forceinline__ void stage_images(char* lds, int first_img, int nimg, const bf16_t* src, long img_stride, long ld,
+                                             int L, int wave, int lane) {
+    constexpr int PPI = NKB * 4;                    // 1-KiB pieces (8 rows) per image
+    for (int p = wave; p < nimg * PPI; p += NKB) {
+        const int img = p / PPI, row = (p % PPI) * 8 + (lane >> 3), slot = lane & 7;
+        const int chunk = slot ^ img_swz(row);
+        const bf16_t* g = src + img * img_stride + (long)min(row, L - 1) * ld + chunk * 8;
+        __builtin_amdgcn_global_load_lds((attn_gptr_t)g, (attn_lptr_t)(lds + (first_img * PPI + p) * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void store_tile_t(bf16_t* out, long ld, int row, int L, const f32x16& acc, int dbase, int hh, float scale) {
+    // accumulator tile [d][row]: lane holds 4 consecutive d per register quad -> 8-byte stores
+    if (row < L) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+            st4(out + (long)row * ld + dbase + 8 * g4 + 4 * hh,
+                make_float4(acc[4 * g4] * scale, acc[4 * g4 + 1] * scale, acc[4 * g4 + 2] * scale, acc[4 * g4 + 3] * scale));
+    }
+}
+
+template <int NKB>
+__global__ __launch_bounds__(64 * NKB) void attn_fwd_short_kernel(AttnArgs a) {
+    constexpr int LP = 32 * NKB;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* Qi = smem; char* Ki = Qi + LP * 128; char* Vi = Ki + LP * 128;
+    float* bias = (float*)(Vi + LP * 128);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
+    const int C = a.H * DH, L = a.L;
+    const long ld = 3L * C;
+    const bf16_t* base = (const bf16_t*)a.qkv + (long)b * L * ld + h * DH;
+    stage_images<NKB>(smem, 0, 3, base, C, ld, L, wave, lane);
+    const unsigned char* kp = a.keypad ? a.keypad + (long)b * L : nullptr;
+    for (int j = tid; j < LP; j += 64 * NKB) bias[j] = (j >= L || (kp && kp[j])) ? -INFINITY : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int q0 = wave * 32;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = img_frag_kc(Qi, q0 + c, 2 * ks + hh);
+    f32x16 s[NKB];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        acc_zero(s[kb]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Ki, 32 * kb + c, 2 * ks + hh), qf[ks], s[kb], 0, 0, 0);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + 32 * kb + 8 * g4 + 4 * hh);
+            const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = s[kb][4 * g4 + e] * 0.125f + bb[e];
+                s[kb][4 * g4 + e] = v;
+                m = fmaxf(m, v);
+            }
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const bool dead = (m == -INFINITY);       // every key padded: the reference yields NaN here; we emit zeros
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = dead ? 0.f : __expf(s[kb][r] - m);
+            s[kb][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = dead ? 0.f : 1.0f / sum;
+    if (hh == 0 && q0 + c < L) a.lse[((long)b * a.H + h) * L + q0 + c] = dead ? -INFINITY : m + logf(sum);
+    f32x16 o[2];
+    acc_zero(o[0]); acc_zero(o[1]);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] *= inv;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bf16x8 pf = acc_frag(s[kb], j);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_tr(Vi, 32 * kb + 16 * j, 32 * db, lane), pf, o[db], 0, 0, 0);
+        }
+    }
+    // O^T tiles -> the wave's own (now dead) q rows in LDS -> 16-byte row-contiguous global stores
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int row = q0 + c, chunk = 4 * db + g4;
+            st4((bf16_t*)(Qi + row * 128 + ((chunk ^ img_swz(row)) << 4) + hh * 8),
+                make_float4(o[db][4 * g4], o[db][4 * g4 + 1], o[db][4 * g4 + 2], o[db][4 * g4 + 3]));
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    bf16_t* out = (bf16_t*)a.o + (long)b * L * C + h * DH;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = q0 + it * 8 + (lane >> 3), chunk = lane & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(Qi + row * 128 + ((chunk ^ img_swz(row)) << 4));
+        if (row < L) *reinterpret_cast<uint4*>(out + (long)row * C + chunk * 8) = v;
+    }
+}
+
+template <int NKB>
+__global__ __launch_bounds__(64 * NKB) void attn_bwd_short_kernel(AttnArgs a) {
+    constexpr int LP = 32 * NKB;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* Qi = smem; char* Ki = Qi + LP * 128; char* Vi = Ki + LP * 128; char* Di = Vi + LP * 128;
+    float* bias = (float*)(Di + LP * 128);
+    float* lse_s = bias + LP;
+    float* delta_s = lse_s + LP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
+    const int C = a.H * DH, L = a.L;
+    const long ld = 3L * C;
+    const bf16_t* base = (const bf16_t*)a.qkv + (long)b * L * ld + h * DH;
+    stage_images<NKB>(smem, 0, 3, base, C, ld, L, wave, lane);
+    stage_images<NKB>(smem, 3, 1, (const bf16_t*)a.d_o + (long)b * L * C + h * DH, 0, C, L, wave, lane);
+    const unsigned char* kp = a.keypad ? a.keypad + (long)b * L : nullptr;
+    for (int j = tid; j < LP; j += 64 * NKB) {
+        bias[j] = (j >= L || (kp && kp[j])) ? -INFINITY : 0.f;
+        float l = INFINITY;                      // rows past L and fully padded rows: p = exp(. - inf) = 0
+        if (j < L) { l = a.lse[((long)b * a.H + h) * L + j]; if (l == -INFINITY) l = INFINITY; }
+        lse_s[j] = l;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bf16_t* out = (bf16_t*)a.dqkv + (long)b * L * ld + h * DH;
+
+    {   // ---- phase A: this wave's 32 queries against every key: delta and dq
+        const int q0 = wave * 32;
+        bf16x8 qf[4], dof[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qf[ks] = img_frag_kc(Qi, q0 + c, 2 * ks + hh); dof[ks] = img_frag_kc(Di, q0 + c, 2 * ks + hh); }
+        const float my_lse = lse_s[q0 + c];
+        f32x16 p[NKB], dp[NKB];
+        float delta = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            acc_zero(p[kb]); acc_zero(dp[kb]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                p[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Ki, 32 * kb + c, 2 * ks + hh), qf[ks], p[kb], 0, 0, 0);
+                dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Vi, 32 * kb + c, 2 * ks + hh), dof[ks], dp[kb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 bv = *reinterpret_cast<const float4*>(bias + 32 * kb + 8 * g4 + 4 * hh);
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pv = __expf(p[kb][4 * g4 + e] * 0.125f + bb[e] - my_lse);
+                    p[kb][4 * g4 + e] = pv;
+                    delta += pv * dp[kb][4 * g4 + e];
+                }
+            }
+        }
+        delta += __shfl_xor(delta, 32, 64);
+        if (hh == 0) delta_s[q0 + c] = delta;
+        f32x16 dq[2];
+        acc_zero(dq[0]); acc_zero(dq[1]);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[kb][r] *= (dp[kb][r] - delta);     // dS^T
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 df = acc_frag(p[kb], j);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_tr(Ki, 32 * kb + 16 * j, 32 * db, lane), df, dq[db], 0, 0, 0);
+            }
+        }
+        store_tile_t(out, ld, q0 + c, L, dq[0], 0, hh, 0.125f);
+        store_tile_t(out, ld, q0 + c, L, dq[1], 32, hh, 0.125f);
+    }
+    __syncthreads();
+    {   // ---- phase B: this wave's 32 keys against every query: dk, dv
+        const int k0 = wave * 32;
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = img_frag_kc(Ki, k0 + c, 2 * ks + hh); vf[ks] = img_frag_kc(Vi, k0 + c, 2 * ks + hh); }
+        const float my_bias = bias[k0 + c];
+        f32x16 dk[2], dv[2];
+        acc_zero(dk[0]); acc_zero(dk[1]); acc_zero(dv[0]); acc_zero(dv[1]);
+#pragma unroll
+        for (int qb = 0; qb < NKB; ++qb) {
+            f32x16 p, dp;
+            acc_zero(p); acc_zero(dp);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Qi, 32 * qb + c, 2 * ks + hh), kf[ks], p, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Di, 32 * qb + c, 2 * ks + hh), vf[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 lv = *reinterpret_cast<const float4*>(lse_s + 32 * qb + 8 * g4 + 4 * hh);
+                const float4 dl = *reinterpret_cast<const float4*>(delta_s + 32 * qb + 8 * g4 + 4 * hh);
+                const float ll[4] = {lv.x, lv.y, lv.z, lv.w}, dd[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pv = __expf(p[4 * g4 + e] * 0.125f + my_bias - ll[e]);
+                    p[4 * g4 + e] = pv;
+                    dp[4 * g4 + e] = pv * (dp[4 * g4 + e] - dd[e]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 pf = acc_frag(p, j), df = acc_frag(dp, j);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_tr(Di, 32 * qb + 16 * j, 32 * db, lane), pf, dv[db], 0, 0, 0);
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_tr(Qi, 32 * qb + 16 * j, 32 * db, lane), df, dk[db], 0, 0, 0);
+                }
+            }
+        }
+        store_tile_t(out + C, ld, k0 + c, L, dk[0], 0, hh, 0.125f);
+        store_tile_t(out + C, ld, k0 + c, L, dk[1], 32, hh, 0.125f);
+        store_tile_t(out + 2 * C, ld, k0 + c, L, dv[0], 0, hh, 1.0f);
+        store_tile_t(out + 2 * C, ld, k0 + c, L, dv[1], 32, hh, 1.0f);
+    }
+}
+
+template <int NKB> static int launch_fwd_short(const AttnArgs& a, hipStream_t st) {
+    const size_t sm = 3 * NKB * 32 * 128 + NKB * 32 * 4;
+    int rc = set_smem(attn_fwd_short_kernel<NKB>, sm);
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_fwd_short_kernel<NKB>), dim3(a.B * a.H), dim3(64 * NKB), sm, st, a);
+    return 0;
+}
+template <int NKB> static int launch_bwd_short(const AttnArgs& a, hipStream_t st) {
+    const size_t sm = 4 * NKB * 32 * 128 + 3 * NKB * 32 * 4;
+    int rc = set_smem(attn_bwd_short_kernel<NKB>, sm);
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_bwd_short_kernel<NKB>), dim3(a.B * a.H), dim3(64 * NKB), sm, st, a);
+    return 0;
+}
+
 }  // namespace tal
 
 using namespace tal;
+
+// TAN_ATTN_GENERIC=1 forces the tiled any-length kernels for bf16 too (A/B measurements)
+static bool short_path(int dtype, int L) {
+    static const bool off = [] { const char* e = getenv("TAN_ATTN_GENERIC"); return e && e[0] == '1'; }();
+    return dtype == TAN_BF16 && L <= 128 && !off;
+}
 
 extern "C" int tan_attn_fwd(const void* qkv, const unsigned char* key_padding_mask, void* o, float* lse, int B, int L, int H,
                             int dtype, void* stream) {
@@ -328,6 +627,11 @@ extern "C" int tan_attn_fwd(const void* qkv, const unsigned char* key_padding_ma
         size_t sm = fwd_smem<float>(a.Lpad);
         if ((rc = set_smem(attn_fwd_kernel<float>, sm))) return rc;
         hipLaunchKernelGGL((attn_fwd_kernel<float>), grid, dim3(256), sm, st, a);
+    } else if (short_path(dtype, L)) {
+        const int nkb = (L + 31) / 32;
+        rc = nkb == 1 ? launch_fwd_short<1>(a, st) : nkb == 2 ? launch_fwd_short<2>(a, st)
+           : nkb == 3 ? launch_fwd_short<3>(a, st) : launch_fwd_short<4>(a, st);
+        if (rc) return rc;
     } else if (dtype == TAN_BF16) {
         size_t sm = fwd_smem<bf16_t>(a.Lpad);
         if ((rc = set_smem(attn_fwd_kernel<bf16_t>, sm))) return rc;
@@ -353,6 +657,11 @@ extern "C" int tan_attn_bwd(const void* qkv, const unsigned char* key_padding_ma
         if ((rc = set_smem(attn_bwd_dkv_kernel<float>, bwd_smem<float>(6)))) return rc;
         hipLaunchKernelGGL((attn_bwd_dq_kernel<float>), grid, dim3(256), bwd_smem<float>(5), st, a);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<float>), grid, dim3(256), bwd_smem<float>(6), st, a);
+    } else if (short_path(dtype, L)) {
+        const int nkb = (L + 31) / 32;
+        rc = nkb == 1 ? launch_bwd_short<1>(a, st) : nkb == 2 ? launch_bwd_short<2>(a, st)
+           : nkb == 3 ? launch_bwd_short<3>(a, st) : launch_bwd_short<4>(a, st);
+        if (rc) return rc;
     } else if (dtype == TAN_BF16) {
         if ((rc = set_smem(attn_bwd_dq_kernel<bf16_t>, bwd_smem<bf16_t>(5)))) return rc;
         if ((rc = set_smem(attn_bwd_dkv_kernel<bf16_t>, bwd_smem<bf16_t>(6)))) return rc;

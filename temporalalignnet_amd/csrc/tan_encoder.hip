@@ -13,6 +13,11 @@
 // deep-supervision stage s < S-1 is layer s+1's xn1 (TemporalEncoder.forward drops the first ln_1 output and appends
 // the final residual stream); the last stage is post-LN'ed by the caller-provided ln_*_post_enc (tan_model.py:174,206).
 #include "tan_common.h"
+#include <cstdlib>
+
+#ifndef TAN_DW_TARGET_WGS
+#define TAN_DW_TARGET_WGS 256
+#endif
 
 using namespace tal;
 
@@ -55,7 +60,8 @@ int linear_bwd_w(int dt, const void* dy, const void* x, float* gw, long M, int N
     d.A = dy; d.lda = N; d.B = x; d.ldb = K; d.ldc = K;
     d.alpha = 1.0f;
     const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
-    long want = (512 + tiles - 1) / tiles;                 // enough workgroups to fill 256 CUs twice over
+    static const long target = [] { const char* e = getenv("TAN_DW_TARGET_WGS"); long v = e ? atol(e) : 0; return v > 0 ? v : (long)TAN_DW_TARGET_WGS; }();
+    long want = (target + tiles - 1) / tiles;   // workgroups per dW GEMM (the other stack co-runs on a 2nd stream)
     const long max_split = (M + 255) / 256;
     if (want > max_split) want = max_split;
     if (want > 32) want = 32;
