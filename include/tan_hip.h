@@ -38,7 +38,8 @@ int tan_abi_sizeof(int which);
 /* Optional in-stream kernel timer (bench.py's `roofline` line): while enabled every tan_gemm / tan_attn_* launch is
  * bracketed by hipEvents on its own stream.  tan_prof_collect synchronises and returns per kind the summed duration
  * [ms], the summed ALGORITHMIC work [flop] (2*M*N*K per GEMM; 4*B*H*L*L*64 attention fwd, 14*... bwd incl. recompute)
- * and the launch count; returns 1 if the record buffer overflowed.  GEMM kinds: base + 2*(A K-strided) + (B K-strided). */
+ * and the launch count; returns 1 if the record buffer overflowed.  tan_prof_enable: on = 1 starts a fresh recording,
+ * on = 0 pauses it (records are kept), on = 2 resumes -- bench.py samples every 4th timed step this way.  GEMM kinds: base + 2*(A K-strided) + (B K-strided). */
 #define TAN_PROF_GEMM_BF16 0
 #define TAN_PROF_GEMM_F32 4
 #define TAN_PROF_ATTN_FWD 8
@@ -245,6 +246,13 @@ typedef struct tan_encoder_desc {
 } tan_encoder_desc;
 int tan_encoder_fwd(const tan_encoder_desc* e, void* stream);
 int tan_encoder_bwd(const tan_encoder_desc* e, void* stream);
+
+/* Weight gradient of a Linear layer (what autograd produces for nn.Linear.weight inside model/tfm_model.py's blocks):
+ * gw[N,K] (f32) += dy[M,N]^T x[M,K].  The long M contraction is cut into slices; with a workspace `ws` (>= slices*N*K floats,
+ * slices <= 32) they are written as partial tiles and folded by tan_reduce_add, otherwise accumulated with f32 atomics. */
+int tan_linear_wgrad(const void* dy, const void* x, float* gw, long M, int N, int K, float* ws, long ws_floats, int dtype,
+                     void* stream);
+
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtan_hip.so")
+LIB_PATH = os.environ.get("TAN_HIP_LIB") or os.path.join(HERE, "libtan_hip.so")   # override: A/B of two builds on one box
 HEADER = os.path.join(HERE, "..", "include", "tan_hip.h")
 
 TAN_F32, TAN_BF16 = 0, 1

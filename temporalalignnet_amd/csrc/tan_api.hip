@@ -49,6 +49,7 @@ extern "C" int tan_abi_sizeof(int which) {
 // returns, per kernel kind, the summed duration [ms], the summed algorithmic work [flop] and the launch count.
 extern "C" int tan_prof_enable(int on, int max_records) {
     ProfState& p = g_prof;
+    if (on == 2) { p.on = p.cap > 0; return 0; }      // resume after a pause (on == 0): records kept
     if (on) {
         if ((int)p.ev.size() < 2 * max_records) {
             const size_t old = p.ev.size();

@@ -84,6 +84,12 @@ int linear_bwd_w(int dt, const void* dy, const void* x, float* gw, long M, int N
 
 }  // namespace
 
+extern "C" int tan_linear_wgrad(const void* dy, const void* x, float* gw, long M, int N, int K, float* ws, long ws_floats,
+                                int dtype, void* stream) {
+    TAN_REQUIRE(dy && x && gw && M > 0 && N > 0 && K > 0);
+    return linear_bwd_w(dtype, dy, x, gw, M, N, K, ws, ws_floats, stream);
+}
+
 extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
     TAN_REQUIRE(e && e->layers > 0 && e->params && e->bufs && e->x0);
     const int dt = e->dtype, C = e->C, H = e->H;

@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "tan_mma.h"
+#include <cstdlib>
 
 namespace tal {
 
@@ -31,6 +32,7 @@ struct GemmArgs2 {
     int act, accumulate, split_k, kchunk, vec_epi;
     float alpha;
     float* colsum;
+    int plane_xcd;
 };
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
@@ -205,23 +207,38 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs2& g, f32x16 (&acc)[2
     }
 }
 
+
+// Work order.  The dispatcher deals consecutive workgroup ids (x fastest, then y, then z) round-robin to the 8 XCDs, each
+// with a private L2.  Within one plane (one batch item / K-slice) id -> (id % 8) * ceil(n/8) + id / 8 (bijective form for any
+// n) hands each XCD a CONTIGUOUS run of tiles, column tile fastest, so the tiles sharing an A row-panel hit one L2 instead of
+// eight.  With several planes (batched GEMM, the dW K-slices) whole planes are pinned to XCDs instead -- 8 | planes: XCD x
+// runs planes x, x+8, ..; planes | 8: 8/planes XCDs split a plane's tiles in contiguous runs -- so the operand slices of a
+// plane are fetched into one or two L2s rather than all eight (dW fc: 120 MB -> 52 MB of fabric reads per launch).
+__device__ __forceinline__ void work_item(const GemmArgs2& g, int& tile, int& z) {
+    const int T = gridDim.x * gridDim.y, nz = gridDim.z;
+    if (g.plane_xcd && nz > 1) {
+        const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const int xcd = id & 7, j = id >> 3;
+        if ((nz & 7) == 0) { z = xcd + 8 * (j / T); tile = j % T; return; }
+        if (8 % nz == 0 && T % (8 / nz) == 0) { z = xcd % nz; tile = (xcd / nz) * (T / (8 / nz)) + j; return; }
+    }
+    int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = wg & 7, q = T >> 3, r = T & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    z = blockIdx.z;
+}
+
 template <typename TC, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs2 g) {
     __shared__ __attribute__((aligned(1024))) char lds[4 * TILE_BYTES];   // [buf][A|B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware tile order: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (private L2 each), so
-    // id -> (id % 8) * ceil(n/8) + id / 8 (bijective form for any n) hands each XCD a CONTIGUOUS run of tiles; with the
-    // column tile varying fastest, the tiles that share an A row-panel then hit the same L2 instead of eight.
-    const int ntn = gridDim.x, nwg = gridDim.x * gridDim.y;
-    int wg = blockIdx.y * gridDim.x + blockIdx.x;
-    {
-        const int xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
-    }
+    const int ntn = gridDim.x;
+    int wg, z;
+    work_item(g, wg, z);
     const int n0 = (wg % ntn) * GBN, m0 = (wg / ntn) * GBM;
-    const int z = blockIdx.z, batch = z / g.split_k, split = z % g.split_k;
+    const int batch = z / g.split_k, split = z % g.split_k;
     const bf16_t* A = g.A + (long)batch * g.sA;
     const bf16_t* B = g.B + (long)batch * g.sB;
     const int kbeg = split * g.kchunk;
@@ -321,14 +338,11 @@ __global__ __launch_bounds__(256, 2) void gemm_glds4_kernel(GemmArgs2 g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = gridDim.x, nwg = gridDim.x * gridDim.y;
-    int wg = blockIdx.y * gridDim.x + blockIdx.x;
-    {
-        const int xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
-    }
+    const int ntn = gridDim.x;
+    int wg, z;
+    work_item(g, wg, z);
     const int n0 = (wg % ntn) * GBN, m0 = (wg / ntn) * GBM;
-    const int z = blockIdx.z, batch = z / g.split_k, split = z % g.split_k;
+    const int batch = z / g.split_k, split = z % g.split_k;
     const bf16_t* A = g.A + (long)batch * g.sA;
     const bf16_t* B = g.B + (long)batch * g.sB;
     const int kbeg = split * g.kchunk;
@@ -440,6 +454,8 @@ int gemm_glds_try(const tan_gemm_desc* d, hipStream_t st) {
     a.vec_epi = !d->accumulate && d->N % 8 == 0 && al16(d->C, d->ldc) && al16(d->residual, d->ldr) && al16(d->aux, d->ldaux) &&
                 ((d->sC * oe) % 16 == 0);
     a.colsum = a.vec_epi ? d->colsum : nullptr;
+    static const int plane_xcd = [] { const char* e = getenv("TAN_GEMM_PLANE_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+    a.plane_xcd = plane_xcd;
     dim3 grid(cdiv(d->N, GBN), cdiv(d->M, GBM), d->batch * d->split_k);
     if (d->colsum && !a.vec_epi) {            // cannot fuse: run the GEMM, caller adds a separate column-sum pass
         int rc = d->out_dtype == TAN_F32 ? launch2<float>(d, a, grid, st) : launch2<bf16_t>(d, a, grid, st);

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         dg[i] = make_float4(0, 0, 0, 0); db[i] = make_float4(0, 0, 0, 0); ds[i] = make_float4(0, 0, 0, 0);
         gm[i] = *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 4);
     }
+#pragma unroll 2
     for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + w; row < rows; row += (long)gridDim.x * ROWS_PER_BLOCK) {
         const float mean = mean_i[row], rstd = rstd_i[row];
         float4 xh[NCH], g[NCH];
@@ -118,24 +119,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
 }
 
-// 256 threads = 16 columns x 16 slices of the partial list; each block owns 16 consecutive entries of the [3][C] tables
+// Folds the per-block partial tables ws[nblk][3][C] into the f32 gradients.  Grid (3C/64, 8): a block owns 64 consecutive
+// table entries (256-B coalesced rows) and one eighth of the partial list; 256 threads = 64 columns x 4 list lanes; the
+// eight list slices meet in the gradient with f32 atomics (3C*8 of them per call).
+constexpr int LN_BWD_MAX_BLOCKS = 1024, LN_FIN_SLICES = 8;
 __global__ __launch_bounds__(256) void ln_bwd_finalize(const float* __restrict__ ws, int nblk, int C, float* __restrict__ dgamma,
                                                        float* __restrict__ dbeta, float* __restrict__ dx_colsum) {
-    __shared__ float red[16][17];
-    const int col = threadIdx.x & 15, part = threadIdx.x >> 4;
-    const int idx = blockIdx.x * 16 + col;          // index into [3][C]
-    float s = 0.f;
-    if (idx < 3 * C)
-        for (int b = part; b < nblk; b += 16) s += ws[(long)b * 3 * C + idx];
-    red[part][col] = s;
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + col;          // index into [3][C]
+    const int per = (nblk + LN_FIN_SLICES - 1) / LN_FIN_SLICES;
+    const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (idx < 3 * C) {
+        const float* p = ws + idx;
+        int b = b0 + part;
+        for (; b + 12 < b1; b += 16) {
+            s0 += p[(long)b * 3 * C]; s1 += p[(long)(b + 4) * 3 * C]; s2 += p[(long)(b + 8) * 3 * C]; s3 += p[(long)(b + 12) * 3 * C];
+        }
+        for (; b < b1; b += 4) s0 += p[(long)b * 3 * C];
+    }
+    red[part][col] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (part == 0 && idx < 3 * C) {
-        s = 0.f;
-#pragma unroll
-        for (int y = 0; y < 16; ++y) s += red[y][col];
+        const float s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
         const int which = idx / C, c = idx % C;
         float* out = which == 0 ? dgamma : (which == 1 ? dbeta : dx_colsum);
-        if (out) out[c] += s;
+        if (out) unsafeAtomicAdd(out + c, s);
     }
 }
 
@@ -207,6 +217,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     const int c = (blockIdx.x * tpr + tx) * 8;
     if (c < C && ty < ny) {
+#pragma unroll 4
         for (long r = r0 + ty; r < r1; r += ny) {
             const float4 a = ld4(x + r * C + c), b = ld4(x + r * C + c + 4);
             acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
@@ -400,19 +411,19 @@ extern "C" int tan_layernorm_fwd(const void* x, const float* gamma, const float*
     return 0;
 }
 
-extern "C" long tan_layernorm_bwd_ws_floats(int C) { return 512L * 3 * C; }
+extern "C" long tan_layernorm_bwd_ws_floats(int C) { return (long)LN_BWD_MAX_BLOCKS * 3 * C; }
 
 extern "C" int tan_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                  const void* dres, void* dx, float* dgamma, float* dbeta, float* dx_colsum, float* ws, long rows,
                                  int C, int dtype, void* stream) {
     TAN_REQUIRE(dy && x && gamma && mean && rstd && dx && ws && rows > 0);
     hipStream_t st = (hipStream_t)stream;
-    const int nblk = (int)min((long)512, (long)cdiv(rows, ROWS_PER_BLOCK));
+    const int nblk = (int)min((long)LN_BWD_MAX_BLOCKS, (long)cdiv(rows, ROWS_PER_BLOCK));
     DISPATCH_T(dtype, DISPATCH_NCH(C, hipLaunchKernelGGL((ln_bwd_kernel<T, NCH>), dim3(nblk), dim3(256), 0, st, (const T*)dy,
                                                          (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, ws, rows)));
     TAN_LAUNCH_CHECK();
     if (dgamma || dbeta || dx_colsum) {
-        hipLaunchKernelGGL(ln_bwd_finalize, dim3(cdiv(3 * C, 16)), dim3(256), 0, st, ws, nblk, C, dgamma, dbeta, dx_colsum);
+        hipLaunchKernelGGL(ln_bwd_finalize, dim3(cdiv(3 * C, 64), LN_FIN_SLICES), dim3(256), 0, st, ws, nblk, C, dgamma, dbeta, dx_colsum);
         TAN_LAUNCH_CHECK();
     }
     return 0;
@@ -451,7 +462,8 @@ extern "C" int tan_colsum_acc(const void* x, float* out, long rows, int C, int d
     int tpr = C / 8;                      // threads spanning one row
     if (tpr > 256) tpr = 256;
     while (256 % tpr) --tpr;              // must divide the block
-    const int rpb = 8 * (256 / tpr);      // 8 rows per thread group
+    if (C % 512 == 0) tpr = 64;           // one wave = 1-KiB row segments, 4 row lanes: fewer, fatter blocks and 4x fewer atomics
+    const int rpb = (C % 512 == 0 ? 16 : 8) * (256 / tpr);      // rows per thread group
     dim3 grid(cdiv(C, tpr * 8), cdiv(rows, rpb));
     DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, st, (const T*)x, out, rows, C, rpb, tpr));
     TAN_LAUNCH_CHECK();

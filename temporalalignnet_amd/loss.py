@@ -196,10 +196,10 @@ class _FusedNCEFn(torch.autograd.Function):
         if shared:       # one text feature for every stage: contract over (stage, row) in a single split-K GEMM
             acc = torch.zeros(Mp, Cw, device=dev)
             ops.gemm(dl, vn, acc, M=Mp, N=Cw, K=S * R, a_kc=False, b_kc=False, lda=Mp, ldb=Cw, accumulate=True,
-                     split_k=max(1, min(32, S * R // 512)))
+                     split_k=max(1, min(8, S * R // 512)))
             d_tn = ops.cast(acc, torch.empty(1, Mp, Cw, dtype=tn.dtype, device=dev))
         else:
-            d_tn = torch.empty_like(tn)
+            d_tn = torch.empty_like(tn)     # S x (Mp/128 x Cw/128) tiles under an R-long contraction: enough workgroups unsplit
             ops.gemm(dl, vn, d_tn, M=Mp, N=Cw, K=R, a_kc=False, b_kc=False, lda=Mp, ldb=Cw, batch=S, sA=R * Mp, sB=R * Cw,
                      sC=Mp * Cw)
         return d_vn, d_tn, None, None, None, None, None, None

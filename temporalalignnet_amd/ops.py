@@ -113,6 +113,13 @@ def colsum_acc(x, out, rows, Cc):
     return out
 
 
+def reduce_add(parts, out, nparts, n):
+    """out[n] (f32) += sum_p parts[p][n] -- folds split-K partial tiles."""
+    assert parts.dtype == torch.float32 and out.dtype == torch.float32 and parts.is_contiguous() and out.is_contiguous()
+    _lib.check(_lib.lib().tan_reduce_add(_f32(parts), _f32(out), C.c_int(nparts), C.c_long(n), _stream()), "tan_reduce_add")
+    return out
+
+
 def rows_copy(src, dst, G, R, Cc, src_grp_rows, src_off, dst_grp_rows, dst_off, accumulate=False):
     assert _dt(src) == _dt(dst)
     _lib.check(_lib.lib().tan_rows_copy(_ptr(src), _ptr(dst), C.c_int(G), C.c_int(R), C.c_int(Cc), C.c_long(src_grp_rows),
