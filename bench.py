@@ -193,9 +193,14 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a, args_ns)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner to the C stdout buffer, which a pipe only flushes at exit: flush it now so that the
+        # JSON line is the LAST line on stdout
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

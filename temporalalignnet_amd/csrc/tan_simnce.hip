@@ -107,10 +107,15 @@ __global__ __launch_bounds__(256, 2) void simnce_kernel(SimArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    // Workgroup order: consecutive ids go round-robin to the 8 XCDs, so each group of 64 consecutive ids is one stage (its
-    // 2 MB of text features then stay resident in every XCD's L2 instead of six stages thrashing it).
+    // Workgroup order: every workgroup of the launch is resident at once (S * R/128 <= 512 slots) and consecutive ids go
+    // round-robin to the 8 XCDs, so id -> (id % 8) * ceil(n/8) + id / 8 (bijective form) gives each XCD a CONTIGUOUS run of
+    // (stage, row panel) items: at most two stages' text features (2 MB each) per 4-MB L2 instead of all S thrashing it.
     const int npanel = gridDim.x;
-    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const int nwg = gridDim.x * gridDim.y, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    }
     const int s = wg / npanel, panel = wg - s * npanel, m0 = panel * 128;
     const int R = a.R, Mp = a.Mp, Cw = a.C, nS = a.S;
     const bf16_t* V = a.V + (long)s * R * Cw;

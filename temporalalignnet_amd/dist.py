@@ -15,6 +15,20 @@ import torch
 import torch.distributed as dist
 
 
+# TAN_FORCE_DIST=1: create the process group and run every collective even at world size 1 -- the only way to drive the
+# RCCL code path (init, async all-reduce on the side stream, barrier) on a 1-GPU box; results are unchanged.
+_FORCE = os.environ.get("TAN_FORCE_DIST") == "1"
+
+
+def _active():
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
+
+
+def active():
+    """True when collectives must run: more than one rank, or TAN_FORCE_DIST=1."""
+    return _active()
+
+
 def env_world():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -22,8 +36,9 @@ def env_world():
 def init_from_env(backend: str | None = None):
     """Initialise torch.distributed from the torchrun environment (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*)."""
     world, rank, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _FORCE) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -50,18 +65,18 @@ def shard_range(n_items: int, world: int, rank_: int):
 
 def allreduce_sum_(flat_grad: torch.Tensor, async_op: bool = False):
     """Sum the flat gradient bucket over ranks in place (the averaging 1/world is folded into the optimizer kernel)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return None
     return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
 def broadcast_(flat: torch.Tensor, src: int = 0):
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.broadcast(flat, src=src)
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -69,5 +84,5 @@ def max_over_ranks(value: float, device) -> float:
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()

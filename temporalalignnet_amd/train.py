@@ -141,7 +141,7 @@ class Trainer:
         for n, p in named:
             if p.grad is None:
                 continue
-            if dist.world_size() > 1:
+            if dist.active():
                 dist.allreduce_sum_(p.grad)
             m, v = self._state["lm"][n]
             wd = 0.0 if n.endswith(".bias") else a.wd
@@ -196,7 +196,7 @@ class Trainer:
         self.zero_grad()
         world = dist.world_size()
         pending = []
-        if world > 1:
+        if dist.active():
             flat = self.online.flat_grad()
             lo, hi = self.online.flat_range("joint_temporal_encoder.")
             self.online._grad_ready_hook = lambda tag: pending.append(dist.allreduce_sum_(flat[lo:hi], async_op=True))
@@ -204,7 +204,7 @@ class Trainer:
             loss_dict = self.forward_backward(batch)
         finally:
             self.online._grad_ready_hook = None
-        if world > 1:
+        if dist.active():
             if pending:
                 dist.allreduce_sum_(flat[:lo])
                 dist.allreduce_sum_(flat[hi:])
