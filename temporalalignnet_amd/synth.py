@@ -245,3 +245,70 @@ def w2v_vocab(n: int):
 
 def w2v_sentences():
     return ["Stir the eggs, don't stop!", "w3 W7 unknownword w11", "", "w1 " * 12, "the THE the's eggs_w2"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# HTM-370K-shaped ON-DISK fixture (row f2: the feature loader).  Formats follow data/readme.md:22-33 and
+# data/loader_htm.py:136-143,173-176: `{vid}.mp4.npy` (or `.webm.npy`) = [vlen, 1024] float32 S3D features, one per second;
+# sentencified ASR = {vid: {"text": [...], "start": [...], "end": [...]}} with float second timestamps; htm_vlen.csv rows
+# "vid,vlen"; htm_holdout_vid.txt one vid per line.
+def htm_fixture(seed: int = 50):
+    """-> dict(vlen={vid: int}, asr={vid: {...}}, holdout=[vid], webm={vid}) covering the loader's edge cases."""
+    vocab = list(w2v_vocab(40))
+    vlen, asr, webm = {}, {}, set()
+
+    def sentence(k, n_words):
+        ids = randint(seed, f"words{k}", 0, len(vocab) - 1, n_words)
+        return " ".join(vocab[i] for i in ids)
+
+    specs = [("vidA0001", 240), ("vidB0002", 180), ("vidC0003", 330), ("vidD0004", 150), ("vidE0005", 90),
+             ("vidF0006", 400), ("vidG0007", 64), ("vidH0008", 1200), ("vidI0009", 200), ("vidJ0010", 130)]
+    for vi, (vid, n) in enumerate(specs):
+        vlen[vid] = n
+        u = uniform(seed, f"times{vi}", 4000)
+        t, k, texts, starts, ends = 2.0 + 3.0 * u[0], 1, [], [], []
+        while t < n + 20:                       # some sentences run past the end of the video (filtered: end < vlen)
+            dur = 0.4 + 8.0 * u[k]
+            s = round(t * 2) / 2 if k % 3 == 0 else round(t, 2)       # x.5 timestamps exercise round-half-to-even
+            e = s + (round(dur * 2) / 2 if k % 4 == 0 else round(dur, 2))
+            n_words = 3 + int(u[k + 1] * 9)
+            txt = sentence(vi * 1000 + k, n_words)
+            if k % 7 == 3:
+                txt = txt.replace(" ", "\n", 1)
+            if vid == "vidC0003" and k == 9:
+                txt = "zzz qqq unknownword"            # every word out of vocabulary: the window's text loop stops here
+            if vid == "vidF0006" and k == 5:
+                txt = sentence(777, 300)                # > 256 words: truncated
+            texts.append(txt); starts.append(float(s)); ends.append(float(e))
+            t = s + (0.5 + 6.0 * u[k + 2])
+            k += 3
+        if vid == "vidE0005":                   # captions stop early: no window start qualifies -> '[UNK]' sample
+            texts, starts, ends = texts[:3], starts[:3], ends[:3]
+        if vid == "vidI0009":
+            webm.add(vid)
+        asr[vid] = {"text": texts, "start": starts, "end": ends}
+    return {"vlen": vlen, "asr": asr, "holdout": ["vidD0004"], "webm": webm}
+
+
+def htm_features(vid: str, vlen: int, d_video: int = 1024) -> np.ndarray:
+    """[vlen, d_video] float32 features of a fixture video: a pure function of the vid string."""
+    return np.abs(normal(sum(vid.encode()), "feat/" + vid, (vlen, d_video), 0.3))
+
+
+def write_htm_fixture(root: str, fx: dict):
+    """Materialise the fixture under `root` in the reference's on-disk formats; returns the paths."""
+    import json
+    import os
+    feat = os.path.join(root, "features")
+    os.makedirs(feat, exist_ok=True)
+    for vid, n in fx["vlen"].items():
+        np.save(os.path.join(feat, f"{vid}.{'webm' if vid in fx['webm'] else 'mp4'}.npy"), htm_features(vid, n))
+    paths = {"features": feat, "asr": os.path.join(root, "sentencified_htm_370k.json"),
+             "vlen": os.path.join(root, "htm_vlen.csv"), "holdout": os.path.join(root, "htm_holdout_vid.txt")}
+    with open(paths["asr"], "w") as f:
+        json.dump(fx["asr"], f)
+    with open(paths["vlen"], "w") as f:
+        f.writelines(f"{v},{n}\n" for v, n in fx["vlen"].items())
+    with open(paths["holdout"], "w") as f:
+        f.writelines(v + "\n" for v in fx["holdout"])
+    return paths

@@ -386,9 +386,56 @@ def g8_word2vec():
     save("g8_word2vec", **arrs)
 
 
+def g9_htm_loader():
+    """G9 (row f2): the reference's HTM_FeatureLoader.__getitem__ / collate_fn on the synthetic on-disk fixture
+    (synth.htm_fixture).  __init__ reads a hard-coded cluster path and asset files that are not shipped, so the instance is
+    made with __new__ and given the attributes __init__ would set; window sampling, text trimming and collation are the
+    reference's own code.  Extra shim: `simplejson` (absent here) -> the stdlib json module."""
+    import json
+    import tempfile
+    sys.modules.setdefault("simplejson", json)
+    sys.path.insert(0, f"{REF}/data")
+    import loader_htm as ref_loader
+    import word2vec_model as ref_w2v
+    fx = synth.htm_fixture()
+    arrs = {}
+    with tempfile.TemporaryDirectory() as root:
+        paths = synth.write_htm_fixture(root, fx)
+        tok = ref_w2v.Word2VecTokenizer.__new__(ref_w2v.Word2VecTokenizer)
+        vocab = synth.w2v_vocab(40)
+        tok.word_to_token = {w_: i + 1 for i, w_ in enumerate(vocab)}
+        tok.max_words = 32
+        for mode, use_tok in (("train", True), ("val", False)):
+            ds = ref_loader.HTM_FeatureLoader.__new__(ref_loader.HTM_FeatureLoader)
+            ds.video_feature_path = paths["features"]
+            ds.text_tag, ds.mode, ds.duration, ds.trim_ratio = "htm-370k", mode, 64, 0.1
+            ds.tokenizer = tok if use_tok else (lambda x, **kw: {"input_ids": [0]})
+            ds.vid_to_asr_dict = fx["asr"]
+            ds.video_info = sorted(v for v in fx["vlen"] if v not in ("vidG0007", "vidH0008"))   # explicit list, incl. hold-out vid
+            for seed in (0, 1, 2):
+                np.random.seed(seed)
+                items = [ds[i] for i in range(len(ds))]
+                b = ds.collate_fn(items)
+                tag = f"{mode}/s{seed}"
+                arrs[f"{tag}/video_sum"] = b["video"].double().sum((1, 2)).numpy()
+                arrs[f"{tag}/video_first"] = b["video"][:, 0, :4].numpy()
+                arrs[f"{tag}/video_last"] = b["video"][:, -1, :4].numpy()
+                arrs[f"{tag}/padding_mask"] = b["padding_mask"].numpy()
+                arrs[f"{tag}/n"] = np.array([len(t) for t in b["text"]])
+                arrs[f"{tag}/start"] = np.concatenate([np.asarray(x, dtype=np.int64) for x in b["start"]])
+                arrs[f"{tag}/end"] = np.concatenate([np.asarray(x, dtype=np.int64) for x in b["end"]])
+                arrs[f"{tag}/token"] = torch.cat([t.reshape(len(tx), -1).long() for t, tx in zip(b["token"], b["text"])], 0).numpy()
+                arrs[f"{tag}/abs_start"] = np.concatenate(b["abs_text_start"])
+                arrs[f"{tag}/abs_end"] = np.concatenate(b["abs_text_end"])
+                arrs[f"{tag}/text"] = np.array(["\x1f".join(t) for t in b["text"]])
+                if mode == "val":
+                    arrs[f"{tag}/cut"] = np.array([b["cut_start"], b["cut_end"]])
+    save("g9_htm_loader", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     table = {"g1": g1_forward_small, "g2": g2_forward_e6d6, "g3": g3_loss_init, "g4": g4_loss_cotrain,
-             "g5": g5_train_steps, "g6": g6_eval_harness, "g7": g7_long_and_interp, "g8": g8_word2vec}
+             "g5": g5_train_steps, "g6": g6_eval_harness, "g7": g7_long_and_interp, "g8": g8_word2vec, "g9": g9_htm_loader}
     for w in which:
         table[w]()
