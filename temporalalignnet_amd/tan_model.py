@@ -941,6 +941,13 @@ class TwinTemporalAligner(nn.Module):
     def lang_model(self):
         return self.bert
 
+    # train/main.py:466-469 adds the stage-1 language-model tensors at top level under `lang_model.`; the attribute is `bert`
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for k in list(state_dict.keys()):
+            if k.startswith(prefix + "lang_model."):
+                state_dict[prefix + "bert." + k[len(prefix + "lang_model."):]] = state_dict.pop(k)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     def _copy_param(self):
         for po, pt in zip(self.online.parameters(), self.target.parameters()):
             pt.data.copy_(po.data)
