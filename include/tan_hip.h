@@ -171,15 +171,21 @@ int tan_masked_quantile(const float* x, const unsigned char* invalid, int n, flo
  * features (t_stage_stride = Mp*C, or 0 when the text features are shared by all stages), other arguments as tan_nce_fwd.
  * One workgroup sweeps a 128-row panel of one stage over all text columns; logits only ever exist as MFMA accumulators.
  * tan_simnce_bwd_dl recomputes them and writes d loss/d logits [S,R,Mp] in bf16 for the two follow-up tan_gemm calls.
- * ws: tan_simnce_ws_floats() f32 scratch.  Requires C % 64 == 0, B*N <= 2048.                                           */
+ * ws: tan_simnce_ws_floats() f32 scratch.  Requires C % 64 == 0, B*N <= 2048.
+ * Column compaction (optional, colmap != NULL): padded text columns take part in nothing (loss.py:64-70 drops them before
+ * the log-sum-exps), so the sweep may run on a COMPACTED text matrix: then `tn` holds Mc <= B*N rows per stage (a multiple of 64 keeps
+ * the follow-up GEMMs on the direct-to-LDS kernel; filler rows flagged in col_invalid), col_invalid / colsum / possum_t / t_terms / g_t have Mc entries
+ * per stage, dl is [S,R,Mc]; `tn_blocks` (stage stride tb_stage_stride) is the UNcompacted [B*N,C] matrix, read only for the
+ * same-video blocks, and colmap[b*N+k] is that sentence's compacted column or -1.                                        */
 long tan_simnce_ws_floats(int S, int B, int T, int N);
 int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
                    const unsigned char* row_leak, float* rowsum, float* colsum, float* possum_v, float* possum_t,
-                   float* v_terms, float* t_terms, float* ws, int S, int B, int T, int N, int C, void* stream);
+                   float* v_terms, float* t_terms, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks,
+                   long tb_stage_stride, const int* colmap, int Mc, void* stream);
 int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
                       const unsigned char* row_leak, const float* rowsum, const float* colsum, const float* possum_v,
                       const float* possum_t, const float* g_v, const float* g_t, void* dl, float* ws, int S, int B, int T, int N,
-                      int C, void* stream);
+                      int C, const void* tn_blocks, long tb_stage_stride, const int* colmap, int Mc, void* stream);
 
 /* ---- sentence embedder (model/word2vec_model.py:76-102) ----------------------------------------
  * tan_embed_gather: out[r, 0:D] = table[ids[r], :] cast to `dtype`, out[r, D:Dpad] = 0 (ids NULL = identity: a padded

@@ -1,4 +1,5 @@
 // Library-level entry points: version and the optional in-stream kernel timer used by bench.py's roofline line.
+#include <atomic>
 #include <vector>
 
 #include "tan_common.h"
@@ -7,7 +8,8 @@ namespace tal {
 
 struct ProfState {
     bool on = false;
-    int cap = 0, n = 0;
+    int cap = 0;
+    std::atomic<int> n{0};           // launches are issued from two host threads (main + side-stream helper)
     std::vector<hipEvent_t> ev;      // 2 per record
     std::vector<int> kind;
     std::vector<double> work;
@@ -16,8 +18,9 @@ static ProfState g_prof;
 
 int prof_begin(hipStream_t st, int kind, double work) {
     ProfState& p = g_prof;
-    if (!p.on || p.n >= p.cap) return -1;
-    const int i = p.n++;
+    if (!p.on || p.n.load(std::memory_order_relaxed) >= p.cap) return -1;
+    const int i = p.n.fetch_add(1);
+    if (i >= p.cap) return -1;
     p.kind[i] = kind;
     p.work[i] = work;
     (void)hipEventRecord(p.ev[2 * i], st);
@@ -71,7 +74,8 @@ extern "C" int tan_prof_enable(int on, int max_records) {
 extern "C" int tan_prof_collect(double* ms_by_kind, double* work_by_kind, long* count_by_kind, int nkinds) {
     ProfState& p = g_prof;
     for (int k = 0; k < nkinds; ++k) { ms_by_kind[k] = 0; work_by_kind[k] = 0; count_by_kind[k] = 0; }
-    for (int i = 0; i < p.n; ++i) {
+    const int nrec = p.n.load() < p.cap ? p.n.load() : p.cap;
+    for (int i = 0; i < nrec; ++i) {
         hipError_t e = hipEventSynchronize(p.ev[2 * i + 1]);
         if (e != hipSuccess) return (int)e;
         float ms = 0.f;

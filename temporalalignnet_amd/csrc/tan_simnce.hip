@@ -218,9 +218,11 @@ __global__ __launch_bounds__(256) void simnce_diag_kernel(const float* __restric
                                                           const unsigned char* __restrict__ row_leak, float* __restrict__ rowsum,
                                                           float* __restrict__ colsum, float* __restrict__ possum_v,
                                                           float* __restrict__ possum_t, const float* __restrict__ g_v,
-                                                          const float* __restrict__ g_t, bf16_t* __restrict__ dl, int B, int T, int N) {
+                                                          const float* __restrict__ g_t, bf16_t* __restrict__ dl, int B, int T, int N,
+                                                          const int* __restrict__ colmap, int Mp) {
+    // colmap (optional): padded column b*N+k -> column of the COMPACTED text matrix the sweep ran on, or -1 (dropped pad column)
     const int b = blockIdx.x, s = blockIdx.y;
-    const int R = B * T, Mp = B * N;
+    const int R = B * T;
     const float inv_tau = 1.0f / S_TAU;
     const float* blk = diag + ((long)s * B + b) * T * N;
     const float* tg = tgt + (long)b * T * N;
@@ -230,7 +232,8 @@ __global__ __launch_bounds__(256) void simnce_diag_kernel(const float* __restric
             float acc = 0.f, lost = 0.f;
             for (int k = 0; k < N; ++k) {
                 const float e = __expf((blk[t * N + k] - 1.0f) * inv_tau);
-                const bool valid = !col_invalid[b * N + k];
+                const int cc = colmap ? colmap[b * N + k] : b * N + k;
+                const bool valid = cc >= 0 && !col_invalid[cc];
                 if (leak) { if (valid) lost += e; }
                 else if (tg[t * N + k] != 0.f && valid) acc += e;
             }
@@ -238,24 +241,28 @@ __global__ __launch_bounds__(256) void simnce_diag_kernel(const float* __restric
             if (leak) rowsum[(long)s * R + b * T + t] -= lost;
         }
         for (int k = threadIdx.x; k < N; k += 256) {
+            const int cc = colmap ? colmap[b * N + k] : b * N + k;
+            if (cc < 0) continue;
             float acc = 0.f, lost = 0.f;
             for (int t = 0; t < T; ++t) {
                 const float e = __expf((blk[t * N + k] - 1.0f) * inv_tau);
                 if (row_leak && row_leak[b * T + t]) lost += e;
                 else if (tg[t * N + k] != 0.f) acc += e;
             }
-            possum_t[(long)s * Mp + b * N + k] = acc;
-            if (lost != 0.f) colsum[(long)s * Mp + b * N + k] -= lost;
+            possum_t[(long)s * Mp + cc] = acc;
+            if (lost != 0.f) colsum[(long)s * Mp + cc] -= lost;
         }
     } else {
         for (int i = threadIdx.x; i < T * N; i += 256) {
             const int t = i / N, k = i - t * N;
-            const long r = (long)s * R + b * T + t, c = (long)s * Mp + b * N + k;
-            bf16_t* out = dl + r * Mp + b * N + k;
+            const int cc = colmap ? colmap[b * N + k] : b * N + k;
+            if (cc < 0) continue;
+            const long r = (long)s * R + b * T + t, c = (long)s * Mp + cc;
+            bf16_t* out = dl + r * Mp + cc;
             if (row_leak && row_leak[b * T + t]) { *out = 0; continue; }
             if (tg[i] == 0.f) continue;
             const float e = __expf((blk[i] - 1.0f) * inv_tau);
-            const bool valid = !col_invalid[b * N + k];
+            const bool valid = !col_invalid[cc];
             float corr = 0.f;
             if (valid && possum_v[r] > 0.f) corr += g_v[r] / possum_v[r];
             if (possum_t[c] > 0.f) corr += g_t[c] / possum_t[c];
@@ -292,13 +299,13 @@ static int simnce_common(SimArgs& a, int S, int B, int T, int N, int C) {
 }
 
 // same-video cosine blocks diag[s,b,t,n] = <vn[s,b*T+t], tn[s,b*N+n]> through the ordinary GEMM (batch = S*B... per stage)
-static int simnce_diag_blocks(const SimArgs& a, float* diag, hipStream_t st) {
+static int simnce_diag_blocks(const SimArgs& a, const bf16_t* tn_blocks, long tb_stage_stride, float* diag, hipStream_t st) {
     for (int s = 0; s < a.S; ++s) {
         tan_gemm_desc d{};
         d.dtype = TAN_BF16; d.out_dtype = TAN_F32;
         d.M = a.T; d.N = a.N; d.K = a.C; d.a_kc = 1; d.b_kc = 1;
         d.A = a.V + (long)s * a.R * a.C; d.lda = a.C;
-        d.B = a.Tt + (long)s * a.t_stage_stride; d.ldb = a.C;
+        d.B = tn_blocks + (long)s * tb_stage_stride; d.ldb = a.C;
         d.C = diag + (long)s * a.B * a.T * a.N; d.ldc = a.N;
         d.split_k = 1; d.alpha = 1.0f;
         d.batch = a.B; d.sA = (long)a.T * a.C; d.sB = (long)a.N * a.C; d.sC = (long)a.T * a.N;
@@ -311,8 +318,10 @@ static int simnce_diag_blocks(const SimArgs& a, float* diag, hipStream_t st) {
 // v_terms / t_terms of loss.py:240-253 straight from unit features (no logits); sums are kept for tan_simnce_bwd_dl.
 extern "C" int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
                               const unsigned char* row_leak, float* rowsum, float* colsum, float* possum_v, float* possum_t,
-                              float* v_terms, float* t_terms, float* ws, int S, int B, int T, int N, int C, void* stream) {
+                              float* v_terms, float* t_terms, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks,
+                              long tb_stage_stride, const int* colmap, int Mc, void* stream) {
     TAN_REQUIRE(vn && tn && tgt && col_invalid && rowsum && colsum && possum_v && possum_t && v_terms && t_terms && ws);
+    TAN_REQUIRE(!colmap || (tn_blocks && Mc > 0 && Mc <= B * N));
     SimArgs a{};
     a.V = (const bf16_t*)vn; a.Tt = (const bf16_t*)tn; a.t_stage_stride = t_stage_stride;
     a.tgt = tgt; a.col_invalid = col_invalid; a.row_leak = row_leak;
@@ -321,7 +330,9 @@ extern "C" int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_strid
     if (rc) return rc;
     const int npanel = cdiv(a.R, 128);
     a.colpart = ws;
-    float* diag = ws + (long)npanel * S * a.Mp;
+    float* diag = ws + (long)npanel * S * a.Mp;          // sized for the padded column count
+    if (colmap) a.Mp = Mc;
+    else { tn_blocks = tn; tb_stage_stride = t_stage_stride; }
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(rowsum, 0, sizeof(float) * (size_t)S * a.R, st);
     if (e != hipSuccess) return (int)e;
@@ -331,9 +342,9 @@ extern "C" int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_strid
     TAN_LAUNCH_CHECK();
     const long SM = (long)S * a.Mp, SR = (long)S * a.R;
     hipLaunchKernelGGL(simnce_col_finalize, dim3(cdiv(SM, 256)), dim3(256), 0, st, a.colpart, colsum, npanel, SM);
-    if ((rc = simnce_diag_blocks(a, diag, st))) return rc;
+    if ((rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;
     hipLaunchKernelGGL((simnce_diag_kernel<false>), dim3(B, S), dim3(256), 0, st, diag, tgt, col_invalid, row_leak, rowsum, colsum,
-                       possum_v, possum_t, (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, B, T, N);
+                       possum_v, possum_t, (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, B, T, N, colmap, a.Mp);
     hipLaunchKernelGGL(simnce_terms, dim3(cdiv(SR, 256)), dim3(256), 0, st, rowsum, possum_v, v_terms, SR, logf((float)a.Mp));
     hipLaunchKernelGGL(simnce_terms, dim3(cdiv(SM, 256)), dim3(256), 0, st, colsum, possum_t, t_terms, SM, logf((float)a.R));
     TAN_LAUNCH_CHECK();
@@ -344,8 +355,10 @@ extern "C" int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_strid
 extern "C" int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_stride, const float* tgt,
                                  const unsigned char* col_invalid, const unsigned char* row_leak, const float* rowsum,
                                  const float* colsum, const float* possum_v, const float* possum_t, const float* g_v, const float* g_t,
-                                 void* dl, float* ws, int S, int B, int T, int N, int C, void* stream) {
+                                 void* dl, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks, long tb_stage_stride,
+                                 const int* colmap, int Mc, void* stream) {
     TAN_REQUIRE(vn && tn && tgt && col_invalid && rowsum && colsum && possum_v && possum_t && g_v && g_t && dl && ws);
+    TAN_REQUIRE(!colmap || (tn_blocks && Mc > 0 && Mc <= B * N));
     SimArgs a{};
     a.V = (const bf16_t*)vn; a.Tt = (const bf16_t*)tn; a.t_stage_stride = t_stage_stride;
     a.tgt = tgt; a.col_invalid = col_invalid; a.row_leak = row_leak;
@@ -355,13 +368,15 @@ extern "C" int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_st
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     float* diag = ws + (long)cdiv(a.R, 128) * S * a.Mp;
+    if (colmap) a.Mp = Mc;
+    else { tn_blocks = tn; tb_stage_stride = t_stage_stride; }
     const int prec = prof_begin(st, TAN_PROF_SIMNCE, 2.0 * S * a.R * (double)a.Mp * C);
     hipLaunchKernelGGL((simnce_kernel<1>), dim3(cdiv(a.R, 128), S), dim3(256), 0, st, a);
     prof_end(st, prec);
     TAN_LAUNCH_CHECK();
-    if ((rc = simnce_diag_blocks(a, diag, st))) return rc;
+    if ((rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;
     hipLaunchKernelGGL((simnce_diag_kernel<true>), dim3(B, S), dim3(256), 0, st, diag, tgt, col_invalid, row_leak, (float*)rowsum,
-                       (float*)colsum, (float*)possum_v, (float*)possum_t, g_v, g_t, (bf16_t*)dl, B, T, N);
+                       (float*)colsum, (float*)possum_v, (float*)possum_t, g_v, g_t, (bf16_t*)dl, B, T, N, colmap, a.Mp);
     TAN_LAUNCH_CHECK();
     return 0;
 }

@@ -147,6 +147,7 @@ class FusedSim:
 
     def __init__(self, vn_d, tn_d, vn_j, tn_j, B, T, N):
         self.vn_d, self.tn_d, self.vn_j, self.tn_j, self.B, self.T, self.N = vn_d, tn_d, vn_j, tn_j, B, T, N
+        self.n_text_valid = None      # host-side count of real (unpadded) sentences when the caller knows it: enables column compaction
 
     def diag_blocks(self, which):
         """[B,T,N] f32 last-stage same-video cosine logits (all that self-labelling / thresholding read of the B^2 tensor)."""
@@ -158,51 +159,78 @@ class FusedSim:
 
 
 class _FusedNCEFn(torch.autograd.Function):
-    """_NCEFn without the logits: tan_simnce_fwd / tan_simnce_bwd_dl + the two d-feature GEMMs."""
+    """_NCEFn without the logits: tan_simnce_fwd / tan_simnce_bwd_dl + the two d-feature GEMMs.
+
+    `n_valid` (host int, optional) = number of real sentences in the batch.  Padded text columns take part in nothing
+    (loss.py:64-70 drops them before the log-sum-exps), so when it is known the sweep runs on the COMPACTED text matrix
+    (Mc = n_valid rounded up to 64 columns instead of B*N; ~37 % fewer similarity FLOPs at N ~ U[4,16]); the returned text terms
+    are scattered back to the padded [S, B*N] layout (zeros at pad columns, which every consumer masks)."""
 
     @staticmethod
-    def forward(ctx, vn, tn, tgt, col_invalid, row_leak, B, T, N):
+    def forward(ctx, vn, tn, tgt, col_invalid, row_leak, B, T, N, n_valid=None):
         S, R, Cw = vn.shape
         Mp, dev = B * N, vn.device
         shared = tn.shape[0] == 1
-        stats = torch.empty(2 * S * R + 2 * S * Mp, device=dev)
+        Mc = Mp if n_valid is None else min(Mp, (int(n_valid) + 63) // 64 * 64)    # the d-feature GEMM contracts over Mc: 64-deep K-steps
+        compact = Mc < Mp
+        if compact:
+            # stable sort of the 0/1 pad flags: real sentences first, in order; static shapes, no host sync
+            idx = torch.sort(col_invalid.to(torch.int16), stable=True).indices[:Mc]
+            colmap = torch.where(col_invalid.bool(), torch.full((Mp,), -1, dtype=torch.int32, device=dev),
+                                 (torch.cumsum(1 - col_invalid.to(torch.int32), 0) - 1).to(torch.int32)).contiguous()
+            tn_run = tn.index_select(1, idx).contiguous()
+            ci_run = col_invalid.index_select(0, idx).contiguous()
+        else:
+            idx = colmap = None
+            tn_run, ci_run = tn, col_invalid
+        stats = torch.empty(2 * S * R + 2 * S * Mc, device=dev)
         rowsum, possum_v = stats[:S * R], stats[S * R:2 * S * R]
-        colsum, possum_t = stats[2 * S * R:2 * S * R + S * Mp], stats[2 * S * R + S * Mp:]
-        v_terms, t_terms = torch.empty(S, R, device=dev), torch.empty(S, Mp, device=dev)
+        colsum, possum_t = stats[2 * S * R:2 * S * R + S * Mc], stats[2 * S * R + S * Mc:]
+        v_terms, t_run = torch.empty(S, R, device=dev), torch.empty(S, Mc, device=dev)
         L = _lib.lib()
         ws = torch.empty(L.tan_simnce_ws_floats(C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N)), device=dev)
-        _lib.check(L.tan_simnce_fwd(_p(vn), _p(tn), C.c_long(0 if shared else Mp * Cw), _p(tgt), _p(col_invalid), _p(row_leak),
-                                    _p(rowsum), _p(colsum), _p(possum_v), _p(possum_t), _p(v_terms), _p(t_terms), _p(ws),
-                                    C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N), C.c_int(Cw), ops._stream()), "tan_simnce_fwd")
-        ctx.saved = (vn, tn, tgt, col_invalid, row_leak, rowsum, colsum, possum_v, possum_t, ws)
-        ctx.dims = (S, B, T, N, Cw, shared)
+        _lib.check(L.tan_simnce_fwd(_p(vn), _p(tn_run), C.c_long(0 if shared else Mc * Cw), _p(tgt), _p(ci_run), _p(row_leak),
+                                    _p(rowsum), _p(colsum), _p(possum_v), _p(possum_t), _p(v_terms), _p(t_run), _p(ws),
+                                    C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N), C.c_int(Cw), _p(tn) if compact else None,
+                                    C.c_long(0 if shared else Mp * Cw), _p(colmap), C.c_int(Mc), ops._stream()), "tan_simnce_fwd")
+        if compact:
+            t_terms = torch.zeros(S, Mp, device=dev).index_copy_(1, idx, t_run)
+        else:
+            t_terms = t_run
+        ctx.saved = (vn, tn, tn_run, tgt, ci_run, row_leak, rowsum, colsum, possum_v, possum_t, ws, idx, colmap)
+        ctx.dims = (S, B, T, N, Cw, shared, Mc)
         return v_terms, t_terms
 
     @staticmethod
     def backward(ctx, g_v, g_t):
-        vn, tn, tgt, col_invalid, row_leak, rowsum, colsum, possum_v, possum_t, ws = ctx.saved
-        S, B, T, N, Cw, shared = ctx.dims
+        vn, tn, tn_run, tgt, ci_run, row_leak, rowsum, colsum, possum_v, possum_t, ws, idx, colmap = ctx.saved
+        S, B, T, N, Cw, shared, Mc = ctx.dims
         R, Mp, dev = B * T, B * N, vn.device
+        compact = idx is not None
         g_v = torch.zeros(S, R, device=dev) if g_v is None else g_v.contiguous()
         g_t = torch.zeros(S, Mp, device=dev) if g_t is None else g_t.contiguous()
-        dl = torch.empty(S, R, Mp, dtype=torch.bfloat16, device=dev)
-        _lib.check(_lib.lib().tan_simnce_bwd_dl(_p(vn), _p(tn), C.c_long(0 if shared else Mp * Cw), _p(tgt), _p(col_invalid),
+        if compact:
+            g_t = g_t.index_select(1, idx).contiguous()
+        dl = torch.empty(S, R, Mc, dtype=torch.bfloat16, device=dev)
+        _lib.check(_lib.lib().tan_simnce_bwd_dl(_p(vn), _p(tn_run), C.c_long(0 if shared else Mc * Cw), _p(tgt), _p(ci_run),
                                                 _p(row_leak), _p(rowsum), _p(colsum), _p(possum_v), _p(possum_t), _p(g_v),
                                                 _p(g_t), _p(dl), _p(ws), C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N),
-                                                C.c_int(Cw), ops._stream()), "tan_simnce_bwd_dl")
+                                                C.c_int(Cw), _p(tn) if compact else None, C.c_long(0 if shared else Mp * Cw),
+                                                _p(colmap), C.c_int(Mc), ops._stream()), "tan_simnce_bwd_dl")
         d_vn = torch.empty_like(vn)
-        ops.gemm(dl, tn, d_vn, M=R, N=Cw, K=Mp, a_kc=True, b_kc=False, lda=Mp, ldb=Cw, batch=S, sA=R * Mp,
-                 sB=0 if shared else Mp * Cw, sC=R * Cw)
+        ops.gemm(dl, tn_run, d_vn, M=R, N=Cw, K=Mc, a_kc=True, b_kc=False, lda=Mc, ldb=Cw, batch=S, sA=R * Mc,
+                 sB=0 if shared else Mc * Cw, sC=R * Cw)
         if shared:       # one text feature for every stage: contract over (stage, row) in a single split-K GEMM
-            acc = torch.zeros(Mp, Cw, device=dev)
-            ops.gemm(dl, vn, acc, M=Mp, N=Cw, K=S * R, a_kc=False, b_kc=False, lda=Mp, ldb=Cw, accumulate=True,
+            acc = torch.zeros(Mc, Cw, device=dev)
+            ops.gemm(dl, vn, acc, M=Mc, N=Cw, K=S * R, a_kc=False, b_kc=False, lda=Mc, ldb=Cw, accumulate=True,
                      split_k=max(1, min(8, S * R // 512)))
-            d_tn = ops.cast(acc, torch.empty(1, Mp, Cw, dtype=tn.dtype, device=dev))
+            d_run = ops.cast(acc, torch.empty(1, Mc, Cw, dtype=tn.dtype, device=dev))
         else:
-            d_tn = torch.empty_like(tn)     # S x (Mp/128 x Cw/128) tiles under an R-long contraction: enough workgroups unsplit
-            ops.gemm(dl, vn, d_tn, M=Mp, N=Cw, K=R, a_kc=False, b_kc=False, lda=Mp, ldb=Cw, batch=S, sA=R * Mp, sB=R * Cw,
-                     sC=Mp * Cw)
-        return d_vn, d_tn, None, None, None, None, None, None
+            d_run = torch.empty(S, Mc, Cw, dtype=tn.dtype, device=dev)   # S x (Mc/128 x Cw/128) tiles under an R-long contraction
+            ops.gemm(dl, vn, d_run, M=Mc, N=Cw, K=R, a_kc=False, b_kc=False, lda=Mc, ldb=Cw, batch=S, sA=R * Mc, sB=R * Cw,
+                     sC=Mc * Cw)
+        d_tn = torch.zeros_like(tn).index_copy_(1, idx, d_run) if compact else d_run
+        return d_vn, d_tn, None, None, None, None, None, None, None
 
 
 def _masked_mean(x, mask_f):
@@ -284,8 +312,9 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
         v_d, t_d = _NCEFn.apply(lg_d, tgt, tpad_u8.view(Mp), row_leak, B, T, N)
         v_j, t_j = _NCEFn.apply(lg_j, tgt, tpad_u8.view(Mp), row_leak, B, T, N)
     else:
-        v_d, t_d = _FusedNCEFn.apply(fused.vn_d, fused.tn_d, tgt, tpad_u8.view(Mp), row_leak, B, T, N)
-        v_j, t_j = _FusedNCEFn.apply(fused.vn_j, fused.tn_j, tgt, tpad_u8.view(Mp), row_leak, B, T, N)
+        nv = getattr(fused, "n_text_valid", None)          # host-side count of real sentences (no sync), or None
+        v_d, t_d = _FusedNCEFn.apply(fused.vn_d, fused.tn_d, tgt, tpad_u8.view(Mp), row_leak, B, T, N, nv)
+        v_j, t_j = _FusedNCEFn.apply(fused.vn_j, fused.tn_j, tgt, tpad_u8.view(Mp), row_leak, B, T, N, nv)
     loss_dual = (_masked_mean(v_d, rows_pos) + _masked_mean(t_d, cols_pos)) / 2
     loss_joint = (_masked_mean(v_j, rows_pos) + _masked_mean(t_j, cols_pos)) / 2
     out["loss-dual"], out["loss-joint"] = loss_dual.detach(), loss_joint.detach()

@@ -46,6 +46,7 @@ class _Flat:
             total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.total = total
         self.flat = self.grad = self.shadow = None
+        self._views = {}
         self.shadow_version = -1
         self.device = None
 
@@ -72,6 +73,7 @@ class _Flat:
                 p.grad = self.grad[o:o + k].view(shp)
         self.shadow = torch.empty(self.total, dtype=torch.bfloat16, device=dev) if want_shadow else None
         self.shadow_version = -1
+        self._views = {}
 
     def sync_shadow(self):
         if self.shadow is not None and self.shadow_version != self.flat._version:
@@ -79,8 +81,20 @@ class _Flat:
             self.shadow_version = self.flat._version
 
     def view(self, buf, name):
+        """Slice `name` of a flat buffer.  Cached: a train step asks for ~500 of these, and building each narrow+view pair
+        was a fifth of the host time of the step."""
         o, k, shp = self.off[name]
-        return buf[o:o + k].view(shp)
+        if buf is not self.flat and buf is not self.grad and buf is not self.shadow:
+            return buf[o:o + k].view(shp)            # a caller's own buffer (e.g. a clone of the gradient): never cached
+        key = (buf.data_ptr(), name)
+        v = self._views.get(key)
+        if v is None:
+            v = self._views[key] = buf[o:o + k].view(shp)
+        return v
+
+    def ptr(self, buf, name):
+        """device address of slice `name` of a flat buffer (no tensor view is built)"""
+        return buf.data_ptr() + self.off[name][0] * buf.element_size()
 
 
 class _Blocks:
@@ -200,6 +214,8 @@ class TemporalAligner(nn.Module):
         self._ws_pool = {}
         self.overlap_stacks = True        # run the video and joint stacks on two HIP streams
         self._side = None
+        self._issuer = None               # helper thread issuing the side-stream stack (see _on_side)
+        self._lp_cache = {}
         self._grad_ready_hook = None      # callable(tag) fired inside backward when a slice of the flat gradient is final
 
     # ------------------------------------------------------------------ init (tan_model.py:76-97)
@@ -299,6 +315,14 @@ class TemporalAligner(nn.Module):
 
     # ------------------------------------------------------------------ encoder descriptors
     def _layer_params(self, prefix, layers):
+        """tan_layer_params[layers] of one stack: addresses into the flat parameter / gradient / bf16-shadow buffers.  Built by
+        pointer arithmetic and cached until one of the three buffers is re-allocated."""
+        f = self._flat
+        wbuf = f.shadow if self.compute_dtype == torch.bfloat16 else f.flat
+        sig = (f.flat.data_ptr(), f.grad.data_ptr(), wbuf.data_ptr())
+        hit = self._lp_cache.get((prefix, layers))
+        if hit is not None and hit[0] == sig:
+            return hit[1]
         arr = (_lib.LayerParams * layers)()
         m = {"w_qkv": "attn.in_proj_weight", "w_out": "attn.out_proj.weight", "w_fc": "mlp.c_fc.weight",
              "w_proj": "mlp.c_proj.weight"}
@@ -308,11 +332,12 @@ class TemporalAligner(nn.Module):
         for i in range(layers):
             base = f"{prefix}.resblocks.{i}."
             for k, v in m.items():
-                setattr(arr[i], k, self._w(base + v).data_ptr())
-                setattr(arr[i], "g_" + k, self._g(base + v).data_ptr())
+                setattr(arr[i], k, f.ptr(wbuf, base + v))
+                setattr(arr[i], "g_" + k, f.ptr(f.grad, base + v))
             for k, v in fm.items():
-                setattr(arr[i], k, self._f(base + v).data_ptr())
-                setattr(arr[i], "g_" + k, self._g(base + v).data_ptr())
+                setattr(arr[i], k, f.ptr(f.flat, base + v))
+                setattr(arr[i], "g_" + k, f.ptr(f.grad, base + v))
+        self._lp_cache[(prefix, layers)] = (sig, arr)
         return arr
 
     def _enc_desc(self, er: _EncRun, x0, keypad, post_name):
@@ -489,6 +514,21 @@ class TemporalAligner(nn.Module):
             self._side = torch.cuda.Stream(device=dev)
         return self._side
 
+    def _on_side(self, side, fn):
+        """Issue `fn` (one stack's launches, ~150 per call) on the side stream from a helper thread: the C entry points
+        release the GIL, so the two stacks' host-side launch work overlaps too -- at ~5 us of host time per launch the step
+        was bound by ONE thread issuing ~530 launches (7.1 of 8.3 ms).  Returns a future; .result() re-raises."""
+        if self._issuer is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._issuer = ThreadPoolExecutor(max_workers=1, thread_name_prefix="tan-side")
+        dev = side.device
+
+        def run():
+            torch.cuda.set_device(dev)                       # device and current stream are thread-local
+            with torch.no_grad(), torch.cuda.stream(side):
+                return fn()
+        return self._issuer.submit(run)
+
     def _take_scratch(self, R, cd, dev):
         key = ("scr", R, cd, dev)
         scr = self._ws_pool.get(key)
@@ -551,9 +591,9 @@ class TemporalAligner(nn.Module):
         main, side = torch.cuda.current_stream(), self._side_stream(dev)
         if side is not None:
             side.wait_stream(main)
-            with torch.cuda.stream(side):
-                ej = self._run_joint_stack(x0j, lang_t, vmask_u8, tmask_u8, B, T, N)
+            fut = self._on_side(side, lambda: self._run_joint_stack(x0j, lang_t, vmask_u8, tmask_u8, B, T, N))
             ev = self._run_video_stack(x0, vmask_u8, B, T)
+            ej = fut.result()
             main.wait_stream(side)
         else:
             ev = self._run_video_stack(x0, vmask_u8, B, T)
@@ -703,11 +743,14 @@ class TemporalAligner(nn.Module):
             # joint stack backward on the side stream (its gradient slice is final first: DDP starts reducing it while
             # the video stack is still in backward), video stack backward on the main stream
             side.wait_stream(main)
-            with torch.cuda.stream(side):
+
+            def joint_bwd():
                 self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dst_j, d_xj)
                 if self._grad_ready_hook is not None:
                     self._grad_ready_hook("joint")
+            fut = self._on_side(side, joint_bwd)
             self._encoder_bwd(ev, run["x0"], run["vmask"], "ln_video_post_enc", dst_v, d_x0)
+            fut.result()
             main.wait_stream(side)
         else:
             if any_j:

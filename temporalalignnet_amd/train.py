@@ -61,6 +61,8 @@ def to_device_batch(batch: dict, device="cuda") -> dict:
     out["padding_mask"] = torch.as_tensor(batch["padding_mask"]).bool().to(device, non_blocking=True)
     T, N = out["video"].shape[1], out["text_embed"].shape[1]
     out["_tgt_raw"], _, _ = get_mask_from_time(batch["start"], batch["end"], T, N, device=device)
+    if "text_padding_mask" in batch and not torch.is_tensor(batch["text_padding_mask"]):
+        out["n_text"] = int(batch["text_padding_mask"].size - np.count_nonzero(batch["text_padding_mask"]))   # host count, no sync
     return out
 
 
@@ -157,9 +159,12 @@ class Trainer:
         if "token" in batch and self.online.bert is not None:      # sentence embeddings from the language model (main.py:55-65)
             batch = dict(batch)
             batch["text_embed"], batch["text_padding_mask"] = embed_sentences(m, batch["token"])
+            batch["n_text"] = int(sum(t.shape[0] for t in batch["token"]))
         logits = m(batch["video"], batch["text_embed"], video_padding_mask=batch["padding_mask"],
                    lang_padding_mask=batch["text_padding_mask"].bool(), text_timestamp=batch.get("_tgt_raw"),
                    abs_text_pos=batch.get("abs_text_pos"), fused=self.fused_loss)
+        if "_fused" in logits and batch.get("n_text") is not None:
+            logits["_fused"].n_text_valid = batch["n_text"]        # padded text columns are skipped by the similarity sweep
         if a.model == "cotrain":
             ema = m.forward_from_ema(batch["video"], batch["text_embed"], video_padding_mask=batch["padding_mask"],
                                      lang_padding_mask=batch["text_padding_mask"].bool(),

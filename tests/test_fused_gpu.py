@@ -68,3 +68,19 @@ def test_fused_forward_has_no_logits_and_three_steps_train():
     assert "_fused" in out and "logits_dual" not in out and "joint_logits_alignability" in out
     losses = [t_fus.step(b)["loss"].item() for _ in range(3)]
     assert all(np.isfinite(losses)) and losses[2] < losses[0]
+
+
+def test_column_compaction_is_a_noop_on_the_result():
+    """The sweep over the compacted text matrix (host-known sentence count) == the sweep over all B*N padded columns."""
+    args, params, (_, t_fus), b_np, b = _setup("init", 2, 2, 12, 64, learn_agreement=1)
+    assert b["n_text"] == int((b_np["text_padding_mask"] == 0).sum()) < b_np["text_padding_mask"].size
+    res = []
+    for nt in (b["n_text"], None):
+        bb = dict(b, n_text=nt)
+        t_fus.zero_grad()
+        ld = t_fus.forward_backward(bb)
+        res.append(({k: v.item() for k, v in ld.items()}, t_fus.online.flat_grad().clone()))
+    (l0, g0), (l1, g1) = res
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 1e-5 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
+    assert (g0 - g1).norm().item() / g1.norm().item() < 2e-3        # bf16 d-logits, different summation order only

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Regenerates profiles/ on an MI355X box: run as  gpurun -- 'bash tools/refresh_profiles.sh'  (writes under gpurun_out/refresh/)
+set -x
+R=$PWD; O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
+python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/under_rocprof.json 2> $O/under_rocprof.err
+cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer > /dev/null 2> $O/pmc_$c.err
+done
+python $R/tools/pmc_summary.py $(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json > $O/pmc_traffic.txt
+tail -1 $O/bench.json | cut -c1-400
