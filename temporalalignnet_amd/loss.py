@@ -15,6 +15,7 @@ Known, documented differences from the reference:
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 import torch.nn.functional as F
@@ -233,6 +234,16 @@ class _FusedNCEFn(torch.autograd.Function):
         return d_vn, d_tn, None, None, None, None, None, None, None
 
 
+_SIDE = {}
+
+
+def _side_stream(dev):
+    st = _SIDE.get(dev)
+    if st is None:
+        st = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def _masked_mean(x, mask_f):
     """mean of x[:, mask] for x [S, K], mask [K] -- (sum x*mask) / (S * sum mask); 0/0 = nan like an empty .mean()."""
     return (x * mask_f[None]).sum() / (x.shape[0] * mask_f.sum())
@@ -313,8 +324,22 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
         v_j, t_j = _NCEFn.apply(lg_j, tgt, tpad_u8.view(Mp), row_leak, B, T, N)
     else:
         nv = getattr(fused, "n_text_valid", None)          # host-side count of real sentences (no sync), or None
-        v_d, t_d = _FusedNCEFn.apply(fused.vn_d, fused.tn_d, tgt, tpad_u8.view(Mp), row_leak, B, T, N, nv)
-        v_j, t_j = _FusedNCEFn.apply(fused.vn_j, fused.tn_j, tgt, tpad_u8.view(Mp), row_leak, B, T, N, nv)
+        # The dual and joint similarity sweeps are independent until the final mean: the joint one runs on a second HIP
+        # stream (each sweep alone fills 75 % of the workgroup slots).  autograd replays a node's backward on the stream its
+        # forward ran on and synchronises producer/consumer streams itself, so the two backward chains (d-logits + the two
+        # feature-gradient GEMMs each) overlap as well.
+        main = torch.cuda.current_stream()
+        side = _side_stream(dev) if os.environ.get("TAN_LOSS_STREAMS", "1") != "0" else None
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                v_j, t_j = _FusedNCEFn.apply(fused.vn_j, fused.tn_j, tgt, tpad_u8.view(Mp), row_leak, B, T, N, nv)
+            v_d, t_d = _FusedNCEFn.apply(fused.vn_d, fused.tn_d, tgt, tpad_u8.view(Mp), row_leak, B, T, N, nv)
+            main.wait_stream(side)
+            v_j.record_stream(main); t_j.record_stream(main)
+        else:
+            v_d, t_d = _FusedNCEFn.apply(fused.vn_d, fused.tn_d, tgt, tpad_u8.view(Mp), row_leak, B, T, N, nv)
+            v_j, t_j = _FusedNCEFn.apply(fused.vn_j, fused.tn_j, tgt, tpad_u8.view(Mp), row_leak, B, T, N, nv)
     loss_dual = (_masked_mean(v_d, rows_pos) + _masked_mean(t_d, cols_pos)) / 2
     loss_joint = (_masked_mean(v_j, rows_pos) + _masked_mean(t_j, cols_pos)) / 2
     out["loss-dual"], out["loss-joint"] = loss_dual.detach(), loss_joint.detach()
