@@ -110,6 +110,11 @@ int tan_group_sum(const void* x, void* out, int G, int R, int C, int dtype, void
 int tan_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
 /* out[i] += sum_s parts[s*n + i]  (folds split-K partial tiles into an f32 gradient); n % 4 == 0 */
 int tan_reduce_add(const float* parts, float* out, int nparts, long n, void* stream);
+/* Batched bf16 transpose inside one flat buffer: matrix i is src[table[3i] ...] with shape [table[3i+1], table[3i+2]] (row-major;
+ * both multiples of 8, offsets multiples of 8); dst gets its transpose at the same element offset.  `table` is DEVICE memory.
+ * Produces the K-contiguous weight copies tan_layer_params.wt_* (dX = dY W reads W^T rows) once per optimizer step.        */
+int tan_transpose_batch(const void* src, void* dst, const long* table, int n, long max_rows, long max_cols, int dtype,
+                        void* stream);
 /* binary_head = nn.Linear(512,1) (tan_model.py:70,147-148): out[r] = <x[r],w> + b (f32 out); bwd accumulates dw, db */
 int tan_head_fwd(const void* x, const float* w, const float* b, float* out, long rows, int C, int dtype, void* stream);
 int tan_head_bwd(const float* dout, const void* x, const float* w, void* dx, float* dw, float* db, long rows, int C,
@@ -187,6 +192,17 @@ int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_stride, const
                       const float* possum_t, const float* g_v, const float* g_t, void* dl, float* ws, int S, int B, int T, int N,
                       int C, const void* tn_blocks, long tb_stage_stride, const int* colmap, int Mc, void* stream);
 
+/* NCE tail (loss.py:236-237,254-275).  tan_pos_masks: rows_pos[b*T+t] = 1 if frame t of video b has a positive among its
+ * unpadded sentences, cols_pos[b*N+k] = 1 if sentence k is unpadded and has a positive frame (tgt [B,T,N] f32, text_pad [B,N]).
+ * tan_nce_tail_fwd: out2[0] = (mean(v_d | rows_mask) + mean(t_d | cols_mask)) / 2 and out2[1] the same for the joint terms,
+ * mean(x | m) = sum_{s,k} x[s,k] m[k] / (S sum m)  (NaN for an empty mask, like .mean() of nothing); counts2 = mask sums, kept
+ * for tan_nce_tail_bwd, which turns d loss/d out2 into the gradients of the four term tensors.  One launch each.          */
+int tan_pos_masks(const float* tgt, const unsigned char* text_pad, float* rows_pos, float* cols_pos, int B, int T, int N, void* stream);
+int tan_nce_tail_fwd(const float* v_d, const float* t_d, const float* v_j, const float* t_j, const float* rows_mask,
+                     const float* cols_mask, int Sd, int Sj, long R, long M, float* out2, float* counts2, void* stream);
+int tan_nce_tail_bwd(const float* g_out2, const float* rows_mask, const float* cols_mask, const float* counts2, int Sd, int Sj,
+                     long R, long M, float* g_v_d, float* g_t_d, float* g_v_j, float* g_t_j, void* stream);
+
 /* ---- sentence embedder (model/word2vec_model.py:76-102) ----------------------------------------
  * tan_embed_gather: out[r, 0:D] = table[ids[r], :] cast to `dtype`, out[r, D:Dpad] = 0 (ids NULL = identity: a padded
  *   cast of a [rows, D] f32 matrix).  Pads the 300-d word vectors / fc1 weight rows to a multiple of 64 for the MFMA GEMM.
@@ -221,6 +237,7 @@ typedef struct tan_layer_params {
     float *g_w_qkv, *g_w_out, *g_w_fc, *g_w_proj;
     float *g_b_qkv, *g_b_out, *g_b_fc, *g_b_proj;
     float *g_ln1_g, *g_ln1_b, *g_ln2_g, *g_ln2_b;
+    const void *wt_qkv, *wt_out, *wt_fc, *wt_proj; /* optional (bf16): W^T copies, [in, out] row-major, for the dX GEMMs; NULL = read W K-strided */
 } tan_layer_params;
 
 /* per-layer saved activations, rows R = B*L */

@@ -36,13 +36,14 @@ int linear_fwd(int dt, const void* x, const void* w, const float* b, void* y, lo
 }
 
 // dx[M,K] = dy[M,N] W[N,K]  (optionally * gelu'(aux) and + residual)
-int linear_bwd_x(int dt, const void* dy, const void* w, void* dx, long M, int N, int K, int act, void* aux, const void* residual,
-                 float* colsum, void* st) {
+int linear_bwd_x(int dt, const void* dy, const void* w, const void* wt, void* dx, long M, int N, int K, int act, void* aux,
+                 const void* residual, float* colsum, void* st) {
     tan_gemm_desc d{};
     d.dtype = dt; d.out_dtype = dt;
     d.M = (int)M; d.N = K; d.K = N;
-    d.a_kc = 1; d.b_kc = 0;               // B = W stored [N(contract), K(out)]
-    d.A = dy; d.lda = N; d.B = w; d.ldb = K; d.C = dx; d.ldc = K;
+    d.A = dy; d.lda = N; d.C = dx; d.ldc = K;
+    if (wt) { d.a_kc = 1; d.b_kc = 1; d.B = wt; d.ldb = N; }     // W^T [K(out), N(contract)]: both operands K-contiguous
+    else    { d.a_kc = 1; d.b_kc = 0; d.B = w; d.ldb = K; }      // W   [N(contract), K(out)] read K-strided
     d.residual = residual; d.ldr = K; d.act = act; d.aux = aux; d.ldaux = K;
     d.split_k = 1; d.alpha = 1.0f; d.batch = 1;
     d.colsum = colsum;
@@ -141,20 +142,20 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         const void* x_in = i == 0 ? e->x0 : e->bufs[i - 1].x_out;
         // ---- MLP branch: x_out = x_mid + c_proj(quickgelu(c_fc(LN2(x_mid))))
         CK(linear_bwd_w(dt, dx, b.h_act, p.g_w_proj, R, C, 4 * C, e->dw_ws, e->dw_ws_floats, st));
-        CK(linear_bwd_x(dt, dx, p.w_proj, e->scr_dh, R, C, 4 * C, TAN_ACT_QUICKGELU_GRAD, b.h_pre, nullptr, p.g_b_fc, st));
+        CK(linear_bwd_x(dt, dx, p.w_proj, p.wt_proj, e->scr_dh, R, C, 4 * C, TAN_ACT_QUICKGELU_GRAD, b.h_pre, nullptr, p.g_b_fc, st));
         CK(linear_bwd_w(dt, e->scr_dh, b.xn2, p.g_w_fc, R, 4 * C, C, e->dw_ws, e->dw_ws_floats, st));
-        CK(linear_bwd_x(dt, e->scr_dh, p.w_fc, e->scr_dxn, R, 4 * C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
+        CK(linear_bwd_x(dt, e->scr_dh, p.w_fc, p.wt_fc, e->scr_dxn, R, 4 * C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
         CK(tan_layernorm_bwd(e->scr_dxn, b.x_mid, p.ln2_g, b.mean2, b.rstd2, dx, dx2, p.g_ln2_g, p.g_ln2_b, p.g_b_out, e->ln_ws, R, C,
                              dt, st));
         // ---- attention branch: x_mid = x_in + out_proj(attn(LN1(x_in)))
         CK(linear_bwd_w(dt, dx2, b.attn_o, p.g_w_out, R, C, C, e->dw_ws, e->dw_ws_floats, st));
-        CK(linear_bwd_x(dt, dx2, p.w_out, e->scr_do, R, C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
+        CK(linear_bwd_x(dt, dx2, p.w_out, p.wt_out, e->scr_do, R, C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
         CK(tan_attn_bwd(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->scr_do, e->scr_dqkv, e->B, e->L, H, dt, st));
         CK(tan_colsum_acc(e->scr_dqkv, p.g_b_qkv, R, 3 * C, dt, st));
         CK(linear_bwd_w(dt, e->scr_dqkv, b.xn1, p.g_w_qkv, R, 3 * C, C, e->dw_ws, e->dw_ws_floats, st));
         // stage i-1 IS this layer's xn1: its gradient joins here
         const void* dstage = i >= 1 ? e->d_stage[i - 1] : nullptr;
-        CK(linear_bwd_x(dt, e->scr_dqkv, p.w_qkv, e->scr_dxn, R, 3 * C, C, TAN_ACT_NONE, nullptr, dstage, nullptr, st));
+        CK(linear_bwd_x(dt, e->scr_dqkv, p.w_qkv, p.wt_qkv, e->scr_dxn, R, 3 * C, C, TAN_ACT_NONE, nullptr, dstage, nullptr, st));
         void* dx_in = i == 0 ? e->d_x0 : dx;
         float* next_b_proj = i > 0 ? e->params[i - 1].g_b_proj : nullptr;       // dx_in is layer i-1's x_out gradient
         CK(tan_layernorm_bwd(e->scr_dxn, x_in, p.ln1_g, b.mean1, b.rstd1, dx2, dx_in, p.g_ln1_g, p.g_ln1_b, next_b_proj, e->ln_ws, R,

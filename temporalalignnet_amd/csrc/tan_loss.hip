@@ -322,6 +322,85 @@ __global__ __launch_bounds__(1024) void masked_quantile_kernel(const float* __re
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NCE tail (loss.py:236-237,254-275): which rows / columns own a positive, and the four masked means.
+// pos_masks: rows_pos[b*T+t] = any_k(tgt[b,t,k] != 0 && !tpad[b,k]); cols_pos[b*N+k] = any_t(tgt[b,t,k] != 0) && !tpad[b,k].
+__global__ __launch_bounds__(256) void pos_masks_kernel(const float* __restrict__ tgt, const unsigned char* __restrict__ tpad,
+                                                        float* __restrict__ rows_pos, float* __restrict__ cols_pos, int T, int N) {
+    const int b = blockIdx.x;
+    const float* tg = tgt + (long)b * T * N;
+    const unsigned char* tp = tpad + (long)b * N;
+    for (int t = threadIdx.x; t < T; t += 256) {
+        bool any = false;
+        for (int k = 0; k < N; ++k) any |= (tg[t * N + k] != 0.f) && !tp[k];
+        rows_pos[(long)b * T + t] = any ? 1.f : 0.f;
+    }
+    for (int k = threadIdx.x; k < N; k += 256) {
+        bool any = false;
+        for (int t = 0; t < T; ++t) any |= tg[t * N + k] != 0.f;
+        cols_pos[(long)b * N + k] = (any && !tp[k]) ? 1.f : 0.f;
+    }
+}
+
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += red[i];
+    return s;
+}
+
+// out[0] = (mean(v_d | rmask) + mean(t_d | cmask)) / 2, out[1] likewise for the joint terms; mean(x | m) = sum_{s,k} x[s,k] m[k]
+// / (S sum_k m[k])  (0/0 = NaN like an empty .mean()).  counts[0..1] = sum(rmask), sum(cmask), kept for the backward.
+__global__ __launch_bounds__(1024) void nce_tail_fwd_kernel(const float* __restrict__ v_d, const float* __restrict__ t_d,
+                                                            const float* __restrict__ v_j, const float* __restrict__ t_j,
+                                                            const float* __restrict__ rmask, const float* __restrict__ cmask, int Sd,
+                                                            int Sj, long R, long M, float* __restrict__ out,
+                                                            float* __restrict__ counts) {
+    __shared__ float red[16];
+    float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // sum v_d, t_d, v_j, t_j, n_r, n_c
+    for (long r = threadIdx.x; r < R; r += 1024) {
+        const float m = rmask[r];
+        a[4] += m;
+        for (int s = 0; s < Sd; ++s) a[0] += v_d[(long)s * R + r] * m;
+        for (int s = 0; s < Sj; ++s) a[2] += v_j[(long)s * R + r] * m;
+    }
+    for (long c = threadIdx.x; c < M; c += 1024) {
+        const float m = cmask[c];
+        a[5] += m;
+        for (int s = 0; s < Sd; ++s) a[1] += t_d[(long)s * M + c] * m;
+        for (int s = 0; s < Sj; ++s) a[3] += t_j[(long)s * M + c] * m;
+    }
+    float tot[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) tot[i] = block_sum_1024(a[i], red);
+    if (threadIdx.x == 0) {
+        out[0] = 0.5f * (tot[0] / (Sd * tot[4]) + tot[1] / (Sd * tot[5]));
+        out[1] = 0.5f * (tot[2] / (Sj * tot[4]) + tot[3] / (Sj * tot[5]));
+        counts[0] = tot[4]; counts[1] = tot[5];
+    }
+}
+
+__global__ void nce_tail_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ rmask, const float* __restrict__ cmask,
+                                    const float* __restrict__ counts, int Sd, int Sj, long R, long M, float* __restrict__ g_v_d,
+                                    float* __restrict__ g_t_d, float* __restrict__ g_v_j, float* __restrict__ g_t_j) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const float gd = 0.5f * g_out[0], gj = 0.5f * g_out[1];
+    if (i < R) {
+        const float m = rmask[i] / counts[0];
+        for (int s = 0; s < Sd; ++s) g_v_d[(long)s * R + i] = gd * m / Sd;
+        for (int s = 0; s < Sj; ++s) g_v_j[(long)s * R + i] = gj * m / Sj;
+    }
+    if (i < M) {
+        const float m = cmask[i] / counts[1];
+        for (int s = 0; s < Sd; ++s) g_t_d[(long)s * M + i] = gd * m / Sd;
+        for (int s = 0; s < Sj; ++s) g_t_j[(long)s * M + i] = gj * m / Sj;
+    }
+}
+
 }  // namespace tal
 
 using namespace tal;
@@ -411,6 +490,33 @@ extern "C" int tan_masked_quantile(const float* x, const unsigned char* invalid,
     int p2 = 1;
     while (p2 < n) p2 <<= 1;
     hipLaunchKernelGGL(masked_quantile_kernel, dim3(1), dim3(1024), (size_t)p2 * 4, (hipStream_t)stream, x, invalid, n, q, out, p2);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_pos_masks(const float* tgt, const unsigned char* text_pad, float* rows_pos, float* cols_pos, int B, int T, int N,
+                             void* stream) {
+    TAN_REQUIRE(tgt && text_pad && rows_pos && cols_pos && B > 0 && T > 0 && N > 0);
+    hipLaunchKernelGGL(pos_masks_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tgt, text_pad, rows_pos, cols_pos, T, N);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_nce_tail_fwd(const float* v_d, const float* t_d, const float* v_j, const float* t_j, const float* rows_mask,
+                                const float* cols_mask, int Sd, int Sj, long R, long M, float* out2, float* counts2, void* stream) {
+    TAN_REQUIRE(v_d && t_d && v_j && t_j && rows_mask && cols_mask && out2 && counts2 && Sd > 0 && Sj > 0 && R > 0 && M > 0);
+    hipLaunchKernelGGL(nce_tail_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v_d, t_d, v_j, t_j, rows_mask, cols_mask, Sd,
+                       Sj, R, M, out2, counts2);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_nce_tail_bwd(const float* g_out2, const float* rows_mask, const float* cols_mask, const float* counts2, int Sd,
+                                int Sj, long R, long M, float* g_v_d, float* g_t_d, float* g_v_j, float* g_t_j, void* stream) {
+    TAN_REQUIRE(g_out2 && rows_mask && cols_mask && counts2 && g_v_d && g_t_d && g_v_j && g_t_j && Sd > 0 && Sj > 0 && R > 0 && M > 0);
+    const long n = R > M ? R : M;
+    hipLaunchKernelGGL(nce_tail_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, g_out2, rows_mask, cols_mask,
+                       counts2, Sd, Sj, R, M, g_v_d, g_t_d, g_v_j, g_t_j);
     TAN_LAUNCH_CHECK();
     return 0;
 }

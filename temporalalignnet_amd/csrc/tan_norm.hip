@@ -236,6 +236,39 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     }
 }
 
+// Batched bf16 matrix transpose: matrix i = src[table[3i] ..] of shape [rows=table[3i+1], cols=table[3i+2]] (row-major) ->
+// dst at the SAME element offset, shape [cols, rows].  Grid (max tiles per matrix, matrices); 64x64 tiles through LDS with
+// 16-byte global accesses on both sides.  Used once per optimizer step for the K-contiguous copies of the Linear weights that
+// the dX GEMMs read (tan_layer_params.wt_*).
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                              const long* __restrict__ table) {
+    __shared__ bf16_t tile[64][72];
+    const long off = table[3 * blockIdx.y];
+    const int rows = (int)table[3 * blockIdx.y + 1], cols = (int)table[3 * blockIdx.y + 2];
+    const int tc = (cols + 63) / 64, ntile = ((rows + 63) / 64) * tc;
+    if ((int)blockIdx.x >= ntile) return;
+    const int r0 = (blockIdx.x / tc) * 64, c0 = (blockIdx.x % tc) * 64;
+    const bf16_t* S = src + off;
+    bf16_t* D = dst + off;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int v = threadIdx.x + 256 * it, r = v >> 3, c = (v & 7) * 8;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (r0 + r < rows && c0 + c < cols) x = *reinterpret_cast<const uint4*>(S + (long)(r0 + r) * cols + c0 + c);
+        *reinterpret_cast<uint4*>(&tile[r][c]) = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int v = threadIdx.x + 256 * it, c = v >> 3, r = (v & 7) * 8;      // output row c0+c, 8 source rows r..r+7
+        if (c0 + c >= cols || r0 + r >= rows) continue;
+        union { uint4 u; bf16_t h[8]; } o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.h[e] = tile[r + e][c];
+        *reinterpret_cast<uint4*>(D + (long)(c0 + c) * rows + r0 + r) = o.u;
+    }
+}
+
 // generic fallback (any C): one thread per column, 64 rows per block
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_generic_kernel(const T* __restrict__ x, float* __restrict__ out, long rows, int C) {
@@ -487,6 +520,17 @@ extern "C" int tan_group_sum(const void* x, void* out, int G, int R, int C, int 
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype, hipLaunchKernelGGL((group_sum_kernel<T>), dim3(cdiv((long)R * C, 256)), dim3(256), 0, st, (const T*)x,
                                          (T*)out, G, R, C));
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_transpose_batch(const void* src, void* dst, const long* table, int n, long max_rows, long max_cols, int dtype,
+                                   void* stream) {
+    TAN_REQUIRE(src && dst && table && n > 0 && max_rows > 0 && max_cols > 0 && dtype == TAN_BF16);
+    TAN_REQUIRE(max_rows % 8 == 0 && max_cols % 8 == 0);          // every matrix: rows % 8 == 0 and cols % 8 == 0 (16-byte accesses)
+    const unsigned tiles = cdiv(max_rows, 64) * cdiv(max_cols, 64);
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3(tiles, n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst,
+                       table);
     TAN_LAUNCH_CHECK();
     return 0;
 }

@@ -159,6 +159,56 @@ class FusedSim:
         return out
 
 
+def compaction_prep(col_invalid, n_valid):
+    """(gather index [Mc], padded column -> compacted column map [Mp] int32, pad flags of the compacted columns [Mc]) for
+    _FusedNCEFn, or None when nothing would be dropped.  Mc = n_valid rounded up to 64 (the d-feature GEMM contracts over Mc in
+    64-deep K-steps); a stable sort of the 0/1 pad flags puts the real sentences first, in order: static shapes, no host sync."""
+    Mp = col_invalid.shape[0]
+    if n_valid is None:
+        return None
+    Mc = min(Mp, (int(n_valid) + 63) // 64 * 64)
+    if Mc >= Mp:
+        return None
+    idx = torch.sort(col_invalid, stable=True).indices[:Mc]
+    colmap = (torch.cumsum(col_invalid == 0, 0, dtype=torch.int32) - 1).masked_fill_(col_invalid != 0, -1)
+    return idx, colmap, col_invalid.index_select(0, idx)
+
+
+class _NCETail(torch.autograd.Function):
+    """loss.py:254-275 in two launches: ((mean(v_d|rows) + mean(t_d|cols))/2, (mean(v_j|rows) + mean(t_j|cols))/2)."""
+
+    @staticmethod
+    def forward(ctx, v_d, t_d, v_j, t_j, rows_mask, cols_mask):
+        v_d, t_d, v_j, t_j = (x.contiguous() for x in (v_d, t_d, v_j, t_j))
+        (Sd, R), (Sj, M) = v_d.shape, t_j.shape
+        assert t_d.shape == (Sd, M) and v_j.shape == (Sj, R)
+        out = torch.empty(4, device=v_d.device)               # [loss_dual, loss_joint, n_rows, n_cols]
+        _lib.check(_lib.lib().tan_nce_tail_fwd(_p(v_d), _p(t_d), _p(v_j), _p(t_j), _p(rows_mask), _p(cols_mask), C.c_int(Sd),
+                                               C.c_int(Sj), C.c_long(R), C.c_long(M), _p(out), _p(out[2:]), ops._stream()),
+                   "tan_nce_tail_fwd")
+        ctx.saved = (rows_mask, cols_mask, out, Sd, Sj, R, M)
+        return out[:2]
+
+    @staticmethod
+    def backward(ctx, g):
+        rows_mask, cols_mask, out, Sd, Sj, R, M = ctx.saved
+        dev = out.device
+        g = g.contiguous()
+        g_v_d, g_t_d = torch.empty(Sd, R, device=dev), torch.empty(Sd, M, device=dev)
+        g_v_j, g_t_j = torch.empty(Sj, R, device=dev), torch.empty(Sj, M, device=dev)
+        _lib.check(_lib.lib().tan_nce_tail_bwd(_p(g), _p(rows_mask), _p(cols_mask), _p(out[2:]), C.c_int(Sd), C.c_int(Sj),
+                                               C.c_long(R), C.c_long(M), _p(g_v_d), _p(g_t_d), _p(g_v_j), _p(g_t_j), ops._stream()),
+                   "tan_nce_tail_bwd")
+        return g_v_d, g_t_d, g_v_j, g_t_j, None, None
+
+
+def _pos_masks(tgt, tpad_u8, B, T, N):
+    rows_pos, cols_pos = torch.empty(B * T, device=tgt.device), torch.empty(B * N, device=tgt.device)
+    _lib.check(_lib.lib().tan_pos_masks(_p(tgt), _p(tpad_u8), _p(rows_pos), _p(cols_pos), C.c_int(B), C.c_int(T), C.c_int(N),
+                                        ops._stream()), "tan_pos_masks")
+    return rows_pos, cols_pos
+
+
 class _FusedNCEFn(torch.autograd.Function):
     """_NCEFn without the logits: tan_simnce_fwd / tan_simnce_bwd_dl + the two d-feature GEMMs.
 
@@ -168,22 +218,18 @@ class _FusedNCEFn(torch.autograd.Function):
     are scattered back to the padded [S, B*N] layout (zeros at pad columns, which every consumer masks)."""
 
     @staticmethod
-    def forward(ctx, vn, tn, tgt, col_invalid, row_leak, B, T, N, n_valid=None):
+    def forward(ctx, vn, tn, tgt, col_invalid, row_leak, B, T, N, prep=None):
         S, R, Cw = vn.shape
         Mp, dev = B * N, vn.device
         shared = tn.shape[0] == 1
-        Mc = Mp if n_valid is None else min(Mp, (int(n_valid) + 63) // 64 * 64)    # the d-feature GEMM contracts over Mc: 64-deep K-steps
-        compact = Mc < Mp
+        compact = prep is not None
         if compact:
-            # stable sort of the 0/1 pad flags: real sentences first, in order; static shapes, no host sync
-            idx = torch.sort(col_invalid.to(torch.int16), stable=True).indices[:Mc]
-            colmap = torch.where(col_invalid.bool(), torch.full((Mp,), -1, dtype=torch.int32, device=dev),
-                                 (torch.cumsum(1 - col_invalid.to(torch.int32), 0) - 1).to(torch.int32)).contiguous()
-            tn_run = tn.index_select(1, idx).contiguous()
-            ci_run = col_invalid.index_select(0, idx).contiguous()
+            idx, colmap, ci_run = prep                       # compaction_prep(): shared by the dual and the joint sweep
+            Mc = idx.shape[0]
+            tn_run = tn.index_select(1, idx)
         else:
             idx = colmap = None
-            tn_run, ci_run = tn, col_invalid
+            Mc, tn_run, ci_run = Mp, tn, col_invalid
         stats = torch.empty(2 * S * R + 2 * S * Mc, device=dev)
         rowsum, possum_v = stats[:S * R], stats[S * R:2 * S * R]
         colsum, possum_t = stats[2 * S * R:2 * S * R + S * Mc], stats[2 * S * R + S * Mc:]
@@ -315,15 +361,14 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
     else:
         tgt = tgt_raw.permute(0, 2, 1).float().contiguous()                                           # [B,T,N]
 
-    tgt_valid = tgt * (~tpad)[:, None, :].float()
-    rows_pos = (tgt_valid.sum(-1) > 0).view(R).float()                                                # loss.py:236
-    cols_pos = ((tgt.sum(1) > 0).view(Mp) & valid).float()                                            # loss.py:237
+    rows_pos, cols_pos = _pos_masks(tgt, tpad_u8, B, T, N)                                            # loss.py:236-237
 
     if fused is None:
         v_d, t_d = _NCEFn.apply(lg_d, tgt, tpad_u8.view(Mp), row_leak, B, T, N)
         v_j, t_j = _NCEFn.apply(lg_j, tgt, tpad_u8.view(Mp), row_leak, B, T, N)
     else:
-        nv = getattr(fused, "n_text_valid", None)          # host-side count of real sentences (no sync), or None
+        # host-side count of real sentences (no sync), or None: padded text columns are then skipped by both sweeps
+        nv = compaction_prep(tpad_u8.view(Mp), getattr(fused, "n_text_valid", None))
         # The dual and joint similarity sweeps are independent until the final mean: the joint one runs on a second HIP
         # stream (each sweep alone fills 75 % of the workgroup slots).  autograd replays a node's backward on the stream its
         # forward ran on and synchronises producer/consumer streams itself, so the two backward chains (d-logits + the two
@@ -340,8 +385,8 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
         else:
             v_d, t_d = _FusedNCEFn.apply(fused.vn_d, fused.tn_d, tgt, tpad_u8.view(Mp), row_leak, B, T, N, nv)
             v_j, t_j = _FusedNCEFn.apply(fused.vn_j, fused.tn_j, tgt, tpad_u8.view(Mp), row_leak, B, T, N, nv)
-    loss_dual = (_masked_mean(v_d, rows_pos) + _masked_mean(t_d, cols_pos)) / 2
-    loss_joint = (_masked_mean(v_j, rows_pos) + _masked_mean(t_j, cols_pos)) / 2
+    pair = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos, cols_pos)
+    loss_dual, loss_joint = pair[0], pair[1]
     out["loss-dual"], out["loss-joint"] = loss_dual.detach(), loss_joint.detach()
 
     if args.loss_threshold > 0 or args.use_alignability_head:
@@ -361,12 +406,13 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
             th = _quantile(metric, tpad_u8.view(-1), float(args.loss_threshold))                      # loss.py:286
             th_mask = (metric <= th) & valid
             th_f = th_mask.float()
+            tgt_valid = tgt * (~tpad)[:, None, :].float()
             rows_pos_th = ((tgt_valid * th_f.view(B, 1, N)).sum(-1) > 0).view(R).float()              # loss.py:288-290
             aux.update(t_th_mask=th_mask, max_logits_dual_per_text=md, max_logits_joint_per_text=mj)
         if args.loss_threshold > 0:
             out["loss-dual-all"], out["loss-joint-all"] = loss_dual.detach(), loss_joint.detach()
-            loss_dual_th = (_masked_mean(v_d, rows_pos_th) + _masked_mean(t_d, th_f)) / 2
-            loss_joint_th = (_masked_mean(v_j, rows_pos_th) + _masked_mean(t_j, th_f)) / 2
+            pair_th = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos_th, th_f)
+            loss_dual_th, loss_joint_th = pair_th[0], pair_th[1]
             out["loss-dual"], out["loss-joint"] = loss_dual_th.detach(), loss_joint_th.detach()
         if args.use_alignability_head:
             with torch.no_grad():

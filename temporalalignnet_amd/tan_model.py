@@ -18,6 +18,7 @@ compute_dtype: 'fp32' = parity mode (exact-f32 MFMA, matches the reference CPU p
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -48,6 +49,9 @@ class _Flat:
         self.flat = self.grad = self.shadow = None
         self._views = {}
         self.shadow_version = -1
+        # transposed bf16 copies of the encoder Linear weights (K-contiguous operand of the dX GEMMs), refreshed lazily:
+        # shadow_epoch counts refreshes of `shadow`, shadow_t_epoch the epoch `shadow_t` was built from
+        self.shadow_t, self.shadow_t_table, self.shadow_epoch, self.shadow_t_epoch = None, None, 0, -1
         self.device = None
 
     def bound(self):
@@ -74,11 +78,30 @@ class _Flat:
         self.shadow = torch.empty(self.total, dtype=torch.bfloat16, device=dev) if want_shadow else None
         self.shadow_version = -1
         self._views = {}
+        self.shadow_t, self.shadow_t_table, self.shadow_t_epoch = None, None, -1
 
     def sync_shadow(self):
         if self.shadow is not None and self.shadow_version != self.flat._version:
             ops.cast(self.flat, self.shadow)
             self.shadow_version = self.flat._version
+            self.shadow_epoch += 1
+
+    def sync_shadow_t(self):
+        """(Re)build the transposed copies of every 2-D `...resblocks.*` weight from the bf16 shadow: one batched launch."""
+        if self.shadow is None:
+            return None
+        if self.shadow_t is None:
+            names = [n for n in self.names if ".resblocks." in n and len(self.off[n][2]) == 2]
+            rows = [[self.off[n][0], self.off[n][2][0], self.off[n][2][1]] for n in names]
+            self.shadow_t = torch.zeros(self.total, dtype=torch.bfloat16, device=self.shadow.device)
+            self.shadow_t_table = (torch.tensor(rows, dtype=torch.int64).to(self.shadow.device), len(rows),
+                                   max(r[1] for r in rows), max(r[2] for r in rows))
+        if self.shadow_t_epoch != self.shadow_epoch:
+            table, n, mr, mc = self.shadow_t_table
+            _lib.check(_lib.lib().tan_transpose_batch(_vp(self.shadow), _vp(self.shadow_t), _vp(table), C.c_int(n), C.c_long(mr),
+                                                      C.c_long(mc), C.c_int(_lib.TAN_BF16), ops._stream()), "tan_transpose_batch")
+            self.shadow_t_epoch = self.shadow_epoch
+        return self.shadow_t
 
     def view(self, buf, name):
         """Slice `name` of a flat buffer.  Cached: a train step asks for ~500 of these, and building each narrow+view pair
@@ -216,6 +239,7 @@ class TemporalAligner(nn.Module):
         self._side = None
         self._issuer = None               # helper thread issuing the side-stream stack (see _on_side)
         self._lp_cache = {}
+        self.transposed_dx = os.environ.get("TAN_TRANSPOSED_DX", "1") != "0"   # dX GEMMs read W^T copies (K-contiguous)
         self._grad_ready_hook = None      # callable(tag) fired inside backward when a slice of the flat gradient is final
 
     # ------------------------------------------------------------------ init (tan_model.py:76-97)
@@ -319,7 +343,8 @@ class TemporalAligner(nn.Module):
         pointer arithmetic and cached until one of the three buffers is re-allocated."""
         f = self._flat
         wbuf = f.shadow if self.compute_dtype == torch.bfloat16 else f.flat
-        sig = (f.flat.data_ptr(), f.grad.data_ptr(), wbuf.data_ptr())
+        wt = f.shadow_t if (self.compute_dtype == torch.bfloat16 and self.transposed_dx) else None
+        sig = (f.flat.data_ptr(), f.grad.data_ptr(), wbuf.data_ptr(), wt.data_ptr() if wt is not None else 0)
         hit = self._lp_cache.get((prefix, layers))
         if hit is not None and hit[0] == sig:
             return hit[1]
@@ -334,6 +359,7 @@ class TemporalAligner(nn.Module):
             for k, v in m.items():
                 setattr(arr[i], k, f.ptr(wbuf, base + v))
                 setattr(arr[i], "g_" + k, f.ptr(f.grad, base + v))
+                setattr(arr[i], "wt_" + k[2:], f.ptr(wt, base + v) if wt is not None else None)
             for k, v in fm.items():
                 setattr(arr[i], k, f.ptr(f.flat, base + v))
                 setattr(arr[i], "g_" + k, f.ptr(f.grad, base + v))
@@ -738,6 +764,8 @@ class TemporalAligner(nn.Module):
         any_j = any(t is not None for t in dst_j)
         d_lang_t = None
         d_xj = torch.empty(B * L, Cw, dtype=cd, device=dev) if any_j else None
+        if cd == torch.bfloat16 and self.transposed_dx:
+            self._flat.sync_shadow_t()         # W^T copies for the dX GEMMs, rebuilt once per optimizer step (main stream)
         main, side = torch.cuda.current_stream(), self._side_stream(dev)
         if any_j and any_v and side is not None:
             # joint stack backward on the side stream (its gradient slice is final first: DDP starts reducing it while

@@ -192,6 +192,9 @@ class Trainer:
             C.c_double(a.wd), C.c_int(self.iteration), C.c_float(grad_scale), _vp(f.shadow),
             _vp(ema.flat) if ema is not None else None, C.c_float(self.model.m if self.twin else 0.0),
             _vp(ema.shadow) if ema is not None else None, ops._stream()), "tan_adamw_step")
+        f.shadow_epoch += 1                             # the kernel rewrote the bf16 shadow: transposed copies are stale
+        if ema is not None:
+            ema.shadow_epoch += 1
         self._lm_step(grad_scale)
 
     def step(self, batch):

@@ -171,3 +171,21 @@ def test_attention_fwd_bwd(dtype, B, L, pad):
     dqkv = torch.full_like(qkv, float("nan"))
     ops.attn_bwd(qkv, keypad, o, lse, d_o, dqkv, B, L, H)
     close(dqkv, qr.grad, 1e-4 if dtype == torch.float32 else 1e-1)
+
+
+def test_transpose_batch():
+    """tan_transpose_batch: several bf16 matrices inside one flat buffer -> their transposes at the same offsets."""
+    import ctypes as C
+    from temporalalignnet_amd import _lib, ops
+    shapes = [(1536, 512), (512, 512), (2048, 512), (512, 2048), (72, 40)]
+    offs, total = [], 0
+    for r, c in shapes:
+        offs.append(total)
+        total += (r * c + 15) // 16 * 16
+    src = rnd((total,), torch.bfloat16, 70)
+    dst = torch.full_like(src, float("nan"))
+    table = torch.tensor([[o, r, c] for o, (r, c) in zip(offs, shapes)], dtype=torch.int64, device="cuda")
+    _lib.check(_lib.lib().tan_transpose_batch(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_void_p(table.data_ptr()),
+                                              len(shapes), C.c_long(2048), C.c_long(2048), _lib.TAN_BF16, ops._stream()), "transpose")
+    for o, (r, c) in zip(offs, shapes):
+        assert torch.equal(dst[o:o + r * c].view(c, r), src[o:o + r * c].view(r, c).t())
