@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--global-negatives", action="store_true", help="row f3: NCE negatives from every rank (W similarity sweeps)")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--timer-every", type=int, default=4, help="HIP-event kernel timer samples every n-th timed step")
     return ap.parse_args()
@@ -97,7 +98,8 @@ def main():
     model = build_model(args_ns, compute_dtype=a.dtype).to(dev)
     if a.stage == 1:
         model.random_pos_start = 1
-    trainer = Trainer(model, args_ns, iter_per_epoch=2890, warmup=1000)   # 370k videos / 128
+    trainer = Trainer(model, args_ns, iter_per_epoch=2890, warmup=1000,   # 370k videos / 128
+                      global_negatives=a.global_negatives)
     trainer.iteration = 1000                                             # past warm-up: non-zero learning rate
     dist.broadcast_(trainer.online.flat_parameters())
     trainer.online._flat.shadow_version = -1          # collectives do not bump the version counter: re-cast the bf16 shadow
@@ -188,7 +190,8 @@ def main():
                                    f"({'init: multi-positive NCE only' if a.stage == 1 else 'cotrain: EMA + alignability + NCE'}) "
                                    f"train step (fwd+loss+bwd+AdamW), synthetic HTM-370K-shaped features, N~U[4,16] sentences/video",
                        "global_batch": a.batch * world, "per_gpu_batch": a.batch, "seq_len": a.seq_len,
-                       "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
+                       "parallelism": f"dp{world}" + ("+global-negatives" if a.global_negatives else ""),
+                       "final_loss": round(final_loss, 4)},
             "roofline": roof,
         }
         if not a.no_cpu_baseline and world == 1:

@@ -181,25 +181,36 @@ int tan_masked_quantile(const float* x, const unsigned char* invalid, int n, flo
  * the log-sum-exps), so the sweep may run on a COMPACTED text matrix: then `tn` holds Mc <= B*N rows per stage (a multiple of 64 keeps
  * the follow-up GEMMs on the direct-to-LDS kernel; filler rows flagged in col_invalid), col_invalid / colsum / possum_t / t_terms / g_t have Mc entries
  * per stage, dl is [S,R,Mc]; `tn_blocks` (stage stride tb_stage_stride) is the UNcompacted [B*N,C] matrix, read only for the
- * same-video blocks, and colmap[b*N+k] is that sentence's compacted column or -1.                                        */
+ * same-video blocks, and colmap[b*N+k] is that sentence's compacted column or -1.
+ * `phases` (0 = everything) selects the steps, for sweeps over SEVERAL column blocks (global negatives across ranks, row f3):
+ *   TAN_SIM_SWEEP  the tile sweep (fwd: row sums += valid columns, column sums of this block -> colsum; bwd: d logits)
+ *   TAN_SIM_ACC_ROWS  with SWEEP: keep accumulating into rowsum instead of zeroing it first
+ *   TAN_SIM_DIAG   same-video blocks: positives + padded-frame quirk (only the block that holds the rows' own sentences)
+ *   TAN_SIM_TERMS  (fwd) v_terms / t_terms from the final sums                                                            */
+#define TAN_SIM_SWEEP 1
+#define TAN_SIM_DIAG 2
+#define TAN_SIM_TERMS 4
+#define TAN_SIM_ACC_ROWS 8
 long tan_simnce_ws_floats(int S, int B, int T, int N);
 int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
                    const unsigned char* row_leak, float* rowsum, float* colsum, float* possum_v, float* possum_t,
                    float* v_terms, float* t_terms, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks,
-                   long tb_stage_stride, const int* colmap, int Mc, void* stream);
+                   long tb_stage_stride, const int* colmap, int Mc, int phases, void* stream);
 int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
                       const unsigned char* row_leak, const float* rowsum, const float* colsum, const float* possum_v,
                       const float* possum_t, const float* g_v, const float* g_t, void* dl, float* ws, int S, int B, int T, int N,
-                      int C, const void* tn_blocks, long tb_stage_stride, const int* colmap, int Mc, void* stream);
+                      int C, const void* tn_blocks, long tb_stage_stride, const int* colmap, int Mc, int phases, void* stream);
 
 /* NCE tail (loss.py:236-237,254-275).  tan_pos_masks: rows_pos[b*T+t] = 1 if frame t of video b has a positive among its
  * unpadded sentences, cols_pos[b*N+k] = 1 if sentence k is unpadded and has a positive frame (tgt [B,T,N] f32, text_pad [B,N]).
  * tan_nce_tail_fwd: out2[0] = (mean(v_d | rows_mask) + mean(t_d | cols_mask)) / 2 and out2[1] the same for the joint terms,
  * mean(x | m) = sum_{s,k} x[s,k] m[k] / (S sum m)  (NaN for an empty mask, like .mean() of nothing); counts2 = mask sums, kept
- * for tan_nce_tail_bwd, which turns d loss/d out2 into the gradients of the four term tensors.  One launch each.          */
+ * for tan_nce_tail_bwd, which turns d loss/d out2 into the gradients of the four term tensors.  One launch each.
+ * counts_in (optional, [2]): divide by these (GLOBAL) mask sums instead of the local ones -- global negatives, row f3.     */
 int tan_pos_masks(const float* tgt, const unsigned char* text_pad, float* rows_pos, float* cols_pos, int B, int T, int N, void* stream);
 int tan_nce_tail_fwd(const float* v_d, const float* t_d, const float* v_j, const float* t_j, const float* rows_mask,
-                     const float* cols_mask, int Sd, int Sj, long R, long M, float* out2, float* counts2, void* stream);
+                     const float* cols_mask, int Sd, int Sj, long R, long M, float* out2, float* counts2, const float* counts_in,
+                     void* stream);
 int tan_nce_tail_bwd(const float* g_out2, const float* rows_mask, const float* cols_mask, const float* counts2, int Sd, int Sj,
                      long R, long M, float* g_v_d, float* g_t_d, float* g_v_j, float* g_t_j, void* stream);
 

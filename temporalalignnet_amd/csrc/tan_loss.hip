@@ -359,7 +359,7 @@ __global__ __launch_bounds__(1024) void nce_tail_fwd_kernel(const float* __restr
                                                             const float* __restrict__ v_j, const float* __restrict__ t_j,
                                                             const float* __restrict__ rmask, const float* __restrict__ cmask, int Sd,
                                                             int Sj, long R, long M, float* __restrict__ out,
-                                                            float* __restrict__ counts) {
+                                                            float* __restrict__ counts, const float* __restrict__ counts_in) {
     __shared__ float red[16];
     float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // sum v_d, t_d, v_j, t_j, n_r, n_c
     for (long r = threadIdx.x; r < R; r += 1024) {
@@ -378,9 +378,10 @@ __global__ __launch_bounds__(1024) void nce_tail_fwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 6; ++i) tot[i] = block_sum_1024(a[i], red);
     if (threadIdx.x == 0) {
-        out[0] = 0.5f * (tot[0] / (Sd * tot[4]) + tot[1] / (Sd * tot[5]));
-        out[1] = 0.5f * (tot[2] / (Sj * tot[4]) + tot[3] / (Sj * tot[5]));
-        counts[0] = tot[4]; counts[1] = tot[5];
+        const float nr = counts_in ? counts_in[0] : tot[4], nc = counts_in ? counts_in[1] : tot[5];    // global counts (row f3)
+        out[0] = 0.5f * (tot[0] / (Sd * nr) + tot[1] / (Sd * nc));
+        out[1] = 0.5f * (tot[2] / (Sj * nr) + tot[3] / (Sj * nc));
+        counts[0] = nr; counts[1] = nc;
     }
 }
 
@@ -503,10 +504,11 @@ extern "C" int tan_pos_masks(const float* tgt, const unsigned char* text_pad, fl
 }
 
 extern "C" int tan_nce_tail_fwd(const float* v_d, const float* t_d, const float* v_j, const float* t_j, const float* rows_mask,
-                                const float* cols_mask, int Sd, int Sj, long R, long M, float* out2, float* counts2, void* stream) {
+                                const float* cols_mask, int Sd, int Sj, long R, long M, float* out2, float* counts2,
+                                const float* counts_in, void* stream) {
     TAN_REQUIRE(v_d && t_d && v_j && t_j && rows_mask && cols_mask && out2 && counts2 && Sd > 0 && Sj > 0 && R > 0 && M > 0);
     hipLaunchKernelGGL(nce_tail_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v_d, t_d, v_j, t_j, rows_mask, cols_mask, Sd,
-                       Sj, R, M, out2, counts2);
+                       Sj, R, M, out2, counts2, counts_in);
     TAN_LAUNCH_CHECK();
     return 0;
 }

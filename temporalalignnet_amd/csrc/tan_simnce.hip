@@ -319,9 +319,10 @@ static int simnce_diag_blocks(const SimArgs& a, const bf16_t* tn_blocks, long tb
 extern "C" int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
                               const unsigned char* row_leak, float* rowsum, float* colsum, float* possum_v, float* possum_t,
                               float* v_terms, float* t_terms, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks,
-                              long tb_stage_stride, const int* colmap, int Mc, void* stream) {
+                              long tb_stage_stride, const int* colmap, int Mc, int phases, void* stream) {
     TAN_REQUIRE(vn && tn && tgt && col_invalid && rowsum && colsum && possum_v && possum_t && v_terms && t_terms && ws);
     TAN_REQUIRE(!colmap || (tn_blocks && Mc > 0 && Mc <= B * N));
+    if (phases == 0) phases = TAN_SIM_SWEEP | TAN_SIM_DIAG | TAN_SIM_TERMS;
     SimArgs a{};
     a.V = (const bf16_t*)vn; a.Tt = (const bf16_t*)tn; a.t_stage_stride = t_stage_stride;
     a.tgt = tgt; a.col_invalid = col_invalid; a.row_leak = row_leak;
@@ -334,19 +335,27 @@ extern "C" int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_strid
     if (colmap) a.Mp = Mc;
     else { tn_blocks = tn; tb_stage_stride = t_stage_stride; }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(rowsum, 0, sizeof(float) * (size_t)S * a.R, st);
-    if (e != hipSuccess) return (int)e;
-    const int prec = prof_begin(st, TAN_PROF_SIMNCE, 2.0 * S * a.R * (double)a.Mp * C);
-    hipLaunchKernelGGL((simnce_kernel<0>), dim3(npanel, S), dim3(256), 0, st, a);
-    prof_end(st, prec);
-    TAN_LAUNCH_CHECK();
     const long SM = (long)S * a.Mp, SR = (long)S * a.R;
-    hipLaunchKernelGGL(simnce_col_finalize, dim3(cdiv(SM, 256)), dim3(256), 0, st, a.colpart, colsum, npanel, SM);
-    if ((rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;
-    hipLaunchKernelGGL((simnce_diag_kernel<false>), dim3(B, S), dim3(256), 0, st, diag, tgt, col_invalid, row_leak, rowsum, colsum,
-                       possum_v, possum_t, (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, B, T, N, colmap, a.Mp);
-    hipLaunchKernelGGL(simnce_terms, dim3(cdiv(SR, 256)), dim3(256), 0, st, rowsum, possum_v, v_terms, SR, logf((float)a.Mp));
-    hipLaunchKernelGGL(simnce_terms, dim3(cdiv(SM, 256)), dim3(256), 0, st, colsum, possum_t, t_terms, SM, logf((float)a.R));
+    if (phases & TAN_SIM_SWEEP) {
+        if (!(phases & TAN_SIM_ACC_ROWS)) {
+            hipError_t e = hipMemsetAsync(rowsum, 0, sizeof(float) * (size_t)S * a.R, st);
+            if (e != hipSuccess) return (int)e;
+        }
+        const int prec = prof_begin(st, TAN_PROF_SIMNCE, 2.0 * S * a.R * (double)a.Mp * C);
+        hipLaunchKernelGGL((simnce_kernel<0>), dim3(npanel, S), dim3(256), 0, st, a);
+        prof_end(st, prec);
+        TAN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(simnce_col_finalize, dim3(cdiv(SM, 256)), dim3(256), 0, st, a.colpart, colsum, npanel, SM);
+    }
+    if (phases & TAN_SIM_DIAG) {
+        if ((rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;
+        hipLaunchKernelGGL((simnce_diag_kernel<false>), dim3(B, S), dim3(256), 0, st, diag, tgt, col_invalid, row_leak, rowsum, colsum,
+                           possum_v, possum_t, (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, B, T, N, colmap, a.Mp);
+    }
+    if (phases & TAN_SIM_TERMS) {
+        hipLaunchKernelGGL(simnce_terms, dim3(cdiv(SR, 256)), dim3(256), 0, st, rowsum, possum_v, v_terms, SR, logf((float)a.Mp));
+        hipLaunchKernelGGL(simnce_terms, dim3(cdiv(SM, 256)), dim3(256), 0, st, colsum, possum_t, t_terms, SM, logf((float)a.R));
+    }
     TAN_LAUNCH_CHECK();
     return 0;
 }
@@ -356,9 +365,10 @@ extern "C" int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_st
                                  const unsigned char* col_invalid, const unsigned char* row_leak, const float* rowsum,
                                  const float* colsum, const float* possum_v, const float* possum_t, const float* g_v, const float* g_t,
                                  void* dl, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks, long tb_stage_stride,
-                                 const int* colmap, int Mc, void* stream) {
+                                 const int* colmap, int Mc, int phases, void* stream) {
     TAN_REQUIRE(vn && tn && tgt && col_invalid && rowsum && colsum && possum_v && possum_t && g_v && g_t && dl && ws);
     TAN_REQUIRE(!colmap || (tn_blocks && Mc > 0 && Mc <= B * N));
+    if (phases == 0) phases = TAN_SIM_SWEEP | TAN_SIM_DIAG;
     SimArgs a{};
     a.V = (const bf16_t*)vn; a.Tt = (const bf16_t*)tn; a.t_stage_stride = t_stage_stride;
     a.tgt = tgt; a.col_invalid = col_invalid; a.row_leak = row_leak;
@@ -370,13 +380,17 @@ extern "C" int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_st
     float* diag = ws + (long)cdiv(a.R, 128) * S * a.Mp;
     if (colmap) a.Mp = Mc;
     else { tn_blocks = tn; tb_stage_stride = t_stage_stride; }
-    const int prec = prof_begin(st, TAN_PROF_SIMNCE, 2.0 * S * a.R * (double)a.Mp * C);
-    hipLaunchKernelGGL((simnce_kernel<1>), dim3(cdiv(a.R, 128), S), dim3(256), 0, st, a);
-    prof_end(st, prec);
-    TAN_LAUNCH_CHECK();
-    if ((rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;
-    hipLaunchKernelGGL((simnce_diag_kernel<true>), dim3(B, S), dim3(256), 0, st, diag, tgt, col_invalid, row_leak, (float*)rowsum,
-                       (float*)colsum, (float*)possum_v, (float*)possum_t, g_v, g_t, (bf16_t*)dl, B, T, N, colmap, a.Mp);
+    if (phases & TAN_SIM_SWEEP) {
+        const int prec = prof_begin(st, TAN_PROF_SIMNCE, 2.0 * S * a.R * (double)a.Mp * C);
+        hipLaunchKernelGGL((simnce_kernel<1>), dim3(cdiv(a.R, 128), S), dim3(256), 0, st, a);
+        prof_end(st, prec);
+        TAN_LAUNCH_CHECK();
+    }
+    if (phases & TAN_SIM_DIAG) {
+        if ((rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;
+        hipLaunchKernelGGL((simnce_diag_kernel<true>), dim3(B, S), dim3(256), 0, st, diag, tgt, col_invalid, row_leak, (float*)rowsum,
+                           (float*)colsum, (float*)possum_v, (float*)possum_t, g_v, g_t, (bf16_t*)dl, B, T, N, colmap, a.Mp);
+    }
     TAN_LAUNCH_CHECK();
     return 0;
 }

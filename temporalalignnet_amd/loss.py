@@ -149,6 +149,7 @@ class FusedSim:
     def __init__(self, vn_d, tn_d, vn_j, tn_j, B, T, N):
         self.vn_d, self.tn_d, self.vn_j, self.tn_j, self.B, self.T, self.N = vn_d, tn_d, vn_j, tn_j, B, T, N
         self.n_text_valid = None      # host-side count of real (unpadded) sentences when the caller knows it: enables column compaction
+        self.global_negatives = False # row f3: sentences of every data-parallel rank are negatives (dist_nce.py)
 
     def diag_blocks(self, which):
         """[B,T,N] f32 last-stage same-video cosine logits (all that self-labelling / thresholding read of the B^2 tensor)."""
@@ -178,13 +179,13 @@ class _NCETail(torch.autograd.Function):
     """loss.py:254-275 in two launches: ((mean(v_d|rows) + mean(t_d|cols))/2, (mean(v_j|rows) + mean(t_j|cols))/2)."""
 
     @staticmethod
-    def forward(ctx, v_d, t_d, v_j, t_j, rows_mask, cols_mask):
+    def forward(ctx, v_d, t_d, v_j, t_j, rows_mask, cols_mask, counts=None):
         v_d, t_d, v_j, t_j = (x.contiguous() for x in (v_d, t_d, v_j, t_j))
         (Sd, R), (Sj, M) = v_d.shape, t_j.shape
         assert t_d.shape == (Sd, M) and v_j.shape == (Sj, R)
         out = torch.empty(4, device=v_d.device)               # [loss_dual, loss_joint, n_rows, n_cols]
         _lib.check(_lib.lib().tan_nce_tail_fwd(_p(v_d), _p(t_d), _p(v_j), _p(t_j), _p(rows_mask), _p(cols_mask), C.c_int(Sd),
-                                               C.c_int(Sj), C.c_long(R), C.c_long(M), _p(out), _p(out[2:]), ops._stream()),
+                                               C.c_int(Sj), C.c_long(R), C.c_long(M), _p(out), _p(out[2:]), _p(counts), ops._stream()),
                    "tan_nce_tail_fwd")
         ctx.saved = (rows_mask, cols_mask, out, Sd, Sj, R, M)
         return out[:2]
@@ -199,7 +200,7 @@ class _NCETail(torch.autograd.Function):
         _lib.check(_lib.lib().tan_nce_tail_bwd(_p(g), _p(rows_mask), _p(cols_mask), _p(out[2:]), C.c_int(Sd), C.c_int(Sj),
                                                C.c_long(R), C.c_long(M), _p(g_v_d), _p(g_t_d), _p(g_v_j), _p(g_t_j), ops._stream()),
                    "tan_nce_tail_bwd")
-        return g_v_d, g_t_d, g_v_j, g_t_j, None, None
+        return g_v_d, g_t_d, g_v_j, g_t_j, None, None, None
 
 
 def _pos_masks(tgt, tpad_u8, B, T, N):
@@ -239,7 +240,7 @@ class _FusedNCEFn(torch.autograd.Function):
         _lib.check(L.tan_simnce_fwd(_p(vn), _p(tn_run), C.c_long(0 if shared else Mc * Cw), _p(tgt), _p(ci_run), _p(row_leak),
                                     _p(rowsum), _p(colsum), _p(possum_v), _p(possum_t), _p(v_terms), _p(t_run), _p(ws),
                                     C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N), C.c_int(Cw), _p(tn) if compact else None,
-                                    C.c_long(0 if shared else Mp * Cw), _p(colmap), C.c_int(Mc), ops._stream()), "tan_simnce_fwd")
+                                    C.c_long(0 if shared else Mp * Cw), _p(colmap), C.c_int(Mc), C.c_int(0), ops._stream()), "tan_simnce_fwd")
         if compact:
             t_terms = torch.zeros(S, Mp, device=dev).index_copy_(1, idx, t_run)
         else:
@@ -263,7 +264,7 @@ class _FusedNCEFn(torch.autograd.Function):
                                                 _p(row_leak), _p(rowsum), _p(colsum), _p(possum_v), _p(possum_t), _p(g_v),
                                                 _p(g_t), _p(dl), _p(ws), C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N),
                                                 C.c_int(Cw), _p(tn) if compact else None, C.c_long(0 if shared else Mp * Cw),
-                                                _p(colmap), C.c_int(Mc), ops._stream()), "tan_simnce_bwd_dl")
+                                                _p(colmap), C.c_int(Mc), C.c_int(0), ops._stream()), "tan_simnce_bwd_dl")
         d_vn = torch.empty_like(vn)
         ops.gemm(dl, tn_run, d_vn, M=R, N=Cw, K=Mc, a_kc=True, b_kc=False, lda=Mc, ldb=Cw, batch=S, sA=R * Mc,
                  sB=0 if shared else Mc * Cw, sC=R * Cw)
@@ -363,12 +364,20 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
 
     rows_pos, cols_pos = _pos_masks(tgt, tpad_u8, B, T, N)                                            # loss.py:236-237
 
+    nce_counts = None            # global (all-rank) mask sums in global-negatives mode, else the tail kernel counts locally
+    ci = tpad_u8.view(Mp)
     if fused is None:
-        v_d, t_d = _NCEFn.apply(lg_d, tgt, tpad_u8.view(Mp), row_leak, B, T, N)
-        v_j, t_j = _NCEFn.apply(lg_j, tgt, tpad_u8.view(Mp), row_leak, B, T, N)
+        v_d, t_d = _NCEFn.apply(lg_d, tgt, ci, row_leak, B, T, N)
+        v_j, t_j = _NCEFn.apply(lg_j, tgt, ci, row_leak, B, T, N)
+    elif getattr(fused, "global_negatives", False):
+        # row f3: every rank's sentences are negatives (dist_nce.py); the collectives stay on the current stream, in order
+        from .dist_nce import _GlobalNCEFn, global_counts
+        v_d, t_d = _GlobalNCEFn.apply(fused.vn_d, fused.tn_d, tgt, ci, row_leak, B, T, N)
+        v_j, t_j = _GlobalNCEFn.apply(fused.vn_j, fused.tn_j, tgt, ci, row_leak, B, T, N)
+        nce_counts = global_counts(rows_pos, cols_pos)
     else:
         # host-side count of real sentences (no sync), or None: padded text columns are then skipped by both sweeps
-        nv = compaction_prep(tpad_u8.view(Mp), getattr(fused, "n_text_valid", None))
+        nv = compaction_prep(ci, getattr(fused, "n_text_valid", None))
         # The dual and joint similarity sweeps are independent until the final mean: the joint one runs on a second HIP
         # stream (each sweep alone fills 75 % of the workgroup slots).  autograd replays a node's backward on the stream its
         # forward ran on and synchronises producer/consumer streams itself, so the two backward chains (d-logits + the two
@@ -378,14 +387,14 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
         if side is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                v_j, t_j = _FusedNCEFn.apply(fused.vn_j, fused.tn_j, tgt, tpad_u8.view(Mp), row_leak, B, T, N, nv)
-            v_d, t_d = _FusedNCEFn.apply(fused.vn_d, fused.tn_d, tgt, tpad_u8.view(Mp), row_leak, B, T, N, nv)
+                v_j, t_j = _FusedNCEFn.apply(fused.vn_j, fused.tn_j, tgt, ci, row_leak, B, T, N, nv)
+            v_d, t_d = _FusedNCEFn.apply(fused.vn_d, fused.tn_d, tgt, ci, row_leak, B, T, N, nv)
             main.wait_stream(side)
             v_j.record_stream(main); t_j.record_stream(main)
         else:
-            v_d, t_d = _FusedNCEFn.apply(fused.vn_d, fused.tn_d, tgt, tpad_u8.view(Mp), row_leak, B, T, N, nv)
-            v_j, t_j = _FusedNCEFn.apply(fused.vn_j, fused.tn_j, tgt, tpad_u8.view(Mp), row_leak, B, T, N, nv)
-    pair = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos, cols_pos)
+            v_d, t_d = _FusedNCEFn.apply(fused.vn_d, fused.tn_d, tgt, ci, row_leak, B, T, N, nv)
+            v_j, t_j = _FusedNCEFn.apply(fused.vn_j, fused.tn_j, tgt, ci, row_leak, B, T, N, nv)
+    pair = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos, cols_pos, nce_counts)
     loss_dual, loss_joint = pair[0], pair[1]
     out["loss-dual"], out["loss-joint"] = loss_dual.detach(), loss_joint.detach()
 
@@ -411,7 +420,7 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
             aux.update(t_th_mask=th_mask, max_logits_dual_per_text=md, max_logits_joint_per_text=mj)
         if args.loss_threshold > 0:
             out["loss-dual-all"], out["loss-joint-all"] = loss_dual.detach(), loss_joint.detach()
-            pair_th = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos_th, th_f)
+            pair_th = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos_th, th_f)       # (thresholded means stay rank-local)
             loss_dual_th, loss_joint_th = pair_th[0], pair_th[1]
             out["loss-dual"], out["loss-joint"] = loss_dual_th.detach(), loss_joint_th.detach()
         if args.use_alignability_head:

@@ -87,7 +87,8 @@ def embed_sentences(model, token_list):
 
 
 class Trainer:
-    def __init__(self, model, args, *, betas=(0.9, 0.999), eps=1e-8, iter_per_epoch=None, warmup=1000, fused_loss=None):
+    def __init__(self, model, args, *, betas=(0.9, 0.999), eps=1e-8, iter_per_epoch=None, warmup=1000, fused_loss=None,
+                 global_negatives=False):
         self.model, self.args = model, args
         online = model.online if isinstance(model, TwinTemporalAligner) else model
         # logits-free similarity+NCE whenever the model runs in bf16 (the fused kernels are bf16-only)
@@ -98,6 +99,9 @@ class Trainer:
         self.iteration = 0
         self.iter_per_epoch, self.warmup = iter_per_epoch, warmup
         self._state = None
+        # row f3: NCE negatives from every rank (fused bf16 path only).  The global loss is then the SUM of the rank losses,
+        # so gradients are summed over ranks instead of averaged.
+        self.global_negatives = bool(global_negatives)
 
     # -------------------------------------------------------------- optimizer state
     def _ensure_state(self):
@@ -165,6 +169,10 @@ class Trainer:
                    abs_text_pos=batch.get("abs_text_pos"), fused=self.fused_loss)
         if "_fused" in logits and batch.get("n_text") is not None:
             logits["_fused"].n_text_valid = batch["n_text"]        # padded text columns are skipped by the similarity sweep
+        if self.global_negatives:
+            if "_fused" not in logits:
+                raise _lib.TanHipError("global_negatives needs the fused (bf16) similarity path")
+            logits["_fused"].global_negatives = True
         if a.model == "cotrain":
             ema = m.forward_from_ema(batch["video"], batch["text_embed"], video_padding_mask=batch["padding_mask"],
                                      lang_padding_mask=batch["text_padding_mask"].bool(),
@@ -220,5 +228,5 @@ class Trainer:
                     w.wait()
             else:
                 dist.allreduce_sum_(flat)
-        self.optimizer_step(grad_scale=1.0 / world)
+        self.optimizer_step(grad_scale=1.0 if self.global_negatives else 1.0 / world)
         return loss_dict
