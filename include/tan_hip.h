@@ -192,6 +192,7 @@ int tan_masked_quantile(const float* x, const unsigned char* invalid, int n, flo
 #define TAN_SIM_TERMS 4
 #define TAN_SIM_ACC_ROWS 8
 long tan_simnce_ws_floats(int S, int B, int T, int N);
+int tan_simnce_max_cols(void);   /* most text columns (B*N, or Mc when compacted) one sweep accepts: callers fall back to tan_nce_* above it */
 int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
                    const unsigned char* row_leak, float* rowsum, float* colsum, float* possum_v, float* possum_t,
                    float* v_terms, float* t_terms, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks,

@@ -285,6 +285,8 @@ __global__ void simnce_terms(const float* __restrict__ allsum, const float* __re
 
 using namespace tal;
 
+extern "C" int tan_simnce_max_cols(void) { return S_MAXCOLS; }
+
 extern "C" long tan_simnce_ws_floats(int S, int B, int T, int N) {
     const long R = (long)B * T, Mp = (long)B * N;
     return (long)cdiv(R, 128) * S * Mp + (long)S * B * T * N;     // column partials + same-video blocks

@@ -164,9 +164,19 @@ class Trainer:
             batch = dict(batch)
             batch["text_embed"], batch["text_padding_mask"] = embed_sentences(m, batch["token"])
             batch["n_text"] = int(sum(t.shape[0] for t in batch["token"]))
+        fused = self.fused_loss
+        if fused:       # the logits-free sweep keeps one LDS accumulator per text column: beyond its limit use materialised logits
+            Bn, Nn = batch["text_embed"].shape[:2]
+            cols = Bn * Nn
+            if batch.get("n_text") is not None and not self.global_negatives:
+                cols = min(cols, (batch["n_text"] + 63) // 64 * 64)
+            if cols > _lib.lib().tan_simnce_max_cols():
+                if self.global_negatives:
+                    raise _lib.TanHipError(f"global_negatives: {Bn}x{Nn} text columns per rank exceed the fused sweep's limit")
+                fused = False
         logits = m(batch["video"], batch["text_embed"], video_padding_mask=batch["padding_mask"],
                    lang_padding_mask=batch["text_padding_mask"].bool(), text_timestamp=batch.get("_tgt_raw"),
-                   abs_text_pos=batch.get("abs_text_pos"), fused=self.fused_loss)
+                   abs_text_pos=batch.get("abs_text_pos"), fused=fused)
         if "_fused" in logits and batch.get("n_text") is not None:
             logits["_fused"].n_text_valid = batch["n_text"]        # padded text columns are skipped by the similarity sweep
         if self.global_negatives:
@@ -177,7 +187,7 @@ class Trainer:
             ema = m.forward_from_ema(batch["video"], batch["text_embed"], video_padding_mask=batch["padding_mask"],
                                      lang_padding_mask=batch["text_padding_mask"].bool(),
                                      text_timestamp=batch.get("_tgt_raw"), abs_text_pos=batch.get("abs_text_pos"),
-                                     fused=self.fused_loss)
+                                     fused=fused)
             logits = {**logits, **{f"ema-{k}": v for k, v in ema.items()}}
         loss_dict = get_loss(batch, batch["video"], batch["text_embed"], batch["padding_mask"], batch["text_padding_mask"],
                              logits, a, batch.get("abs_text_pos"))

@@ -84,3 +84,19 @@ def test_column_compaction_is_a_noop_on_the_result():
     for k in l0:
         assert abs(l0[k] - l1[k]) <= 1e-5 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
     assert (g0 - g1).norm().item() / g1.norm().item() < 2e-3        # bf16 d-logits, different summation order only
+
+
+def test_more_text_columns_than_the_fused_sweep_accepts_falls_back_to_logits():
+    """B*N beyond tan_simnce_max_cols(): the trainer silently uses the materialised-logits path for that batch."""
+    from temporalalignnet_amd import _lib
+    from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
+    lim = _lib.lib().tan_simnce_max_cols()
+    B, N = 72, 40
+    b_np = synth.make_batch(3, B=B, T=16, n_min=N - 2, n_max=N)
+    assert b_np["text_embed"].shape[1] == N and (b_np["text_padding_mask"] == 0).sum() > lim
+    args = default_args(model="init", num_encoder_layers=1, num_decoder_layers=1)
+    torch.manual_seed(0)
+    tr = Trainer(build_model(args, compute_dtype="bf16").cuda(), args)
+    assert tr.fused_loss
+    losses = [tr.step(to_device_batch(b_np))["loss"].item() for _ in range(2)]
+    assert all(np.isfinite(losses))
