@@ -291,11 +291,6 @@ def _side_stream(dev):
     return st
 
 
-def _masked_mean(x, mask_f):
-    """mean of x[:, mask] for x [S, K], mask [K] -- (sum x*mask) / (S * sum mask); 0/0 = nan like an empty .mean()."""
-    return (x * mask_f[None]).sum() / (x.shape[0] * mask_f.sum())
-
-
 def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding_mask, logits, args, abs_text_pos=None,
              return_aux=False):
     """Reference signature (train/loss.py:55-57); returns the reference's loss_dict ('loss' carries the graph)."""
