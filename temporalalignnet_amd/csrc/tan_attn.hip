@@ -358,12 +358,12 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int j) {
 // stage `nimg` [LP][64] head slices (image i from src + i * img_stride, row stride ld) into consecutive LDS images
 template <int NKB>
 __device__ __forceinline__ void stage_images(char* lds, int first_img, int nimg, const bf16_t* src, long img_stride, long ld,
-                                             int L, int wave, int lane) {
+                                             int L, int wave, int lane, int row0 = 0) {
     constexpr int PPI = NKB * 4;                    // 1-KiB pieces (8 rows) per image
     for (int p = wave; p < nimg * PPI; p += NKB) {
         const int img = p / PPI, row = (p % PPI) * 8 + (lane >> 3), slot = lane & 7;
         const int chunk = slot ^ img_swz(row);
-        const bf16_t* g = src + img * img_stride + (long)min(row, L - 1) * ld + chunk * 8;
+        const bf16_t* g = src + img * img_stride + (long)min(row0 + row, L - 1) * ld + chunk * 8;
         __builtin_amdgcn_global_load_lds((attn_gptr_t)g, (attn_lptr_t)(lds + (first_img * PPI + p) * 1024), 16, 0, 0);
     }
 }
@@ -588,6 +588,284 @@ __global__ __launch_bounds__(64 * NKB) void attn_bwd_short_kernel(AttnArgs a) {
     }
 }
 
+
+// ======================================================================================================
+// Long-sequence bf16 path (L > 128, e.g. the len=256 configuration: L = 256 / 272): the same wave-private transposed-score
+// scheme, streamed.  A workgroup (4 waves x 32) owns 128 queries (forward, dq) or 128 keys (dk/dv) of one (video, head) and
+// walks the other axis in 128-row blocks staged in LDS; the forward keeps a running (max, sum) per query column -- a
+// per-LANE scalar in this layout, so the online-softmax rescale is one multiply per accumulator register.
+// delta_i = rowsum(dO*O) is recomputed from the staged O rows where it is needed (no scratch buffer in the ABI).
+constexpr int LBLK = 128;
+
+__device__ __forceinline__ void long_bias(float* bias, const unsigned char* kp, int k0, int L, int tid) {
+    if (tid < LBLK) { const int j = k0 + tid; bias[tid] = (j >= L || (kp && kp[j])) ? -INFINITY : 0.f; }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_long_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(1024))) char smem[3 * LBLK * 128 + LBLK * 4];
+    char* Qi = smem; char* Ki = Qi + LBLK * 128; char* Vi = Ki + LBLK * 128;
+    float* bias = (float*)(Vi + LBLK * 128);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y % a.H, b = blockIdx.y / a.H, qt0 = blockIdx.x * LBLK;
+    const int C = a.H * DH, L = a.L;
+    const long ld = 3L * C;
+    const bf16_t* base = (const bf16_t*)a.qkv + (long)b * L * ld + h * DH;
+    const unsigned char* kp = a.keypad ? a.keypad + (long)b * L : nullptr;
+    stage_images<4>(smem, 0, 1, base, 0, ld, L, wave, lane, qt0);
+    const int q0 = wave * 32;
+    bf16x8 qf[4];
+    f32x16 o[2];
+    acc_zero(o[0]); acc_zero(o[1]);
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < L; k0 += LBLK) {
+        __syncthreads();                                   // every wave is done with the previous K/V block
+        stage_images<4>(smem, 1, 2, base + C, C, ld, L, wave, lane, k0);
+        long_bias(bias, kp, k0, L, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (k0 == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = img_frag_kc(Qi, q0 + c, 2 * ks + hh);
+        }
+        f32x16 s[4];
+        float bm = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            acc_zero(s[kb]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Ki, 32 * kb + c, 2 * ks + hh), qf[ks], s[kb], 0, 0, 0);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 bv = *reinterpret_cast<const float4*>(bias + 32 * kb + 8 * g4 + 4 * hh);
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = s[kb][4 * g4 + e] * 0.125f + bb[e];
+                    s[kb][4 * g4 + e] = v;
+                    bm = fmaxf(bm, v);
+                }
+            }
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float m_new = fmaxf(m, bm);
+        const bool dead = (m_new == -INFINITY);           // nothing but padded keys so far
+        const float alpha = dead ? 1.f : __expf(m - m_new);
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = dead ? 0.f : __expf(s[kb][r] - m_new);
+                s[kb][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        l = l * alpha + sum;
+        m = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 pf = acc_frag(s[kb], j);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_tr(Vi, 32 * kb + 16 * j, 32 * db, lane), pf, o[db], 0, 0, 0);
+            }
+    }
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    const int qrow = qt0 + q0 + c;
+    if (hh == 0 && qrow < L) a.lse[((long)b * a.H + h) * L + qrow] = l > 0.f ? m + logf(l) : -INFINITY;
+    // O^T tiles -> the wave's own (now dead) q rows in LDS -> 16-byte row-contiguous global stores
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int row = q0 + c, chunk = 4 * db + g4;
+            st4((bf16_t*)(Qi + row * 128 + ((chunk ^ img_swz(row)) << 4) + hh * 8),
+                make_float4(o[db][4 * g4] * inv, o[db][4 * g4 + 1] * inv, o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv));
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    bf16_t* out = (bf16_t*)a.o + (long)b * L * C + h * DH;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = q0 + it * 8 + (lane >> 3), chunk = lane & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(Qi + row * 128 + ((chunk ^ img_swz(row)) << 4));
+        if (qt0 + row < L) *reinterpret_cast<uint4*>(out + (long)(qt0 + row) * C + chunk * 8) = v;
+    }
+}
+
+// delta[row] = sum_d dO[row][d] * O[row][d] for the 128 staged rows (two threads per row)
+__device__ __forceinline__ void long_delta(const char* Di, const char* Oi, float* delta_s, int tid) {
+    const int row = tid >> 1, half = tid & 1;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int off = row * 128 + (((4 * half + j) ^ img_swz(row)) << 4);
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(Di + off), o = *reinterpret_cast<const bf16x8*>(Oi + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += (float)d[e] * (float)o[e];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    if (half == 0) delta_s[row] = acc;
+}
+
+__device__ __forceinline__ void long_lse(float* lse_s, const float* lse_g, int r0, int L, int tid) {
+    if (tid < LBLK) {
+        float v = INFINITY;                    // rows past L and fully padded rows: p = exp(. - inf) = 0
+        if (r0 + tid < L) { v = lse_g[r0 + tid]; if (v == -INFINITY) v = INFINITY; }
+        lse_s[tid] = v;
+    }
+}
+
+// dq: workgroup = 128 queries, loop over key blocks
+__global__ __launch_bounds__(256) void attn_bwd_dq_long_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(1024))) char smem[4 * LBLK * 128 + 3 * LBLK * 4];
+    char* Qi = smem; char* Di = Qi + LBLK * 128; char* Ki = Di + LBLK * 128; char* Vi = Ki + LBLK * 128;
+    char* Oi = Ki;                                         // O rows are only read for delta, before the first K block lands
+    float* bias = (float*)(Vi + LBLK * 128);
+    float* lse_s = bias + LBLK;
+    float* delta_s = lse_s + LBLK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y % a.H, b = blockIdx.y / a.H, qt0 = blockIdx.x * LBLK;
+    const int C = a.H * DH, L = a.L;
+    const long ld = 3L * C;
+    const bf16_t* base = (const bf16_t*)a.qkv + (long)b * L * ld + h * DH;
+    const unsigned char* kp = a.keypad ? a.keypad + (long)b * L : nullptr;
+    stage_images<4>(smem, 0, 1, base, 0, ld, L, wave, lane, qt0);
+    stage_images<4>(smem, 1, 1, (const bf16_t*)a.d_o + (long)b * L * C + h * DH, 0, C, L, wave, lane, qt0);
+    stage_images<4>(smem, 2, 1, (const bf16_t*)a.o + (long)b * L * C + h * DH, 0, C, L, wave, lane, qt0);
+    long_lse(lse_s, a.lse + ((long)b * a.H + h) * L, qt0, L, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    long_delta(Di, Oi, delta_s, tid);
+    __syncthreads();
+    const int q0 = wave * 32;
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { qf[ks] = img_frag_kc(Qi, q0 + c, 2 * ks + hh); dof[ks] = img_frag_kc(Di, q0 + c, 2 * ks + hh); }
+    const float my_lse = lse_s[q0 + c], my_delta = delta_s[q0 + c];
+    f32x16 dq[2];
+    acc_zero(dq[0]); acc_zero(dq[1]);
+    for (int k0 = 0; k0 < L; k0 += LBLK) {
+        __syncthreads();
+        stage_images<4>(smem, 2, 2, base + C, C, ld, L, wave, lane, k0);
+        long_bias(bias, kp, k0, L, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            f32x16 p, dp;
+            acc_zero(p); acc_zero(dp);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Ki, 32 * kb + c, 2 * ks + hh), qf[ks], p, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Vi, 32 * kb + c, 2 * ks + hh), dof[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 bv = *reinterpret_cast<const float4*>(bias + 32 * kb + 8 * g4 + 4 * hh);
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pv = __expf(p[4 * g4 + e] * 0.125f + bb[e] - my_lse);
+                    p[4 * g4 + e] = pv * (dp[4 * g4 + e] - my_delta);            // dS^T
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 df = acc_frag(p, j);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_tr(Ki, 32 * kb + 16 * j, 32 * db, lane), df, dq[db], 0, 0, 0);
+            }
+        }
+    }
+    bf16_t* out = (bf16_t*)a.dqkv + (long)b * L * ld + h * DH;
+    store_tile_t(out, ld, qt0 + q0 + c, L, dq[0], 0, hh, 0.125f);
+    store_tile_t(out, ld, qt0 + q0 + c, L, dq[1], 32, hh, 0.125f);
+}
+
+// dk, dv: workgroup = 128 keys, loop over query blocks
+__global__ __launch_bounds__(256) void attn_bwd_dkv_long_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(1024))) char smem[3 * LBLK * 128 + 3 * LBLK * 4];
+    char* Ki = smem; char* Vi = Ki + LBLK * 128;           // only until the wave's K / V fragments are in registers
+    char* Qi = smem; char* Di = Qi + LBLK * 128; char* Oi = Di + LBLK * 128;
+    float* bias = (float*)(Oi + LBLK * 128);
+    float* lse_s = bias + LBLK;
+    float* delta_s = lse_s + LBLK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y % a.H, b = blockIdx.y / a.H, kt0 = blockIdx.x * LBLK;
+    const int C = a.H * DH, L = a.L;
+    const long ld = 3L * C;
+    const bf16_t* base = (const bf16_t*)a.qkv + (long)b * L * ld + h * DH;
+    const bf16_t* dO = (const bf16_t*)a.d_o + (long)b * L * C + h * DH;
+    const bf16_t* Og = (const bf16_t*)a.o + (long)b * L * C + h * DH;
+    const unsigned char* kp = a.keypad ? a.keypad + (long)b * L : nullptr;
+    stage_images<4>(smem, 0, 2, base + C, C, ld, L, wave, lane, kt0);
+    long_bias(bias, kp, kt0, L, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int k0 = wave * 32;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { kf[ks] = img_frag_kc(Ki, k0 + c, 2 * ks + hh); vf[ks] = img_frag_kc(Vi, k0 + c, 2 * ks + hh); }
+    const float my_bias = bias[k0 + c];
+    f32x16 dk[2], dv[2];
+    acc_zero(dk[0]); acc_zero(dk[1]); acc_zero(dv[0]); acc_zero(dv[1]);
+    for (int qb0 = 0; qb0 < L; qb0 += LBLK) {
+        __syncthreads();
+        stage_images<4>(smem, 0, 1, base, 0, ld, L, wave, lane, qb0);
+        stage_images<4>(smem, 1, 1, dO, 0, C, L, wave, lane, qb0);
+        stage_images<4>(smem, 2, 1, Og, 0, C, L, wave, lane, qb0);
+        long_lse(lse_s, a.lse + ((long)b * a.H + h) * L, qb0, L, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        long_delta(Di, Oi, delta_s, tid);
+        __syncthreads();
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            f32x16 p, dp;
+            acc_zero(p); acc_zero(dp);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Qi, 32 * qb + c, 2 * ks + hh), kf[ks], p, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Di, 32 * qb + c, 2 * ks + hh), vf[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 lv = *reinterpret_cast<const float4*>(lse_s + 32 * qb + 8 * g4 + 4 * hh);
+                const float4 dl = *reinterpret_cast<const float4*>(delta_s + 32 * qb + 8 * g4 + 4 * hh);
+                const float ll[4] = {lv.x, lv.y, lv.z, lv.w}, dd[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pv = __expf(p[4 * g4 + e] * 0.125f + my_bias - ll[e]);
+                    p[4 * g4 + e] = pv;
+                    dp[4 * g4 + e] = pv * (dp[4 * g4 + e] - dd[e]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 pf = acc_frag(p, j), df = acc_frag(dp, j);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_tr(Di, 32 * qb + 16 * j, 32 * db, lane), pf, dv[db], 0, 0, 0);
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_tr(Qi, 32 * qb + 16 * j, 32 * db, lane), df, dk[db], 0, 0, 0);
+                }
+            }
+        }
+    }
+    bf16_t* out = (bf16_t*)a.dqkv + (long)b * L * ld + h * DH;
+    store_tile_t(out + C, ld, kt0 + k0 + c, L, dk[0], 0, hh, 0.125f);
+    store_tile_t(out + C, ld, kt0 + k0 + c, L, dk[1], 32, hh, 0.125f);
+    store_tile_t(out + 2 * C, ld, kt0 + k0 + c, L, dv[0], 0, hh, 1.0f);
+    store_tile_t(out + 2 * C, ld, kt0 + k0 + c, L, dv[1], 32, hh, 1.0f);
+}
+
 template <int NKB> static int launch_fwd_short(const AttnArgs& a, hipStream_t st) {
     const size_t sm = 3 * NKB * 32 * 128 + NKB * 32 * 4;
     int rc = set_smem(attn_fwd_short_kernel<NKB>, sm);
@@ -608,6 +886,10 @@ template <int NKB> static int launch_bwd_short(const AttnArgs& a, hipStream_t st
 using namespace tal;
 
 // TAN_ATTN_GENERIC=1 forces the tiled any-length kernels for bf16 too (A/B measurements)
+static bool long_path() {
+    static const bool off = [] { const char* e = getenv("TAN_ATTN_GENERIC"); return e && e[0] == '1'; }();
+    return !off;
+}
 static bool short_path(int dtype, int L) {
     static const bool off = [] { const char* e = getenv("TAN_ATTN_GENERIC"); return e && e[0] == '1'; }();
     return dtype == TAN_BF16 && L <= 128 && !off;
@@ -632,6 +914,8 @@ extern "C" int tan_attn_fwd(const void* qkv, const unsigned char* key_padding_ma
         rc = nkb == 1 ? launch_fwd_short<1>(a, st) : nkb == 2 ? launch_fwd_short<2>(a, st)
            : nkb == 3 ? launch_fwd_short<3>(a, st) : launch_fwd_short<4>(a, st);
         if (rc) return rc;
+    } else if (dtype == TAN_BF16 && long_path()) {
+        hipLaunchKernelGGL(attn_fwd_long_kernel, dim3(cdiv(L, LBLK), B * H), dim3(256), 0, st, a);
     } else if (dtype == TAN_BF16) {
         size_t sm = fwd_smem<bf16_t>(a.Lpad);
         if ((rc = set_smem(attn_fwd_kernel<bf16_t>, sm))) return rc;
@@ -662,6 +946,9 @@ extern "C" int tan_attn_bwd(const void* qkv, const unsigned char* key_padding_ma
         rc = nkb == 1 ? launch_bwd_short<1>(a, st) : nkb == 2 ? launch_bwd_short<2>(a, st)
            : nkb == 3 ? launch_bwd_short<3>(a, st) : launch_bwd_short<4>(a, st);
         if (rc) return rc;
+    } else if (dtype == TAN_BF16 && long_path()) {
+        hipLaunchKernelGGL(attn_bwd_dq_long_kernel, dim3(cdiv(L, LBLK), B * H), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(attn_bwd_dkv_long_kernel, dim3(cdiv(L, LBLK), B * H), dim3(256), 0, st, a);
     } else if (dtype == TAN_BF16) {
         if ((rc = set_smem(attn_bwd_dq_kernel<bf16_t>, bwd_smem<bf16_t>(5)))) return rc;
         if ((rc = set_smem(attn_bwd_dkv_kernel<bf16_t>, bwd_smem<bf16_t>(6)))) return rc;

@@ -150,7 +150,7 @@ def _attn_ref(qkv, keypad, B, L, H):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("B,L,pad", [(2, 64, False), (3, 80, True), (1, 272, True), (2, 17, True), (2, 128, True), (2, 100, False)])
+@pytest.mark.parametrize("B,L,pad", [(2, 64, False), (3, 80, True), (1, 272, True), (2, 17, True), (2, 128, True), (2, 100, False), (2, 200, True), (1, 400, False)])
 def test_attention_fwd_bwd(dtype, B, L, pad):
     from temporalalignnet_amd import ops
     H, C = 8, 512
