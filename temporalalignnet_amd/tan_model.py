@@ -768,17 +768,19 @@ class TemporalAligner(nn.Module):
             self._flat.sync_shadow_t()         # W^T copies for the dX GEMMs, rebuilt once per optimizer step (main stream)
         main, side = torch.cuda.current_stream(), self._side_stream(dev)
         if any_j and any_v and side is not None:
-            # joint stack backward on the side stream (its gradient slice is final first: DDP starts reducing it while
-            # the video stack is still in backward), video stack backward on the main stream
+            # joint stack backward on the side stream (issued by the helper thread), video stack backward on the main stream
             side.wait_stream(main)
-
-            def joint_bwd():
-                self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dst_j, d_xj)
-                if self._grad_ready_hook is not None:
-                    self._grad_ready_hook("joint")
-            fut = self._on_side(side, joint_bwd)
+            fut = self._on_side(side, lambda: self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dst_j, d_xj))
             self._encoder_bwd(ev, run["x0"], run["vmask"], "ln_video_post_enc", dst_v, d_x0)
+            # DDP: each stack's slice of the flat gradient is final once its backward is enqueued.  Both collectives are issued
+            # from THIS thread, video first (every rank must issue them in the same order), each in the stream context whose
+            # work it has to wait for; they overlap whatever backward work is still running.
+            if self._grad_ready_hook is not None:
+                self._grad_ready_hook("video")
             fut.result()
+            if self._grad_ready_hook is not None:
+                with torch.cuda.stream(side):
+                    self._grad_ready_hook("joint")
             main.wait_stream(side)
         else:
             if any_j:
@@ -787,6 +789,8 @@ class TemporalAligner(nn.Module):
                     self._grad_ready_hook("joint")
             if any_v:
                 self._encoder_bwd(ev, run["x0"], run["vmask"], "ln_video_post_enc", dst_v, d_x0)
+                if self._grad_ready_hook is not None:
+                    self._grad_ready_hook("video")
         if any_j:
             if run["sv_video_j"] is not None:
                 d_x0j = torch.empty(R, Cw, dtype=cd, device=dev)

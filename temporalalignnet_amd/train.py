@@ -217,26 +217,33 @@ class Trainer:
 
     def step(self, batch):
         """One optimizer step on an already device-resident batch (see to_device_batch).  With N>1 ranks the flat gradient
-        is summed over RCCL in two pieces: the joint stack's slice (47% of the bytes) is launched asynchronously from inside
-        backward as soon as it is final and overlaps the video stack's backward; the rest follows at the end."""
+        is summed over RCCL in pieces: each encoder stack's slice (45 % / 47 % of the bytes) is launched asynchronously from
+        inside backward as soon as that stack's backward is enqueued (video first, then joint -- the same order on every
+        rank) and overlaps the rest of backward; the few remaining tensors (embeddings, heads) follow at the end."""
         self.zero_grad()
         world = dist.world_size()
-        pending = []
+        pending, done = [], []
         if dist.active():
             flat = self.online.flat_grad()
-            lo, hi = self.online.flat_range("joint_temporal_encoder.")
-            self.online._grad_ready_hook = lambda tag: pending.append(dist.allreduce_sum_(flat[lo:hi], async_op=True))
+            ranges = {"video": self.online.flat_range("video_temporal_encoder."),
+                      "joint": self.online.flat_range("joint_temporal_encoder.")}
+
+            def hook(tag):
+                lo, hi = ranges[tag]
+                pending.append(dist.allreduce_sum_(flat[lo:hi], async_op=True))
+                done.append((lo, hi))
+            self.online._grad_ready_hook = hook
         try:
             loss_dict = self.forward_backward(batch)
         finally:
             self.online._grad_ready_hook = None
         if dist.active():
-            if pending:
-                dist.allreduce_sum_(flat[:lo])
-                dist.allreduce_sum_(flat[hi:])
-                for w in pending:
-                    w.wait()
-            else:
-                dist.allreduce_sum_(flat)
+            pos = 0
+            for lo, hi in sorted(done) + [(flat.numel(), flat.numel())]:     # whatever the hooks did not cover
+                if lo > pos:
+                    dist.allreduce_sum_(flat[pos:lo])
+                pos = max(pos, hi)
+            for w in pending:
+                w.wait()
         self.optimizer_step(grad_scale=1.0 if self.global_negatives else 1.0 / world)
         return loss_dict
