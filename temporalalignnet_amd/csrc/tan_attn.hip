@@ -368,13 +368,29 @@ __device__ __forceinline__ void stage_images(char* lds, int first_img, int nimg,
     }
 }
 
-__device__ __forceinline__ void store_tile_t(bf16_t* out, long ld, int row, int L, const f32x16& acc, int dbase, int hh, float scale) {
-    // accumulator tile [d][row]: lane holds 4 consecutive d per register quad -> 8-byte stores
-    if (row < L) {
+
+
+// Accumulator tiles [d][row] of one wave (32 rows x 64 d) -> 32 wave-private rows of an LDS image -> 16-byte row-contiguous
+// global stores (8 rows x 128 B per instruction) instead of 8-byte stores scattered over 32 rows.
+__device__ __forceinline__ void tiles_to_rows(char* img, int r0, int c, int hh, const f32x16 (&t)[2], float scale) {
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
-            st4(out + (long)row * ld + dbase + 8 * g4 + 4 * hh,
-                make_float4(acc[4 * g4] * scale, acc[4 * g4 + 1] * scale, acc[4 * g4 + 2] * scale, acc[4 * g4 + 3] * scale));
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int row = r0 + c, chunk = 4 * db + g4;
+            st4((bf16_t*)(img + row * 128 + ((chunk ^ img_swz(row)) << 4) + hh * 8),
+                make_float4(t[db][4 * g4] * scale, t[db][4 * g4 + 1] * scale, t[db][4 * g4 + 2] * scale, t[db][4 * g4 + 3] * scale));
+        }
+}
+__device__ __forceinline__ void rows_to_global(const char* img, int r0, int lane, bf16_t* out, long ld, int grow0, int L) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = r0 + it * 8 + (lane >> 3), chunk = lane & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(img + row * 128 + ((chunk ^ img_swz(row)) << 4));
+        if (grow0 + row < L) *reinterpret_cast<uint4*>(out + (long)(grow0 + row) * ld + chunk * 8) = v;
     }
 }
 
@@ -494,6 +510,7 @@ __global__ __launch_bounds__(64 * NKB) void attn_bwd_short_kernel(AttnArgs a) {
     __syncthreads();
     bf16_t* out = (bf16_t*)a.dqkv + (long)b * L * ld + h * DH;
 
+    f32x16 dq[2];
     {   // ---- phase A: this wave's 32 queries against every key: delta and dq
         const int q0 = wave * 32;
         bf16x8 qf[4], dof[4];
@@ -524,7 +541,6 @@ __global__ __launch_bounds__(64 * NKB) void attn_bwd_short_kernel(AttnArgs a) {
         }
         delta += __shfl_xor(delta, 32, 64);
         if (hh == 0) delta_s[q0 + c] = delta;
-        f32x16 dq[2];
         acc_zero(dq[0]); acc_zero(dq[1]);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
@@ -538,8 +554,6 @@ __global__ __launch_bounds__(64 * NKB) void attn_bwd_short_kernel(AttnArgs a) {
                     dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_tr(Ki, 32 * kb + 16 * j, 32 * db, lane), df, dq[db], 0, 0, 0);
             }
         }
-        store_tile_t(out, ld, q0 + c, L, dq[0], 0, hh, 0.125f);
-        store_tile_t(out, ld, q0 + c, L, dq[1], 32, hh, 0.125f);
     }
     __syncthreads();
     {   // ---- phase B: this wave's 32 keys against every query: dk, dv
@@ -581,10 +595,13 @@ __global__ __launch_bounds__(64 * NKB) void attn_bwd_short_kernel(AttnArgs a) {
                 }
             }
         }
-        store_tile_t(out + C, ld, k0 + c, L, dk[0], 0, hh, 0.125f);
-        store_tile_t(out + C, ld, k0 + c, L, dk[1], 32, hh, 0.125f);
-        store_tile_t(out + 2 * C, ld, k0 + c, L, dv[0], 0, hh, 1.0f);
-        store_tile_t(out + 2 * C, ld, k0 + c, L, dv[1], 32, hh, 1.0f);
+        __syncthreads();            // every wave is done with the images: each parks its three result tiles in its own rows
+        tiles_to_rows(Qi, k0, c, hh, dq, 0.125f);
+        tiles_to_rows(Ki, k0, c, hh, dk, 0.125f);
+        tiles_to_rows(Vi, k0, c, hh, dv, 1.0f);
+        rows_to_global(Qi, k0, lane, out, ld, 0, L);
+        rows_to_global(Ki, k0, lane, out + C, ld, 0, L);
+        rows_to_global(Vi, k0, lane, out + 2 * C, ld, 0, L);
     }
 }
 
@@ -786,8 +803,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_long_kernel(AttnArgs a) {
         }
     }
     bf16_t* out = (bf16_t*)a.dqkv + (long)b * L * ld + h * DH;
-    store_tile_t(out, ld, qt0 + q0 + c, L, dq[0], 0, hh, 0.125f);
-    store_tile_t(out, ld, qt0 + q0 + c, L, dq[1], 32, hh, 0.125f);
+    tiles_to_rows(Qi, q0, c, hh, dq, 0.125f);           // the q rows are wave-private (their fragments live in registers)
+    rows_to_global(Qi, q0, lane, out, ld, qt0, L);
 }
 
 // dk, dv: workgroup = 128 keys, loop over query blocks
@@ -860,10 +877,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_long_kernel(AttnArgs a) {
         }
     }
     bf16_t* out = (bf16_t*)a.dqkv + (long)b * L * ld + h * DH;
-    store_tile_t(out + C, ld, kt0 + k0 + c, L, dk[0], 0, hh, 0.125f);
-    store_tile_t(out + C, ld, kt0 + k0 + c, L, dk[1], 32, hh, 0.125f);
-    store_tile_t(out + 2 * C, ld, kt0 + k0 + c, L, dv[0], 0, hh, 1.0f);
-    store_tile_t(out + 2 * C, ld, kt0 + k0 + c, L, dv[1], 32, hh, 1.0f);
+    __syncthreads();
+    tiles_to_rows(Qi, k0, c, hh, dk, 0.125f);
+    tiles_to_rows(Di, k0, c, hh, dv, 1.0f);
+    rows_to_global(Qi, k0, lane, out + C, ld, kt0, L);
+    rows_to_global(Di, k0, lane, out + 2 * C, ld, kt0, L);
 }
 
 template <int NKB> static int launch_fwd_short(const AttnArgs& a, hipStream_t st) {
