@@ -228,6 +228,67 @@ __device__ __forceinline__ void work_item(const GemmArgs2& g, int& tile, int& z)
     z = blockIdx.z;
 }
 
+
+// ---- hand-issued transposing fragment reads -----------------------------------------------------------------------
+// hipcc cannot tell the address of a `__builtin_amdgcn_ds_read_tr16_b64` from the destination of the LDS-DMA still in flight
+// for the NEXT K-tile and drains it (`s_waitcnt vmcnt(0)`) before the first such read of every K-tile -- the two-buffer
+// pipeline then overlaps nothing inside a workgroup (visible in the .s of every K-strided instantiation; the ds_read_b128
+// instantiation has no such wait).  Where BOTH operands are K-strided (dW = dY^T X) the reads are therefore issued from inline
+// asm, which the compiler neither waits for nor counts: form (ii) of the guide's section 5.7 -- "=v" destinations, then one
+// `s_waitcnt lgkmcnt(0)` statement naming every destination "+v" before the first consumer -- software-pipelined by hand
+// across the four 16-deep steps of a K-tile: [wait step s] [issue step s+1] [MFMAs of step s].
+typedef short tr_s16x4 __attribute__((ext_vector_type(4)));
+struct TrFrag { tr_s16x4 lo, hi; };
+struct TrStep { TrFrag a[2], b[2]; };
+
+template <int OFF>
+__device__ __forceinline__ void tr_issue(TrFrag& f, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                 : "=v"(f.lo), "=v"(f.hi) : "v"(addr), "i"(OFF), "i"(OFF + 1024));
+}
+template <int OFF>    // OFF = byte offset of (buffer, k-step) inside the LDS array; the B tile follows the A tile
+__device__ __forceinline__ void tr_issue_step(TrStep& s, const unsigned (&a_addr)[2], const unsigned (&b_addr)[2]) {
+    tr_issue<OFF>(s.a[0], a_addr[0]);
+    tr_issue<OFF>(s.a[1], a_addr[1]);
+    tr_issue<OFF + TILE_BYTES>(s.b[0], b_addr[0]);
+    tr_issue<OFF + TILE_BYTES>(s.b[1], b_addr[1]);
+}
+__device__ __forceinline__ void tr_wait(TrStep& s) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(s.a[0].lo), "+v"(s.a[0].hi), "+v"(s.a[1].lo), "+v"(s.a[1].hi), "+v"(s.b[0].lo), "+v"(s.b[0].hi),
+                   "+v"(s.b[1].lo), "+v"(s.b[1].hi));
+}
+__device__ __forceinline__ bf16x8 tr_frag(const TrFrag& f) {
+    union { bf16x8 v; tr_s16x4 h[2]; } u;
+    u.h[0] = f.lo; u.h[1] = f.hi;
+    return u.v;
+}
+__device__ __forceinline__ void tr_mma(f32x16 (&acc)[2][2], const TrStep& s) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(s.a[i]), tr_frag(s.b[j]), acc[i][j], 0, 0, 0);
+}
+// per-lane byte address (LDS offset) of a K-strided fragment at k-step 0 of buffer 0: the arithmetic of load_frag<false>
+__device__ __forceinline__ unsigned tr_lane_addr(const char* lds_tile, int o0, int lane) {
+    const int g = lane >> 4, p = lane & 15, r = p >> 2, q = p & 3;
+    const int col = o0 + 16 * (g & 1) + 4 * q;
+    const int k = 8 * (g >> 1) + r;
+    const int slot = (col >> 3) ^ (r << 2);
+    return (unsigned)(uintptr_t)(lds_tile + k * 256 + slot * 16 + (q & 1) * 8);
+}
+template <int CUR>
+__device__ __forceinline__ void tr_tile(f32x16 (&acc)[2][2], const unsigned (&a_addr)[2], const unsigned (&b_addr)[2]) {
+    constexpr int BASE = CUR * 2 * TILE_BYTES;       // k-step s starts 16 k-rows = 4096 bytes further
+    TrStep s0, s1;
+    tr_issue_step<BASE>(s0, a_addr, b_addr);
+    tr_wait(s0); tr_issue_step<BASE + 4096>(s1, a_addr, b_addr); tr_mma(acc, s0);
+    tr_wait(s1); tr_issue_step<BASE + 8192>(s0, a_addr, b_addr); tr_mma(acc, s1);
+    tr_wait(s0); tr_issue_step<BASE + 12288>(s1, a_addr, b_addr); tr_mma(acc, s0);
+    tr_wait(s1); tr_mma(acc, s1);
+}
+
 template <typename TC, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs2 g) {
     __shared__ __attribute__((aligned(1024))) char lds[4 * TILE_BYTES];   // [buf][A|B]
@@ -251,6 +312,10 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs2 g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
 
+    // per-lane LDS addresses of the hand-issued transposing reads (K-strided x K-strided instantiation only)
+    const unsigned tr_a[2] = {tr_lane_addr(lds, wm * 64, lane), tr_lane_addr(lds, wm * 64 + 32, lane)};
+    const unsigned tr_b[2] = {tr_lane_addr(lds, wn * 64, lane), tr_lane_addr(lds, wn * 64 + 32, lane)};
+
     // One K-step: start the DMA of tile t+1 into the OTHER buffer, multiply tile t, then wait + barrier.  The two buffers
     // are addressed with compile-time offsets (loop unrolled by two) so that the compiler can tell the DMA destination
     // from the fragment reads; with a runtime buffer index it drains the DMA (s_waitcnt vmcnt(0)) before the first ds_read.
@@ -261,17 +326,21 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs2 g) {
             stage_tile<A_KC>(A, g.lda, m0, g.M, k0, lds + NXT * 2 * TILE_BYTES, wave, lane);
             stage_tile<B_KC>(B, g.ldb, n0, g.N, k0, lds + NXT * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
         }
+        if constexpr (!A_KC && !B_KC) {
+            tr_tile<CUR>(acc, tr_a, tr_b);
+        } else {
 #pragma unroll
-        for (int ks = 0; ks < GBK; ks += 16) {
-            bf16x8 a[2], b[2];
+            for (int ks = 0; ks < GBK; ks += 16) {
+                bf16x8 a[2], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = load_frag<A_KC>(lds + CUR * 2 * TILE_BYTES, wm * 64 + i * 32, ks, lane);
+                for (int i = 0; i < 2; ++i) a[i] = load_frag<A_KC>(lds + CUR * 2 * TILE_BYTES, wm * 64 + i * 32, ks, lane);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = load_frag<B_KC>(lds + CUR * 2 * TILE_BYTES + TILE_BYTES, wn * 64 + j * 32, ks, lane);
+                for (int j = 0; j < 2; ++j) b[j] = load_frag<B_KC>(lds + CUR * 2 * TILE_BYTES + TILE_BYTES, wn * 64 + j * 32, ks, lane);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
