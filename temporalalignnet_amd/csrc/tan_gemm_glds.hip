@@ -289,6 +289,37 @@ __device__ __forceinline__ void tr_tile(f32x16 (&acc)[2][2], const unsigned (&a_
     tr_wait(s1); tr_mma(acc, s1);
 }
 
+// K-contiguous A (compiler-scheduled ds_read_b128) x K-strided B (hand-issued transposing reads, same pipelining)
+struct TrStepB { TrFrag b[2]; };
+template <int OFF>
+__device__ __forceinline__ void tr_issue_b(TrStepB& s, const unsigned (&b_addr)[2]) {
+    tr_issue<OFF + TILE_BYTES>(s.b[0], b_addr[0]);
+    tr_issue<OFF + TILE_BYTES>(s.b[1], b_addr[1]);
+}
+__device__ __forceinline__ void tr_wait_b(TrStepB& s) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s.b[0].lo), "+v"(s.b[0].hi), "+v"(s.b[1].lo), "+v"(s.b[1].hi));
+}
+template <int CUR, int KS>
+__device__ __forceinline__ void kc_tr_mma(f32x16 (&acc)[2][2], const char* lds, const TrStepB& s, int wm, int lane) {
+    bf16x8 a[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = load_frag<true>(lds + CUR * 2 * TILE_BYTES, wm * 64 + i * 32, KS, lane);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], tr_frag(s.b[j]), acc[i][j], 0, 0, 0);
+}
+template <int CUR>
+__device__ __forceinline__ void kc_tr_tile(f32x16 (&acc)[2][2], const char* lds, const unsigned (&b_addr)[2], int wm, int lane) {
+    constexpr int BASE = CUR * 2 * TILE_BYTES;
+    TrStepB s0, s1;
+    tr_issue_b<BASE>(s0, b_addr);
+    tr_wait_b(s0); tr_issue_b<BASE + 4096>(s1, b_addr); kc_tr_mma<CUR, 0>(acc, lds, s0, wm, lane);
+    tr_wait_b(s1); tr_issue_b<BASE + 8192>(s0, b_addr); kc_tr_mma<CUR, 16>(acc, lds, s1, wm, lane);
+    tr_wait_b(s0); tr_issue_b<BASE + 12288>(s1, b_addr); kc_tr_mma<CUR, 32>(acc, lds, s0, wm, lane);
+    tr_wait_b(s1); kc_tr_mma<CUR, 48>(acc, lds, s1, wm, lane);
+}
+
 template <typename TC, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs2 g) {
     __shared__ __attribute__((aligned(1024))) char lds[4 * TILE_BYTES];   // [buf][A|B]
@@ -328,6 +359,8 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs2 g) {
         }
         if constexpr (!A_KC && !B_KC) {
             tr_tile<CUR>(acc, tr_a, tr_b);
+        } else if constexpr (A_KC && !B_KC) {
+            kc_tr_tile<CUR>(acc, lds, tr_b, wm, lane);
         } else {
 #pragma unroll
             for (int ks = 0; ks < GBK; ks += 16) {
