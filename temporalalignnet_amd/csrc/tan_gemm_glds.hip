@@ -513,9 +513,11 @@ static int use_four_stage(const tan_gemm_desc* d, const GemmArgs2& a) {
     if (forced == -2) { const char* e = getenv("TAN_GEMM_STAGES"); forced = e ? atoi(e) : -1; }
     if (forced == 2) return 0;
     if (forced == 4) return 1;
-    // measured (tools/gemm_bench.py): +10 % on K-contiguous x K-contiguous with K >= 1024 (c_proj forward), but -10..20 % on
-    // the K-strided (tr-read) operand layouts, where the extra barrier per 8 MFMAs costs more than the deeper prefetch gains
-    return d->a_kc && d->b_kc && a.kchunk >= 1024;
+    // measured (tools/gemm_shapes.py, 100 reps): the deeper prefetch pays when a CU holds ONE workgroup (<= ~1.5 tiles per CU:
+    // the N=512 outputs, 11.3 vs 12.0 us at K=512, 25.0 vs 28.3 us at K=2048) and costs 3-12 % once two workgroups per CU hide
+    // each other's DMA latency (N >= 1536, or the 8192^3-class shapes: 870 vs 990 TF/s); K-strided layouts never use it
+    const long wgs = (long)cdiv(d->M, GBM) * cdiv(d->N, GBN) * d->batch * d->split_k;
+    return d->a_kc && d->b_kc && wgs <= 384 && a.kchunk >= 128;
 }
 
 template <typename TC>
