@@ -31,7 +31,8 @@ import torch  # noqa: E402
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
 F32_MFMA_PEAK_TFLOPS = 157.3
-GEMM_KIND_NAMES = {0: "gemm_bf16<A:K-contig,B:K-contig> (Linear fwd, similarity)", 1: "gemm_bf16<A:K-contig,B:K-strided> (dX)",
+GEMM_KIND_NAMES = {0: "gemm_bf16<A:K-contig,B:K-contig> (Linear fwd, dX through W^T copies, same-video similarity blocks)",
+                   1: "gemm_bf16<A:K-contig,B:K-strided> (d video features = dlogits x text features)",
                    2: "gemm_bf16<A:K-strided,B:K-contig>", 3: "gemm_bf16<A:K-strided,B:K-strided> (dW)",
                    4: "gemm_f32<kc,kc>", 5: "gemm_f32<kc,ks>", 6: "gemm_f32<ks,kc>", 7: "gemm_f32<ks,ks>",
                    8: "attn_fwd", 9: "attn_bwd", 10: "simnce (logits-free similarity+NCE, fwd stats / bwd dlogits)"}
