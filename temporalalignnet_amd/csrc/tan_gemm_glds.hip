@@ -155,15 +155,30 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs2& g, f32x16 (&acc)[2
             for (int r = 0; r < 16; ++r) tile[(wm * 64 + i * 32 + acc_row(r, lane)) * 128 + lc] = acc[i][j][r] * g.alpha + bv;
         }
     __syncthreads();
-    // phase 2: 8 rows x 8 columns per thread, 16-byte global accesses
+    // phase 2: 8 rows x 8 columns per thread, 16-byte global accesses.  Branch-free by construction: out-of-range rows /
+    // columns are CLAMPED for the loads and predicated only at the stores, and the residual / pre-activation vectors of all
+    // eight rows are loaded up front under ONE wave-uniform condition -- a per-row `if (R) load` made hipcc branch around
+    // every load and wait `vmcnt(0)` behind it (and behind the previous row's store): eight serialised round trips per tile.
     const int cv = (tid & 15) * 8, col = n0 + cv;
+    const bool col_ok = col < g.N;
+    const int colc = col_ok ? col : g.N - 8;
     float cs[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+    float rv[8][8], av[8][8];
+    const bool has_r = R != nullptr, grad = g.act == TAN_ACT_QUICKGELU_GRAD;
+    if (has_r) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) ld8(R + (long)min(m0 + (tid >> 4) + 16 * p, g.M - 1) * g.ldr + colc, rv[p]);
+    }
+    if (grad) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) ld8(AUX + (long)min(m0 + (tid >> 4) + 16 * p, g.M - 1) * g.ldaux + colc, av[p]);
+    }
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int lr = (tid >> 4) + 16 * p, row = m0 + lr;
-        if (row >= g.M || col >= g.N) break;
+        const bool ok = col_ok && row < g.M;
         float v[8];
         {
             const float4 a = *reinterpret_cast<const float4*>(tile + lr * 128 + cv);
@@ -171,27 +186,25 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs2& g, f32x16 (&acc)[2
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
         }
         if (g.act == TAN_ACT_QUICKGELU) {
-            if (AUX) st8(AUX + (long)row * g.ldaux + col, v);
+            if (AUX && ok) st8(AUX + (long)row * g.ldaux + col, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = quick_gelu(v[e]);
-        } else if (g.act == TAN_ACT_QUICKGELU_GRAD) {
-            float x[8];
-            ld8(AUX + (long)row * g.ldaux + col, x);
+        } else if (grad) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= quick_gelu_grad(x[e]);
+            for (int e = 0; e < 8; ++e) v[e] *= quick_gelu_grad(av[p][e]);
         } else if (g.act == TAN_ACT_RELU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
         }
-        if (R) {
-            float x[8];
-            ld8(R + (long)row * g.ldr + col, x);
+        if (has_r) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += x[e];
+            for (int e = 0; e < 8; ++e) v[e] += rv[p][e];
         }
-        st8(C + (long)row * g.ldc + col, v);
+        if (ok) {
+            st8(C + (long)row * g.ldc + col, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) cs[e] += v[e];
+            for (int e = 0; e < 8; ++e) cs[e] += v[e];
+        }
     }
     if (g.colsum) {      // fused bias gradient: column sums of this tile -> one atomic per column
         __syncthreads();
