@@ -75,8 +75,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll 2
     for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + w; row < rows; row += (long)gridDim.x * ROWS_PER_BLOCK) {
         const float mean = mean_i[row], rstd = rstd_i[row];
-        float4 xh[NCH], g[NCH];
+        float4 xh[NCH], g[NCH], rs[NCH];
         float s1 = 0.f, s2 = 0.f;
+        // the residual gradient is loaded UNCONDITIONALLY with the other loads of the row (from x when there is none): a load
+        // behind `if (dres)` gets a branch and its own s_waitcnt -- after the reductions it was two dependent round trips
+        const T* rsrc = dres ? dres : x;
+        const float rmul = dres ? 1.0f : 0.0f;          // arithmetic, not a branch: keeps both chunk loads in the batch
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) rs[i] = ld4(rsrc + row * C + (i * 64 + lane) * 4);
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = (i * 64 + lane) * 4;
@@ -94,10 +100,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             const int c = (i * 64 + lane) * 4;
             float4 o = make_float4(rstd * (g[i].x - m1 - xh[i].x * m2), rstd * (g[i].y - m1 - xh[i].y * m2),
                                    rstd * (g[i].z - m1 - xh[i].z * m2), rstd * (g[i].w - m1 - xh[i].w * m2));
-            if (dres) {
-                const float4 r = ld4(dres + row * C + c);
-                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-            }
+            o.x += rs[i].x * rmul; o.y += rs[i].y * rmul; o.z += rs[i].z * rmul; o.w += rs[i].w * rmul;
             st4(dx + row * C + c, o);
             ds[i].x += o.x; ds[i].y += o.y; ds[i].z += o.z; ds[i].w += o.w;
         }
