@@ -302,7 +302,9 @@ static int simnce_common(SimArgs& a, int S, int B, int T, int N, int C) {
 
 // same-video cosine blocks diag[s,b,t,n] = <vn[s,b*T+t], tn[s,b*N+n]> through the ordinary GEMM (batch = S*B... per stage)
 static int simnce_diag_blocks(const SimArgs& a, const bf16_t* tn_blocks, long tb_stage_stride, float* diag, hipStream_t st) {
-    for (int s = 0; s < a.S; ++s) {
+    // per-stage text features laid out back to back: (stage, video) is ONE batch index for all three operands
+    const bool one_launch = tb_stage_stride == (long)a.B * a.N * a.C;
+    for (int s = 0; s < (one_launch ? 1 : a.S); ++s) {
         tan_gemm_desc d{};
         d.dtype = TAN_BF16; d.out_dtype = TAN_F32;
         d.M = a.T; d.N = a.N; d.K = a.C; d.a_kc = 1; d.b_kc = 1;
@@ -310,7 +312,8 @@ static int simnce_diag_blocks(const SimArgs& a, const bf16_t* tn_blocks, long tb
         d.B = tn_blocks + (long)s * tb_stage_stride; d.ldb = a.C;
         d.C = diag + (long)s * a.B * a.T * a.N; d.ldc = a.N;
         d.split_k = 1; d.alpha = 1.0f;
-        d.batch = a.B; d.sA = (long)a.T * a.C; d.sB = (long)a.N * a.C; d.sC = (long)a.T * a.N;
+        d.batch = one_launch ? a.S * a.B : a.B;
+        d.sA = (long)a.T * a.C; d.sB = (long)a.N * a.C; d.sC = (long)a.T * a.N;
         int rc = tan_gemm(&d, st);
         if (rc) return rc;
     }
