@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_QUICKGELU, ACT_QUICKGELU_GRAD, TAN_BF16, TAN_F32  # noqa: F401
+from ._lib import ACT_NONE, ACT_QUICKGELU, ACT_QUICKGELU_GRAD, ACT_RELU, TAN_BF16, TAN_F32  # noqa: F401
 
 
 def _dt(t: torch.Tensor) -> int:

@@ -114,3 +114,56 @@ def test_gemm_fused_colsum(dtype, M, N, K):
     assert (out.double() - ref).abs().max().item() < _tol(dtype, K) * (ref.abs().max().item() + 1)
     err = (cs.double() - ref.sum(0) - 1).abs().max().item()
     assert err < (1e-5 * M * K ** 0.5 if dtype == torch.float32 else 0.05 * M ** 0.5 + 0.5), err
+
+
+def test_gemm_random_configurations():
+    """Seeded sweep over shapes (incl. ragged M / N, every K-step count parity), layouts, epilogues, batching and split-K: the
+    direct-to-LDS kernels, their hand-issued transposing reads, the 4-stage variant and the clamped epilogue all get hit."""
+    import numpy as np
+    from temporalalignnet_amd import ops
+    rs = np.random.RandomState(1234)
+    for case in range(48):
+        M = int(rs.choice([8, 40, 128, 136, 264, 520, 1000]))
+        N = int(rs.choice([8, 16, 72, 128, 256, 520]))
+        K = int(rs.choice([64, 128, 192, 320, 512, 1088]))
+        a_kc, b_kc = bool(rs.randint(2)), bool(rs.randint(2))
+        batch = int(rs.choice([1, 1, 3]))
+        mode = rs.choice(["plain", "bias_res", "gelu", "gelu_grad", "relu", "f32_split"])
+        A = _mk((batch, M, K) if a_kc else (batch, K, M), torch.bfloat16, 100 + case)
+        B = _mk((batch, N, K) if b_kc else (batch, K, N), torch.bfloat16, 200 + case) * 0.1
+        Af = (A if a_kc else A.transpose(1, 2)).double()
+        Bf = (B.transpose(1, 2) if b_kc else B).double()
+        ref = Af @ Bf
+        kw = dict(M=M, N=N, K=K, a_kc=a_kc, b_kc=b_kc, batch=batch, sA=M * K, sB=N * K, sC=M * N)
+        tol = 3e-2 * max(1.0, (K / 512) ** 0.5)
+        if mode == "f32_split":
+            out = torch.zeros(batch, M, N, device="cuda")
+            ops.gemm(A, B, out, accumulate=True, split_k=int(rs.choice([1, 2, 4])), **kw)
+            want = ref
+        else:
+            out = torch.full((batch, M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+            bias = _mk((N,), torch.float32, 300 + case) if mode != "plain" else None
+            pre = ref + (bias.double() if bias is not None else 0.0)
+            if mode == "bias_res":
+                res = _mk((batch, M, N), torch.bfloat16, 400 + case)
+                ops.gemm(A, B, out, bias=bias, residual=res, **kw)
+                want = pre + res.double()
+            elif mode == "gelu":
+                aux = torch.full((batch, M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+                ops.gemm(A, B, out, bias=bias, act=ops.ACT_QUICKGELU, aux=aux, **kw)
+                want = pre * torch.sigmoid(1.702 * pre)
+                assert (aux.double() - pre).abs().max().item() < tol * (pre.abs().max().item() + 1.0), (case, "aux")
+            elif mode == "gelu_grad":
+                aux = _mk((batch, M, N), torch.bfloat16, 500 + case)
+                ops.gemm(A, B, out, bias=bias, act=ops.ACT_QUICKGELU_GRAD, aux=aux, **kw)
+                p = aux.double()
+                sg = torch.sigmoid(1.702 * p)
+                want = pre * (sg + 1.702 * p * sg * (1 - sg))
+            elif mode == "relu":
+                ops.gemm(A, B, out, bias=bias, act=ops.ACT_RELU, **kw)
+                want = pre.clamp(min=0)
+            else:
+                ops.gemm(A, B, out, **kw)
+                want = pre
+        err = (out.double() - want).abs().max().item()
+        assert err < tol * (want.abs().max().item() + 1.0), (case, M, N, K, a_kc, b_kc, batch, mode, err)
