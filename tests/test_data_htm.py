@@ -122,3 +122,19 @@ def test_train_steps_from_disk(fixture_dir):
             assert b["video"].is_cuda and b["token"][0].is_cuda
             losses.append(float(tr.step(b)["loss"].item()))
     assert len(losses) == 6 and all(np.isfinite(losses))
+
+
+def test_loader_with_worker_processes(fixture_dir):
+    """DataLoader workers (the reference trains with 8): the dataset pickles, every worker seeds its own numpy stream, and an
+    epoch visits every video exactly once."""
+    fx, paths = fixture_dir
+    tok = Word2VecTokenizer(max_words=32, vocab=synth.w2v_vocab(40))
+    ds = data_htm.HTMFeatureDataset(paths["features"], paths["asr"], paths["vlen"], paths["holdout"], tokenizer=tok, mode="train")
+    torch.manual_seed(0)
+    loader = data_htm.make_loader(ds, batch_size=2, num_workers=2, shuffle=True, drop_last=False)
+    seen = []
+    for epoch in range(2):
+        vids = [v for b in loader for v in b["vid"]]
+        assert sorted(vids) == sorted(ds.video_info)
+        seen.append(vids)
+    del loader
