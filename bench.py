@@ -8,7 +8,9 @@
 Workload (BASELINE.json configs[1]): E6D6, T=64, bf16, stage-1 ('init': NCE only), B=128 videos per GPU
 (train/readme.md:10), N ~ U[4,16] sentences per video, synthetic HTM-370K-shaped features (random S3D-like 1024-d
 clip features and 512-d sentence embeddings), random-init weights.  One step = zero_grad + forward + get_loss +
-backward + (gradient all-reduce over RCCL when N>1) + fused AdamW, inputs already resident in HBM.  Multi-GPU shards
+backward + (gradient all-reduce over RCCL when N>1) + fused AdamW, inputs already resident in HBM (features, sentence
+embeddings, padding masks and the [B,N,T] timestamp mask derived from the batch's start/end lists: `to_device_batch`; everything
+that depends on the model -- and all of get_loss, including its positive masks and the column compaction -- runs every step).  Multi-GPU shards
 by video (weak scaling: every rank its own 128 videos), one all-reduce of the flat gradient per step.
 
 Prints ONE JSON line (rank 0): value = whole-job video-seq/s; `roofline` = the dominant kernel (the MFMA GEMM family)
