@@ -168,9 +168,12 @@ class _AlignerFn(torch.autograd.Function):
     def forward(ctx, model, video, lang, vmask_u8, tmask_u8, opts, *params):
         ctx.set_materialize_grads(False)      # unused outputs must not materialise 100s of MB of zero gradients
         run = model._run_forward(video, lang, vmask_u8, tmask_u8, opts)
+        # the returned tensor OBJECTS must not stay reachable from ctx: tensor -> grad_fn (this node, held from C++) -> ctx -> run
+        # -> tensor is a cycle Python's gc cannot see -- it kept every step's whole activation record alive (1.3 MB per video)
+        outputs = tuple(run.pop("outputs"))
         ctx.model, ctx.run = model, run
         ctx.lang_requires_grad = lang.requires_grad
-        return tuple(run["outputs"])
+        return outputs
 
     @staticmethod
     def backward(ctx, *grads):
@@ -639,7 +642,8 @@ class TemporalAligner(nn.Module):
             ops.l2norm_fwd(ej.stage(s), tn_j[s], inv["tj"][s * Mp:(s + 1) * Mp], Mp, Cw, N, L, T)
         if opts.get("fused"):
             # logits-free mode: hand the unit features to get_loss (tan_simnce_* never materialises [S,R,Mp])
-            outputs = [vn_d.view(Se, B, T, Cw).permute(1, 0, 2, 3), tn_d.view(B, N, Cw), vn_j, tn_j]
+            # (fresh view objects: the returned tensors must not be the objects kept in `run`, see _AlignerFn.forward)
+            outputs = [vn_d.view(Se, B, T, Cw).permute(1, 0, 2, 3), tn_d.view(B, N, Cw), vn_j.view(Sd, R, Cw), tn_j.view(Sd, Mp, Cw)]
             names = ["vn_d", "tn_d", "vn_j", "tn_j"]
         else:
             # cosine logits, stage-major [S, R, Mp] f32; the reference layout [B,S,T,B,N] is a permuted view (tan_model.py:118,138)

@@ -113,3 +113,23 @@ def test_lr_schedule_lag_matches_reference_lambda_lr():
             sched.step(max(it - 1, 0)) if it > 0 else None
             tr.iteration = it + 1
             assert tr.current_lr() == pytest.approx(opt.param_groups[0]["lr"], rel=1e-12, abs=1e-18)
+
+
+@pytest.mark.gpu
+def test_steps_do_not_accumulate_device_memory():
+    """Regression: the autograd node of the forward once kept its own output tensors reachable from ctx (a cycle through C++
+    that Python's gc cannot collect) and every step leaked its activation record."""
+    import gc
+    from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
+    for kind, dtype in (("init", "bf16"), ("cotrain", "bf16"), ("init", "fp32")):
+        args = default_args(model=kind, num_encoder_layers=3, num_decoder_layers=3, loss_threshold=0.5 if kind == "cotrain" else 0.0)
+        tr = Trainer(build_model(args, compute_dtype=dtype).cuda(), args)
+        b = to_device_batch(synth.make_batch(4, B=8, T=32, n_min=3, n_max=7))
+        for _ in range(3):
+            tr.step(b)
+        torch.cuda.synchronize(); gc.collect()
+        before = torch.cuda.memory_allocated()
+        for _ in range(6):
+            tr.step(b)
+        torch.cuda.synchronize(); gc.collect()
+        assert torch.cuda.memory_allocated() - before < (1 << 20), (kind, dtype, torch.cuda.memory_allocated() - before)
