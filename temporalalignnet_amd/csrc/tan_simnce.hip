@@ -296,7 +296,6 @@ static int simnce_common(SimArgs& a, int S, int B, int T, int N, int C) {
     a.S = S; a.B = B; a.T = T; a.N = N; a.C = C; a.R = B * T; a.Mp = B * N;
     if (S <= 0 || B <= 0 || T <= 0 || N <= 0 || C <= 0 || C % 64 != 0) return TAN_ERR_BAD_ARG;
     if (((uintptr_t)a.V % 16) || ((uintptr_t)a.Tt % 16)) return TAN_ERR_BAD_ARG;
-    if (a.Mp > S_MAXCOLS) return TAN_ERR_BAD_ARG;
     return 0;
 }
 
@@ -339,6 +338,7 @@ extern "C" int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_strid
     float* diag = ws + (long)npanel * S * a.Mp;          // sized for the padded column count
     if (colmap) a.Mp = Mc;
     else { tn_blocks = tn; tb_stage_stride = t_stage_stride; }
+    if (a.Mp > S_MAXCOLS) return TAN_ERR_BAD_ARG;        // columns of the sweep (compacted or not): one LDS accumulator each
     hipStream_t st = (hipStream_t)stream;
     const long SM = (long)S * a.Mp, SR = (long)S * a.R;
     if (phases & TAN_SIM_SWEEP) {
@@ -385,6 +385,7 @@ extern "C" int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_st
     float* diag = ws + (long)cdiv(a.R, 128) * S * a.Mp;
     if (colmap) a.Mp = Mc;
     else { tn_blocks = tn; tb_stage_stride = t_stage_stride; }
+    if (a.Mp > S_MAXCOLS) return TAN_ERR_BAD_ARG;        // columns of the sweep (compacted or not): one LDS accumulator each
     if (phases & TAN_SIM_SWEEP) {
         const int prec = prof_begin(st, TAN_PROF_SIMNCE, 2.0 * S * a.R * (double)a.Mp * C);
         hipLaunchKernelGGL((simnce_kernel<1>), dim3(cdiv(a.R, 128), S), dim3(256), 0, st, a);

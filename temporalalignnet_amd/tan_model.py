@@ -237,7 +237,9 @@ class TemporalAligner(nn.Module):
         # reference registration order differs from construction order only for the two pos-embeds, which the
         # reference registers before the encoders' parameters appear in state_dict(); key *names* are what matter.
         self._flat = _Flat(self, [(n, p) for n, p in self.named_parameters() if not n.startswith("bert.")])
-        self._ws_pool = {}
+        self._ws_pool, self._ws_lru, self._ws_tick = {}, {}, 0
+        import threading
+        self._ws_lock = threading.Lock()
         self.overlap_stacks = True        # run the video and joint stacks on two HIP streams
         self._side = None
         self._issuer = None               # helper thread issuing the side-stream stack (see _on_side)
@@ -522,18 +524,38 @@ class TemporalAligner(nn.Module):
     # Activation workspaces (~1 GB per stack at B=128) are pooled per shape: allocating them afresh every step costs
     # tens of ms of hipMalloc/hipFree on the host.  A workspace is taken at forward and handed back after backward
     # (or right after a no-grad forward, whose outputs never alias it).
+    # Workspaces (saved activations of a stack, backward scratch) are pooled per shape: allocating ~1 GB afresh each step costs
+    # 13 ms/GB of host time.  Real batches vary in N (hence in the joint length L = T + N), so the pool is an LRU over shapes
+    # bounded to _WS_POOL_KEYS entries -- at most ~1.3 GB each at B=128.
+    _WS_POOL_KEYS = 10
+
+    def _pool_touch(self, key):
+        with self._ws_lock:
+            self._ws_tick += 1
+            self._ws_lru[key] = self._ws_tick
+            if len(self._ws_lru) > self._WS_POOL_KEYS:
+                for old in sorted(self._ws_lru, key=self._ws_lru.get)[:len(self._ws_lru) - self._WS_POOL_KEYS]:
+                    self._ws_lru.pop(old)
+                    self._ws_pool.pop(old, None)          # tensors return to the caching allocator (stream-ordered reuse)
+
     def _take_ws(self, prefix, layers, B, L, cd, dev):
         key = (prefix, layers, B, L, cd, dev)
-        pool = self._ws_pool.setdefault(key, [])
-        er = pool.pop() if pool else _EncRun(self, prefix, layers, B, L, cd, dev)
+        self._pool_touch(key)
+        with self._ws_lock:
+            pool = self._ws_pool.setdefault(key, [])
+            er = pool.pop() if pool else None
+        if er is None:
+            er = _EncRun(self, prefix, layers, B, L, cd, dev)
         er.pool_key = key
         return er
 
     def _release_ws(self, er):
         if er is not None and getattr(er, "pool_key", None) is not None:
-            pool = self._ws_pool.setdefault(er.pool_key, [])
-            if len(pool) < 2:
-                pool.append(er)
+            with self._ws_lock:
+                if er.pool_key in self._ws_lru:           # its shape may have been evicted meanwhile: then just drop it
+                    pool = self._ws_pool.setdefault(er.pool_key, [])
+                    if len(pool) < 2:
+                        pool.append(er)
             er.pool_key = None
 
     def _side_stream(self, dev):
@@ -560,6 +582,7 @@ class TemporalAligner(nn.Module):
 
     def _take_scratch(self, R, cd, dev):
         key = ("scr", R, cd, dev)
+        self._pool_touch(key)
         scr = self._ws_pool.get(key)
         if scr is None:
             scr = _Blocks(cd, dev, {"dx": R * WIDTH, "dx2": R * WIDTH, "do": R * WIDTH, "dxn": R * WIDTH,

@@ -100,3 +100,23 @@ def test_more_text_columns_than_the_fused_sweep_accepts_falls_back_to_logits():
     assert tr.fused_loss
     losses = [tr.step(to_device_batch(b_np))["loss"].item() for _ in range(2)]
     assert all(np.isfinite(losses))
+
+
+def test_compaction_lifts_the_padded_column_count_over_the_sweep_limit():
+    """B*N padded columns exceed tan_simnce_max_cols() but the real sentences fit: the fused sweep runs on the compacted
+    matrix and agrees with the materialised-logits loss."""
+    from temporalalignnet_amd import _lib
+    from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
+    lim = _lib.lib().tan_simnce_max_cols()
+    b_np = synth.make_batch(5, B=72, T=16, n_min=2, n_max=40)
+    B, N = b_np["text_embed"].shape[:2]
+    n_text = int((b_np["text_padding_mask"] == 0).sum())
+    assert B * N > lim and (n_text + 63) // 64 * 64 <= lim
+    args = default_args(model="init", num_encoder_layers=1, num_decoder_layers=1)
+    losses = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        tr = Trainer(build_model(args, compute_dtype="bf16", random_pos_start=0).cuda(), args, fused_loss=fused)
+        tr.zero_grad()
+        losses.append(tr.forward_backward(to_device_batch(b_np))["loss"].item())
+    assert abs(losses[0] - losses[1]) < 2e-3 * abs(losses[1]), losses
