@@ -34,6 +34,9 @@ def expand_for_cotrain(state_dict: dict) -> dict:
     out = {f"target.{k}": v for k, v in state_dict.items()}
     out.update({f"online.{k}": v for k, v in state_dict.items()})
     out.update({k: v for k, v in state_dict.items() if "lang_model." in k})
+    # checkpoints written by this build (and by the reference's own save) spell the module attribute, `bert.`: the twin's
+    # top-level alias of the online language model expects those keys too (superset of main.py:467-469)
+    out.update({k: v for k, v in state_dict.items() if k.startswith("bert.")})
     return out
 
 
