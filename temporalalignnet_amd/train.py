@@ -102,6 +102,9 @@ class Trainer:
         # row f3: NCE negatives from every rank (fused bf16 path only).  The global loss is then the SUM of the rank losses,
         # so gradients are summed over ranks instead of averaged.
         self.global_negatives = bool(global_negatives)
+        self._lr_iter = None              # batch counter driving the LR schedule when it differs from the optimizer-step count
+        self.batches_seen = 0
+        self._accum_open = False          # gradients of earlier batches are waiting in the flat buffer (backprop_freq > 1)
 
     # -------------------------------------------------------------- optimizer state
     def _ensure_state(self):
@@ -121,7 +124,8 @@ class Trainer:
         (main.py:137-139), so the k-th optimizer step (0-based) runs at lambda(max(k-1, 0)); self.iteration == k+1 here."""
         if self.iter_per_epoch is None:
             return self.args.lr
-        return self.args.lr * lr_multiplier(max(self.iteration - 2, 0), self.iter_per_epoch, self.args.epochs, self.warmup)
+        k = self.iteration - 1 if self._lr_iter is None else self._lr_iter      # batches seen before this one (args.iteration)
+        return self.args.lr * lr_multiplier(max(k - 1, 0), self.iter_per_epoch, self.args.epochs, self.warmup)
 
     def _lm_params(self):
         lm = self.online.bert
@@ -197,8 +201,8 @@ class Trainer:
     def optimizer_step(self, grad_scale=1.0):
         f, st = self._ensure_state()
         a = self.args
-        if a.clip_grad > 0:                            # per-parameter L2 clip, utils/train_utils.py:3-13
-            for p in f.params:
+        if a.clip_grad > 0:                            # per-parameter L2 clip, utils/train_utils.py:3-13 (language model included)
+            for p in list(f.params) + [q for _, q in self._lm_params()]:
                 if p.grad is not None:
                     coef = a.clip_grad / (p.grad.norm(2) * grad_scale + 1e-6)
                     p.grad.mul_(torch.clamp(coef, max=1.0))
@@ -214,6 +218,31 @@ class Trainer:
         if ema is not None:
             ema.shadow_epoch += 1
         self._lm_step(grad_scale)
+
+    def train_iteration(self, batch, idx):
+        """One iteration of the reference loop INCLUDING its gradient accumulation (train/main.py:112-139): backward every
+        batch; clip / optimizer step / zero_grad / EMA only when `idx % backprop_freq == 0` (idx = batch index inside the epoch,
+        so the first batch of an epoch always steps; accumulated gradients are summed, not averaged); the LR schedule advances
+        with every batch.  With backprop_freq == 1 this is `step`."""
+        freq = int(getattr(self.args, "backprop_freq", 1))
+        if freq <= 1:
+            return self.step(batch)
+        if not self._accum_open:
+            self.zero_grad()
+            self._accum_open = True
+        loss_dict = self.forward_backward(batch)
+        if idx % freq == 0:
+            world = dist.world_size()
+            if dist.active():
+                dist.allreduce_sum_(self.online.flat_grad())
+            self._lr_iter = self.batches_seen
+            try:
+                self.optimizer_step(grad_scale=1.0 if self.global_negatives else 1.0 / world)
+            finally:
+                self._lr_iter = None
+            self._accum_open = False
+        self.batches_seen += 1
+        return loss_dict
 
     def step(self, batch):
         """One optimizer step on an already device-resident batch (see to_device_batch).  With N>1 ranks the flat gradient
@@ -246,4 +275,5 @@ class Trainer:
             for w in pending:
                 w.wait()
         self.optimizer_step(grad_scale=1.0 if self.global_negatives else 1.0 / world)
+        self.batches_seen += 1
         return loss_dict

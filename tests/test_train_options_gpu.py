@@ -1,0 +1,74 @@
+"""The train-loop options of train/main.py:112-139,330-356 that the goldens do not exercise: per-parameter gradient clipping
+(utils/train_utils.py:3-13), the 'bce' optimisation policy, gradient accumulation (backprop_freq)."""
+import numpy as np
+import pytest
+import torch
+
+from temporalalignnet_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _trainer(seed=0, dtype="fp32", **akw):
+    from temporalalignnet_amd.train import Trainer, build_model, default_args
+    args = default_args(num_encoder_layers=2, num_decoder_layers=3, lr=1e-3, wd=1e-2, **akw)
+    torch.manual_seed(seed)
+    m = build_model(args, compute_dtype=dtype, random_pos_start=0).cuda()
+    return Trainer(m, args, iter_per_epoch=50, warmup=5), args
+
+
+def _batch(seed, B=4, T=16):
+    from temporalalignnet_amd.train import to_device_batch
+    return to_device_batch(synth.make_batch(seed, B=B, T=T, n_min=2, n_max=5))
+
+
+def test_per_parameter_gradient_clipping_matches_the_reference_rule():
+    tr, args = _trainer(model="init", clip_grad=0.05)
+    tr.iteration = 7
+    tr.zero_grad()
+    tr.forward_backward(_batch(1))
+    named = [(n, p) for n, p in tr.online.named_parameters() if p.grad is not None and p.grad.abs().max() > 0]
+    before = {n: (p.detach().clone(), p.grad.detach().clone()) for n, p in named}
+    assert any(g.norm() > 0.05 for _, g in before.values()) and any(g.norm() < 0.05 for _, g in before.values())
+    tr.optimizer_step()
+    lr = tr.current_lr()
+    for n, p in named:
+        w, g = before[n]
+        coef = 0.05 / (g.norm(2) + 1e-6)
+        g = g * coef if coef < 1 else g                                   # clip_gradients()
+        wd = 0.0 if any(t in n for t in (".ln_", ".bias")) else args.wd   # optim_policy()
+        ref = w.clone().requires_grad_(True)
+        ref.grad = g
+        opt = torch.optim.AdamW([ref], lr=lr, weight_decay=wd)
+        opt.state[ref] = {"step": torch.tensor(7.0), "exp_avg": torch.zeros_like(w), "exp_avg_sq": torch.zeros_like(w)}
+        opt.step()
+        torch.testing.assert_close(p.detach(), ref.detach(), rtol=1e-5, atol=1e-7, msg=n)
+
+
+def test_bce_policy_trains_the_alignability_head_only():
+    tr, args = _trainer(model="cotrain", optim_policy="bce", loss_threshold=0.5)
+    tr.iteration = 10                                   # past the warm-up: non-zero learning rate
+    before = {n: p.detach().clone() for n, p in tr.model.named_parameters()}
+    for s in range(2):
+        tr.step(_batch(10 + s, B=6))
+    changed = {n for n, p in tr.model.named_parameters() if not torch.equal(p.detach(), before[n])}
+    assert changed and all("binary_head" in n for n in changed), sorted(changed)[:5]      # online head + its EMA copy
+
+
+def test_gradient_accumulation_follows_the_reference_loop():
+    """backprop_freq = 2 over batches 0,1,2: step on batch 0 alone, then ONE step on the summed gradients of batches 1 and 2, with
+    the learning rate of the third iteration (the schedule advances per batch, the Adam step count per optimizer step)."""
+    batches = [_batch(20 + i) for i in range(3)]
+    ta, _ = _trainer(model="init", backprop_freq=2)
+    for i, b in enumerate(batches):
+        ta.train_iteration(b, i)
+    tb, _ = _trainer(model="init", backprop_freq=1)
+    tb.zero_grad(); tb.forward_backward(batches[0]); tb._lr_iter = 0; tb.optimizer_step()
+    tb.zero_grad(); tb.forward_backward(batches[1]); tb.forward_backward(batches[2]); tb._lr_iter = 2; tb.optimizer_step()
+    assert ta.iteration == tb.iteration == 2 and ta.batches_seen == 3
+    torch.testing.assert_close(ta.online.flat_parameters(), tb.online.flat_parameters(), rtol=1e-5, atol=2e-5)   # Adam on near-zero gradients: f32-atomic noise is a few % of one lr-sized (2e-4) update
+    # and it differs from stepping three times
+    tc, _ = _trainer(model="init", backprop_freq=1)
+    for b in batches:
+        tc.step(b)
+    assert (tc.online.flat_parameters() - ta.online.flat_parameters()).abs().max() > 1e-4
