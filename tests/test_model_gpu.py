@@ -126,3 +126,41 @@ def test_state_dict_keys_match_reference_layout():
     tw = TwinTemporalAligner(0.999, num_encoder_layers=1, num_decoder_layers=3, use_alignability_head=1, language_model=None)
     keys = set(tw.state_dict())
     assert len(keys) == 132 and all(k.startswith(("online.", "target.")) for k in keys)
+
+
+@gpu
+@pytest.mark.parametrize("text_pos,rps,dual", [(1, 1, 1), (0, 1, 0), (1, 0, 1)])
+def test_constructor_options_match_oracle(text_pos, rps, dual):
+    """use_text_pos_enc (tan_model.py:212-228), random_pos_start (the np.random draws of :163,195,224 in the reference's
+    order) and return_dual_feature=0: forward outputs and gradients vs the CPU oracle under the same numpy seed."""
+    from temporalalignnet_amd.tan_model import TemporalAligner
+    E, D = 2, 2
+    params = synth.make_params(404, E, D, True)
+    m = TemporalAligner(num_encoder_layers=E, num_decoder_layers=D, use_alignability_head=1, language_model=None,
+                        use_text_pos_enc=text_pos, random_pos_start=rps, return_dual_feature=dual)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    m.cuda()
+    b = synth.make_batch(31, B=3, T=32, n_min=2, n_max=6, video_pad_tail=4)
+    np.random.seed(77)
+    out = hip_forward(m, b)
+    assert ("dual_feature_video" in out) == bool(dual)
+    gen = torch.Generator().manual_seed(9)
+    ws = {k: torch.randn(v.shape, generator=gen) for k, v in out.items()}
+    sum((out[k] * ws[k].cuda()).sum() for k in out).backward()
+    p = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in params.items()}
+    tb = train_ref.to_torch_batch(b)
+    np.random.seed(77)
+    ref = tan_ref.forward(p, tb["video"], tb["text_embed"], tb["padding_mask"], tb["text_padding_mask"].bool(), E=E, D=D,
+                          use_alignability_head=True, use_text_pos_enc=bool(text_pos), random_pos_start=bool(rps),
+                          return_dual_feature=bool(dual))
+    assert set(ref) == set(out)
+    for k in ref:
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), ref[k].detach().numpy(), rtol=1e-4, atol=2e-5, err_msg=k)
+    sum((ref[k] * ws[k]).sum() for k in ref).backward()
+    for name in ("temporal_pos_embed", "text_temporal_pos_embed", "text_pre_proj.weight", "ln_position_init.weight"):
+        want, got = p[name].grad, dict(m.named_parameters())[name].grad
+        if want is None:
+            assert got is None or got.abs().max().item() == 0, name
+            continue
+        scale = want.abs().max().item() + 1e-6
+        assert (got.cpu() - want).abs().max().item() / scale < 2e-3, name
