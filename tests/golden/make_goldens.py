@@ -433,9 +433,17 @@ def g9_htm_loader():
     save("g9_htm_loader", **arrs)
 
 
+def g10_sine_pos():
+    """G10: get_position_embedding_sine(512, 1024) of model/tfm_model.py (pos_enc='sine', tan_model.py:60-61): corner block and
+    column / row checksums of the reference table."""
+    import tfm_model as ref_tfm
+    t = ref_tfm.get_position_embedding_sine(512, 1024).double()
+    save("g10_sine_pos", corner=t[:6, :10].numpy(), tail=t[-3:, -6:].numpy(), row_sum=t.sum(1).numpy(), col_sum=t.sum(0).numpy())
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     table = {"g1": g1_forward_small, "g2": g2_forward_e6d6, "g3": g3_loss_init, "g4": g4_loss_cotrain,
-             "g5": g5_train_steps, "g6": g6_eval_harness, "g7": g7_long_and_interp, "g8": g8_word2vec, "g9": g9_htm_loader}
+             "g5": g5_train_steps, "g6": g6_eval_harness, "g7": g7_long_and_interp, "g8": g8_word2vec, "g9": g9_htm_loader, "g10": g10_sine_pos}
     for w in which:
         table[w]()

@@ -97,3 +97,16 @@ def test_eval_auc_matches_sklearn():
     y = rng.randint(0, 2, 300)
     s = np.round(rng.randn(300), 1)
     assert roc_auc_score(y, s) == pytest.approx(metrics.roc_auc_score(y, s), abs=1e-12)
+
+
+def test_sine_position_table_matches_reference(golden):
+    """pos_enc='sine': the fixed table of model/tfm_model.py:get_position_embedding_sine (golden G10)."""
+    import numpy as np
+    from temporalalignnet_amd.tan_model import get_position_embedding_sine
+    g = golden("g10_sine_pos")
+    t = get_position_embedding_sine(512, 1024).double()
+    assert t.shape == (1024, 512)
+    np.testing.assert_allclose(t[:6, :10].numpy(), g["corner"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(t[-3:, -6:].numpy(), g["tail"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(t.sum(1).numpy(), g["row_sum"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(t.sum(0).numpy(), g["col_sum"], rtol=0, atol=1e-5)
