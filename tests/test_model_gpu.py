@@ -164,3 +164,40 @@ def test_constructor_options_match_oracle(text_pos, rps, dual):
             continue
         scale = want.abs().max().item() + 1e-6
         assert (got.cpu() - want).abs().max().item() / scale < 2e-3, name
+
+
+@gpu
+def test_feature_entry_points_match_oracle():
+    """get_visual_feature / get_textual_feature / get_textual_feature_with_time / get_joint_feature (the methods drivers and the
+    retrieval evaluation call directly, tan_model.py:152-234) vs the CPU oracle; TwinTemporalAligner routes them to `online`."""
+    from temporalalignnet_amd.tan_model import TwinTemporalAligner
+    E, D = 2, 3
+    params = synth.make_params(505, E, D, True)
+    tw = TwinTemporalAligner(0.999, num_encoder_layers=E, num_decoder_layers=D, use_alignability_head=1, language_model=None,
+                             random_pos_start=0)
+    tw.online.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    tw._copy_param()
+    tw.cuda()
+    b = synth.make_batch(41, B=3, T=32, n_min=2, n_max=6, video_pad_tail=5)
+    d = dev_batch(b)
+    tb = train_ref.to_torch_batch(b)
+    p = {k: torch.from_numpy(v) for k, v in params.items()}
+    tpad = tb["text_padding_mask"].bool()
+    with torch.no_grad():
+        vf = tw.get_visual_feature(d["video"], d["padding_mask"])
+        tf = tw.get_textual_feature(d["text_embed"])
+        tft = tw.get_textual_feature_with_time(d["text_embed"])
+        jv, jt = tw.get_joint_feature(d["video"], d["padding_mask"], tf, d["text_padding_mask"].bool())
+        ema = tw.forward_from_ema(d["video"], d["text_embed"], d["padding_mask"], d["text_padding_mask"].bool(), None)
+        onl = tw(d["video"], d["text_embed"], d["padding_mask"], d["text_padding_mask"].bool(), None)
+    rvf = tan_ref.visual_feature(tb["video"], tb["padding_mask"], p, E)
+    rtf = tan_ref.textual_feature(tb["text_embed"], p)
+    rtft = tan_ref.textual_feature_with_time(tb["text_embed"], p, 0)
+    rjv, rjt = tan_ref.joint_feature(tb["video"], tb["padding_mask"], rtf, tpad, p, D)
+    for got, want, name in ((vf, rvf, "visual"), (tf, rtf, "textual"), (tft, rtft, "textual+time"), (jv, rjv, "joint video"),
+                            (jt, rjt, "joint text")):
+        assert tuple(got.shape) == tuple(want.shape), name
+        valid = slice(None)
+        np.testing.assert_allclose(got.cpu().numpy()[valid], want.numpy()[valid], rtol=1e-4, atol=3e-5, err_msg=name)
+    for k in onl:                                         # target == online right after _copy_param
+        torch.testing.assert_close(ema[k], onl[k], rtol=0, atol=0, msg=k)
