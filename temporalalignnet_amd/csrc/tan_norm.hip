@@ -19,11 +19,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const T* xr = x + row * C;
-    float4 v[NCH];
+    // every load of the row is issued up front (x, the affine parameters, the optional addend -- read from x itself when there
+    // is none, so that no load sits behind a branch): behind the two reductions they were a dependent L2 round trip
+    const T* ar = add ? add + (long)(row % add_period) * C : xr;
+    const float amul = add ? 1.0f : 0.0f;
+    float4 v[NCH], gmm[NCH], bta[NCH], adv[NCH];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        v[i] = ld4(xr + (i * 64 + lane) * 4);
+        const int c = (i * 64 + lane) * 4;
+        v[i] = ld4(xr + c);
+        gmm[i] = *reinterpret_cast<const float4*>(gamma + c);
+        bta[i] = *reinterpret_cast<const float4*>(beta + c);
+        adv[i] = ld4(ar + c);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) * (1.0f / C);
@@ -38,20 +46,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         if (mean_o) mean_o[row] = mean;
         if (rstd_o) rstd_o[row] = rstd;
     }
-    const T* ar = add ? add + (long)(row % add_period) * C : nullptr;
     T* yr = y + row * C;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = (i * 64 + lane) * 4;
-        const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-        const float4 b = *reinterpret_cast<const float4*>(beta + c);
-        float4 o = make_float4(v[i].x * rstd * g.x + b.x, v[i].y * rstd * g.y + b.y, v[i].z * rstd * g.z + b.z,
-                               v[i].w * rstd * g.w + b.w);
-        if (ar) {
-            const float4 a = ld4(ar + c);
-            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-        }
-        st4(yr + c, o);
+        const float4 g = gmm[i], b = bta[i], a = adv[i];
+        st4(yr + c, make_float4(v[i].x * rstd * g.x + b.x + a.x * amul, v[i].y * rstd * g.y + b.y + a.y * amul,
+                                v[i].z * rstd * g.z + b.z + a.z * amul, v[i].w * rstd * g.w + b.w + a.w * amul));
     }
 }
 

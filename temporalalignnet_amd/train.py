@@ -124,7 +124,8 @@ class Trainer:
         (main.py:137-139), so the k-th optimizer step (0-based) runs at lambda(max(k-1, 0)); self.iteration == k+1 here."""
         if self.iter_per_epoch is None:
             return self.args.lr
-        k = self.iteration - 1 if self._lr_iter is None else self._lr_iter      # batches seen before this one (args.iteration)
+        lr_iter = getattr(self, "_lr_iter", None)
+        k = self.iteration - 1 if lr_iter is None else lr_iter                  # batches seen before this one (args.iteration)
         return self.args.lr * lr_multiplier(max(k - 1, 0), self.iter_per_epoch, self.args.epochs, self.warmup)
 
     def _lm_params(self):
