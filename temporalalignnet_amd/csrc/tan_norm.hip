@@ -285,9 +285,9 @@ __global__ __launch_bounds__(256) void colsum_generic_kernel(const T* __restrict
 }
 
 // grouped row copy / add: dst[(g*dgs + doff + r)*C + c] (=|+=) src[(g*sgs + soff + r)*C + c]
-template <typename T>
+template <typename T, bool ACC>
 __global__ __launch_bounds__(256) void rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int G, int R, int C,
-                                                   long sgs, long soff, long dgs, long doff, int accumulate) {
+                                                   long sgs, long soff, long dgs, long doff) {
     const long n4 = (long)G * R * C / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const long e = i * 4;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void rows_kernel(const T* __restrict__ src, T*
         const T* s = src + ((g * sgs + soff + r) * C + c);
         T* d = dst + ((g * dgs + doff + r) * C + c);
         float4 v = ld4(s);
-        if (accumulate) {
+        if constexpr (ACC) {                       // compile-time: both loads issue together
             const float4 o = ld4(d);
             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         }
@@ -309,18 +309,48 @@ __global__ __launch_bounds__(256) void rows_kernel(const T* __restrict__ src, T*
 // out[r][c] = sum_g x[(g*R + r)][c]   (broadcast-add backward: position embedding gradient)
 template <typename T>
 __global__ __launch_bounds__(256) void group_sum_kernel(const T* __restrict__ x, T* __restrict__ out, int G, int R, int C) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)R * C) return;
-    float s = 0.f;
-    for (int g = 0; g < G; ++g) s += ld_f(x + (long)g * R * C + i);
-    st_f(out + i, s);
+    // a lane owns 4 consecutive elements of the [R,C] plane, the 4 waves of a workgroup take the groups g = wave (mod 4);
+    // 4 group loads in flight per iteration (a plain g-loop compiles to one load + s_waitcnt vmcnt(0) per group)
+    __shared__ float4 part[4][64];
+    const long n = (long)R * C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long i = ((long)blockIdx.x * 64 + lane) * 4;
+    const long ic = i < n ? i : 0;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int g = wave;
+    for (; g + 12 < G; g += 16) {
+        const float4 a = ld4(x + (long)g * n + ic), b = ld4(x + (long)(g + 4) * n + ic);
+        const float4 c = ld4(x + (long)(g + 8) * n + ic), d = ld4(x + (long)(g + 12) * n + ic);
+        s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
+        s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
+    }
+    for (; g < G; g += 4) {
+        const float4 a = ld4(x + (long)g * n + ic);
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && i < n) {
+        const float4 p1 = part[1][lane], p2 = part[2][lane], p3 = part[3][lane];
+        st4(out + i, make_float4((s.x + p1.x) + (p2.x + p3.x), (s.y + p1.y) + (p2.y + p3.y), (s.z + p1.z) + (p2.z + p3.z),
+                                 (s.w + p1.w) + (p2.w + p3.w)));
+    }
 }
 
 // out[i] += sum_s parts[s][i]   (split-K partial tiles -> f32 gradient)
 __global__ __launch_bounds__(256) void reduce_add_kernel(const float* __restrict__ parts, float* __restrict__ out, int nparts, long n) {
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
         float4 a = *reinterpret_cast<const float4*>(out + i);
-        for (int s = 0; s < nparts; ++s) {
+        int s = 0;
+        for (; s + 4 <= nparts; s += 4) {                      // 4 partial tiles in flight (see group_sum_kernel)
+            const float4 p0 = *reinterpret_cast<const float4*>(parts + (long)s * n + i);
+            const float4 p1 = *reinterpret_cast<const float4*>(parts + (long)(s + 1) * n + i);
+            const float4 p2 = *reinterpret_cast<const float4*>(parts + (long)(s + 2) * n + i);
+            const float4 p3 = *reinterpret_cast<const float4*>(parts + (long)(s + 3) * n + i);
+            a.x += (p0.x + p1.x) + (p2.x + p3.x); a.y += (p0.y + p1.y) + (p2.y + p3.y);
+            a.z += (p0.z + p1.z) + (p2.z + p3.z); a.w += (p0.w + p1.w) + (p2.w + p3.w);
+        }
+        for (; s < nparts; ++s) {
             const float4 p = *reinterpret_cast<const float4*>(parts + (long)s * n + i);
             a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
         }
@@ -513,14 +543,19 @@ extern "C" int tan_rows_copy(const void* src, void* dst, int G, int R, int C, lo
     hipStream_t st = (hipStream_t)stream;
     const long n4 = (long)G * R * C / 4;
     const unsigned grid = (unsigned)min((long)4096, (long)cdiv(n4, 256));
-    DISPATCH_T(dtype, hipLaunchKernelGGL((rows_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)src, (T*)dst, G, R, C,
-                                         src_grp_rows, src_off, dst_grp_rows, dst_off, accumulate));
+    if (accumulate) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((rows_kernel<T, true>), dim3(grid), dim3(256), 0, st, (const T*)src, (T*)dst, G, R, C,
+                                             src_grp_rows, src_off, dst_grp_rows, dst_off));
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((rows_kernel<T, false>), dim3(grid), dim3(256), 0, st, (const T*)src, (T*)dst, G, R, C,
+                                             src_grp_rows, src_off, dst_grp_rows, dst_off));
+    }
     TAN_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int tan_group_sum(const void* x, void* out, int G, int R, int C, int dtype, void* stream) {
-    TAN_REQUIRE(x && out && G > 0 && R > 0 && C > 0);
+    TAN_REQUIRE(x && out && G > 0 && R > 0 && C > 0 && C % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype, hipLaunchKernelGGL((group_sum_kernel<T>), dim3(cdiv((long)R * C, 256)), dim3(256), 0, st, (const T*)x,
                                          (T*)out, G, R, C));

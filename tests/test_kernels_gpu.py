@@ -99,6 +99,18 @@ def test_small_helpers(dtype):
     gs = torch.empty(T, C, device="cuda", dtype=dtype)
     ops.group_sum(v, gs, B, T, C)
     close(gs, v.double().view(B, T, C).sum(0), 1e-5 if dtype == torch.float32 else 5e-2)
+    for G, R, Cc in ((1, 3, 12), (7, 5, 36), (16, 2, 512), (37, 9, 260), (128, 64, 512)):   # every wave / unroll remainder
+        xg = rnd((G * R, Cc), dtype, 20 + G)
+        gs = torch.empty(R, Cc, device="cuda", dtype=dtype)
+        ops.group_sum(xg, gs, G, R, Cc)
+        close(gs, xg.double().view(G, R, Cc).sum(0), 1e-4 if dtype == torch.float32 else 0.25)
+    if dtype == torch.float32:
+        for nparts, n in ((1, 1024), (3, 4096 + 8), (4, 640), (9, 70000), (16, 512 * 2048)):
+            parts = rnd((nparts, n), torch.float32, 40 + nparts)
+            o = rnd((n,), torch.float32, 60 + nparts)
+            want_o = o.double() + parts.double().sum(0)
+            ops.reduce_add(parts, o, nparts, n)
+            close(o, want_o, 1e-4)
     # cast round trip
     f = rnd((1000 + 3,), torch.float32, 12)
     h = torch.empty(1003, device="cuda", dtype=torch.bfloat16)
