@@ -447,6 +447,23 @@ __device__ __forceinline__ bf16x8 load_frag4(const char* lds_tile, int o0, int k
     }
 }
 
+// K-strided x K-strided stage of the 4-stage kernel: two 16-deep steps, reads issued by hand (see tr_tile)
+template <int OFF>
+__device__ __forceinline__ void tr_issue_step4(TrStep& s, const unsigned (&a_addr)[2], const unsigned (&b_addr)[2]) {
+    tr_issue<OFF>(s.a[0], a_addr[0]);
+    tr_issue<OFF>(s.a[1], a_addr[1]);
+    tr_issue<OFF + T4_BYTES>(s.b[0], b_addr[0]);
+    tr_issue<OFF + T4_BYTES>(s.b[1], b_addr[1]);
+}
+template <int CUR>
+__device__ __forceinline__ void tr_stage4(f32x16 (&acc)[2][2], const unsigned (&a_addr)[2], const unsigned (&b_addr)[2]) {
+    constexpr int BASE = CUR * 2 * T4_BYTES;
+    TrStep s0, s1;
+    tr_issue_step4<BASE>(s0, a_addr, b_addr);
+    tr_wait(s0); tr_issue_step4<BASE + 4096>(s1, a_addr, b_addr); tr_mma(acc, s0);
+    tr_wait(s1); tr_mma(acc, s1);
+}
+
 template <typename TC, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm_glds4_kernel(GemmArgs2 g) {
     __shared__ __attribute__((aligned(1024))) char lds[8 * T4_BYTES];   // [stage][A|B]
@@ -472,6 +489,9 @@ __global__ __launch_bounds__(256, 2) void gemm_glds4_kernel(GemmArgs2 g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
 
+    const unsigned tr_a[2] = {tr_lane_addr(lds, wm * 64, lane), tr_lane_addr(lds, wm * 64 + 32, lane)};
+    const unsigned tr_b[2] = {tr_lane_addr(lds, wn * 64, lane), tr_lane_addr(lds, wn * 64 + 32, lane)};
+
 #define G4_STAGE(T_, S_)                                                                                    \
     {                                                                                                       \
         stage_tile4<A_KC>(A, lda, m0, M, kbeg + (T_) * 32, lds + (S_) * 2 * T4_BYTES, wave, lane);          \
@@ -483,7 +503,8 @@ __global__ __launch_bounds__(256, 2) void gemm_glds4_kernel(GemmArgs2 g) {
     {                                                                                                       \
         const int t_ = (T_);                                                                                \
         G4_STAGE(min(t_ + 3, nt - 1), PRE)                                                                  \
-        _Pragma("unroll") for (int ks = 0; ks < 32; ks += 16) {                                             \
+        if constexpr (!A_KC && !B_KC) tr_stage4<CUR>(acc, tr_a, tr_b);                                      \
+        else _Pragma("unroll") for (int ks = 0; ks < 32; ks += 16) {                                        \
             bf16x8 a[2], b[2];                                                                              \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) a[i] = load_frag4<A_KC>(lds + (CUR) * 2 * T4_BYTES, wm * 64 + i * 32, ks, lane); \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
@@ -528,8 +549,13 @@ static int use_four_stage(const tan_gemm_desc* d, const GemmArgs2& a) {
     if (forced == 4) return 1;
     // measured (tools/gemm_shapes.py, 100 reps): the deeper prefetch pays when a CU holds ONE workgroup (<= ~1.5 tiles per CU:
     // the N=512 outputs, 11.3 vs 12.0 us at K=512, 25.0 vs 28.3 us at K=2048) and costs 3-12 % once two workgroups per CU hide
-    // each other's DMA latency (N >= 1536, or the 8192^3-class shapes: 870 vs 990 TF/s); K-strided layouts never use it
+    // each other's DMA latency (N >= 1536, or the 8192^3-class shapes: 870 vs 990 TF/s)
     const long wgs = (long)cdiv(d->M, GBM) * cdiv(d->N, GBN) * d->batch * d->split_k;
+    // K-strided x K-strided (dW, hand-issued transposing reads in both kernels): three tiles in flight are worth 3-9 % once the
+    // K-slice is long (tools/gemm_shapes.py: dW c_fc 35.7 -> 33.8 us, c_proj 35.8 -> 33.3 us at 8192 rows)
+    static int ks4 = -1;
+    if (ks4 < 0) { const char* e = getenv("TAN_GEMM_KS4"); ks4 = e ? atoi(e) : 1; }
+    if (!d->a_kc && !d->b_kc) return ks4 && a.kchunk >= 1024;
     return d->a_kc && d->b_kc && wgs <= 384 && a.kchunk >= 128;
 }
 
