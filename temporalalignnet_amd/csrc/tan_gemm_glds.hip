@@ -547,16 +547,19 @@ static int use_four_stage(const tan_gemm_desc* d, const GemmArgs2& a) {
     if (forced == -2) { const char* e = getenv("TAN_GEMM_STAGES"); forced = e ? atoi(e) : -1; }
     if (forced == 2) return 0;
     if (forced == 4) return 1;
-    // measured (tools/gemm_shapes.py, 100 reps): the deeper prefetch pays when a CU holds ONE workgroup (<= ~1.5 tiles per CU:
-    // the N=512 outputs, 11.3 vs 12.0 us at K=512, 25.0 vs 28.3 us at K=2048) and costs 3-12 % once two workgroups per CU hide
-    // each other's DMA latency (N >= 1536, or the 8192^3-class shapes: 870 vs 990 TF/s)
+    // K-contiguous x K-contiguous: stand-alone (tools/gemm_shapes.py, 100 reps) the deeper prefetch wins 6-12 % when a CU holds
+    // ONE workgroup (the N=512 outputs: 11.3 vs 12.0 us at K=512, 25.0 vs 28.3 us at K=2048) -- but inside the training step,
+    // where two stacks' kernels share the CUs and hide each other's DMA latency, it LOSES 2.4 % of the whole step (7.21 vs
+    // 7.04 ms, three interleaved A/B rounds), so it is off by default (TAN_GEMM_KC4=1: the stand-alone rule, =2: K >= 1024 only)
     const long wgs = (long)cdiv(d->M, GBM) * cdiv(d->N, GBN) * d->batch * d->split_k;
     // K-strided x K-strided (dW, hand-issued transposing reads in both kernels): three tiles in flight are worth 3-9 % once the
     // K-slice is long (tools/gemm_shapes.py: dW c_fc 35.7 -> 33.8 us, c_proj 35.8 -> 33.3 us at 8192 rows)
     static int ks4 = -1;
     if (ks4 < 0) { const char* e = getenv("TAN_GEMM_KS4"); ks4 = e ? atoi(e) : 1; }
     if (!d->a_kc && !d->b_kc) return ks4 && a.kchunk >= 1024;
-    return d->a_kc && d->b_kc && wgs <= 384 && a.kchunk >= 128;
+    static int kc4 = -1;
+    if (kc4 < 0) { const char* e = getenv("TAN_GEMM_KC4"); kc4 = e ? atoi(e) : 0; }
+    return kc4 && d->a_kc && d->b_kc && wgs <= 384 && a.kchunk >= (kc4 == 2 ? 1024 : 128);
 }
 
 template <typename TC>
