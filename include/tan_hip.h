@@ -49,6 +49,13 @@ int tan_abi_sizeof(int which);
 int tan_prof_enable(int on, int max_records);
 int tan_prof_collect(double* ms_by_kind, double* work_by_kind, long* count_by_kind, int nkinds);
 
+/* Stream-ordering events (no timing) for tan_encoder_desc.layer_done: the reference's DDP (end2end/main_nce.py:142-158) hooks
+ * autograd to start reducing a gradient bucket while backward continues; here one call runs a whole stack's backward, so the
+ * library records an event per layer and the caller makes its communication stream wait for it. */
+int tan_event_create(void** event);
+int tan_event_destroy(void* event);
+int tan_stream_wait_event(void* stream, void* event);
+
 /* ---- GEMM (nn.Linear fwd/bwd: tfm_model.py:21-27, tan_model.py:48-49,70; einsum tan_model.py:118,138) ----
  * C[M,N] (=|+=) alpha * opA(A)[M,K] * opB(B)[K,N]  (+ bias[N]) (activation) (+ residual[M,N])
  *   a_kc=1: A stored [M,K] (lda = row stride)   a_kc=0: A stored [K,M] (lda = stride between k)
@@ -278,6 +285,10 @@ typedef struct tan_encoder_desc {
     long dw_ws_floats;                          /* >= 32 * 4*C*C to cover every layer shape */
     const void* const* d_stage;                 /* HOST array [layers]: grad w.r.t. stage s ([R,C] dtype) or NULL */
     void* d_x0;                                 /* [R,C] out: grad w.r.t. x0 */
+    void* const* layer_done;                    /* HOST array [layers] of tan_event handles or NULL: layer_done[i] is recorded on
+                                                   the stream once every gradient of layer i's parameters is final (layers finish
+                                                   last to first) -- lets a data-parallel caller start reducing a layer's slice of
+                                                   the flat gradient while the earlier layers' backward still runs */
 } tan_encoder_desc;
 int tan_encoder_fwd(const tan_encoder_desc* e, void* stream);
 int tan_encoder_bwd(const tan_encoder_desc* e, void* stream);

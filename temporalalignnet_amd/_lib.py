@@ -92,4 +92,5 @@ class EncoderDesc(C.Structure):
         ("scr_dh", C.c_void_p), ("scr_dqkv", C.c_void_p), ("ln_ws", C.c_void_p),
         ("dw_ws", C.c_void_p), ("dw_ws_floats", C.c_long),
         ("d_stage", C.POINTER(C.c_void_p)), ("d_x0", C.c_void_p),
+        ("layer_done", C.POINTER(C.c_void_p)),
     ]

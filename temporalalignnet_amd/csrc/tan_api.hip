@@ -88,3 +88,21 @@ extern "C" int tan_prof_collect(double* ms_by_kind, double* work_by_kind, long* 
     p.n = 0;
     return dropped ? 1 : 0;   // 1 = record buffer filled up (later launches were not timed)
 }
+
+// ---- stream-ordering events for tan_encoder_desc.layer_done
+extern "C" int tan_event_create(void** event) {
+    TAN_REQUIRE(event);
+    hipEvent_t ev;
+    const hipError_t err = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (err != hipSuccess) return (int)err;
+    *event = (void*)ev;
+    return 0;
+}
+extern "C" int tan_event_destroy(void* event) {
+    TAN_REQUIRE(event);
+    return (int)hipEventDestroy((hipEvent_t)event);
+}
+extern "C" int tan_stream_wait_event(void* stream, void* event) {
+    TAN_REQUIRE(event);
+    return (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0);
+}

@@ -160,6 +160,11 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         float* next_b_proj = i > 0 ? e->params[i - 1].g_b_proj : nullptr;       // dx_in is layer i-1's x_out gradient
         CK(tan_layernorm_bwd(e->scr_dxn, x_in, p.ln1_g, b.mean1, b.rstd1, dx2, dx_in, p.g_ln1_g, p.g_ln1_b, next_b_proj, e->ln_ws, R,
                              C, dt, st));
+        // every gradient of layer i is final here (g_b_proj[i] was written during iteration i+1 / by the post-LN backward)
+        if (e->layer_done && e->layer_done[i]) {
+            const hipError_t err = hipEventRecord((hipEvent_t)e->layer_done[i], (hipStream_t)st);
+            if (err != hipSuccess) return (int)err;
+        }
     }
     return 0;
 }

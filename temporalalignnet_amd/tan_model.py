@@ -245,7 +245,17 @@ class TemporalAligner(nn.Module):
         self._issuer = None               # helper thread issuing the side-stream stack (see _on_side)
         self._lp_cache = {}
         self.transposed_dx = os.environ.get("TAN_TRANSPOSED_DX", "1") != "0"   # dX GEMMs read W^T copies (K-contiguous)
-        self._grad_ready_hook = None      # callable(tag) fired inside backward when a slice of the flat gradient is final
+        self._grad_ready_hook = None      # callable(tag, layer_events) fired inside backward once a stack's backward is enqueued
+        # load_state_dict copies into the parameter tensors, whose version counters are not the flat buffer's: the bf16
+        # shadow (and the W^T copies built from it) must be rebuilt from the f32 masters on the next forward
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_shadow())
+
+    def invalidate_shadow(self):
+        """Call after writing parameters in place other than through the optimizer kernel / load_state_dict (e.g.
+        `p.data.copy_(...)`): the next forward re-casts the bf16 shadow weights from the f32 masters."""
+        f = self.__dict__.get("_flat")
+        if f is not None:
+            f.shadow_version = -1
 
     # ------------------------------------------------------------------ init (tan_model.py:76-97)
     def initialize_parameters(self):
@@ -390,9 +400,27 @@ class TemporalAligner(nn.Module):
         d = self._enc_desc(er, x0, keypad, post_name)
         _lib.check(_lib.lib().tan_encoder_fwd(C.byref(d), ops._stream()), "tan_encoder_fwd")
 
+    def _layer_events(self, prefix, layers):
+        """tan_event handles (one per layer of a stack, created once) for tan_encoder_desc.layer_done; only used while a
+        `_grad_ready_hook` is installed (data-parallel training)."""
+        cache = self.__dict__.setdefault("_layer_event_cache", {})
+        evs = cache.get(prefix)
+        if evs is None or len(evs) != layers:
+            evs = []
+            for _ in range(layers):
+                h = C.c_void_p()
+                _lib.check(_lib.lib().tan_event_create(C.byref(h)), "tan_event_create")
+                evs.append(h.value)
+            cache[prefix] = evs
+        return evs
+
     def _encoder_bwd(self, er, x0, keypad, post_name, d_stage, d_x0):
         cd, dev, R = x0.dtype, x0.device, er.R
         d = self._enc_desc(er, x0, keypad, post_name)
+        if self._grad_ready_hook is not None:
+            evs = self._layer_events(er.prefix, er.layers)
+            ev_arr = (C.c_void_p * er.layers)(*evs)
+            d.layer_done = ev_arr
         scr = self._take_scratch(R, cd, dev)       # stream-ordered reuse: one backward at a time per model
         d.scr_dx, d.scr_dx2, d.scr_do, d.scr_dxn = (_vp(scr[k]) for k in ("dx", "dx2", "do", "dxn"))
         d.scr_dh, d.scr_dqkv = _vp(scr["dh"]), _vp(scr["dqkv"])
@@ -803,21 +831,21 @@ class TemporalAligner(nn.Module):
             # from THIS thread, video first (every rank must issue them in the same order), each in the stream context whose
             # work it has to wait for; they overlap whatever backward work is still running.
             if self._grad_ready_hook is not None:
-                self._grad_ready_hook("video")
+                self._grad_ready_hook("video", self._layer_events(ev.prefix, ev.layers))
             fut.result()
             if self._grad_ready_hook is not None:
                 with torch.cuda.stream(side):
-                    self._grad_ready_hook("joint")
+                    self._grad_ready_hook("joint", self._layer_events(ej.prefix, ej.layers))
             main.wait_stream(side)
         else:
             if any_j:
                 self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dst_j, d_xj)
                 if self._grad_ready_hook is not None:    # joint-stack gradients are final: DDP starts reducing them now
-                    self._grad_ready_hook("joint")
+                    self._grad_ready_hook("joint", self._layer_events(ej.prefix, ej.layers))
             if any_v:
                 self._encoder_bwd(ev, run["x0"], run["vmask"], "ln_video_post_enc", dst_v, d_x0)
                 if self._grad_ready_hook is not None:
-                    self._grad_ready_hook("video")
+                    self._grad_ready_hook("video", self._layer_events(ev.prefix, ev.layers))
         if any_j:
             if run["sv_video_j"] is not None:
                 d_x0j = torch.empty(R, Cw, dtype=cd, device=dev)

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import types
 
 import numpy as np
@@ -88,7 +89,7 @@ def embed_sentences(model, token_list):
 
 class Trainer:
     def __init__(self, model, args, *, betas=(0.9, 0.999), eps=1e-8, iter_per_epoch=None, warmup=1000, fused_loss=None,
-                 global_negatives=False):
+                 global_negatives=False, ddp_bucket_layers=None):
         self.model, self.args = model, args
         online = model.online if isinstance(model, TwinTemporalAligner) else model
         # logits-free similarity+NCE whenever the model runs in bf16 (the fused kernels are bf16-only)
@@ -105,6 +106,10 @@ class Trainer:
         self._lr_iter = None              # batch counter driving the LR schedule when it differs from the optimizer-step count
         self.batches_seen = 0
         self._accum_open = False          # gradients of earlier batches are waiting in the flat buffer (backprop_freq > 1)
+        # data parallelism: encoder layers per gradient all-reduce bucket (one layer = 12.6 MB of f32 gradient)
+        self.ddp_bucket_layers = max(1, int(os.environ.get("TAN_DDP_BUCKET_LAYERS", "2") if ddp_bucket_layers is None
+                                            else ddp_bucket_layers))
+        self._comm_streams = {}
 
     # -------------------------------------------------------------- optimizer state
     def _ensure_state(self):
@@ -127,6 +132,14 @@ class Trainer:
         lr_iter = getattr(self, "_lr_iter", None)
         k = self.iteration - 1 if lr_iter is None else lr_iter                  # batches seen before this one (args.iteration)
         return self.args.lr * lr_multiplier(max(k - 1, 0), self.iter_per_epoch, self.args.epochs, self.warmup)
+
+    def _comm_order_stream(self, device):
+        """The stream the gradient collectives are issued under: it only ever waits for layer events, so a bucket's all-reduce
+        is ordered after ITS layers and not after whatever else the compute streams have queued."""
+        st = self._comm_streams.get(device)
+        if st is None:
+            st = self._comm_streams[device] = torch.cuda.Stream(device=device)
+        return st
 
     def _lm_params(self):
         lm = self.online.bert
@@ -245,23 +258,50 @@ class Trainer:
         self.batches_seen += 1
         return loss_dict
 
+    def _ddp_buckets(self, tag, layers):
+        """[(lo, hi, last_layer)] in the order backward finishes them (last layers first): `bucket_layers` consecutive layers of
+        one stack per bucket; the bucket is final once layer `last_layer` (its lowest) is.  Cached per stack."""
+        cache = self.__dict__.setdefault("_bucket_cache", {})
+        key = (tag, layers, self.ddp_bucket_layers)
+        if key not in cache:
+            prefix = {"video": "video_temporal_encoder.", "joint": "joint_temporal_encoder."}[tag]
+            out, top = [], layers
+            while top > 0:
+                bot = max(0, top - self.ddp_bucket_layers)
+                spans = [self.online.flat_range(f"{prefix}resblocks.{i}.") for i in range(bot, top)]
+                lo, hi = min(sp[0] for sp in spans), max(sp[1] for sp in spans)
+                assert sum(sp[1] - sp[0] for sp in spans) == hi - lo, "layers of a stack are not contiguous in the flat buffer"
+                out.append((lo, hi, bot))
+                top = bot
+            slo, shi = self.online.flat_range(prefix)
+            assert all(slo <= lo and hi <= shi for lo, hi, _ in out)
+            cache[key] = out
+        return cache[key]
+
     def step(self, batch):
         """One optimizer step on an already device-resident batch (see to_device_batch).  With N>1 ranks the flat gradient
-        is summed over RCCL in pieces: each encoder stack's slice (45 % / 47 % of the bytes) is launched asynchronously from
-        inside backward as soon as that stack's backward is enqueued (video first, then joint -- the same order on every
-        rank) and overlaps the rest of backward; the few remaining tensors (embeddings, heads) follow at the end."""
+        is summed over RCCL in buckets that overlap backward: `tan_encoder_bwd` records an event per layer, and as soon as a
+        stack's backward is ENQUEUED the hook below issues one asynchronous all-reduce per `ddp_bucket_layers` layers
+        (~25 MB at 2 layers), each made to wait -- on the GPU -- only for the event of its lowest layer, so the reduction of
+        layers 5,4 runs while layers 3..0 are still being differentiated.  Order of issue is fixed (video buckets last layer
+        first, then joint buckets: identical on every rank); the few remaining tensors (embeddings, projections, heads,
+        post-LNs) follow at the end in one call."""
         self.zero_grad()
         world = dist.world_size()
         pending, done = [], []
         if dist.active():
             flat = self.online.flat_grad()
-            ranges = {"video": self.online.flat_range("video_temporal_encoder."),
-                      "joint": self.online.flat_range("joint_temporal_encoder.")}
+            comm = self._comm_order_stream(flat.device)
 
-            def hook(tag):
-                lo, hi = ranges[tag]
-                pending.append(dist.allreduce_sum_(flat[lo:hi], async_op=True))
-                done.append((lo, hi))
+            def hook(tag, layer_events):
+                for lo, hi, last in self._ddp_buckets(tag, len(layer_events)):
+                    # comm waits (on the GPU) for the event of the bucket's lowest layer; the process group's own stream
+                    # then waits for comm, i.e. for exactly the layers this bucket covers
+                    _lib.check(_lib.lib().tan_stream_wait_event(C.c_void_p(comm.cuda_stream), C.c_void_p(layer_events[last])),
+                               "tan_stream_wait_event")
+                    with torch.cuda.stream(comm):
+                        pending.append(dist.allreduce_sum_(flat[lo:hi], async_op=True))
+                    done.append((lo, hi))
             self.online._grad_ready_hook = hook
         try:
             loss_dict = self.forward_backward(batch)
@@ -270,6 +310,7 @@ class Trainer:
         if dist.active():
             pos = 0
             for lo, hi in sorted(done) + [(flat.numel(), flat.numel())]:     # whatever the hooks did not cover
+                assert lo >= pos, "overlapping gradient buckets"
                 if lo > pos:
                     dist.allreduce_sum_(flat[pos:lo])
                 pos = max(pos, hi)

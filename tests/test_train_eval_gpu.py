@@ -133,3 +133,24 @@ def test_steps_do_not_accumulate_device_memory():
             tr.step(b)
         torch.cuda.synchronize(); gc.collect()
         assert torch.cuda.memory_allocated() - before < (1 << 20), (kind, dtype, torch.cuda.memory_allocated() - before)
+
+
+def test_load_state_dict_into_a_used_model_refreshes_the_bf16_shadow():
+    """Regression: parameters are views of a flat f32 buffer and the bf16 weights the kernels read are a shadow of it;
+    load_state_dict writes through the parameter tensors (own version counters), so the shadow has to be invalidated
+    explicitly -- otherwise a model that already ran keeps computing with the old weights."""
+    from temporalalignnet_amd import synth
+    from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
+    args = default_args(model="init", num_encoder_layers=2, num_decoder_layers=2)
+    b = to_device_batch(synth.make_batch(5, B=4, T=32, n_min=3, n_max=6))
+    torch.manual_seed(0)
+    m = build_model(args, compute_dtype="bf16", random_pos_start=0).cuda()
+    state0 = {k: v.clone() for k, v in m.state_dict().items()}
+    tr = Trainer(m, args)
+    tr.iteration = 2000                                   # past warm-up: a visible update
+    l0 = tr.step(b)["loss"].item()
+    l1 = Trainer(m, args).forward_backward(b)["loss"].item()
+    assert abs(l1 - l0) > 1e-4                            # the step changed the weights
+    m.load_state_dict(state0)
+    l2 = Trainer(m, args).forward_backward(b)["loss"].item()
+    assert abs(l2 - l0) <= 1e-5 * max(1.0, abs(l0)), (l0, l1, l2)
