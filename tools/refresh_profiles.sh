@@ -10,4 +10,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer > /dev/null 2> $O/pmc_$c.err
 done
 python $R/tools/pmc_summary.py $(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json > $O/pmc_traffic.txt
-tail -1 $O/bench.json | cut -c1-400
+# ---- BASELINE configs[3]: len=256 (joint L = 272), B=32 -- streamed attention kernels, HBM GB/s per kernel
+cd $R; python bench.py --seq-len 256 --batch 32 --steps 20 --warmup 5 --no-cpu-baseline > $O/cfg4_bench.json 2> $O/cfg4_bench.err
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats4 -- python $R/bench.py --seq-len 256 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timer > /dev/null 2> $O/cfg4_under_rocprof.err
+cp $(find /tmp/prof_stats4 -name "*kernel_stats.csv" | head -1) $O/cfg4_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc4_$c -- python $R/bench.py --seq-len 256 --batch 32 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer > /dev/null 2> $O/cfg4_pmc_$c.err
+done
+python $R/tools/pmc_summary.py $(find /tmp/pmc4_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/pmc4_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/cfg4_pmc_traffic.json > $O/cfg4_pmc_traffic.txt
+tail -1 $O/bench.json | cut -c1-400; tail -1 $O/cfg4_bench.json | cut -c1-300
