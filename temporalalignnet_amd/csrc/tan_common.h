@@ -50,15 +50,59 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     *reinterpret_cast<uint2*>(p) = u;
 }
 
+// Wave-wide (64-lane) reductions, result in every lane.  `__shfl_xor` compiles to six dependent ds_bpermute_b32 (an LDS-crossbar
+// round trip each); here the four steps inside a row of 16 lanes are DPP modifiers of the add itself (quad_perm, row_half_mirror,
+// row_mirror) and the two cross-row steps are gfx950's v_permlane16_swap / v_permlane32_swap (with both operands = v, the swap
+// leaves [v.row0,v.row0,v.row2,v.row2] / [v.row1,v.row1,v.row3,v.row3], resp. [lo,lo] / [hi,hi]: their sum is the xor-16 / xor-32 step).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);     // row_half_mirror
+    v += dpp_move<0x140>(v);     // row_mirror
+    auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+    v = __int_as_float(r16[0]) + __int_as_float(r16[1]);
+    auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+    return __int_as_float(r32[0]) + __int_as_float(r32[1]);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_move<0xB1>(v));
+    v = fmaxf(v, dpp_move<0x4E>(v));
+    v = fmaxf(v, dpp_move<0x141>(v));
+    v = fmaxf(v, dpp_move<0x140>(v));
+    auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+    v = fmaxf(__int_as_float(r16[0]), __int_as_float(r16[1]));
+    auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+    return fmaxf(__int_as_float(r32[0]), __int_as_float(r32[1]));
+}
+
+// 8 consecutive bf16 <-> 8 floats (one 16-byte access per lane: the widest, and per byte the cheapest, global access)
+struct f8 { float v[8]; };
+__device__ __forceinline__ f8 ld8(const bf16_t* p) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    f8 r;
+    r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xffff0000u);
+    r.v[2] = __uint_as_float(u.y << 16); r.v[3] = __uint_as_float(u.y & 0xffff0000u);
+    r.v[4] = __uint_as_float(u.z << 16); r.v[5] = __uint_as_float(u.z & 0xffff0000u);
+    r.v[6] = __uint_as_float(u.w << 16); r.v[7] = __uint_as_float(u.w & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ void st8(bf16_t* p, const f8& a) {
+    uint4 u;
+    u.x = (uint32_t)f2bf(a.v[0]) | ((uint32_t)f2bf(a.v[1]) << 16);
+    u.y = (uint32_t)f2bf(a.v[2]) | ((uint32_t)f2bf(a.v[3]) << 16);
+    u.z = (uint32_t)f2bf(a.v[4]) | ((uint32_t)f2bf(a.v[5]) << 16);
+    u.w = (uint32_t)f2bf(a.v[6]) | ((uint32_t)f2bf(a.v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = u;
+}
+__device__ __forceinline__ f8 ld8f(const float* p) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    f8 r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
 }
 
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
