@@ -44,11 +44,51 @@ def make_sim_fn(model, embed_text, use_alignability_head=True):
     return get_text_visual_sim
 
 
+def make_batched_sim_fn(model, embed_text, use_alignability_head=True, max_windows=256):
+    """Batched counterpart of make_sim_fn for `test_alignment_htm(batched_sim=...)`: all windows of a video go through
+    `model.eval_windows` in chunks of `max_windows` (one pass of each stack per chunk instead of four B=1 passes per window).
+    `run(video [1,vlen,Dv], text list[str], windows [(s0, e0, bool mask [K])], seq_len)` returns, per window, the dict
+    `get_text_visual_sim` would have returned for it."""
+
+    @torch.no_grad()
+    def run(video, text_str, windows, seq_len):
+        dev = video.device
+        emb = embed_text(list(text_str))                                  # [K, 512]: sentences are embedded independently
+        out = []
+        for c0 in range(0, len(windows), max_windows):
+            chunk = windows[c0:c0 + max_windows]
+            W, kmax = len(chunk), max(int(m.sum()) for _, _, m in chunk)
+            vid = torch.zeros(W, seq_len, video.shape[-1], device=dev, dtype=video.dtype)
+            vmask = torch.ones(W, seq_len, dtype=torch.bool, device=dev)
+            txt = torch.zeros(W, kmax, emb.shape[-1], device=dev, dtype=emb.dtype)
+            tmask = torch.ones(W, kmax, dtype=torch.bool, device=dev)
+            for w, (s0, e0, m) in enumerate(chunk):
+                k = int(m.sum())
+                vid[w, :e0 - s0] = video[0, s0:e0]
+                vmask[w, :e0 - s0] = False
+                txt[w, :k] = emb[torch.from_numpy(m).to(dev)]
+                tmask[w, :k] = False
+            r = model.eval_windows(vid, txt, vmask, tmask)
+            sim_j = r["sim"].transpose(-1, -2) / 0.07                     # [W,S,K,T]
+            sim_d = r["dual-sim"].transpose(-1, -2) / 0.07
+            for w, (s0, e0, m) in enumerate(chunk):
+                k, t = int(m.sum()), e0 - s0
+                d = {"sim": sim_j[w:w + 1, :, :k, :t], "dual-sim": sim_d[w:w + 1, :, :k, :t]}
+                if use_alignability_head:
+                    d["alignability-dual"] = r["alignability-dual"][w:w + 1, :k]
+                    d["alignability-joint"] = r["alignability-joint"][w:w + 1, :, :k]
+                out.append(d)
+        return out
+
+    return run
+
+
 @torch.no_grad()
 def test_alignment_htm(get_text_visual_sim, videos, device="cuda", seq_len=64, use_alignability_head=True,
-                       method="overlap-seq", return_per_video=False):
+                       method="overlap-seq", return_per_video=False, batched_sim=None):
     """`videos`: iterable of {'video' [vlen, Dv], 'start' [K], 'end' [K], 'aligned' [K] 0/1, 'str' list[str]}
-    (htm_align.json schema, htm_align/readme.md:11-20).  Returns {'Recall', 'AUC'}."""
+    (htm_align.json schema, htm_align/readme.md:11-20).  Returns {'Recall', 'AUC'}.  `batched_sim` (make_batched_sim_fn): the
+    windows of a video are evaluated together instead of one model call per window (same results, see the GPU tests)."""
     recall, scores, tgts, per_video = [], [], [], []
     for item in videos:
         video = torch.as_tensor(item["video"]).float().to(device)[None]
@@ -66,6 +106,7 @@ def test_alignment_htm(get_text_visual_sim, videos, device="cuda", seq_len=64, u
             cnt = torch.zeros(K, vlen, device=device)
             a_d, a_j, tcnt = (torch.zeros(K, device=device) for _ in range(3))
             na_idx, na_mid = np.arange(K)[~aligned], mid[~aligned]
+            windows = []
             for i, s0 in enumerate(steps):
                 inside = (s0 - seq_len <= na_mid) & (na_mid <= s0 + 2 * seq_len)
                 act = na_idx[inside]
@@ -80,9 +121,15 @@ def test_alignment_htm(get_text_visual_sim, videos, device="cuda", seq_len=64, u
                 m[left:right + 1] = True
                 if not m.any():
                     continue
+                windows.append((int(s0), int(min(vlen, s0 + seq_len)), m))
+            if batched_sim is not None:
+                results = batched_sim(video, text, windows, seq_len)
+            else:
+                results = (get_text_visual_sim(video[:, s0:e0], [t for t, k in zip(text, m) if k],
+                                               abs_text_pos=abs_pos[torch.from_numpy(m).to(device)][None])
+                           for s0, e0, m in windows)
+            for (s0, e0, m), r in zip(windows, results):
                 mt = torch.from_numpy(m).to(device)
-                e0 = min(vlen, s0 + seq_len)
-                r = get_text_visual_sim(video[:, s0:e0], [t for t, k in zip(text, m) if k], abs_text_pos=abs_pos[mt][None])
                 if use_alignability_head:
                     a_d[mt] += r["alignability-dual"][0, :, 0]
                     a_j[mt] += r["alignability-joint"][0, 2, :, 0]

@@ -965,8 +965,9 @@ class TemporalAligner(nn.Module):
             return interpolate_from[0], interpolate_from[1]
         return interpolate_from, None
 
-    def _eval_joint(self, video_embed, lang_embed, interpolate_from):
-        """shared by get_text_visual_sim_joint / get_alignability: zero masks, joint stack on (video, text)."""
+    def _eval_joint(self, video_embed, lang_embed, interpolate_from, video_padding_mask=None, lang_padding_mask=None):
+        """shared by get_text_visual_sim_joint / get_alignability: joint stack on (video, text); the reference passes zero
+        masks (tan_model.py:246-247,296-297), the batched evaluation passes the padding of its stacked windows."""
         vi, ti = self._split_interp(interpolate_from)
         self._ensure_flat()
         B, T, _ = video_embed.shape
@@ -977,7 +978,7 @@ class TemporalAligner(nn.Module):
         else:
             lang_t, _ = self._text_embed(lang_c, False, 0, None, False)
         x0, _ = self._video_embed(video_c, self._draw(T, vi), vi, False)
-        ej = self._run_joint_stack(x0, lang_t, None, None, B, T, N)
+        ej = self._run_joint_stack(x0, lang_t, self._mask_u8(video_padding_mask), self._mask_u8(lang_padding_mask), B, T, N)
         return ej, lang_c, B, T, N
 
     def _within_sample_sim(self, vn, tn, S, B, T, N, t_stage_stride):
@@ -1039,6 +1040,49 @@ class TemporalAligner(nn.Module):
         ops.head_fwd(jt, w, b, a_j, S * B * N, WIDTH)
         return {"alignability-dual": a_d.view(B, N, 1), "alignability-joint": a_j.view(S, B, N, 1).permute(1, 0, 2, 3)}
 
+    @torch.no_grad()
+    def eval_windows(self, video_embed, lang_embed, video_padding_mask=None, lang_padding_mask=None, interpolate_from=None):
+        """Everything the evaluation closure of train/main.py:171-189 asks of the model, for a BATCH of windows in one pass of each
+        stack: {'sim' [B,S_d,T,K], 'dual-sim' [B,S_e,T,K], 'alignability-dual' [B,K,1], 'alignability-joint' [B,S_d,K,1]} (raw
+        cosines / logits; the closure transposes and divides by 0.07).  The reference evaluates window by window at B=1 and runs
+        the joint stack twice per window (get_text_visual_sim_joint + get_alignability) -- ~600 launches of a few microseconds each,
+        latency-bound on any GPU; here the windows of a video are stacked, short last windows / unequal sentence counts are
+        padded and masked as attention keys (a masked key has probability exactly 0, so real rows are unaffected)."""
+        ej, lang_c, B, T, N = self._eval_joint(video_embed, lang_embed, interpolate_from, video_padding_mask, lang_padding_mask)
+        vi, _ = self._split_interp(interpolate_from)
+        Sd, Se, L, cd, dev = self.num_decoder_layers, self.num_encoder_layers, T + N, self.compute_dtype, video_embed.device
+        vn = torch.empty(Sd, B * T, WIDTH, dtype=cd, device=dev)
+        tn = torch.empty(Sd, B * N, WIDTH, dtype=cd, device=dev)
+        for s in range(Sd):
+            ops.l2norm_fwd(ej.stage(s), vn[s], None, B * T, WIDTH, T, L, 0)
+            ops.l2norm_fwd(ej.stage(s), tn[s], None, B * N, WIDTH, N, L, T)
+        out = {"sim": self._within_sample_sim(vn, tn, Sd, B, T, N, True)}
+        lang_raw, _ = self._text_embed(lang_c, False, 0, None, False)
+        if self.use_alignability_head:
+            w, b = self._f("binary_head.weight").view(-1), self._f("binary_head.bias")
+            a_d = torch.empty(B * N, device=dev)
+            ops.head_fwd(lang_raw, w, b, a_d, B * N, WIDTH)
+            jt = torch.empty(Sd, B * N, WIDTH, dtype=cd, device=dev)
+            for s in range(Sd):
+                ops.rows_copy(ej.stage(s), jt[s], B, N, WIDTH, L, T, N, 0)
+            a_j = torch.empty(Sd, B * N, device=dev)
+            ops.head_fwd(jt, w, b, a_j, Sd * B * N, WIDTH)
+            out["alignability-dual"] = a_d.view(B, N, 1)
+            out["alignability-joint"] = a_j.view(Sd, B, N, 1).permute(1, 0, 2, 3)
+        self._release_ws(ej)
+        # dual encoder on the same windows
+        video_c, _ = self._prep_inputs(video_embed, None)
+        x0, _ = self._video_embed(video_c, self._draw(T, vi), vi, False)
+        ev = self._run_video_stack(x0, self._mask_u8(video_padding_mask), B, T)
+        vd = torch.empty(Se, B * T, WIDTH, dtype=cd, device=dev)
+        td = torch.empty(B * N, WIDTH, dtype=cd, device=dev)
+        for s in range(Se):
+            ops.l2norm_fwd(ev.stage(s), vd[s], None, B * T, WIDTH)
+        ops.l2norm_fwd(lang_raw, td, None, B * N, WIDTH)
+        self._release_ws(ev)
+        out["dual-sim"] = self._within_sample_sim(vd, td, Se, B, T, N, False)
+        return out
+
     # checkpoint compatibility: the released checkpoint spells the language model `lang_model.` (train/main.py:467-469)
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         for k in list(state_dict.keys()):
@@ -1065,6 +1109,7 @@ class TwinTemporalAligner(nn.Module):
         self.get_text_visual_sim_joint = self.online.get_text_visual_sim_joint
         self.get_text_visual_sim_dual = self.online.get_text_visual_sim_dual
         self.get_alignability = self.online.get_alignability
+        self.eval_windows = self.online.eval_windows
         self.target.random_pos_start = 0
 
     @property
@@ -1082,6 +1127,7 @@ class TwinTemporalAligner(nn.Module):
         for po, pt in zip(self.online.parameters(), self.target.parameters()):
             pt.data.copy_(po.data)
             pt.requires_grad = False
+        self.target.invalidate_shadow()         # the copies went through the parameter tensors, not the flat buffer
 
     @torch.no_grad()
     def _momentum_update(self):

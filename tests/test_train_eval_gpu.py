@@ -92,6 +92,61 @@ def test_g6_eval_harness(golden):
         np.testing.assert_allclose(pv["score"].numpy(), g[f"v{i}/align_score"], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("max_windows", [256, 3])
+def test_g6_eval_harness_with_batched_windows(golden, max_windows):
+    """The batched evaluation (all windows of a video through `eval_windows`: one pass of each stack, short windows and
+    unequal sentence counts padded + masked) must reproduce the reference's window-by-window numbers -- the same golden."""
+    from temporalalignnet_amd.eval_align import make_batched_sim_fn, make_sim_fn, test_alignment_htm
+    from temporalalignnet_amd.tan_model import TemporalAligner
+    g = golden("g6_eval_harness")
+    m = TemporalAligner(1, 3, use_alignability_head=1, random_pos_start=0, language_model=None)
+    load(m, synth.make_params(108, 1, 3, True))
+    m.cuda().eval()
+    videos = synth.align_videos()
+    emb = {s: torch.from_numpy(e).cuda() for v in videos for s, e in zip(v["str"], v["emb"])}
+    embed = lambda strs: torch.stack([emb[s] for s in strs])
+    metric, per_video = test_alignment_htm(None, videos, return_per_video=True,
+                                           batched_sim=make_batched_sim_fn(m, embed, max_windows=max_windows))
+    assert metric["Recall"] == pytest.approx(float(g["Recall"]), abs=1e-12)
+    assert metric["AUC"] == pytest.approx(float(g["AUC"]), abs=1e-9)
+    ref_metric, ref_pv = test_alignment_htm(make_sim_fn(m, embed), videos, return_per_video=True)
+    for i, pv in enumerate(per_video):
+        al = torch.from_numpy(np.asarray(videos[i]["aligned"]).astype(bool))
+        assert (pv["argmax"].numpy() == g[f"v{i}/argmax"]).all()
+        np.testing.assert_allclose(pv["sim"][al].numpy(), g[f"v{i}/sim_aligned"], rtol=1e-4, atol=2e-4)
+        np.testing.assert_allclose(pv["score"].numpy(), g[f"v{i}/align_score"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(pv["sim"].numpy(), ref_pv[i]["sim"].numpy(), rtol=1e-4, atol=2e-4)   # every sentence
+
+
+def test_batched_eval_in_bf16_agrees_with_window_by_window_and_is_faster():
+    import time
+    from temporalalignnet_amd.eval_align import make_batched_sim_fn, make_sim_fn, test_alignment_htm
+    from temporalalignnet_amd.train import build_model, default_args
+    args = default_args(model="init", num_encoder_layers=3, num_decoder_layers=3, use_alignability_head=1)
+    torch.manual_seed(3)
+    m = build_model(args, compute_dtype="bf16", random_pos_start=0).cuda().eval()
+    videos = synth.align_videos()
+    emb = {s: torch.from_numpy(e).cuda() for v in videos for s, e in zip(v["str"], v["emb"])}
+    embed = lambda strs: torch.stack([emb[s] for s in strs])
+    out = {}
+    for name, kw in (("window", dict(get_text_visual_sim=make_sim_fn(m, embed))),
+                     ("batched", dict(get_text_visual_sim=None, batched_sim=make_batched_sim_fn(m, embed)))):
+        test_alignment_htm(videos=videos, return_per_video=True, **kw)           # warm-up (workspaces)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        metric, pv = test_alignment_htm(videos=videos, return_per_video=True, **kw)
+        torch.cuda.synchronize()
+        out[name] = (metric, pv, time.perf_counter() - t0)
+    (m0, pv0, t_w), (m1, pv1, t_b) = out["window"], out["batched"]
+    print(f"eval harness: window-by-window {t_w * 1e3:.1f} ms, batched {t_b * 1e3:.1f} ms")
+    for a, b in zip(pv0, pv1):
+        # logits are cosines / 0.07 in bf16: one bf16 ulp of a feature moves them by ~1e-2
+        assert (a["sim"] - b["sim"]).abs().max() <= 0.25
+        assert (a["argmax"] == b["argmax"]).float().mean() >= 0.9
+    assert abs(m0["AUC"] - m1["AUC"]) <= 0.05
+    assert t_b < t_w
+
+
 def test_lr_schedule_lag_matches_reference_lambda_lr():
     """Replays the reference's LambdaLR usage (train/main.py:495-499,137-139) with torch on a dummy parameter."""
     import functools
