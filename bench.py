@@ -88,9 +88,16 @@ def cpu_baseline(a, args_ns):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (the driver's own launch line, same flags)
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+                                   "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29517"),
+                                   os.path.abspath(__file__)] + sys.argv[1:])
     from temporalalignnet_amd import _lib, dist, synth
     from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
     world, rank, local = dist.init_from_env()
+    if a.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); reporting n_gpus={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     torch.cuda.set_device(local)
