@@ -51,8 +51,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--stage", type=int, default=1, choices=[1, 2], help="1 = 'init' NCE only; 2 = 'cotrain'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-steps", type=int, default=12, help="timed CPU-oracle steps (~1 s each at the default --cpu-batch: a 10-15 s sample)")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--global-negatives", action="store_true", help="row f3: NCE negatives from every rank (W similarity sweeps)")
     ap.add_argument("--no-kernel-timer", action="store_true")
