@@ -110,3 +110,26 @@ def test_sine_position_table_matches_reference(golden):
     np.testing.assert_allclose(t[-3:, -6:].numpy(), g["tail"], rtol=0, atol=1e-7)
     np.testing.assert_allclose(t.sum(1).numpy(), g["row_sum"], rtol=0, atol=1e-5)
     np.testing.assert_allclose(t.sum(0).numpy(), g["col_sum"], rtol=0, atol=1e-5)
+
+
+def test_ddp_gradient_buckets_tile_each_stack_on_cpu():
+    """Host logic of the overlapped gradient reduction (Trainer._ddp_buckets): per-layer ranges of the flat gradient grouped
+    into buckets, last layers first, disjoint and covering the stack -- no GPU involved."""
+    from temporalalignnet_amd.train import Trainer, build_model, default_args
+    args = default_args(model="init", num_encoder_layers=6, num_decoder_layers=6)
+    model = build_model(args, compute_dtype="bf16")
+    for bucket_layers in (1, 2, 4, 6, 7):
+        tr = Trainer(model, args, ddp_bucket_layers=bucket_layers)
+        covered = 0
+        for tag, prefix in (("video", "video_temporal_encoder."), ("joint", "joint_temporal_encoder.")):
+            b = tr._ddp_buckets(tag, 6)
+            assert len(b) == -(-6 // bucket_layers)
+            assert [x[2] for x in b] == sorted((x[2] for x in b), reverse=True) and b[-1][2] == 0
+            lo_s, hi_s = tr.online.flat_range(prefix)
+            spans = sorted((lo, hi) for lo, hi, _ in b)
+            assert spans[0][0] == lo_s and spans[-1][1] == hi_s
+            assert all(x[1] == y[0] for x, y in zip(spans, spans[1:]))
+            per_layer = 3 * 512 * 512 + 3 * 512 + 512 * 512 + 512 + 2 * 4 * 512 * 512 + 4 * 512 + 512 + 4 * 512   # 12 tensors
+            assert hi_s - lo_s >= 6 * per_layer
+            covered += hi_s - lo_s
+        assert 0.9 < covered / tr.online._flat.total < 0.95              # the two stacks: 92 % of the gradient bytes
