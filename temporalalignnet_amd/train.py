@@ -87,6 +87,19 @@ def embed_sentences(model, token_list):
     return text_embed, pad
 
 
+def uncovered_ranges(done, total):
+    """[lo, hi) pieces of [0, total) that none of the `done` ranges covers; overlapping `done` ranges are an error (a slice of
+    the gradient would be summed over ranks twice)."""
+    out, pos = [], 0
+    for lo, hi in sorted(done) + [(total, total)]:
+        if lo < pos:
+            raise ValueError(f"overlapping gradient buckets at {lo} < {pos}")
+        if lo > pos:
+            out.append((pos, lo))
+        pos = max(pos, hi)
+    return out
+
+
 class Trainer:
     def __init__(self, model, args, *, betas=(0.9, 0.999), eps=1e-8, iter_per_epoch=None, warmup=1000, fused_loss=None,
                  global_negatives=False, ddp_bucket_layers=None):
@@ -308,12 +321,8 @@ class Trainer:
         finally:
             self.online._grad_ready_hook = None
         if dist.active():
-            pos = 0
-            for lo, hi in sorted(done) + [(flat.numel(), flat.numel())]:     # whatever the hooks did not cover
-                assert lo >= pos, "overlapping gradient buckets"
-                if lo > pos:
-                    dist.allreduce_sum_(flat[pos:lo])
-                pos = max(pos, hi)
+            for lo, hi in uncovered_ranges(done, flat.numel()):              # whatever the hooks did not cover
+                dist.allreduce_sum_(flat[lo:hi])
             for w in pending:
                 w.wait()
         self.optimizer_step(grad_scale=1.0 if self.global_negatives else 1.0 / world)

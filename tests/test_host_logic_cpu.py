@@ -133,3 +133,13 @@ def test_ddp_gradient_buckets_tile_each_stack_on_cpu():
             assert hi_s - lo_s >= 6 * per_layer
             covered += hi_s - lo_s
         assert 0.9 < covered / tr.online._flat.total < 0.95              # the two stacks: 92 % of the gradient bytes
+
+
+def test_uncovered_gradient_ranges():
+    from temporalalignnet_amd.train import uncovered_ranges
+    assert uncovered_ranges([], 10) == [(0, 10)]
+    assert uncovered_ranges([(0, 10)], 10) == []
+    assert uncovered_ranges([(6, 8), (2, 4)], 10) == [(0, 2), (4, 6), (8, 10)]
+    assert uncovered_ranges([(2, 4), (4, 10)], 10) == [(0, 2)]
+    with pytest.raises(ValueError):
+        uncovered_ranges([(2, 6), (4, 8)], 10)
