@@ -1,0 +1,87 @@
+"""Two REAL ranks through `Trainer.step` on one MI355X: both processes use cuda:0 and the gloo backend (RCCL refuses two ranks
+on one device; gloo all-reduces CUDA tensors through pinned host memory), so everything above the transport is the production
+path -- per-rank batches, the per-layer events recorded inside tan_encoder_bwd, the bucketed asynchronous all-reduces issued
+under the communication-order stream, the trailing remainder, the 1/world scale in the AdamW kernel.  Checked against ONE
+process that runs the two batches one after the other into the same flat gradient (sum) and steps with grad_scale = 1/2
+(averaged per-rank gradients of the local-batch loss)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+B, T = 8, 32
+
+
+def _setup(seed_batch, kind, layers, bucket):
+    from temporalalignnet_amd import synth
+    from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
+    args = default_args(model=kind, num_encoder_layers=layers, num_decoder_layers=layers,
+                        loss_threshold=0.5 if kind == "cotrain" else 0.0)
+    torch.manual_seed(0)
+    model = build_model(args, compute_dtype="bf16", random_pos_start=0).cuda()
+    if kind == "cotrain":
+        model._copy_param()
+    tr = Trainer(model, args, ddp_bucket_layers=bucket)
+    tr.iteration = 2000                                      # past warm-up
+    batch = to_device_batch(synth.make_batch(seed_batch, B=B, T=T, n_min=3, n_max=7))
+    return tr, batch
+
+
+def _worker(rank, world, port, out_dir, kind, layers, bucket):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as tdist
+    from temporalalignnet_amd import dist
+    torch.cuda.set_device(0)
+    w, r, _ = dist.init_from_env(backend="gloo")
+    assert (w, r) == (world, rank) and dist.active()
+    tr, batch = _setup(100 + rank, kind, layers, bucket)
+    dist.broadcast_(tr.online.flat_parameters())
+    tr.online.invalidate_shadow()
+    ld = tr.step(batch)
+    torch.cuda.synchronize()
+    torch.save({"loss": ld["loss"].item(), "grad": tr.online.flat_grad().cpu(), "param": tr.online._flat.flat.cpu()},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    tdist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,layers,bucket", [("init", 2, 1), ("cotrain", 3, 2)])
+def test_two_ranks_equal_one_process_with_both_batches(tmp_path, kind, layers, bucket):
+    ctx = mp.get_context("spawn")
+    port = 29600 + (os.getpid() + layers) % 1000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), kind, layers, bucket)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(2))
+    # both ranks hold the same reduced gradient and the same parameters after the step
+    assert torch.equal(r0["grad"], r1["grad"])
+    assert torch.equal(r0["param"], r1["param"])
+    # ---- one process, both batches
+    tr, b0 = _setup(100, kind, layers, bucket)
+    _, b1 = _setup(101, kind, layers, bucket)
+    tr.zero_grad()
+    l0 = tr.forward_backward(b0)["loss"].item()
+    l1 = tr.forward_backward(b1)["loss"].item()            # gradients accumulate in the flat buffer
+    g = tr.online.flat_grad().clone().cpu()
+    tr.optimizer_step(grad_scale=0.5)
+    torch.cuda.synchronize()
+    assert abs(l0 - r0["loss"]) <= 1e-4 * max(1.0, abs(l0)) and abs(l1 - r1["loss"]) <= 1e-4 * max(1.0, abs(l1))
+    f = tr.online._flat
+    for n in f.names:                                        # every parameter tensor: summed over the two ranks, once
+        o, k, _ = f.off[n]
+        a, b = r0["grad"][o:o + k], g[o:o + k]
+        assert (a - b).norm() <= 2e-2 * b.norm() + 1e-7, (n, float((a - b).norm()), float(b.norm()))
+    lr = tr.current_lr()
+    dp = (r0["param"] - f.flat.cpu()).abs()
+    # Adam with zero moments at step 2001: |update| = lr * 0.1 / sqrt(0.001 / (1 - 0.999**2001)) = 2.94 lr, so a noise-level gradient
+    # whose sign differs between the two runs moves a parameter by up to 5.9 lr; nothing else may differ
+    assert dp.max() <= 6.0 * lr + 1e-7
+    assert (dp > 0.1 * lr).float().mean() < 0.01
