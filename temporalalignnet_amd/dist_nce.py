@@ -137,6 +137,10 @@ def _reduce_scatter(parts):
     W, r = _world()
     if not dist.is_initialized():
         return parts[0]
+    if dist.get_backend() == "gloo":          # no reduce-scatter in gloo (CPU / single-GPU test transport): all-reduce + own slice
+        full = parts.contiguous()
+        dist.all_reduce(full, op=dist.ReduceOp.SUM)
+        return full[r].clone()
     out = torch.empty_like(parts[0])
     dist.reduce_scatter_tensor(out, parts.contiguous(), op=dist.ReduceOp.SUM)
     return out

@@ -85,3 +85,68 @@ def test_two_ranks_equal_one_process_with_both_batches(tmp_path, kind, layers, b
     # whose sign differs between the two runs moves a parameter by up to 5.9 lr; nothing else may differ
     assert dp.max() <= 6.0 * lr + 1e-7
     assert (dp > 0.1 * lr).float().mean() < 0.01
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Row f3: negatives from every rank.  The reference semantics is simply "the loss at B = W * B_local on one device"
+# (tan_model.py:118,138), so two ranks holding the halves of a batch must reproduce ONE process on the whole batch:
+# loss = sum of the rank losses, gradient = sum of the rank gradients (grad_scale 1).
+GB = 12
+
+
+def _slice(batch, lo, hi):
+    import numpy as np
+    return {k: (v[lo:hi] if isinstance(v, (np.ndarray, list)) else v) for k, v in batch.items()}
+
+
+def _gn_setup(global_negatives):
+    from temporalalignnet_amd import synth
+    from temporalalignnet_amd.train import Trainer, build_model, default_args
+    args = default_args(model="init", num_encoder_layers=2, num_decoder_layers=2)
+    torch.manual_seed(0)
+    model = build_model(args, compute_dtype="bf16", random_pos_start=0).cuda()
+    tr = Trainer(model, args, global_negatives=global_negatives, ddp_bucket_layers=1)
+    tr.iteration = 2000
+    return tr, synth.make_batch(300, B=GB, T=32, n_min=3, n_max=7)
+
+
+def _gn_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as tdist
+    from temporalalignnet_amd import dist
+    from temporalalignnet_amd.train import to_device_batch
+    torch.cuda.set_device(0)
+    dist.init_from_env(backend="gloo")
+    tr, full = _gn_setup(True)
+    lo, hi = dist.shard_range(GB, world, rank)
+    ld = tr.step(to_device_batch(_slice(full, lo, hi)))
+    torch.cuda.synchronize()
+    torch.save({"loss": ld["loss"].item(), "grad": tr.online.flat_grad().cpu()}, os.path.join(out_dir, f"gn{rank}.pt"))
+    dist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_two_ranks_with_global_negatives_equal_one_process_on_the_whole_batch(tmp_path):
+    from temporalalignnet_amd.train import to_device_batch
+    ctx = mp.get_context("spawn")
+    port = 29700 + os.getpid() % 1000
+    procs = [ctx.Process(target=_gn_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    r0, r1 = (torch.load(tmp_path / f"gn{r}.pt") for r in range(2))
+    assert torch.equal(r0["grad"], r1["grad"])
+    tr, full = _gn_setup(False)                               # local negatives on the WHOLE batch = the global semantics
+    tr.zero_grad()
+    loss = tr.forward_backward(to_device_batch(full))["loss"].item()
+    g = tr.online.flat_grad().cpu()
+    assert abs((r0["loss"] + r1["loss"]) - loss) <= 2e-3 * max(1.0, abs(loss)), (r0["loss"], r1["loss"], loss)
+    f = tr.online._flat
+    for n in f.names:
+        o, k, _ = f.off[n]
+        a, b = r0["grad"][o:o + k], g[o:o + k]
+        assert (a - b).norm() <= 4e-2 * b.norm() + 1e-6, (n, float((a - b).norm()), float(b.norm()))
+
