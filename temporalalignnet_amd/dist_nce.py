@@ -19,7 +19,9 @@ each rank divides its local sums by the GLOBAL number of rows / sentences that o
 the rank losses and gradients are summed (not averaged) over ranks (`Trainer(global_negatives=True)` passes grad_scale=1).
 
 `BlockNCE` holds one rank's state and exposes the phases; `_GlobalNCEFn` strings them together with torch.distributed
-collectives (RCCL over xGMI when the tensors are on MI355X GPUs).  Batch-global statistics of the stage-2 extras (quantiles of
+collectives (RCCL over xGMI when the tensors are on MI355X GPUs).  Every rank must present the same B_local and the same
+padded sentence count N per step (the all-gathers exchange equal-shaped blocks): pad `text_embed` / `text_padding_mask` to the
+loader's maximum when the per-batch maximum can differ between ranks.  Batch-global statistics of the stage-2 extras (quantiles of
 loss.py:191-194,286,315-320) stay local to the rank: only the NCE core is made global here.
 """
 from __future__ import annotations
