@@ -484,8 +484,11 @@ __global__ __launch_bounds__(64 * NKB) void attn_fwd_short_kernel(AttnArgs a) {
     }
 }
 
+// launch bound "2 waves per SIMD": without it hipcc kept the accumulators in 128 AGPRs next to 131-148 VGPRs (259-276 registers
+// per lane -> ONE wave per SIMD, one workgroup per CU, four rounds of 1024 workgroups); with it 186 / 214 VGPRs, no spill, two
+// workgroups per CU: 7.01 -> 6.89 ms per step.  (Three waves per SIMD at L = 64 needs an 80-byte spill and gains nothing.)
 template <int NKB>
-__global__ __launch_bounds__(64 * NKB) void attn_bwd_short_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * NKB, 2) void attn_bwd_short_kernel(AttnArgs a) {
     constexpr int LP = 32 * NKB;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* Qi = smem; char* Ki = Qi + LP * 128; char* Vi = Ki + LP * 128; char* Di = Vi + LP * 128;
@@ -808,7 +811,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_long_kernel(AttnArgs a) {
 }
 
 // dk, dv: workgroup = 128 keys, loop over query blocks
-__global__ __launch_bounds__(256) void attn_bwd_dkv_long_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_long_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(1024))) char smem[3 * LBLK * 128 + 3 * LBLK * 4];
     char* Ki = smem; char* Vi = Ki + LBLK * 128;           // only until the wave's K / V fragments are in registers
     char* Qi = smem; char* Di = Qi + LBLK * 128; char* Oi = Di + LBLK * 128;

@@ -155,7 +155,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
 }
 
 template <typename T, typename TC, bool A_KC, bool B_KC, bool FAST>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     typedef GemmCfg<T> Cfg;
     constexpr int BK = Cfg::BK;
     constexpr int NV = BM * BK * (int)sizeof(T) / 16 / 256;  // staging vectors per thread per operand
