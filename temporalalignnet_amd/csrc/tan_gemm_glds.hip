@@ -542,6 +542,114 @@ __global__ __launch_bounds__(256, 2) void gemm_glds4_kernel(GemmArgs2 g) {
     else epilogue2<TC, true>(g, acc, C, R, AUX, m0, n0, wm, wn, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Grouped weight-gradient GEMM: up to four problems gw_p[M_p,N_p] (partials) = dy_p[rows,M_p]^T x_p[rows,N_p] (both operands
+// K-strided, the four Linear layers of one encoder block) in ONE launch of (sum of tiles) x (K slices) workgroups.  Launched one
+// by one, each of the four is split 4-16 ways just to fill the chip and pays launch, first-tile latency and drain per slice
+// (9 of the ~12 us of a short slice); together 192 tiles x 2 slices fill it with 64-80 K-steps each.
+// Same pipeline as gemm_glds4_kernel<float, false, false> (three tiles in flight, hand-issued transposing reads).
+struct GroupedDwArgs {
+    const bf16_t* A[4]; const bf16_t* B[4]; float* C[4];
+    int accumulate;                  // 1: C += (single K slice straight into the gradient), 0: C = (partial planes)
+    int M[4], N[4];
+    int tile_end[4];                 // running sum of tiles
+    long plane[4];                   // M_p * N_p: stride between the K-slice partial planes of problem p
+    int nprob, kchunk, K;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_dw_grouped_kernel(GroupedDwArgs ga) {
+    __shared__ __attribute__((aligned(1024))) char lds[8 * T4_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-contiguous tile order inside one K slice (see work_item); slices are blockIdx.y
+    const int T = gridDim.x;
+    int t;
+    {
+        const int id = blockIdx.x, xcd = id & 7, q = T >> 3, r = T & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    int p = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p += (i + 1 < ga.nprob && t >= ga.tile_end[i]) ? 1 : 0;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const int t0 = p ? ga.tile_end[p - 1] : 0;
+    const int M = ga.M[p], N = ga.N[p];
+    const int ntn = (N + GBN - 1) / GBN;
+    const int lt = t - t0, n0 = (lt % ntn) * GBN, m0 = (lt / ntn) * GBM;
+    const int split = blockIdx.y;
+    const int kbeg = split * ga.kchunk, kend = min(ga.K, kbeg + ga.kchunk);
+    const int nt = (kend - kbeg) / 32;
+    const long lda = M, ldb = N;
+    const bf16_t* A = ga.A[p];
+    const bf16_t* B = ga.B[p];
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
+    const unsigned tr_a[2] = {tr_lane_addr(lds, wm * 64, lane), tr_lane_addr(lds, wm * 64 + 32, lane)};
+    const unsigned tr_b[2] = {tr_lane_addr(lds, wn * 64, lane), tr_lane_addr(lds, wn * 64 + 32, lane)};
+
+#define GD_STAGE(T_, S_)                                                                                     \
+    {                                                                                                        \
+        stage_tile4<false>(A, lda, m0, M, kbeg + (T_) * 32, lds + (S_) * 2 * T4_BYTES, wave, lane);          \
+        stage_tile4<false>(B, ldb, n0, N, kbeg + (T_) * 32, lds + (S_) * 2 * T4_BYTES + T4_BYTES, wave, lane); \
+    }
+#define GD_STEP(T_, CUR, PRE)                                                                                \
+    {                                                                                                        \
+        const int t_ = (T_);                                                                                 \
+        GD_STAGE(min(t_ + 3, nt - 1), PRE)                                                                   \
+        tr_stage4<CUR>(acc, tr_a, tr_b);                                                                     \
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                          \
+        __builtin_amdgcn_s_barrier();                                                                        \
+    }
+    if (nt > 0) {
+        GD_STAGE(0, 0)
+        GD_STAGE(min(1, nt - 1), 1)
+        GD_STAGE(min(2, nt - 1), 2)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int tt = 0; tt < nt; tt += 4) {
+            GD_STEP(tt, 0, 3)
+            if (tt + 1 < nt) GD_STEP(tt + 1, 1, 0)
+            if (tt + 2 < nt) GD_STEP(tt + 2, 2, 1)
+            if (tt + 3 < nt) GD_STEP(tt + 3, 3, 2)
+        }
+    }
+#undef GD_STEP
+#undef GD_STAGE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    GemmArgs2 g{};                       // what the shared epilogue reads
+    g.M = M; g.N = N; g.ldc = N; g.ldr = N; g.alpha = 1.0f; g.act = TAN_ACT_NONE; g.vec_epi = 1;
+    float* C = ga.C[p] + (long)split * ga.plane[p];
+    epilogue_vec<float>(g, acc, reinterpret_cast<float*>(lds), C, ga.accumulate ? C : nullptr, nullptr, m0, n0, wm, wn, lane, tid);
+}
+
+// host side: returns -2 when the group is not eligible (caller runs the problems one by one)
+int gemm_dw_grouped(int nprob, const void* const* dy, const void* const* x, float* const* parts, const int* Ms, const int* Ns,
+                    long rows, int split, int accumulate, hipStream_t st) {
+    if (nprob < 1 || nprob > 4 || split < 1 || (accumulate && split != 1) || rows % split != 0 || (rows / split) % 32 != 0) return -2;
+    GroupedDwArgs ga{};
+    int tiles = 0;
+    for (int p = 0; p < nprob; ++p) {
+        if (Ms[p] % 8 || Ns[p] % 8 || ((uintptr_t)dy[p] | (uintptr_t)x[p] | (uintptr_t)parts[p]) % 16) return -2;
+        ga.A[p] = (const bf16_t*)dy[p]; ga.B[p] = (const bf16_t*)x[p]; ga.C[p] = parts[p];
+        ga.M[p] = Ms[p]; ga.N[p] = Ns[p];
+        tiles += cdiv(Ms[p], GBM) * cdiv(Ns[p], GBN);
+        ga.tile_end[p] = tiles;
+        ga.plane[p] = (long)Ms[p] * Ns[p];
+    }
+    for (int p = nprob; p < 4; ++p) { ga.tile_end[p] = tiles; ga.A[p] = ga.A[0]; ga.B[p] = ga.B[0]; ga.C[p] = ga.C[0]; ga.M[p] = ga.M[0]; ga.N[p] = ga.N[0]; }
+    ga.nprob = nprob; ga.kchunk = (int)(rows / split); ga.K = (int)rows; ga.accumulate = accumulate;
+    hipLaunchKernelGGL(gemm_dw_grouped_kernel, dim3(tiles, split), dim3(256), 0, st, ga);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
 static int use_four_stage(const tan_gemm_desc* d, const GemmArgs2& a) {
     static int forced = -2;
     if (forced == -2) { const char* e = getenv("TAN_GEMM_STAGES"); forced = e ? atoi(e) : -1; }
