@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16x8_kernel(const bf16_t* __rest
 
 // ATOMIC = false: per-block partial table ws[block][3][C] (folded by ln_bwd_finalize); ATOMIC = true: the block adds its column
 // sums straight into dgamma / dbeta / dx_colsum (each may be NULL) with f32 atomics -- no second kernel, no workspace.
-template <bool ATOMIC>
+template <bool ATOMIC, int RPI>
 __global__ __launch_bounds__(256) void ln_bwd_bf16x8_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                             const float* __restrict__ rstd_i, const bf16_t* __restrict__ dres,
@@ -195,38 +195,45 @@ __global__ __launch_bounds__(256) void ln_bwd_bf16x8_kernel(const bf16_t* __rest
     const bf16_t* rsrc = dres ? dres : x;                   // unconditional third load (see ln_bwd_kernel)
     const float rmul = dres ? 1.0f : 0.0f;
     const long stride = (long)gridDim.x * ROWS_PER_BLOCK;
-    // two rows per iteration, all six loads up front; the second row of the last pair may not exist: clamped + weight 0
-    for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + w; row < rows; row += 2 * stride) {
-        const long row1 = row + stride;
-        const float w1 = row1 < rows ? 1.0f : 0.0f;
-        const long r1 = row1 < rows ? row1 : row;
-        const f8 xa = ld8(x + row * C + c), da = ld8(dy + row * C + c), ra = ld8(rsrc + row * C + c);
-        const f8 xb = ld8(x + r1 * C + c), dbv = ld8(dy + r1 * C + c), rb = ld8(rsrc + r1 * C + c);
-        const float mean_a = mean_i[row], rstd_a = rstd_i[row], mean_b = mean_i[r1], rstd_b = rstd_i[r1];
-        f8 xha, ga, xhb, gb;
-        float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+    // RPI rows per iteration, all 3*RPI row loads up front (a block is alone on its CU in the atomic mode: the latency has to be
+    // covered inside the wave); rows past the end are clamped to the first row of the group and weighted 0
+    for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + w; row < rows; row += RPI * stride) {
+        f8 xv[RPI], dv[RPI], rv[RPI];
+        float mean[RPI], rstd[RPI], wgt[RPI];
+        long rr[RPI];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            xha.v[j] = (xa.v[j] - mean_a) * rstd_a;
-            ga.v[j] = da.v[j] * gm.v[j];
-            s1a += ga.v[j]; s2a += ga.v[j] * xha.v[j];
-            xhb.v[j] = (xb.v[j] - mean_b) * rstd_b;
-            gb.v[j] = dbv.v[j] * gm.v[j];
-            s1b += gb.v[j]; s2b += gb.v[j] * xhb.v[j];
-            dg.v[j] += da.v[j] * xha.v[j] + w1 * (dbv.v[j] * xhb.v[j]);
-            db.v[j] += da.v[j] + w1 * dbv.v[j];
+        for (int q = 0; q < RPI; ++q) {
+            const long rq = row + q * stride;
+            wgt[q] = rq < rows ? 1.0f : 0.0f;
+            rr[q] = rq < rows ? rq : row;
+            xv[q] = ld8(x + rr[q] * C + c); dv[q] = ld8(dy + rr[q] * C + c); rv[q] = ld8(rsrc + rr[q] * C + c);
+            mean[q] = mean_i[rr[q]]; rstd[q] = rstd_i[rr[q]];
         }
-        const float m1a = wave_sum(s1a) * (1.0f / C), m2a = wave_sum(s2a) * (1.0f / C);
-        const float m1b = wave_sum(s1b) * (1.0f / C), m2b = wave_sum(s2b) * (1.0f / C);
-        f8 oa, ob;
+        float s1[RPI], s2[RPI];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            oa.v[j] = rstd_a * (ga.v[j] - m1a - xha.v[j] * m2a) + ra.v[j] * rmul;
-            ob.v[j] = rstd_b * (gb.v[j] - m1b - xhb.v[j] * m2b) + rb.v[j] * rmul;
-            ds.v[j] += oa.v[j] + w1 * ob.v[j];
+        for (int q = 0; q < RPI; ++q) {
+            s1[q] = 0.f; s2[q] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xv[q].v[j] = (xv[q].v[j] - mean[q]) * rstd[q];              // xhat
+                const float d = dv[q].v[j];
+                dv[q].v[j] = d * gm.v[j];                                    // g = dy * gamma
+                s1[q] += dv[q].v[j]; s2[q] += dv[q].v[j] * xv[q].v[j];
+                dg.v[j] += wgt[q] * (d * xv[q].v[j]);
+                db.v[j] += wgt[q] * d;
+            }
         }
-        st8(dx + row * C + c, oa);
-        if (row1 < rows) st8(dx + row1 * C + c, ob);
+#pragma unroll
+        for (int q = 0; q < RPI; ++q) {
+            const float m1 = wave_sum(s1[q]) * (1.0f / C), m2 = wave_sum(s2[q]) * (1.0f / C);
+            f8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o.v[j] = rstd[q] * (dv[q].v[j] - m1 - xv[q].v[j] * m2) + rv[q].v[j] * rmul;
+                ds.v[j] += wgt[q] * o.v[j];
+            }
+            if (row + q * stride < rows) st8(dx + rr[q] * C + c, o);
+        }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { red[w][0][c + j] = dg.v[j]; red[w][1][c + j] = db.v[j]; red[w][2][c + j] = ds.v[j]; }
@@ -625,13 +632,13 @@ extern "C" int tan_layernorm_bwd(const void* dy, const void* x, const float* gam
     static const int atomic_blocks = [] { const char* e = getenv("TAN_LN_ATOMIC"); return e ? atoi(e) : 256; }();
     if (dtype == TAN_BF16 && C == 512 && aligned16(dy, x, dres, dx, gamma) && atomic_blocks > 0) {
         const int nb = (int)min((long)atomic_blocks, (long)cdiv(rows, ROWS_PER_BLOCK));
-        hipLaunchKernelGGL(ln_bwd_bf16x8_kernel<true>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean,
+        hipLaunchKernelGGL((ln_bwd_bf16x8_kernel<true, 4>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean,
                            rstd, (const bf16_t*)dres, (bf16_t*)dx, ws, rows, dgamma, dbeta, dx_colsum);
         TAN_LAUNCH_CHECK();
         return 0;
     }
     if (dtype == TAN_BF16 && C == 512 && aligned16(dy, x, dres, dx, gamma)) {
-        hipLaunchKernelGGL(ln_bwd_bf16x8_kernel<false>, dim3(nblk), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean,
+        hipLaunchKernelGGL((ln_bwd_bf16x8_kernel<false, 2>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean,
                            rstd, (const bf16_t*)dres, (bf16_t*)dx, ws, rows, nullptr, nullptr, nullptr);
     } else {
         DISPATCH_T(dtype, DISPATCH_NCH(C, hipLaunchKernelGGL((ln_bwd_kernel<T, NCH>), dim3(nblk), dim3(256), 0, st, (const T*)dy,
