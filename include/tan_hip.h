@@ -45,7 +45,8 @@ int tan_abi_sizeof(int which);
 #define TAN_PROF_ATTN_FWD 8
 #define TAN_PROF_ATTN_BWD 9
 #define TAN_PROF_SIMNCE 10
-#define TAN_PROF_NKINDS 11
+#define TAN_PROF_PANEL 11 /* row-panel fused kernels (tan_mlp_*, tan_attnblock_*) */
+#define TAN_PROF_NKINDS 12
 int tan_prof_enable(int on, int max_records);
 int tan_prof_collect(double* ms_by_kind, double* work_by_kind, long* count_by_kind, int nkinds);
 
@@ -299,6 +300,36 @@ int tan_encoder_bwd(const tan_encoder_desc* e, void* stream);
 int tan_linear_wgrad(const void* dy, const void* x, float* gw, long M, int N, int K, float* ws, long ws_floats, int dtype,
                      void* stream);
 
+/* ---- row-panel fused kernels: one launch per half block ("fused layer") ------------------------
+ * A workgroup owns a 64-row panel of the residual stream and keeps it in LDS while the weights stream past it from L2; the
+ * weights are PRE-PACKED (once per optimizer step) into the LDS image of the tiles the kernels consume, in consumption order.
+ * tan_pack_weights: entry i packs the row-major bf16 matrix src[src_off ..] of shape [N][K] (the nn.Linear layout, or a W^T
+ *   copy) into dst[dst_off ..] as tiles [TN][TK] in (n-block, k-block) order; TN*TK*2 bytes must be 16384, TK in {16,32,64}
+ *   (kernels here: TN=256,TK=32 for N > 512, TN=512,TK=16 for N == 512).  `table` is DEVICE memory; max_tiles = the largest
+ *   N/TN * K/TK of the table. */
+typedef struct tan_pack_entry { long src_off, dst_off; int N, K, TN, TK; } tan_pack_entry;
+int tan_pack_weights(const void* src, void* dst, const tan_pack_entry* table, int n, int max_tiles, void* stream);
+
+/* tan_mlp_fwd: the MLP half of ResidualAttentionBlock_Step.forward (model/tfm_model.py:23-27,37) for rows % 64 == 0, bf16:
+ *   xn2 = LN2(x_mid) ; h = QuickGELU(xn2 W_fc^T + b_fc) ; x_out = x_mid + h W_proj^T + b_proj ; xn_next = LN_next(x_out)
+ * xn2 / mean2 / rstd2 / h_pre / h_act are saved for backward (h_pre / h_act may be NULL: not stored); xn_next (optional) is the
+ * NEXT block's ln_1 output (= this block's deep-supervision feature, tfm_model.py:48-55) or the stack's post-LN.
+ * pw_fc = packed c_fc.weight [2048][512] (TN=256,TK=32), pw_proj = packed c_proj.weight [512][2048] (TN=512,TK=16).      */
+typedef struct tan_mlp_desc {
+    long rows; int C, FF;                    /* 512, 2048 */
+    const void* x_mid;                       /* [rows, C] bf16 */
+    const float *ln_g, *ln_b;                /* ln_2 */
+    const void *pw_fc, *pw_proj;
+    const float *b_fc, *b_proj;
+    void* xn2; float *mean2, *rstd2;         /* out */
+    void *h_pre, *h_act;                     /* out [rows, FF] bf16 or NULL */
+    void* x_out;                             /* out [rows, C] */
+    const float *nln_g, *nln_b;              /* optional fused LayerNorm of x_out */
+    void* xn_next; float *nmean, *nrstd;
+    float eps;
+    int variant;                             /* 0; (1: stream only, 2: no streaming -- timing experiments, results undefined) */
+} tan_mlp_desc;
+int tan_mlp_fwd(const tan_mlp_desc* d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,22 @@ class LayerBufs(C.Structure):
         "xn1", "qkv", "attn_o", "x_mid", "xn2", "h_pre", "h_act", "x_out", "mean1", "rstd1", "mean2", "rstd2", "lse")]
 
 
+class PackEntry(C.Structure):
+    _fields_ = [("src_off", C.c_long), ("dst_off", C.c_long), ("N", C.c_int), ("K", C.c_int), ("TN", C.c_int), ("TK", C.c_int)]
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [
+        ("rows", C.c_long), ("C", C.c_int), ("FF", C.c_int),
+        ("x_mid", C.c_void_p), ("ln_g", C.c_void_p), ("ln_b", C.c_void_p),
+        ("pw_fc", C.c_void_p), ("pw_proj", C.c_void_p), ("b_fc", C.c_void_p), ("b_proj", C.c_void_p),
+        ("xn2", C.c_void_p), ("mean2", C.c_void_p), ("rstd2", C.c_void_p),
+        ("h_pre", C.c_void_p), ("h_act", C.c_void_p), ("x_out", C.c_void_p),
+        ("nln_g", C.c_void_p), ("nln_b", C.c_void_p), ("xn_next", C.c_void_p), ("nmean", C.c_void_p), ("nrstd", C.c_void_p),
+        ("eps", C.c_float), ("variant", C.c_int),
+    ]
+
+
 class EncoderDesc(C.Structure):
     _fields_ = [
         ("dtype", C.c_int), ("B", C.c_int), ("L", C.c_int), ("C", C.c_int), ("H", C.c_int), ("layers", C.c_int),

@@ -15,13 +15,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int WAVE = 64;
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-// round-to-nearest-even, NaN kept quiet
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// round-to-nearest-even, NaN kept quiet: gfx950's v_cvt_pk_bf16_f32 (one instruction per PAIR; the integer emulation it replaces
+// was ~7 VALU operations per element and made every bf16 epilogue VALU-bound)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {      // bf16(lo) | bf16(hi) << 16
+    f32x2_t v;
+    v[0] = lo; v[1] = hi;
+    const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+    uint32_t u;
+    __builtin_memcpy(&u, &b, 4);
+    return u;
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(f2bf2(f, 0.0f) & 0xffffu); }
 
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {
@@ -45,8 +51,8 @@ __device__ __forceinline__ float4 ld4(const bf16_t* p) {
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     uint2 u;
-    u.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-    u.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    u.x = f2bf2(v.x, v.y);
+    u.y = f2bf2(v.z, v.w);
     *reinterpret_cast<uint2*>(p) = u;
 }
 
@@ -92,10 +98,10 @@ __device__ __forceinline__ f8 ld8(const bf16_t* p) {
 }
 __device__ __forceinline__ void st8(bf16_t* p, const f8& a) {
     uint4 u;
-    u.x = (uint32_t)f2bf(a.v[0]) | ((uint32_t)f2bf(a.v[1]) << 16);
-    u.y = (uint32_t)f2bf(a.v[2]) | ((uint32_t)f2bf(a.v[3]) << 16);
-    u.z = (uint32_t)f2bf(a.v[4]) | ((uint32_t)f2bf(a.v[5]) << 16);
-    u.w = (uint32_t)f2bf(a.v[6]) | ((uint32_t)f2bf(a.v[7]) << 16);
+    u.x = f2bf2(a.v[0], a.v[1]);
+    u.y = f2bf2(a.v[2], a.v[3]);
+    u.z = f2bf2(a.v[4], a.v[5]);
+    u.w = f2bf2(a.v[6], a.v[7]);
     *reinterpret_cast<uint4*>(p) = u;
 }
 __device__ __forceinline__ f8 ld8f(const float* p) {
@@ -110,6 +116,22 @@ __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf
 __device__ __forceinline__ float quick_gelu_grad(float x) {
     float s = 1.0f / (1.0f + __expf(-1.702f * x));
     return s + 1.702f * x * s * (1.0f - s);
+}
+
+// bf16-output variants: v_exp_f32 + v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 VALU operations); the results
+// are rounded to bf16 anyway.  The f32 parity mode keeps the exact forms above.
+__device__ __forceinline__ float quick_gelu_fast(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
+}
+__device__ __forceinline__ float quick_gelu_grad_fast(float x) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
+    return s + 1.702f * x * s * (1.0f - s);
+}
+template <typename TC> __device__ __forceinline__ float quick_gelu_t(float x) {
+    if constexpr (sizeof(TC) == 2) return quick_gelu_fast(x); else return quick_gelu(x);
+}
+template <typename TC> __device__ __forceinline__ float quick_gelu_grad_t(float x) {
+    if constexpr (sizeof(TC) == 2) return quick_gelu_grad_fast(x); else return quick_gelu_grad(x);
 }
 
 inline int hip_ok(hipError_t e) { return (int)e; }

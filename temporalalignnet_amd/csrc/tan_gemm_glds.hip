@@ -101,9 +101,9 @@ __device__ __forceinline__ void epilogue2(const GemmArgs2& g, f32x16 (&acc)[2][2
                 float v = acc[i][j][r] * g.alpha + bv;
                 if (g.act == TAN_ACT_QUICKGELU) {
                     if (AUX) st_f(AUX + (long)row * g.ldaux + col, v);
-                    v = quick_gelu(v);
+                    v = quick_gelu_t<TC>(v);
                 } else if (g.act == TAN_ACT_QUICKGELU_GRAD) {
-                    v *= quick_gelu_grad(ld_f(AUX + (long)row * g.ldaux + col));
+                    v *= quick_gelu_grad_t<TC>(ld_f(AUX + (long)row * g.ldaux + col));
                 } else if (g.act == TAN_ACT_RELU) {
                     v = fmaxf(v, 0.0f);
                 }
@@ -131,8 +131,8 @@ __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
 }
 __device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
     uint4 u;
-    u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-    u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    u.x = f2bf2(v[0], v[1]); u.y = f2bf2(v[2], v[3]);
+    u.z = f2bf2(v[4], v[5]); u.w = f2bf2(v[6], v[7]);
     *reinterpret_cast<uint4*>(p) = u;
 }
 __device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
@@ -188,10 +188,10 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs2& g, f32x16 (&acc)[2
         if (g.act == TAN_ACT_QUICKGELU) {
             if (AUX && ok) st8(AUX + (long)row * g.ldaux + col, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = quick_gelu(v[e]);
+            for (int e = 0; e < 8; ++e) v[e] = quick_gelu_t<TC>(v[e]);
         } else if (grad) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= quick_gelu_grad(av[p][e]);
+            for (int e = 0; e < 8; ++e) v[e] *= quick_gelu_grad_t<TC>(av[p][e]);
         } else if (g.act == TAN_ACT_RELU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);

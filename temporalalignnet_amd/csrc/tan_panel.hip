@@ -1,0 +1,374 @@
+// Row-panel kernels (gfx950): the MLP branch of a pre-LN block (model/tfm_model.py:23-27,37) as ONE launch per direction.
+// See tan_panel.h for the scheme.  A workgroup = 8 waves = one 64-row panel; LDS (160 KiB) holds the normalised input panel
+// (64 KiB), the current 256-wide chunk of the hidden activation (32 KiB) and a ring of streamed weight tiles (64 KiB).
+//
+//   forward, per panel:   xn2 = LN2(x_mid)                                  (prologue; xn2 / mean / rstd also go to HBM for backward)
+//     for the 8 chunks c of the 2048 hidden features:
+//        h_c  = quickgelu(xn2 W_fc[c]^T + b_fc[c])      64 x 256, K = 512   (h_pre / h_act also go to HBM: dW operands)
+//        acc += h_c W_proj[:, c]^T                      64 x 512, K = 256
+//     x_out = x_mid + acc + b_proj ;  xn_next = LN_next(x_out)              (epilogue: next block's ln_1, or the stack's post-LN)
+//
+// Replaces four launches (LayerNorm, c_fc GEMM, c_proj GEMM, next LayerNorm) and their three HBM round trips.
+#include "tan_panel.h"
+
+namespace tal {
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight packer: table entry e packs the row-major matrix src[e.src_off ..] of shape [N][K] into tiles [TN][TK], tile order
+// (n-block, k-block).  Inside a tile the data is FRAGMENT-MAJOR: wave w (of PN_WAVES) owns rows w*TN/PN_WAVES .. and its MFMA A-operand
+// fragments follow each other, [row block of 32][k step of 16] -> 1 KiB each, lane l's 16 bytes = W[row0 + (l & 31)][k0 + 8 * (l >> 5) ..]
+// -- exactly what one global_load_dwordx4 per lane puts into the fragment registers.
+__global__ __launch_bounds__(256) void pack_tiles_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                         const tan_pack_entry* __restrict__ table) {
+    const tan_pack_entry e = table[blockIdx.y];
+    const int tiles_k = e.K / e.TK, ntiles = (e.N / e.TN) * tiles_k;
+    const int KS = e.TK / 16, RB = e.TN / (32 * PN_WAVES); // k steps, 32-row blocks per wave
+    const int slots = e.TN * e.TK / 8;                    // 16-byte slots per tile
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int nb = t / tiles_k, kt = t % tiles_k;
+        const bf16_t* s0 = src + e.src_off + (long)nb * e.TN * e.K + (long)kt * e.TK;
+        bf16_t* d0 = dst + e.dst_off + (long)t * e.TN * e.TK;
+        for (int s = threadIdx.x; s < slots; s += blockDim.x) {
+            const int lane = s & 63, frag = s >> 6;
+            const int ks = frag % KS, rb = (frag / KS) % RB, w = frag / (KS * RB);
+            const int row = w * (e.TN / PN_WAVES) + rb * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5);
+            *reinterpret_cast<uint4*>(d0 + (long)s * 8) = *reinterpret_cast<const uint4*>(s0 + (long)row * e.K + k);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+struct MlpFwdArgs {
+    const bf16_t* x_mid; const float* ln_g; const float* ln_b;
+    const char* pw_fc; const char* pw_proj;
+    const float* b_fc; const float* b_proj;
+    bf16_t* xn2; float* mean2; float* rstd2;
+    bf16_t* h_pre; bf16_t* h_act; bf16_t* x_out;
+    const float* nln_g; const float* nln_b; bf16_t* xn_next; float* nmean; float* nrstd;
+    float eps;
+};
+
+// address of tile JJ (chunk-relative; JJ >= TPC is a tile of the next chunk) of the interleaved fc / proj stream
+template <int JJ, int TF, int TP, int TILE>
+__device__ __forceinline__ const char* mlp_tile_src(const char* pfc, const char* ppj, int c) {
+    constexpr int TPC = TF + TP;
+    constexpr int j = JJ >= TPC ? JJ - TPC : JJ;
+    int cc = JJ >= TPC ? c + 1 : c;
+    if (JJ >= TPC) cc = min(cc, 7);      // past the last chunk: re-load a valid tile (keeps the per-step DMA count uniform)
+    return j < TF ? pfc + (long)(cc * TF + j) * TILE : ppj + (long)(cc * TP + (j - TF)) * TILE;
+}
+
+// Tiles are 16 KiB: c_fc [256 features][32 k], c_proj [512 features][16 k].  A weight fragment is consumed by exactly ONE wave
+// (the wave that owns those output features), so the weights never touch LDS: every wave streams its own fragments straight into
+// registers, global_load_dwordx4 per lane = 1 KiB per wave-instruction of the fragment-major packed image, MLP_D steps (32 KiB per
+// wave, 128 KiB per CU) ahead of their use -- the compiler's own counted vmcnt keeps that many loads in flight.  LDS holds only
+// the activation panels (the normalised input, and the hidden chunk double-buffered), read by all waves; one workgroup barrier
+// per chunk hands the hidden chunk over.  FOUR waves, one per SIMD, each with the whole 512-entry register file: 192 accumulator
+// registers (64 rows x 64 hidden features + 64 rows x 128 output features) sit in AGPRs, the weight ring (128) and the
+// activation fragments in VGPRs.  Steps are software-pipelined one deep on the LDS side (fragments of step j+1 are read before
+// the MFMAs of step j), so a lone wave keeps its SIMD's matrix pipe busy.
+constexpr int MLP_KDF = 32, MLP_KDP = 16, MLP_TILE = 16384, MLP_TF = 512 / MLP_KDF, MLP_TP = 256 / MLP_KDP, MLP_TPC = MLP_TF + MLP_TP;
+constexpr int MLP_D = 8;                 // weight prefetch distance in steps
+constexpr int MLP_XN_OFF = 0, MLP_H_OFF = 65536, MLP_LDS = 131072;
+static_assert(PN_WAVES == 4, "fragment bookkeeping below is written for four waves");
+
+struct MlpXFrags { bf16x8 f[4]; };       // activation fragments of one step: c_fc [k step][row block], c_proj [row block]
+struct MlpWFrags { bf16x8 f[4]; };       // weight fragments of one step: c_fc [feature block][k step], c_proj [feature block]
+
+template <int J>      // activation fragments step J (chunk-relative) consumes; hb = hidden-panel buffer of the chunk
+__device__ __forceinline__ void mlp_load_x(MlpXFrags& F, const char* lds, int hb, int lane) {
+    if constexpr (J < MLP_TF) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            F.f[2 * i + 0] = pn_pfrag<1024>(lds + MLP_XN_OFF, 0, J * MLP_KDF + 16 * i, lane);
+            F.f[2 * i + 1] = pn_pfrag<1024>(lds + MLP_XN_OFF, 1, J * MLP_KDF + 16 * i, lane);
+        }
+    } else {
+        constexpr int KT = J - MLP_TF;
+        F.f[0] = pn_pfrag<512>(lds + MLP_H_OFF + hb * 32768, 0, KT * MLP_KDP, lane);
+        F.f[1] = pn_pfrag<512>(lds + MLP_H_OFF + hb * 32768, 1, KT * MLP_KDP, lane);
+    }
+}
+
+__device__ __forceinline__ void mlp_load_w(MlpWFrags& W, const char* tile, int wave, int lane) {
+    const char* p = tile + wave * 4096 + lane * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) W.f[i] = *reinterpret_cast<const bf16x8*>(p + i * 1024);
+}
+
+template <int J>
+__device__ __forceinline__ void mlp_mma(const MlpWFrags& W, const MlpXFrags& F, f32x16 (&acc_h)[2][2], f32x16 (&acc_o)[4][2]) {
+    if constexpr (J < MLP_TF) {       // W.f[2 * nb + i]: hidden features wave*64 + nb*32 .., k step i
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    acc_h[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[2 * nb + i], F.f[2 * i + mb], acc_h[nb][mb], 0, 0, 0);
+    } else {                          // W.f[nb]: output features wave*128 + nb*32 .., one k step
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) acc_o[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], F.f[mb], acc_o[nb][mb], 0, 0, 0);
+    }
+}
+
+// MODE 0: the kernel.  Timing experiments of tools/lab/mlp_lab.py (results undefined), bit mask: 1 no MFMAs, 2 no weight
+// streaming (loaded once), 4 no activation-fragment reads in the loop, 8 no chunk-epilogue arithmetic / stores
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
+    constexpr int TILE = MLP_TILE, TF = MLP_TF, TP = MLP_TP, TPC = MLP_TPC, D = MLP_D;
+    constexpr int XN_OFF = MLP_XN_OFF, H_OFF = MLP_H_OFF;
+    static_assert(TPC % D == 0 && TPC % 2 == 0, "register ring slot and fragment set must be static per chunk");
+    __shared__ __attribute__((aligned(1024))) char lds[MLP_LDS];
+
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long row0 = (long)blockIdx.x * PN_ROWS;
+    const char* const pfc = a.pw_fc;
+    const char* const ppj = a.pw_proj;
+
+    // the weight stream does not depend on the activations: start it before anything else
+    MlpWFrags WQ[D];
+    pn_static_for<0, D>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        mlp_load_w(WQ[J], mlp_tile_src<J, TF, TP, TILE>(pfc, ppj, 0), wave, lane);
+    });
+
+    // ---- prologue: LN2 of the panel, 16 rows per wave (two batches of 8), one 16-byte chunk per lane ------------------
+    {
+        const f8 g = ld8f(a.ln_g + lane * 8), b = ld8f(a.ln_b + lane * 8);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f8 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = ld8(a.x_mid + (row0 + wave * 16 + half * 8 + r) * 512 + lane * 8);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[r].v[j];
+                const float mean = wave_sum(s) * (1.0f / 512);
+                float q = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[r].v[j] -= mean; q += v[r].v[j] * v[r].v[j]; }
+                const float rstd = rsqrtf(wave_sum(q) * (1.0f / 512) + a.eps);
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = v[r].v[j] * rstd * g.v[j] + b.v[j];
+                const uint4 u = pn_pack8(o);
+                const int m = wave * 16 + half * 8 + r;
+                *reinterpret_cast<uint4*>(a.xn2 + (row0 + m) * 512 + lane * 8) = u;
+                *reinterpret_cast<uint4*>(pn_panel_slot<1024>(lds + XN_OFF, m, lane)) = u;
+                if (lane == 0) { a.mean2[row0 + m] = mean; a.rstd2[row0 + m] = rstd; }
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc_o[4][2];      // [feature block of the wave's 128 output features][row block]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc_zero(acc_o[i][j]);
+    f32x16 acc_h[2][2];      // [feature block of the wave's 64 hidden features][row block]
+    MlpXFrags FA, FB;        // activation fragments of the even / odd steps
+    mlp_load_x<0>(FA, lds, 0, lane);
+    mlp_load_x<1>(FB, lds, 0, lane);
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc_zero(acc_h[i][j]);
+        const int hb = c & 1;
+        pn_static_for<0, TPC>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            constexpr int JN = (J + 1) % TPC;                       // the step whose activation fragments are fetched now
+            MlpXFrags& cur = (J & 1) ? FB : FA;
+            MlpXFrags& nxt = (J & 1) ? FA : FB;
+            if constexpr (J != TF - 1) {
+                if (!(MODE & 4)) mlp_load_x<JN>(nxt, lds, hb, lane);
+                if (!(MODE & 1)) mlp_mma<J>(WQ[J % D], cur, acc_h, acc_o);
+                if (!(MODE & 2)) mlp_load_w(WQ[J % D], mlp_tile_src<J + D, TF, TP, TILE>(pfc, ppj, c), wave, lane);
+            } else {
+                if (!(MODE & 1)) mlp_mma<J>(WQ[J % D], cur, acc_h, acc_o);
+                if (!(MODE & 2)) mlp_load_w(WQ[J % D], mlp_tile_src<J + D, TF, TP, TILE>(pfc, ppj, c), wave, lane);
+                // ---- chunk epilogue: + bias, QuickGELU, hidden chunk -> LDS panel hb (and HBM for the weight gradients).  Panel hb
+                // was last read in chunk c-2; every wave has since passed the barrier of chunk c-1.
+#pragma unroll
+                for (int nb = 0; nb < ((MODE & 8) ? 0 : 2); ++nb) {
+                    const int nloc = wave * 64 + nb * 32;             // wave-uniform
+                    pn_cfptr_t bp = (pn_cfptr_t)(uintptr_t)(a.b_fc) + c * 256 + nloc;
+                    float bias[2][8];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) pn_uniform8(bp + 16 * p, bp + 16 * p + 8, hi, bias[p]);
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        float o[2][8];
+                        pn_rows_from_acc(acc_h[nb][mb], o);
+                        const int m = mb * 32 + (lane & 31);
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            const int ch = 2 * p + hi;
+                            float pre[8], act[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { pre[e] = o[p][e] + bias[p][e]; act[e] = quick_gelu_fast(pre[e]); }
+                            const uint4 ua = pn_pack8(act);
+                            *reinterpret_cast<uint4*>(pn_panel_slot<512>(lds + H_OFF + hb * 32768, m, (nloc >> 3) + ch)) = ua;
+                            const long gi = (row0 + m) * 2048 + c * 256 + nloc + ch * 8;
+                            if (a.h_pre) *reinterpret_cast<uint4*>(a.h_pre + gi) = pn_pack8(pre);
+                            if (a.h_act) *reinterpret_cast<uint4*>(a.h_act + gi) = ua;
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // LDS only: the weight loads stay in flight across the barrier
+                __builtin_amdgcn_s_barrier();
+                if (!(MODE & 4)) mlp_load_x<JN>(nxt, lds, hb, lane);
+            }
+            // the machine scheduler would otherwise sink each weight load to just before its use eight steps later (shorter
+            // live range) and the ring would hold one step instead of MLP_D: nothing moves across a step boundary
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    if (MODE & 1) {          // stream-only experiment: keep the loaded fragments alive
+#pragma unroll
+        for (int i = 0; i < D; ++i) asm volatile("" ::"v"(WQ[i].f[0]), "v"(WQ[i].f[1]), "v"(WQ[i].f[2]), "v"(WQ[i].f[3]));
+    }
+
+    // ---- epilogue: + bias + residual -> x_out; LayerNorm of the (bf16-rounded) output row -> xn_next ------------------
+    __syncthreads();         // every wave is done with the hidden panels: their space becomes the LayerNorm scratch
+    float* red = reinterpret_cast<float*>(lds + MLP_H_OFF);      // [2][4 waves][64 rows]
+    float xr[4][2][2][8];    // [nb][mb][p][e], rounded like the stored x_out
+    float rs[2] = {0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int nbase = wave * 128 + nb * 32;
+        pn_cfptr_t bp = (pn_cfptr_t)(uintptr_t)(a.b_proj) + nbase;
+        uint4 resq[2][2];    // this feature block's residual chunks: four loads in flight
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                resq[mb][p] = *reinterpret_cast<const uint4*>(a.x_mid + (row0 + mb * 32 + (lane & 31)) * 512 + nbase + (2 * p + hi) * 8);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            float o[2][8];
+            pn_rows_from_acc(acc_o[nb][mb], o);
+            const int m = mb * 32 + (lane & 31);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int ch = 2 * p + hi;
+                float bias[8], res[8];
+                pn_uniform8(bp + 16 * p, bp + 16 * p + 8, hi, bias);
+                const long gi = (row0 + m) * 512 + nbase + ch * 8;
+                pn_unpack8(resq[mb][p], res);
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = o[p][e] + bias[e] + res[e];
+                const uint4 u = pn_pack8(v);
+                *reinterpret_cast<uint4*>(a.x_out + gi) = u;
+                pn_unpack8(u, xr[nb][mb][p]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rs[mb] += xr[nb][mb][p][e];
+            }
+        }
+    }
+    if (a.xn_next) {
+        float mean[2], rstd[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const float s = pn_half_sum(rs[mb]);
+            if (lane < 32) red[wave * 64 + mb * 32 + lane] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < PN_WAVES; ++w) s += red[w * 64 + mb * 32 + (lane & 31)];
+            mean[mb] = s * (1.0f / 512);
+            float q = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float d = xr[nb][mb][p][e] - mean[mb]; xr[nb][mb][p][e] = d; q += d * d; }
+            q = pn_half_sum(q);
+            if (lane < 32) red[256 + wave * 64 + mb * 32 + lane] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            float q = 0.f;
+#pragma unroll
+            for (int w = 0; w < PN_WAVES; ++w) q += red[256 + w * 64 + mb * 32 + (lane & 31)];
+            rstd[mb] = rsqrtf(q * (1.0f / 512) + a.eps);
+            const int m = mb * 32 + (lane & 31);
+            if (wave == 0 && lane < 32) { a.nmean[row0 + m] = mean[mb]; a.nrstd[row0 + m] = rstd[mb]; }
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int nu = wave * 128 + nb * 32 + 16 * p;         // wave-uniform: gamma / beta come through scalar loads
+                const int n = nu + 8 * hi;
+                pn_cfptr_t gp = (pn_cfptr_t)(uintptr_t)(a.nln_g) + nu;
+                pn_cfptr_t bp = (pn_cfptr_t)(uintptr_t)(a.nln_b) + nu;
+                float g[8], b[8];
+                pn_uniform8(gp, gp + 8, hi, g);
+                pn_uniform8(bp, bp + 8, hi, b);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    float y[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = xr[nb][mb][p][e] * rstd[mb] * g[e] + b[e];
+                    *reinterpret_cast<uint4*>(a.xn_next + (row0 + mb * 32 + (lane & 31)) * 512 + n) = pn_pack8(y);
+                }
+            }
+    }
+}
+
+}  // namespace tal
+
+using namespace tal;
+
+extern "C" int tan_pack_weights(const void* src, void* dst, const tan_pack_entry* table, int n, int max_tiles, void* stream) {
+    TAN_REQUIRE(src && dst && table && n > 0 && max_tiles > 0);
+    hipLaunchKernelGGL(pack_tiles_kernel, dim3(max_tiles < 64 ? max_tiles : 64, n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                       (bf16_t*)dst, table);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
+    TAN_REQUIRE(d && d->x_mid && d->ln_g && d->ln_b && d->pw_fc && d->pw_proj && d->b_fc && d->b_proj && d->xn2 && d->mean2 && d->rstd2 &&
+                d->x_out);
+    TAN_REQUIRE(d->rows > 0 && d->rows % PN_ROWS == 0 && d->C == 512 && d->FF == 2048);
+    TAN_REQUIRE(!d->xn_next || (d->nln_g && d->nln_b && d->nmean && d->nrstd));
+    MlpFwdArgs a;
+    a.x_mid = (const bf16_t*)d->x_mid; a.ln_g = d->ln_g; a.ln_b = d->ln_b;
+    a.pw_fc = (const char*)d->pw_fc; a.pw_proj = (const char*)d->pw_proj; a.b_fc = d->b_fc; a.b_proj = d->b_proj;
+    a.xn2 = (bf16_t*)d->xn2; a.mean2 = d->mean2; a.rstd2 = d->rstd2;
+    a.h_pre = (bf16_t*)d->h_pre; a.h_act = (bf16_t*)d->h_act; a.x_out = (bf16_t*)d->x_out;
+    a.nln_g = d->nln_g; a.nln_b = d->nln_b; a.xn_next = (bf16_t*)d->xn_next; a.nmean = d->nmean; a.nrstd = d->nrstd;
+    a.eps = d->eps;
+    const dim3 grid((unsigned)(d->rows / PN_ROWS));
+    const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0);
+    switch (d->variant) {
+#ifdef TAN_PANEL_LAB
+        case 5: hipLaunchKernelGGL((mlp_fwd_panel_kernel<5>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        case 2: hipLaunchKernelGGL((mlp_fwd_panel_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        case 6: hipLaunchKernelGGL((mlp_fwd_panel_kernel<6>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        case 14: hipLaunchKernelGGL((mlp_fwd_panel_kernel<14>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        case 15: hipLaunchKernelGGL((mlp_fwd_panel_kernel<15>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+#endif
+        default: hipLaunchKernelGGL((mlp_fwd_panel_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
+    prof_end((hipStream_t)stream, rec);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}

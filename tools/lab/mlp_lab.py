@@ -1,0 +1,167 @@
+"""Lab: fused row-panel MLP forward (tan_mlp_fwd) vs the four-launch path it replaces -- numerics and timing.  Tool only."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import numpy as np
+import torch
+
+from temporalalignnet_amd import _lib, ops
+
+L = _lib.lib()
+dev = "cuda"
+torch.manual_seed(0)
+
+
+def pack(mats, variant):
+    """mats: list of [N,K] bf16 tensors -> list of packed flat tensors (one launch)"""
+    src = torch.cat([m.reshape(-1) for m in mats])
+    dst = torch.empty_like(src)
+    ents, off, mx = [], 0, 0
+    for m in mats:
+        N, K = m.shape
+        TN, TK = (512, 16) if N == 512 else (256, 32)
+        ents.append((off, off, N, K, TN, TK))
+        mx = max(mx, (N // TN) * (K // TK))
+        off += N * K
+    arr = (_lib.PackEntry * len(ents))(*[_lib.PackEntry(*e) for e in ents])
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    _lib.check(L.tan_pack_weights(ops._ptr(src), ops._ptr(dst), C.c_void_p(tab.data_ptr()), len(ents), mx, ops._stream()), "pack")
+    torch.cuda.synchronize()
+    outs, off = [], 0
+    for m in mats:
+        outs.append(dst[off:off + m.numel()])
+        off += m.numel()
+    return outs
+
+
+def run_fused(t, variant, store_h=True, next_ln=True):
+    d = _lib.MlpDesc()
+    d.rows, d.C, d.FF = t["R"], 512, 2048
+    d.x_mid = t["x_mid"].data_ptr(); d.ln_g = t["g2"].data_ptr(); d.ln_b = t["b2"].data_ptr()
+    d.pw_fc = t["pw"][0].data_ptr(); d.pw_proj = t["pw"][1].data_ptr()
+    d.b_fc = t["bfc"].data_ptr(); d.b_proj = t["bpj"].data_ptr()
+    d.xn2 = t["f_xn2"].data_ptr(); d.mean2 = t["f_mean2"].data_ptr(); d.rstd2 = t["f_rstd2"].data_ptr()
+    d.h_pre = t["f_hpre"].data_ptr() if store_h else None
+    d.h_act = t["f_hact"].data_ptr() if store_h else None
+    d.x_out = t["f_xout"].data_ptr()
+    if next_ln:
+        d.nln_g = t["g1"].data_ptr(); d.nln_b = t["b1"].data_ptr(); d.xn_next = t["f_xn1"].data_ptr()
+        d.nmean = t["f_mean1"].data_ptr(); d.nrstd = t["f_rstd1"].data_ptr()
+    d.eps = 1e-5; d.variant = variant
+    _lib.check(L.tan_mlp_fwd(C.byref(d), ops._stream()), "tan_mlp_fwd")
+
+
+def run_unfused(t):
+    R = t["R"]
+    ops.layernorm_fwd(t["x_mid"], t["g2"], t["b2"], t["u_xn2"], t["u_mean2"], t["u_rstd2"])
+    ops.gemm(t["u_xn2"], t["wfc"], t["u_hact"], M=R, N=2048, K=512, bias=t["bfc"], act=ops.ACT_QUICKGELU, aux=t["u_hpre"])
+    ops.gemm(t["u_hact"], t["wpj"], t["u_xout"], M=R, N=512, K=2048, bias=t["bpj"], residual=t["x_mid"])
+    ops.layernorm_fwd(t["u_xout"], t["g1"], t["b1"], t["u_xn1"], t["u_mean1"], t["u_rstd1"])
+
+
+def make(R):
+    bf = torch.bfloat16
+    t = {"R": R}
+    t["x_mid"] = (torch.randn(R, 512, device=dev) * 1.5).to(bf)
+    t["wfc"] = (torch.randn(2048, 512, device=dev) * 1024 ** -0.5).to(bf)
+    t["wpj"] = (torch.randn(512, 2048, device=dev) * 0.03).to(bf)
+    t["bfc"] = torch.randn(2048, device=dev) * 0.1
+    t["bpj"] = torch.randn(512, device=dev) * 0.1
+    for k in ("g1", "g2"):
+        t[k] = 1 + 0.1 * torch.randn(512, device=dev)
+    for k in ("b1", "b2"):
+        t[k] = 0.1 * torch.randn(512, device=dev)
+    for pre in ("f_", "u_"):
+        for k in ("xn2", "xout", "xn1"):
+            t[pre + k] = torch.zeros(R, 512, device=dev, dtype=bf)
+        for k in ("hpre", "hact"):
+            t[pre + k] = torch.zeros(R, 2048, device=dev, dtype=bf)
+        for k in ("mean2", "rstd2", "mean1", "rstd1"):
+            t[pre + k] = torch.zeros(R, device=dev)
+    t["pw"] = pack([t["wfc"], t["wpj"]], 0)
+    return t
+
+
+def timeit(fn, reps=50):
+    fn(); fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def check(R=1024):
+    t = make(R)
+    run_unfused(t)
+    # fp32 reference from the same bf16 inputs
+    x = t["x_mid"].float()
+    xn2 = torch.nn.functional.layer_norm(x, (512,), t["g2"], t["b2"], 1e-5)
+    xn2b = xn2.to(torch.bfloat16).float()
+    pre = xn2b @ t["wfc"].float().T + t["bfc"]
+    act = pre * torch.sigmoid(1.702 * pre)
+    xo = x + act.to(torch.bfloat16).float() @ t["wpj"].float().T + t["bpj"]
+    xob = xo.to(torch.bfloat16).float()
+    xn1 = torch.nn.functional.layer_norm(xob, (512,), t["g1"], t["b1"], 1e-5)
+    ref = {"xn2": xn2, "hpre": pre, "hact": act, "xout": xo, "xn1": xn1, "mean2": x.mean(-1), "rstd2": (x.var(-1, unbiased=False) + 1e-5).rsqrt(),
+           "mean1": xob.mean(-1), "rstd1": (xob.var(-1, unbiased=False) + 1e-5).rsqrt()}
+    ok = True
+    for v in (0,):
+        for k in list(t):
+            if k.startswith("f_"):
+                t[k].zero_()
+        run_fused(t, v)
+        torch.cuda.synchronize()
+        for k, r in ref.items():
+            ef = (t["f_" + k].float() - r).abs().max().item()
+            eu = (t["u_" + k].float() - r).abs().max().item()
+            scale = r.abs().max().item()
+            flag = "" if ef <= max(2.5 * eu, 1e-5 * scale) + 1e-6 else "   <-- WORSE THAN UNFUSED"
+            if flag:
+                ok = False
+            print(f"variant {v} {k:6s}: max|fused-ref| {ef:.3e}  max|unfused-ref| {eu:.3e}  (scale {scale:.2f}){flag}")
+    print("NUMERICS", "OK" if ok else "MISMATCH")
+    return ok
+
+
+if __name__ == "__main__":
+    check(1024)
+    for R in (8192, 10240):
+        t = make(R)
+        fl = 2.0 * R * 512 * 2048 * 2
+        tu = timeit(lambda: run_unfused(t))
+        print(f"R={R}: unfused (LN, fc, proj, LN)            {tu:7.1f} us   {fl / tu / 1e6:6.0f} TF/s", flush=True)
+        for v in (0, 5, 2, 6, 14, 15):
+            for sh, nl in ((True, True), (False, False)):
+                tf = timeit(lambda: run_fused(t, v, sh, nl))
+                print(f"R={R}: fused v{v} store_h={int(sh)} next_ln={int(nl)}          {tf:7.1f} us   {fl / tf / 1e6:6.0f} TF/s", flush=True)
+    # two panels' worth of work on two streams at once (video + joint stack sizes)
+    ta, tb = make(8192), make(10240)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def both(fa, fb):
+        with torch.cuda.stream(s1):
+            fa()
+        with torch.cuda.stream(s2):
+            fb()
+
+    def time_both(fa, fb, reps=30):
+        both(fa, fb); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        s1.wait_stream(torch.cuda.current_stream()); s2.wait_stream(torch.cuda.current_stream())
+        for _ in range(reps):
+            both(fa, fb)
+        torch.cuda.current_stream().wait_stream(s1); torch.cuda.current_stream().wait_stream(s2)
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
+
+    fl2 = 2.0 * (8192 + 10240) * 512 * 2048 * 2
+    tu = time_both(lambda: run_unfused(ta), lambda: run_unfused(tb))
+    print(f"two streams 8192+10240: unfused {tu:7.1f} us {fl2 / tu / 1e6:6.0f} TF/s")
+    for v in (0,):
+        tf = time_both(lambda: run_fused(ta, v), lambda: run_fused(tb, v))
+        print(f"two streams 8192+10240: fused v{v} {tf:7.1f} us {fl2 / tf / 1e6:6.0f} TF/s")
