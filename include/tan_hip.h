@@ -258,6 +258,8 @@ typedef struct tan_layer_params {
     float *g_b_qkv, *g_b_out, *g_b_fc, *g_b_proj;
     float *g_ln1_g, *g_ln1_b, *g_ln2_g, *g_ln2_b;
     const void *wt_qkv, *wt_out, *wt_fc, *wt_proj; /* optional (bf16): W^T copies, [in, out] row-major, for the dX GEMMs; NULL = read W K-strided */
+    const void *wp_qkv, *wp_out, *wp_fc, *wp_proj; /* optional (bf16): tan_pack_weights images of w_* for the row-panel kernels; NULL = unfused path */
+    const void *wtp_qkv, *wtp_out, *wtp_fc, *wtp_proj; /* optional (bf16): tan_pack_weights images of wt_* (backward row-panel kernels) */
 } tan_layer_params;
 
 /* per-layer saved activations, rows R = B*L */

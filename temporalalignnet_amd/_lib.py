@@ -73,7 +73,8 @@ class LayerParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "w_qkv", "w_out", "w_fc", "w_proj", "b_qkv", "b_out", "b_fc", "b_proj", "ln1_g", "ln1_b", "ln2_g", "ln2_b",
         "g_w_qkv", "g_w_out", "g_w_fc", "g_w_proj", "g_b_qkv", "g_b_out", "g_b_fc", "g_b_proj",
-        "g_ln1_g", "g_ln1_b", "g_ln2_g", "g_ln2_b", "wt_qkv", "wt_out", "wt_fc", "wt_proj")]
+        "g_ln1_g", "g_ln1_b", "g_ln2_g", "g_ln2_b", "wt_qkv", "wt_out", "wt_fc", "wt_proj",
+        "wp_qkv", "wp_out", "wp_fc", "wp_proj", "wtp_qkv", "wtp_out", "wtp_fc", "wtp_proj")]
 
 
 class LayerBufs(C.Structure):

@@ -136,24 +136,56 @@ extern "C" int tan_linear_wgrad(const void* dy, const void* x, float* gw, long M
     return linear_bwd_w(dtype, dy, x, gw, M, N, K, ws, ws_floats, stream);
 }
 
+// Row-panel path (tan_panel.hip): the MLP half of a block -- LN2, c_fc + QuickGELU, c_proj + residual AND the LayerNorm that
+// consumes the block's output (the next block's ln_1, or the stack's post-LN) -- is ONE launch.  Opt-in (TAN_PANEL=1): stand-alone
+// it matches the four launches it replaces (83 vs 77 us at 8192 rows, 81 vs 91 us at 10240), two stacks side by side it is 9 %
+// ahead, but inside the training step -- where its 128 / 160 one-per-CU workgroups meet the other stream's kernels -- the step
+// is 3 % slower (DESIGN.md section 3.5 has the ablation that explains why).
+static int panel_enabled() {
+    static const int on = [] { const char* e = getenv("TAN_PANEL"); return e ? atoi(e) : 0; }();
+    return on;
+}
+
 extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
     TAN_REQUIRE(e && e->layers > 0 && e->params && e->bufs && e->x0);
     const int dt = e->dtype, C = e->C, H = e->H;
     const long R = (long)e->B * e->L;
     const void* x_in = e->x0;
+    const bool panel_ok = panel_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0;
+    bool ln1_done = false;        // the previous block's panel kernel already produced this block's xn1 / mean1 / rstd1
     for (int i = 0; i < e->layers; ++i) {
         const tan_layer_params& p = e->params[i];
         const tan_layer_bufs& b = e->bufs[i];
-        CK(tan_layernorm_fwd(x_in, p.ln1_g, p.ln1_b, b.xn1, b.mean1, b.rstd1, nullptr, 0, R, C, 1e-5f, dt, st));
+        if (!ln1_done) CK(tan_layernorm_fwd(x_in, p.ln1_g, p.ln1_b, b.xn1, b.mean1, b.rstd1, nullptr, 0, R, C, 1e-5f, dt, st));
+        ln1_done = false;
         CK(linear_fwd(dt, b.xn1, p.w_qkv, p.b_qkv, b.qkv, R, 3 * C, C, TAN_ACT_NONE, nullptr, nullptr, st));
         CK(tan_attn_fwd(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->B, e->L, H, dt, st));
         CK(linear_fwd(dt, b.attn_o, p.w_out, p.b_out, b.x_mid, R, C, C, TAN_ACT_NONE, nullptr, x_in, st));
-        CK(tan_layernorm_fwd(b.x_mid, p.ln2_g, p.ln2_b, b.xn2, b.mean2, b.rstd2, nullptr, 0, R, C, 1e-5f, dt, st));
-        CK(linear_fwd(dt, b.xn2, p.w_fc, p.b_fc, b.h_act, R, 4 * C, C, TAN_ACT_QUICKGELU, b.h_pre, nullptr, st));
-        CK(linear_fwd(dt, b.h_act, p.w_proj, p.b_proj, b.x_out, R, C, 4 * C, TAN_ACT_NONE, nullptr, b.x_mid, st));
+        if (panel_ok && p.wp_fc && p.wp_proj) {
+            tan_mlp_desc m{};
+            m.rows = R; m.C = C; m.FF = 4 * C;
+            m.x_mid = b.x_mid; m.ln_g = p.ln2_g; m.ln_b = p.ln2_b;
+            m.pw_fc = p.wp_fc; m.pw_proj = p.wp_proj; m.b_fc = p.b_fc; m.b_proj = p.b_proj;
+            m.xn2 = b.xn2; m.mean2 = b.mean2; m.rstd2 = b.rstd2; m.h_pre = b.h_pre; m.h_act = b.h_act; m.x_out = b.x_out;
+            m.eps = 1e-5f;
+            if (i + 1 < e->layers) {
+                const tan_layer_params& pn = e->params[i + 1];
+                const tan_layer_bufs& bn = e->bufs[i + 1];
+                m.nln_g = pn.ln1_g; m.nln_b = pn.ln1_b; m.xn_next = bn.xn1; m.nmean = bn.mean1; m.nrstd = bn.rstd1;
+                ln1_done = true;
+            } else if (e->post_out) {
+                m.nln_g = e->post_g; m.nln_b = e->post_b; m.xn_next = e->post_out; m.nmean = e->post_mean; m.nrstd = e->post_rstd;
+                ln1_done = true;      // = the post-LN is done
+            }
+            CK(tan_mlp_fwd(&m, st));
+        } else {
+            CK(tan_layernorm_fwd(b.x_mid, p.ln2_g, p.ln2_b, b.xn2, b.mean2, b.rstd2, nullptr, 0, R, C, 1e-5f, dt, st));
+            CK(linear_fwd(dt, b.xn2, p.w_fc, p.b_fc, b.h_act, R, 4 * C, C, TAN_ACT_QUICKGELU, b.h_pre, nullptr, st));
+            CK(linear_fwd(dt, b.h_act, p.w_proj, p.b_proj, b.x_out, R, C, 4 * C, TAN_ACT_NONE, nullptr, b.x_mid, st));
+        }
         x_in = b.x_out;
     }
-    if (e->post_out)
+    if (e->post_out && !ln1_done)
         CK(tan_layernorm_fwd(x_in, e->post_g, e->post_b, e->post_out, e->post_mean, e->post_rstd, nullptr, 0, R, C, 1e-5f, dt, st));
     return 0;
 }

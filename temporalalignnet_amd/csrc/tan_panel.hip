@@ -48,46 +48,63 @@ struct MlpFwdArgs {
     float eps;
 };
 
-// address of tile JJ (chunk-relative; JJ >= TPC is a tile of the next chunk) of the interleaved fc / proj stream
-template <int JJ, int TF, int TP, int TILE>
-__device__ __forceinline__ const char* mlp_tile_src(const char* pfc, const char* ppj, int c) {
-    constexpr int TPC = TF + TP;
-    constexpr int j = JJ >= TPC ? JJ - TPC : JJ;
-    int cc = JJ >= TPC ? c + 1 : c;
-    if (JJ >= TPC) cc = min(cc, 7);      // past the last chunk: re-load a valid tile (keeps the per-step DMA count uniform)
-    return j < TF ? pfc + (long)(cc * TF + j) * TILE : ppj + (long)(cc * TP + (j - TF)) * TILE;
-}
-
 // Tiles are 16 KiB: c_fc [256 features][32 k], c_proj [512 features][16 k].  A weight fragment is consumed by exactly ONE wave
 // (the wave that owns those output features), so the weights never touch LDS: every wave streams its own fragments straight into
 // registers, global_load_dwordx4 per lane = 1 KiB per wave-instruction of the fragment-major packed image, MLP_D steps (32 KiB per
 // wave, 128 KiB per CU) ahead of their use -- the compiler's own counted vmcnt keeps that many loads in flight.  LDS holds only
-// the activation panels (the normalised input, and the hidden chunk double-buffered), read by all waves; one workgroup barrier
-// per chunk hands the hidden chunk over.  FOUR waves, one per SIMD, each with the whole 512-entry register file: 192 accumulator
-// registers (64 rows x 64 hidden features + 64 rows x 128 output features) sit in AGPRs, the weight ring (128) and the
-// activation fragments in VGPRs.  Steps are software-pipelined one deep on the LDS side (fragments of step j+1 are read before
-// the MFMAs of step j), so a lone wave keeps its SIMD's matrix pipe busy.
-constexpr int MLP_KDF = 32, MLP_KDP = 16, MLP_TILE = 16384, MLP_TF = 512 / MLP_KDF, MLP_TP = 256 / MLP_KDP, MLP_TPC = MLP_TF + MLP_TP;
+// the activation panels (the normalised input, and the hidden chunk double-buffered), read by all waves.  FOUR waves, one per
+// SIMD, each with the whole 512-entry register file: 192 accumulator registers (64 rows x 64 hidden features + 64 rows x 128
+// output features) sit in AGPRs, the weight ring (128) and the activation fragments in VGPRs.
+//
+// A lone wave per SIMD overlaps nothing by itself, so the schedule does: the chunk epilogue of chunk c (bias, QuickGELU, bf16,
+// stores: VALU / LDS / VMEM work) is cut into 16 half-units and dealt one per step into the c_proj steps of chunk c-1 (matrix
+// work that does not depend on it):
+//     body(c):  [16 steps: c_fc(c)]  [16 steps: c_proj(c-1) MFMAs || epilogue(c) half-units]  barrier
+// with body(0) = c_fc(0) + epilogue(0), body(8) = c_proj(7); every step also reads the NEXT step's activation fragments from
+// LDS and re-loads the ring slot it just consumed.  One barrier per body hands hidden chunk c over (written by all waves, read
+// by all waves in body(c+1)); the two hidden-panel buffers alternate.
+constexpr int MLP_KDF = 32, MLP_KDP = 16, MLP_TILE = 16384, MLP_TF = 512 / MLP_KDF, MLP_TP = 256 / MLP_KDP;
 constexpr int MLP_D = 8;                 // weight prefetch distance in steps
 constexpr int MLP_XN_OFF = 0, MLP_H_OFF = 65536, MLP_LDS = 131072;
 static_assert(PN_WAVES == 4, "fragment bookkeeping below is written for four waves");
+static_assert(MLP_TF == 16 && MLP_TP == 16 && MLP_TF % MLP_D == 0, "step bookkeeping");
 
 struct MlpXFrags { bf16x8 f[4]; };       // activation fragments of one step: c_fc [k step][row block], c_proj [row block]
 struct MlpWFrags { bf16x8 f[4]; };       // weight fragments of one step: c_fc [feature block][k step], c_proj [feature block]
 
-template <int J>      // activation fragments step J (chunk-relative) consumes; hb = hidden-panel buffer of the chunk
-__device__ __forceinline__ void mlp_load_x(MlpXFrags& F, const char* lds, int hb, int lane) {
-    if constexpr (J < MLP_TF) {
+// Activation-fragment addresses.  Chunk c = cJ + hi (cJ = first 16-byte chunk of the k step, even; hi = lane >> 5) of row r sits at
+// slot c ^ (r & 15) = (cJ & ~15) + ((cJ & 15) ^ t) with t = hi ^ (r & 15): the part that depends on the lane takes only EIGHT values
+// per panel, held in registers (xa[e] for cJ & 15 = 2e), the rest is an immediate offset.  Left to the compiler, every step of the
+// unrolled loop kept its own pre-computed address register (48 of them) and the weight ring spilled.
+struct MlpXAddr { unsigned xn[8], h[8]; };       // LDS byte addresses, row block 0; row block 1 = + 32 rows
+__device__ __forceinline__ void mlp_xaddr_init(MlpXAddr& A, const char* lds, int lane) {
+    const int row = lane & 31, t = (lane >> 5) ^ (row & 15);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            F.f[2 * i + 0] = pn_pfrag<1024>(lds + MLP_XN_OFF, 0, J * MLP_KDF + 16 * i, lane);
-            F.f[2 * i + 1] = pn_pfrag<1024>(lds + MLP_XN_OFF, 1, J * MLP_KDF + 16 * i, lane);
-        }
-    } else {
-        constexpr int KT = J - MLP_TF;
-        F.f[0] = pn_pfrag<512>(lds + MLP_H_OFF + hb * 32768, 0, KT * MLP_KDP, lane);
-        F.f[1] = pn_pfrag<512>(lds + MLP_H_OFF + hb * 32768, 1, KT * MLP_KDP, lane);
+    for (int e = 0; e < 8; ++e) {
+        A.xn[e] = (unsigned)(uintptr_t)(lds + MLP_XN_OFF + row * 1024 + (((2 * e) ^ t) << 4));
+        A.h[e] = (unsigned)(uintptr_t)(lds + MLP_H_OFF + row * 512 + (((2 * e) ^ t) << 4));
     }
+}
+typedef __attribute__((address_space(3))) const bf16x8* mlp_lds_frag_t;
+template <int OFF>
+__device__ __forceinline__ bf16x8 mlp_lds_frag(unsigned addr) { return *(mlp_lds_frag_t)(uintptr_t)(addr + OFF); }
+
+template <int KT>
+__device__ __forceinline__ void mlp_load_x_fc(MlpXFrags& F, const MlpXAddr& A) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        constexpr int dummy = 0; (void)dummy;
+        const int cJ = KT * 4 + 2 * i;                       // 16-byte chunk of k = KT*32 + 16*i
+        F.f[2 * i + 0] = mlp_lds_frag<0>(A.xn[(cJ & 15) >> 1] + (cJ & ~15) * 16);
+        F.f[2 * i + 1] = mlp_lds_frag<32 * 1024>(A.xn[(cJ & 15) >> 1] + (cJ & ~15) * 16);
+    }
+}
+template <int KT>
+__device__ __forceinline__ void mlp_load_x_proj(MlpXFrags& F, const MlpXAddr& A, int hb) {
+    constexpr int cJ = KT * 2;                               // k = KT*16
+    const unsigned a0 = A.h[(cJ & 15) >> 1] + (cJ & ~15) * 16 + hb * 32768;
+    F.f[0] = mlp_lds_frag<0>(a0);
+    F.f[1] = mlp_lds_frag<32 * 512>(a0);
 }
 
 __device__ __forceinline__ void mlp_load_w(MlpWFrags& W, const char* tile, int wave, int lane) {
@@ -96,21 +113,69 @@ __device__ __forceinline__ void mlp_load_w(MlpWFrags& W, const char* tile, int w
     for (int i = 0; i < 4; ++i) W.f[i] = *reinterpret_cast<const bf16x8*>(p + i * 1024);
 }
 
-template <int J>
-__device__ __forceinline__ void mlp_mma(const MlpWFrags& W, const MlpXFrags& F, f32x16 (&acc_h)[2][2], f32x16 (&acc_o)[4][2]) {
-    if constexpr (J < MLP_TF) {       // W.f[2 * nb + i]: hidden features wave*64 + nb*32 .., k step i
+__device__ __forceinline__ void mlp_mma_fc(const MlpWFrags& W, const MlpXFrags& F, f32x16 (&acc_h)[2][2]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)          // W.f[2 * nb + i]: hidden features wave*64 + nb*32 .., k step i
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
-                    acc_h[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[2 * nb + i], F.f[2 * i + mb], acc_h[nb][mb], 0, 0, 0);
-    } else {                          // W.f[nb]: output features wave*128 + nb*32 .., one k step
+            for (int mb = 0; mb < 2; ++mb)
+                acc_h[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[2 * nb + i], F.f[2 * i + mb], acc_h[nb][mb], 0, 0, 0);
+}
+__device__ __forceinline__ void mlp_mma_proj(const MlpWFrags& W, const MlpXFrags& F, f32x16 (&acc_o)[4][2]) {
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+    for (int nb = 0; nb < 4; ++nb)       // W.f[nb]: output features wave*128 + nb*32 .., one k step
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) acc_o[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], F.f[mb], acc_o[nb][mb], 0, 0, 0);
+        for (int mb = 0; mb < 2; ++mb) acc_o[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], F.f[mb], acc_o[nb][mb], 0, 0, 0);
+}
+
+// Half-unit U (0..15) of the chunk epilogue: unit = U >> 1 = (feature block nb, row block mb, register half p), 8 values per lane;
+// half h = U & 1 finishes elements {2h, 2h+1, 4+2h, 5+2h} (two v_permlane32_swap), the second half stores the 16-byte runs.
+// The 16 bias values a unit needs (b_fc[c*256 + wave*64 + nb*32 + 16p ..]) are wave-uniform: they come through ONE scalar load
+// (s_load_dwordx16) issued a whole unit ahead into the other of two SGPR sets -- used straight after the load they cost an
+// s_waitcnt lgkmcnt(0) of a few hundred cycles per half-unit, 128 times per panel.
+struct MlpEpiState { uint32_t pre[4], act[4]; };
+struct MlpBias { float b[16]; };
+template <int UNIT>     // UNIT 0..7 of chunk c; UNIT == 8: unit 0 of chunk c + 1
+__device__ __forceinline__ void mlp_bias_load(MlpBias& B, const float* b_fc, int c, int wave) {
+    constexpr int u = UNIT & 7, nb = u >> 2, p = u & 1;
+    const int cc = UNIT == 8 ? min(c + 1, 7) : c;
+    pn_cfptr_t bp = (pn_cfptr_t)(uintptr_t)b_fc + cc * 256 + wave * 64 + nb * 32 + 16 * p;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) B.b[e] = bp[e];
+}
+template <int U>
+__device__ __forceinline__ void mlp_epi_half(MlpEpiState& E, const MlpBias& B, const f32x16 (&acc_h)[2][2], const MlpFwdArgs& a, char* lds,
+                                             int c, int hb, long row0, int wave, int lane) {
+    constexpr int unit = U >> 1, h = U & 1, nb = unit >> 2, mb = (unit >> 1) & 1, p = unit & 1;
+    const int hi = lane >> 5;
+    const int nloc = wave * 64 + nb * 32;                                 // wave-uniform
+    float v[4];
+#pragma unroll
+    for (int x2 = 0; x2 < 2; ++x2) {
+        constexpr int dummy = 0; (void)dummy;
+        const int x = 2 * h + x2;
+        // explicit AGPR reads: left to itself the allocator moves the whole hidden accumulator into VGPRs for this VALU use
+        // (64 registers the weight ring needs) and spills the ring
+        int ra, rb;
+        asm("v_accvgpr_read_b32 %0, %1" : "=v"(ra) : "a"(acc_h[nb][mb][8 * p + x]));
+        asm("v_accvgpr_read_b32 %0, %1" : "=v"(rb) : "a"(acc_h[nb][mb][8 * p + 4 + x]));
+        auto r = __builtin_amdgcn_permlane32_swap(ra, rb, false, false);
+        const float blo = hi ? B.b[8 + x] : B.b[x], bhi = hi ? B.b[12 + x] : B.b[4 + x];
+        v[x2] = __int_as_float(r[0]) + blo;               // element x
+        v[2 + x2] = __int_as_float(r[1]) + bhi;           // element 4 + x
+    }
+    E.pre[h] = f2bf2(v[0], v[1]);
+    E.pre[2 + h] = f2bf2(v[2], v[3]);
+    E.act[h] = f2bf2(quick_gelu_fast(v[0]), quick_gelu_fast(v[1]));
+    E.act[2 + h] = f2bf2(quick_gelu_fast(v[2]), quick_gelu_fast(v[3]));
+    if constexpr (h == 1) {
+        const int ch = 2 * p + hi, m = mb * 32 + (lane & 31);
+        const uint4 ua = make_uint4(E.act[0], E.act[1], E.act[2], E.act[3]);
+        *reinterpret_cast<uint4*>(pn_panel_slot<512>(lds + MLP_H_OFF + hb * 32768, m, (nloc >> 3) + ch)) = ua;
+        const long gi = (row0 + m) * 2048 + c * 256 + nloc + ch * 8;
+        *reinterpret_cast<uint4*>(a.h_pre + gi) = make_uint4(E.pre[0], E.pre[1], E.pre[2], E.pre[3]);
+        *reinterpret_cast<uint4*>(a.h_act + gi) = ua;
     }
 }
 
@@ -118,9 +183,8 @@ __device__ __forceinline__ void mlp_mma(const MlpWFrags& W, const MlpXFrags& F, 
 // streaming (loaded once), 4 no activation-fragment reads in the loop, 8 no chunk-epilogue arithmetic / stores
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
-    constexpr int TILE = MLP_TILE, TF = MLP_TF, TP = MLP_TP, TPC = MLP_TPC, D = MLP_D;
-    constexpr int XN_OFF = MLP_XN_OFF, H_OFF = MLP_H_OFF;
-    static_assert(TPC % D == 0 && TPC % 2 == 0, "register ring slot and fragment set must be static per chunk");
+    constexpr int TILE = MLP_TILE, D = MLP_D;
+    constexpr int XN_OFF = MLP_XN_OFF;
     __shared__ __attribute__((aligned(1024))) char lds[MLP_LDS];
 
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
@@ -129,11 +193,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
     const char* const pfc = a.pw_fc;
     const char* const ppj = a.pw_proj;
 
-    // the weight stream does not depend on the activations: start it before anything else
+    // the weight stream does not depend on the activations: start it before anything else (ring slots 0..7 = c_fc(0) tiles 0..7)
     MlpWFrags WQ[D];
     pn_static_for<0, D>([&](auto jc) {
         constexpr int J = decltype(jc)::value;
-        mlp_load_w(WQ[J], mlp_tile_src<J, TF, TP, TILE>(pfc, ppj, 0), wave, lane);
+        mlp_load_w(WQ[J], pfc + (long)J * TILE, wave, lane);
     });
 
     // ---- prologue: LN2 of the panel, 16 rows per wave (two batches of 8), one 16-byte chunk per lane ------------------
@@ -174,65 +238,111 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
         for (int j = 0; j < 2; ++j) acc_zero(acc_o[i][j]);
     f32x16 acc_h[2][2];      // [feature block of the wave's 64 hidden features][row block]
     MlpXFrags FA, FB;        // activation fragments of the even / odd steps
-    mlp_load_x<0>(FA, lds, 0, lane);
-    mlp_load_x<1>(FB, lds, 0, lane);
+    MlpEpiState ES;
+    MlpBias BA, BB;          // bias values of the even / odd epilogue units
+    mlp_bias_load<0>(BA, a.b_fc, 0, wave);
+    MlpXAddr XA;
+    mlp_xaddr_init(XA, lds, lane);
+    mlp_load_x_fc<0>(FA, XA);
     __builtin_amdgcn_sched_barrier(0);
 
-    for (int c = 0; c < 8; ++c) {
+    // the two 16-step phases; the flags are compile-time so that every step is ONE basic block (the scheduler interleaves the
+    // epilogue half-unit with the MFMAs only inside a block)
+    auto fc_phase = [&](int c) __attribute__((always_inline)) {            // c_fc(c)
+        const int hb = c & 1;
+        pn_static_for<0, 16>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            MlpXFrags& cur = (J & 1) ? FB : FA;
+            MlpXFrags& nxt = (J & 1) ? FA : FB;
+            if (!(MODE & 4)) {
+                if constexpr (J < 15) mlp_load_x_fc<J + 1>(nxt, XA);
+                else mlp_load_x_proj<0>(nxt, XA, hb ^ 1);      // body(0): reads a not yet written panel, unused
+            }
+            if (!(MODE & 1)) mlp_mma_fc(WQ[J % D], cur, acc_h);
+            if (!(MODE & 2)) {      // the tile eight steps on: c_fc(c) J+8, else the first half of the next phase that streams
+                const char* src = J + D < 16 ? pfc + (long)(c * 16 + J + D) * TILE
+                                             : (c == 0 ? pfc + (long)(16 + J + D - 16) * TILE      // body(0) has no c_proj phase
+                                                       : ppj + (long)((c - 1) * 16 + J + D - 16) * TILE);
+                mlp_load_w(WQ[J % D], src, wave, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto proj_phase = [&](int c, auto has_proj, auto has_epi) __attribute__((always_inline)) {   // c_proj(c-1) MFMAs || epilogue(c) half-units
+        constexpr bool PROJ = decltype(has_proj)::value, EPI = decltype(has_epi)::value;
+        const int hb = c & 1;
+        if constexpr (EPI) {        // MFMA result -> v_accvgpr_read inside asm: the hazard pad the compiler cannot see (c_fc's last MFMAs)
+            asm volatile("s_nop 15\n\ts_nop 15");
+        }
+        pn_static_for<0, 16>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            MlpXFrags& cur = (J & 1) ? FB : FA;
+            MlpXFrags& nxt = (J & 1) ? FA : FB;
+            if constexpr (PROJ) {
+                if (!(MODE & 4)) {
+                    if constexpr (J < 15) mlp_load_x_proj<J + 1>(nxt, XA, hb ^ 1);
+                }
+                if (!(MODE & 1)) mlp_mma_proj(WQ[J % D], cur, acc_o);
+                if (!(MODE & 2)) {  // c_proj(c-1) J+8, else the first half of the next body's first phase
+                    if constexpr (J + D < 16) mlp_load_w(WQ[J % D], ppj + (long)((c - 1) * 16 + J + D) * TILE, wave, lane);
+                    else if constexpr (EPI)     // c <= 7: body(c+1) starts with c_fc(c+1), body(8) with c_proj(7)
+                        mlp_load_w(WQ[J % D], c < 7 ? pfc + (long)((c + 1) * 16 + J + D - 16) * TILE : ppj + (long)(7 * 16 + J + D - 16) * TILE,
+                                   wave, lane);
+                }
+            }
+            if constexpr (EPI) {
+                constexpr int unit = J >> 1;
+                MlpBias& bcur = (unit & 1) ? BB : BA;
+                MlpBias& bnxt = (unit & 1) ? BA : BB;
+                if constexpr ((J & 1) == 0) mlp_bias_load<unit + 1>(bnxt, a.b_fc, c, wave);     // a whole unit ahead
+                if (!(MODE & 8)) mlp_epi_half<J>(ES, bcur, acc_h, a, lds, c, hb, row0, wave, lane);
+            }
+            if constexpr (PROJ && EPI) {
+                // in-order issue: eight MFMAs followed by ~55 VALU instructions overlap nothing; deal the epilogue half-unit into
+                // the gaps between the MFMAs (a 32-cycle MFMA hides ~6 single-issue instructions of a lone wave)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x406, 7, 0);        // 7 VALU / SALU / transcendental
+                    if (i < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 weight load
+                    if (i >= 4 && i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 fragment read
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+
+    auto body_end = [&](int c) __attribute__((always_inline)) {
+        // hidden chunk c is complete (LDS only: the weight loads stay in flight across the barrier)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    auto zero_h = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc_zero(acc_h[i][j]);
-        const int hb = c & 1;
-        pn_static_for<0, TPC>([&](auto jc) {
-            constexpr int J = decltype(jc)::value;
-            constexpr int JN = (J + 1) % TPC;                       // the step whose activation fragments are fetched now
-            MlpXFrags& cur = (J & 1) ? FB : FA;
-            MlpXFrags& nxt = (J & 1) ? FA : FB;
-            if constexpr (J != TF - 1) {
-                if (!(MODE & 4)) mlp_load_x<JN>(nxt, lds, hb, lane);
-                if (!(MODE & 1)) mlp_mma<J>(WQ[J % D], cur, acc_h, acc_o);
-                if (!(MODE & 2)) mlp_load_w(WQ[J % D], mlp_tile_src<J + D, TF, TP, TILE>(pfc, ppj, c), wave, lane);
-            } else {
-                if (!(MODE & 1)) mlp_mma<J>(WQ[J % D], cur, acc_h, acc_o);
-                if (!(MODE & 2)) mlp_load_w(WQ[J % D], mlp_tile_src<J + D, TF, TP, TILE>(pfc, ppj, c), wave, lane);
-                // ---- chunk epilogue: + bias, QuickGELU, hidden chunk -> LDS panel hb (and HBM for the weight gradients).  Panel hb
-                // was last read in chunk c-2; every wave has since passed the barrier of chunk c-1.
-#pragma unroll
-                for (int nb = 0; nb < ((MODE & 8) ? 0 : 2); ++nb) {
-                    const int nloc = wave * 64 + nb * 32;             // wave-uniform
-                    pn_cfptr_t bp = (pn_cfptr_t)(uintptr_t)(a.b_fc) + c * 256 + nloc;
-                    float bias[2][8];
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) pn_uniform8(bp + 16 * p, bp + 16 * p + 8, hi, bias[p]);
-#pragma unroll
-                    for (int mb = 0; mb < 2; ++mb) {
-                        float o[2][8];
-                        pn_rows_from_acc(acc_h[nb][mb], o);
-                        const int m = mb * 32 + (lane & 31);
-#pragma unroll
-                        for (int p = 0; p < 2; ++p) {
-                            const int ch = 2 * p + hi;
-                            float pre[8], act[8];
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) { pre[e] = o[p][e] + bias[p][e]; act[e] = quick_gelu_fast(pre[e]); }
-                            const uint4 ua = pn_pack8(act);
-                            *reinterpret_cast<uint4*>(pn_panel_slot<512>(lds + H_OFF + hb * 32768, m, (nloc >> 3) + ch)) = ua;
-                            const long gi = (row0 + m) * 2048 + c * 256 + nloc + ch * 8;
-                            if (a.h_pre) *reinterpret_cast<uint4*>(a.h_pre + gi) = pn_pack8(pre);
-                            if (a.h_act) *reinterpret_cast<uint4*>(a.h_act + gi) = ua;
-                        }
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // LDS only: the weight loads stay in flight across the barrier
-                __builtin_amdgcn_s_barrier();
-                if (!(MODE & 4)) mlp_load_x<JN>(nxt, lds, hb, lane);
-            }
-            // the machine scheduler would otherwise sink each weight load to just before its use eight steps later (shorter
-            // live range) and the ring would hold one step instead of MLP_D: nothing moves across a step boundary
-            __builtin_amdgcn_sched_barrier(0);
-        });
+    };
+    // body(0) and body(8) are peeled as straight-line code around the loop: as if / else arms INSIDE the loop every extra variant of
+    // a phase cost ~300 spilled registers at the joins
+    zero_h();
+    fc_phase(0);
+    proj_phase(0, F_{}, T_{});
+    body_end(0);
+    mlp_load_x_fc<0>(FA, XA);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = 1; c < 8; ++c) {
+        zero_h();
+        fc_phase(c);
+        proj_phase(c, T_{}, T_{});
+        body_end(c);
+        if (c < 7) mlp_load_x_fc<0>(FA, XA);                        // fragments of the next body's first step
+        else mlp_load_x_proj<0>(FA, XA, 1);                          // body(8): c_proj(7) reads hidden panel 7 & 1
+        __builtin_amdgcn_sched_barrier(0);
     }
+    proj_phase(8, T_{}, F_{});
     if (MODE & 1) {          // stream-only experiment: keep the loaded fragments alive
 #pragma unroll
         for (int i = 0; i < D; ++i) asm volatile("" ::"v"(WQ[i].f[0]), "v"(WQ[i].f[1]), "v"(WQ[i].f[2]), "v"(WQ[i].f[3]));
@@ -346,7 +456,7 @@ extern "C" int tan_pack_weights(const void* src, void* dst, const tan_pack_entry
 
 extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
     TAN_REQUIRE(d && d->x_mid && d->ln_g && d->ln_b && d->pw_fc && d->pw_proj && d->b_fc && d->b_proj && d->xn2 && d->mean2 && d->rstd2 &&
-                d->x_out);
+                d->x_out && d->h_pre && d->h_act);
     TAN_REQUIRE(d->rows > 0 && d->rows % PN_ROWS == 0 && d->C == 512 && d->FF == 2048);
     TAN_REQUIRE(!d->xn_next || (d->nln_g && d->nln_b && d->nmean && d->nrstd));
     MlpFwdArgs a;
@@ -363,6 +473,8 @@ extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
         case 5: hipLaunchKernelGGL((mlp_fwd_panel_kernel<5>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
         case 2: hipLaunchKernelGGL((mlp_fwd_panel_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
         case 6: hipLaunchKernelGGL((mlp_fwd_panel_kernel<6>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        case 8: hipLaunchKernelGGL((mlp_fwd_panel_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        case 10: hipLaunchKernelGGL((mlp_fwd_panel_kernel<10>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
         case 14: hipLaunchKernelGGL((mlp_fwd_panel_kernel<14>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
         case 15: hipLaunchKernelGGL((mlp_fwd_panel_kernel<15>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
 #endif

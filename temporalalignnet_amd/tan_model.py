@@ -52,6 +52,8 @@ class _Flat:
         # transposed bf16 copies of the encoder Linear weights (K-contiguous operand of the dX GEMMs), refreshed lazily:
         # shadow_epoch counts refreshes of `shadow`, shadow_t_epoch the epoch `shadow_t` was built from
         self.shadow_t, self.shadow_t_table, self.shadow_epoch, self.shadow_t_epoch = None, None, 0, -1
+        # tan_pack_weights images (row-panel kernels) of the same weights / of their transposes, same element offsets
+        self.shadow_p, self.shadow_tp, self.pack_table, self.shadow_p_epoch, self.shadow_tp_epoch = None, None, None, -1, -1
         self.device = None
 
     def bound(self):
@@ -79,6 +81,40 @@ class _Flat:
         self.shadow_version = -1
         self._views = {}
         self.shadow_t, self.shadow_t_table, self.shadow_t_epoch = None, None, -1
+        self.shadow_p, self.shadow_tp, self.pack_table, self.shadow_p_epoch, self.shadow_tp_epoch = None, None, None, -1, -1
+
+    def _pack_tables(self):
+        """device tables of tan_pack_entry for the encoder Linear weights ([out, in]) and for their transposes ([in, out])"""
+        if self.pack_table is None:
+            names = [n for n in self.names if ".resblocks." in n and len(self.off[n][2]) == 2]
+
+            def table(transposed):
+                ents, mx = [], 0
+                for n in names:
+                    o, _, (N, K) = self.off[n]
+                    if transposed:
+                        N, K = K, N
+                    TN, TK = (512, 16) if N == 512 else (256, 32)
+                    ents.append(_lib.PackEntry(o, o, N, K, TN, TK))
+                    mx = max(mx, (N // TN) * (K // TK))
+                arr = (_lib.PackEntry * len(ents))(*ents)
+                dev_t = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.shadow.device)
+                return dev_t, len(ents), mx
+            self.pack_table = (table(False), table(True))
+        return self.pack_table
+
+    def sync_shadow_p(self):
+        """(Re)build the packed images of every 2-D `...resblocks.*` weight from the bf16 shadow: one launch."""
+        if self.shadow is None:
+            return None
+        if self.shadow_p is None:
+            self.shadow_p = torch.zeros(self.total, dtype=torch.bfloat16, device=self.shadow.device)
+        if self.shadow_p_epoch != self.shadow_epoch:
+            tab, n, mx = self._pack_tables()[0]
+            _lib.check(_lib.lib().tan_pack_weights(_vp(self.shadow), _vp(self.shadow_p), _vp(tab), C.c_int(n), C.c_int(mx),
+                                                   ops._stream()), "tan_pack_weights")
+            self.shadow_p_epoch = self.shadow_epoch
+        return self.shadow_p
 
     def sync_shadow(self):
         if self.shadow is not None and self.shadow_version != self.flat._version:
@@ -245,6 +281,7 @@ class TemporalAligner(nn.Module):
         self._issuer = None               # helper thread issuing the side-stream stack (see _on_side)
         self._lp_cache = {}
         self.transposed_dx = os.environ.get("TAN_TRANSPOSED_DX", "1") != "0"   # dX GEMMs read W^T copies (K-contiguous)
+        self.panel_kernels = os.environ.get("TAN_PANEL", "0") == "1"           # row-panel fused kernels (packed weight images), opt-in
         self._grad_ready_hook = None      # callable(tag, layer_events) fired inside backward once a stack's backward is enqueued
         # load_state_dict copies into the parameter tensors, whose version counters are not the flat buffer's: the bf16
         # shadow (and the W^T copies built from it) must be rebuilt from the f32 masters on the next forward
@@ -287,6 +324,8 @@ class TemporalAligner(nn.Module):
                                        "call .cuda() first")
             f.bind(want_shadow=self.compute_dtype == torch.bfloat16)
         f.sync_shadow()
+        if self.panel_kernels:
+            f.sync_shadow_p()
         return f
 
     def flat_parameters(self):
@@ -359,7 +398,9 @@ class TemporalAligner(nn.Module):
         f = self._flat
         wbuf = f.shadow if self.compute_dtype == torch.bfloat16 else f.flat
         wt = f.shadow_t if (self.compute_dtype == torch.bfloat16 and self.transposed_dx) else None
-        sig = (f.flat.data_ptr(), f.grad.data_ptr(), wbuf.data_ptr(), wt.data_ptr() if wt is not None else 0)
+        wp = f.shadow_p if (self.compute_dtype == torch.bfloat16 and self.panel_kernels) else None
+        sig = (f.flat.data_ptr(), f.grad.data_ptr(), wbuf.data_ptr(), wt.data_ptr() if wt is not None else 0,
+               wp.data_ptr() if wp is not None else 0)
         hit = self._lp_cache.get((prefix, layers))
         if hit is not None and hit[0] == sig:
             return hit[1]
@@ -375,6 +416,7 @@ class TemporalAligner(nn.Module):
                 setattr(arr[i], k, f.ptr(wbuf, base + v))
                 setattr(arr[i], "g_" + k, f.ptr(f.grad, base + v))
                 setattr(arr[i], "wt_" + k[2:], f.ptr(wt, base + v) if wt is not None else None)
+                setattr(arr[i], "wp_" + k[2:], f.ptr(wp, base + v) if wp is not None else None)
             for k, v in fm.items():
                 setattr(arr[i], k, f.ptr(f.flat, base + v))
                 setattr(arr[i], "g_" + k, f.ptr(f.grad, base + v))

@@ -1,0 +1,113 @@
+"""Row-panel fused kernels (csrc/tan_panel.hip) through the C ABI: tan_pack_weights + tan_mlp_fwd against a PyTorch fp32
+reference of model/tfm_model.py:23-27,35-37 and against the four launches they replace (LayerNorm, c_fc GEMM, c_proj GEMM,
+LayerNorm).  bf16 throughput mode only; tolerances are bf16 rounding (the f32 parity mode never takes this path)."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib_ops():
+    from temporalalignnet_amd import _lib, ops
+    return _lib, ops
+
+
+def pack(mats):
+    _lib, ops = _lib_ops()
+    src = torch.cat([m.reshape(-1) for m in mats])
+    dst = torch.empty_like(src)
+    ents, off, mx = [], 0, 0
+    for m in mats:
+        N, K = m.shape
+        TN, TK = (512, 16) if N == 512 else (256, 32)
+        ents.append(_lib.PackEntry(off, off, N, K, TN, TK))
+        mx = max(mx, (N // TN) * (K // TK))
+        off += N * K
+    arr = (_lib.PackEntry * len(ents))(*ents)
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    _lib.check(_lib.lib().tan_pack_weights(ops._ptr(src), ops._ptr(dst), C.c_void_p(tab.data_ptr()), len(ents), mx, ops._stream()),
+               "tan_pack_weights")
+    outs, off = [], 0
+    for m in mats:
+        outs.append(dst[off:off + m.numel()])
+        off += m.numel()
+    return outs
+
+
+def test_pack_weights_is_a_permutation_with_the_documented_fragment_layout():
+    torch.manual_seed(1)
+    for (N, K) in ((2048, 512), (512, 2048), (1536, 512), (512, 512)):
+        w = torch.randn(N, K, device="cuda").bfloat16()
+        (p,) = pack([w])
+        assert torch.equal(torch.sort(p.view(torch.int16).flatten())[0], torch.sort(w.view(torch.int16).flatten())[0])
+        TN, TK = (512, 16) if N == 512 else (256, 32)
+        KS, RB = TK // 16, TN // 128
+        tiles = p.view(N // TN, K // TK, 4, RB, KS, 64, 8)          # [n-block][k-block][wave][row block][k step][lane][8]
+        nb, kb, wv, rb, ks, lane = 0, (K // TK) - 1, 3, RB - 1, KS - 1, 45
+        row = nb * TN + wv * (TN // 4) + rb * 32 + (lane & 31)
+        k = kb * TK + ks * 16 + 8 * (lane >> 5)
+        assert torch.equal(tiles[nb, kb, wv, rb, ks, lane], w[row, k:k + 8])
+
+
+@pytest.mark.parametrize("R,next_ln", [(64, True), (640, True), (1024, False)])
+def test_mlp_fwd_matches_reference_and_unfused_path(R, next_ln):
+    _lib, ops = _lib_ops()
+    torch.manual_seed(R)
+    bf = torch.bfloat16
+    x_mid = (torch.randn(R, 512, device="cuda") * 1.5).to(bf)
+    wfc = (torch.randn(2048, 512, device="cuda") * 1024 ** -0.5).to(bf)
+    wpj = (torch.randn(512, 2048, device="cuda") * 0.03).to(bf)
+    bfc, bpj = torch.randn(2048, device="cuda") * 0.1, torch.randn(512, device="cuda") * 0.1
+    g2, b2 = 1 + 0.1 * torch.randn(512, device="cuda"), 0.1 * torch.randn(512, device="cuda")
+    g1, b1 = 1 + 0.1 * torch.randn(512, device="cuda"), 0.1 * torch.randn(512, device="cuda")
+    pw_fc, pw_pj = pack([wfc, wpj])
+    out = {k: torch.zeros(R, 512, device="cuda", dtype=bf) for k in ("xn2", "xout", "xn1")}
+    out |= {k: torch.zeros(R, 2048, device="cuda", dtype=bf) for k in ("hpre", "hact")}
+    out |= {k: torch.zeros(R, device="cuda") for k in ("mean2", "rstd2", "mean1", "rstd1")}
+    d = _lib.MlpDesc()
+    d.rows, d.C, d.FF = R, 512, 2048
+    d.x_mid, d.ln_g, d.ln_b = x_mid.data_ptr(), g2.data_ptr(), b2.data_ptr()
+    d.pw_fc, d.pw_proj, d.b_fc, d.b_proj = pw_fc.data_ptr(), pw_pj.data_ptr(), bfc.data_ptr(), bpj.data_ptr()
+    d.xn2, d.mean2, d.rstd2 = out["xn2"].data_ptr(), out["mean2"].data_ptr(), out["rstd2"].data_ptr()
+    d.h_pre, d.h_act, d.x_out = out["hpre"].data_ptr(), out["hact"].data_ptr(), out["xout"].data_ptr()
+    if next_ln:
+        d.nln_g, d.nln_b, d.xn_next = g1.data_ptr(), b1.data_ptr(), out["xn1"].data_ptr()
+        d.nmean, d.nrstd = out["mean1"].data_ptr(), out["rstd1"].data_ptr()
+    d.eps, d.variant = 1e-5, 0
+    _lib.check(_lib.lib().tan_mlp_fwd(C.byref(d), ops._stream()), "tan_mlp_fwd")
+    torch.cuda.synchronize()
+    # fp32 reference from the same bf16 inputs, rounded where the kernel rounds
+    x = x_mid.float()
+    xn2 = torch.nn.functional.layer_norm(x, (512,), g2, b2, 1e-5)
+    pre = xn2.to(bf).float() @ wfc.float().T + bfc
+    act = pre * torch.sigmoid(1.702 * pre)
+    xo = x + act.to(bf).float() @ wpj.float().T + bpj
+    xob = xo.to(bf).float()
+    ref = {"xn2": xn2, "hpre": pre, "hact": act, "xout": xo, "mean2": x.mean(-1), "rstd2": (x.var(-1, unbiased=False) + 1e-5).rsqrt()}
+    if next_ln:
+        ref |= {"xn1": torch.nn.functional.layer_norm(xob, (512,), g1, b1, 1e-5), "mean1": xob.mean(-1),
+                "rstd1": (xob.var(-1, unbiased=False) + 1e-5).rsqrt()}
+    for k, r in ref.items():
+        got = out[k].float()
+        tol = 2.0 ** -7 * r.abs().max().item() if out[k].dtype == bf else 2e-4      # one bf16 ulp at the top of the range
+        assert (got - r).abs().max().item() <= tol, (k, (got - r).abs().max().item(), tol)
+    # the unfused launches it replaces: same roundings, so agreement to a bf16 ulp of each tensor
+    u_xn2, u_hpre, u_hact, u_xout = (torch.empty_like(out[k]) for k in ("xn2", "hpre", "hact", "xout"))
+    ops.layernorm_fwd(x_mid, g2, b2, u_xn2)
+    ops.gemm(u_xn2, wfc, u_hact, M=R, N=2048, K=512, bias=bfc, act=ops.ACT_QUICKGELU, aux=u_hpre)
+    ops.gemm(u_hact, wpj, u_xout, M=R, N=512, K=2048, bias=bpj, residual=x_mid)
+    torch.cuda.synchronize()
+    assert torch.equal(u_xn2, out["xn2"])
+    for u, k in ((u_hpre, "hpre"), (u_hact, "hact"), (u_xout, "xout")):
+        diff = (u.float() - out[k].float()).abs()
+        assert diff.max().item() <= 2.0 ** -7 * u.float().abs().max().item(), k
+        assert (diff > 0).float().mean().item() < 0.02, k        # different summation order flips a rounding now and then
+
+
+def test_mlp_fwd_rejects_what_it_cannot_do():
+    _lib, ops = _lib_ops()
+    d = _lib.MlpDesc()
+    d.rows, d.C, d.FF = 100, 512, 2048       # not a multiple of 64 rows, and nothing bound
+    assert _lib.lib().tan_mlp_fwd(C.byref(d), ops._stream()) == -1

@@ -43,8 +43,8 @@ def run_fused(t, variant, store_h=True, next_ln=True):
     d.pw_fc = t["pw"][0].data_ptr(); d.pw_proj = t["pw"][1].data_ptr()
     d.b_fc = t["bfc"].data_ptr(); d.b_proj = t["bpj"].data_ptr()
     d.xn2 = t["f_xn2"].data_ptr(); d.mean2 = t["f_mean2"].data_ptr(); d.rstd2 = t["f_rstd2"].data_ptr()
-    d.h_pre = t["f_hpre"].data_ptr() if store_h else None
-    d.h_act = t["f_hact"].data_ptr() if store_h else None
+    d.h_pre = t["f_hpre"].data_ptr()
+    d.h_act = t["f_hact"].data_ptr()
     d.x_out = t["f_xout"].data_ptr()
     if next_ln:
         d.nln_g = t["g1"].data_ptr(); d.nln_b = t["b1"].data_ptr(); d.xn_next = t["f_xn1"].data_ptr()
@@ -134,8 +134,8 @@ if __name__ == "__main__":
         fl = 2.0 * R * 512 * 2048 * 2
         tu = timeit(lambda: run_unfused(t))
         print(f"R={R}: unfused (LN, fc, proj, LN)            {tu:7.1f} us   {fl / tu / 1e6:6.0f} TF/s", flush=True)
-        for v in (0, 5, 2, 6, 14, 15):
-            for sh, nl in ((True, True), (False, False)):
+        for v in (0, 5, 2, 6, 8, 10, 14, 15):
+            for sh, nl in ((True, True), (True, False)):
                 tf = timeit(lambda: run_fused(t, v, sh, nl))
                 print(f"R={R}: fused v{v} store_h={int(sh)} next_ln={int(nl)}          {tf:7.1f} us   {fl / tf / 1e6:6.0f} TF/s", flush=True)
     # two panels' worth of work on two streams at once (video + joint stack sizes)
