@@ -40,8 +40,17 @@ def expand_for_cotrain(state_dict: dict) -> dict:
     return out
 
 
+def _is_frozen_word_table(name: str) -> bool:
+    """The language model's word-embedding table.  The reference keeps it a plain nn.Embedding (requires_grad=True,
+    model/s3d_milnce/s3dg.py:197) that is only ever read under no_grad (word2vec_model.py:84-85): optim_policy therefore lists it
+    in the with-decay group as a member that never gets optimizer state.  This build freezes it (requires_grad=False), so it
+    has to be put back when numbering parameters the reference's way."""
+    return name.endswith(("bert.word_embd.weight", "lang_model.word_embd.weight")) and not name.startswith("target.")
+
+
 def _trainable_named(model):
-    return [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    """named_parameters() the reference's optimizer would see (main.py:336-338): requires_grad, plus the word table above."""
+    return [(n, p) for n, p in model.named_parameters() if p.requires_grad or _is_frozen_word_table(n)]
 
 
 def _groups(model, policy="default"):
@@ -125,9 +134,11 @@ def load_optimizer_state_dict(trainer, opt_state: dict):
 
 
 def make_state(trainer, epoch: int, best_acc: float) -> dict:
-    """The dict train/main.py:515-520 saves."""
+    """The dict train/main.py:515-520 saves.  'iteration' is the reference's BATCH counter args.iteration (starts at 1,
+    main.py:281, +1 per batch, main.py:140) -- not the optimizer-step count, which differs once backprop_freq > 1 and which the
+    AdamW state carries itself (state[*]['step'])."""
     return {"epoch": epoch, "state_dict": {k: v.detach().cpu().clone() for k, v in trainer.model.state_dict().items()},
-            "best_acc": best_acc, "optimizer": optimizer_state_dict(trainer), "iteration": trainer.iteration}
+            "best_acc": best_acc, "optimizer": optimizer_state_dict(trainer), "iteration": trainer.batches_seen + 1}
 
 
 def save_checkpoint(state: dict, is_best=0, gap=1, filename="models/checkpoint.pth.tar", keep_all=False):
@@ -174,8 +185,11 @@ def load_for_resume(trainer, path):
     """--resume (main.py:437-456) -> dict(start_epoch, best_acc, missing, unexpected); restores iteration + AdamW moments."""
     ckpt = torch.load(path, map_location="cpu", weights_only=False)
     missing, unexpected = _load_state(trainer.model, ckpt["state_dict"])
-    load_optimizer_state_dict(trainer, ckpt["optimizer"])
-    trainer.iteration = ckpt["iteration"]
+    load_optimizer_state_dict(trainer, ckpt["optimizer"])            # restores the Adam bias-correction step from the state
+    # args.iteration = checkpoint['iteration'] (main.py:444) drives the LR schedule; lr_scheduler.step(args.iteration) right
+    # after (main.py:499) makes the FIRST batch after a resume run at lambda(iteration) -- one ahead of the uninterrupted run
+    trainer.batches_seen = max(int(ckpt["iteration"]) - 1, 0)
+    trainer._resume_bump = 1
     return {"start_epoch": ckpt["epoch"] + 1, "best_acc": ckpt["best_acc"], "missing": missing, "unexpected": unexpected}
 
 

@@ -413,9 +413,16 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
             tgt_valid = tgt * (~tpad)[:, None, :].float()
             rows_pos_th = ((tgt_valid * th_f.view(B, 1, N)).sum(-1) > 0).view(R).float()              # loss.py:288-290
             aux.update(t_th_mask=th_mask, max_logits_dual_per_text=md, max_logits_joint_per_text=mj)
+        glob = nce_counts is not None        # global negatives: the rank losses are SUMMED over ranks (gradients too), so every mean
+        #                                      below divides its rank-local sum by the ALL-rank count (a rank-local mean
+        #                                      would weigh these terms W times too much against the globally normalised NCE)
         if args.loss_threshold > 0:
             out["loss-dual-all"], out["loss-joint-all"] = loss_dual.detach(), loss_joint.detach()
-            pair_th = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos_th, th_f)       # (thresholded means stay rank-local)
+            th_counts = None
+            if glob:
+                from .dist_nce import global_counts
+                th_counts = global_counts(rows_pos_th, th_f)
+            pair_th = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos_th, th_f, th_counts)   # (the thresholds themselves stay rank-local)
             loss_dual_th, loss_joint_th = pair_th[0], pair_th[1]
             out["loss-dual"], out["loss-joint"] = loss_dual_th.detach(), loss_joint_th.detach()
         if args.use_alignability_head:
@@ -430,14 +437,19 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
                     lab = lab.masked_fill((centre < 0.2) | (centre > 0.8), 0.0)
                 sel = ((lab != 2) & valid).float()
                 y = lab * sel
-                n_sel = sel.sum()
-                pos_weight = n_sel / y.sum() - 1.0                                                    # 1/mean(y) - 1
+                n_sel, n_pos = sel.sum(), y.sum()
+                if glob:
+                    from . import dist as _dist
+                    cnt = torch.stack([n_sel, n_pos])
+                    _dist.allreduce_sum_(cnt)
+                    n_sel, n_pos = cnt[0], cnt[1]
+                pos_weight = n_sel / n_pos - 1.0                                                      # 1/mean(y) - 1
                 aux["t_align_th_mask"] = torch.where(valid, lab, torch.full_like(lab, float("nan")))
             a_joint = logits["joint_logits_alignability"][:, 2, :, 0].reshape(Mp)                     # stage index 2 (loss.py:341)
             bce = F.binary_cross_entropy_with_logits(a_joint, y, pos_weight=pos_weight.expand(Mp), reduction="none")
             bce_joint = (bce * sel).sum() / n_sel
             out["loss-joint-bce"] = bce_joint.detach()
-            out["alignability_top1"] = ((((a_joint.detach() > 0).float() == y).float()) * sel).sum() / n_sel
+            out["alignability_top1"] = ((((a_joint.detach() > 0).float() == y).float()) * sel).sum() / sel.sum()
 
     nce_w = 0 if args.optim_policy == "bce" else 1
     if args.loss_threshold > 0:

@@ -116,8 +116,9 @@ class Trainer:
         # row f3: NCE negatives from every rank (fused bf16 path only).  The global loss is then the SUM of the rank losses,
         # so gradients are summed over ranks instead of averaged.
         self.global_negatives = bool(global_negatives)
-        self._lr_iter = None              # batch counter driving the LR schedule when it differs from the optimizer-step count
-        self.batches_seen = 0
+        self._lr_iter = None              # (kept for callers that pin the schedule position explicitly)
+        self.batches_seen = 0             # batches processed so far = the reference's args.iteration - 1 (main.py:281,140)
+        self._resume_bump = 0             # 1 for the first batch after checkpoint.load_for_resume (see there)
         self._accum_open = False          # gradients of earlier batches are waiting in the flat buffer (backprop_freq > 1)
         # data parallelism: encoder layers per gradient all-reduce bucket (one layer = 12.6 MB of f32 gradient)
         self.ddp_bucket_layers = max(1, int(os.environ.get("TAN_DDP_BUCKET_LAYERS", "2") if ddp_bucket_layers is None
@@ -138,13 +139,17 @@ class Trainer:
         return f, self._state
 
     def current_lr(self):
-        """The reference steps its LambdaLR with the pre-increment iteration AFTER the optimizer step
-        (main.py:137-139), so the k-th optimizer step (0-based) runs at lambda(max(k-1, 0)); self.iteration == k+1 here."""
+        """Learning rate of the batch being processed.  The reference starts args.iteration at 1 (main.py:281), calls
+        lr_scheduler.step(args.iteration) once before training (main.py:499) and again after every batch with the
+        PRE-increment counter (main.py:138-140): batch b (0-based) therefore runs at lambda(max(b, 1)) -- replayed against
+        torch's LambdaLR in tests/test_train_eval_gpu.py::test_lr_schedule_lag_matches_reference_lambda_lr -- and the first
+        batch after a resume at lambda(b + 1)."""
         if self.iter_per_epoch is None:
             return self.args.lr
         lr_iter = getattr(self, "_lr_iter", None)
-        k = self.iteration - 1 if lr_iter is None else lr_iter                  # batches seen before this one (args.iteration)
-        return self.args.lr * lr_multiplier(max(k - 1, 0), self.iter_per_epoch, self.args.epochs, self.warmup)
+        b = self.batches_seen if lr_iter is None else lr_iter
+        return self.args.lr * lr_multiplier(max(b + getattr(self, "_resume_bump", 0), 1), self.iter_per_epoch, self.args.epochs,
+                                            self.warmup)
 
     def _comm_order_stream(self, device):
         """The stream the gradient collectives are issued under: it only ever waits for layer events, so a bucket's all-reduce
@@ -176,10 +181,11 @@ class Trainer:
         tgt = dict(self.model.target.bert.named_parameters()) if self.twin and self.model.target.bert is not None else {}
         a = self.args
         for n, p in named:
-            if p.grad is None:
+            if p.grad is None:       # no gradient this step: AdamW skips the tensor, the EMA twin still moves (tan_model.py:339-344)
+                if n in tgt:
+                    _lib.check(_lib.lib().tan_ema_update(_vp(tgt[n].data), _vp(p.data), C.c_long(p.numel()), C.c_float(self.model.m),
+                                                         None, ops._stream()), "tan_ema_update")
                 continue
-            if dist.active():
-                dist.allreduce_sum_(p.grad)
             m, v = self._state["lm"][n]
             wd = 0.0 if n.endswith(".bias") else a.wd
             ema = tgt.get(n)
@@ -225,9 +231,25 @@ class Trainer:
         loss_dict["loss"].backward()
         return loss_dict
 
+    def _lm_allreduce(self):
+        """Sum the language model's gradients over ranks in ONE bucket (they live outside the flat buffer).  Must run before
+        the per-parameter clip: the clip coefficient is a function of the AVERAGED gradient (utils/train_utils.py:3-13)."""
+        if not dist.active():
+            return
+        grads = [p.grad for _, p in self._lm_params() if p.grad is not None]
+        if not grads:
+            return
+        bucket = torch.cat([g.reshape(-1) for g in grads])
+        dist.allreduce_sum_(bucket)
+        off = 0
+        for g in grads:
+            g.copy_(bucket[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
     def optimizer_step(self, grad_scale=1.0):
         f, st = self._ensure_state()
         a = self.args
+        self._lm_allreduce()
         if a.clip_grad > 0:                            # per-parameter L2 clip, utils/train_utils.py:3-13 (language model included)
             for p in list(f.params) + [q for _, q in self._lm_params()]:
                 if p.grad is not None:
@@ -269,6 +291,7 @@ class Trainer:
                 self._lr_iter = None
             self._accum_open = False
         self.batches_seen += 1
+        self._resume_bump = 0
         return loss_dict
 
     def _ddp_buckets(self, tag, layers):
@@ -327,4 +350,5 @@ class Trainer:
                 w.wait()
         self.optimizer_step(grad_scale=1.0 if self.global_negatives else 1.0 / world)
         self.batches_seen += 1
+        self._resume_bump = 0
         return loss_dict

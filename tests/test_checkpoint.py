@@ -87,12 +87,14 @@ def test_resume_is_exact_and_optimizer_state_is_torch_compatible(tmp_path):
         t1.step(batch)
     path = str(tmp_path / "epoch0.pth.tar")
     ck.save_checkpoint(ck.make_state(t1, epoch=0, best_acc=2.5), filename=path)
+    t1._resume_bump = 1        # what the reference's resume does to the first batch (main.py:499): one schedule position ahead
     l4 = float(t1.step(batch)["loss"].detach())
     p4 = t1.online.flat_parameters().clone()
 
     m2, t2 = fresh(1)                                   # different init: everything must come from the file
     info = ck.load_for_resume(t2, path)
     assert info["start_epoch"] == 1 and info["best_acc"] == 2.5 and info["missing"] == [] and t2.iteration == 3
+    assert t2.batches_seen == 3 and torch.load(path, weights_only=False)["iteration"] == 4     # args.iteration = 1 + batches
     l4b = float(t2.step(batch)["loss"].detach())
     assert abs(l4b - l4) <= 1e-6 * abs(l4)              # f32 atomics in the gradient reductions: not bitwise reproducible
     torch.testing.assert_close(t2.online.flat_parameters(), p4, rtol=1e-5, atol=5e-6)   # Adam normalises near-zero gradients: noise of a few % of one lr-sized update
@@ -129,3 +131,75 @@ def test_resume_is_exact_and_optimizer_state_is_torch_compatible(tmp_path):
     opt3.step()
     for c, (n, p) in zip(clones, nd3 + wd3):
         torch.testing.assert_close(c.detach(), p.detach(), rtol=2e-6, atol=2e-7, msg=n)
+
+
+def test_word_table_is_numbered_like_the_reference_optimizer():
+    """the reference's word-embedding table is a plain nn.Embedding (requires_grad=True, s3dg.py:197) used under
+    no_grad, so optim_policy (main.py:336-343) lists it in the with-decay group, stateless; this build freezes it and must
+    still number it.  Group sizes for the twin E1D3 model: [28, 19] in the reference."""
+    torch.manual_seed(0)
+    tw = build_model(default_args(model="cotrain", num_encoder_layers=1, num_decoder_layers=3), language_model=None)
+    tw.online.bert, tw.target.bert = Word2VecModel(num_embeddings=50), Word2VecModel(num_embeddings=50)
+    tw.bert = tw.online.bert
+    tw._copy_param()
+    nd, wd = ck._groups(tw, "default")
+    # the reference's rule applied to a replica whose word table is trainable, as in the reference
+    replica = [(n, p.requires_grad or n.endswith("online.bert.word_embd.weight")) for n, p in tw.named_parameters()]
+    ref_nd = [n for n, rg in replica if rg and any(t in n for t in ck.NO_DECAY_TOKENS)]
+    ref_wd = [n for n, rg in replica if rg and not any(t in n for t in ck.NO_DECAY_TOKENS)]
+    assert [n for n, _ in nd] == ref_nd and [n for n, _ in wd] == ref_wd
+    names_wd = [n for n, _ in wd]
+    assert "online.bert.word_embd.weight" in names_wd and not any(n.startswith("target.") for n in names_wd)
+    i = names_wd.index("online.bert.word_embd.weight")
+    assert names_wd[i + 1] == "online.bert.fc1.weight"          # sits between the aligner's parameters and fc1, as in the reference
+    single = _init_model(E=1, D=1)
+    nd1, wd1 = ck._groups(single, "default")
+    assert "bert.word_embd.weight" in [n for n, _ in wd1]
+
+
+@pytest.mark.gpu
+def test_optimizer_state_round_trips_with_the_word2vec_language_model(tmp_path):
+    """The saved AdamW state loads into a torch.optim.AdamW built by the reference's grouping rule (word table included, without
+    state), and back into a fresh Trainer; resume with backprop_freq = 2 restores the batch counter and the Adam step separately."""
+    args = default_args(model="init", num_encoder_layers=1, num_decoder_layers=1, backprop_freq=2)
+    b_np = synth.make_batch(5, B=4, T=16, n_min=2, n_max=5)
+    batch = to_device_batch(b_np)
+    ids, _ = synth.w2v_tokens(6, int(b_np["n_per"].sum()), 50)
+    batch["token"] = [t.cuda() for t in torch.split(torch.from_numpy(ids), [int(n) for n in b_np["n_per"]])]
+
+    def fresh(seed):
+        torch.manual_seed(seed)
+        m = build_model(args, compute_dtype="fp32", language_model=None)
+        m.bert = Word2VecModel(num_embeddings=50)
+        m = m.cuda()
+        m.random_pos_start = 0
+        return m, Trainer(m, args, iter_per_epoch=100, warmup=2)
+
+    m1, t1 = fresh(0)
+    for idx in range(5):                   # batches 0, 2, 4 step the optimizer (idx % 2 == 0, main.py:113)
+        t1.train_iteration(batch, idx)
+    assert (t1.batches_seen, t1.iteration) == (5, 3)
+    path = str(tmp_path / "epoch0.pth.tar")
+    ck.save_checkpoint(ck.make_state(t1, epoch=0, best_acc=1.0), filename=path)
+    state = torch.load(path, weights_only=False)
+    assert state["iteration"] == 6
+    nd, wd = ck._groups(m1, "default")
+    assert [len(nd), len(wd)] == [len(g["params"]) for g in state["optimizer"]["param_groups"]]
+    clones = [torch.nn.Parameter(p.detach().clone()) for _, p in nd + wd]
+    opt = torch.optim.AdamW([{"params": clones[:len(nd)], "weight_decay": 0.0}, {"params": clones[len(nd):], "weight_decay": args.wd}],
+                            lr=args.lr)
+    opt.load_state_dict(state["optimizer"])                    # torch accepts it: same group sizes and numbering
+    names = [n for n, _ in nd + wd]
+    k = names.index("bert.word_embd.weight")
+    assert k not in state["optimizer"]["state"] and names.index("bert.fc1.weight") in state["optimizer"]["state"]
+    assert all(float(s["step"]) == 3.0 for s in state["optimizer"]["state"].values())
+    m2, t2 = fresh(1)
+    ck.load_for_resume(t2, path)
+    assert (t2.batches_seen, t2.iteration, t2._resume_bump) == (5, 3, 1)
+    lm1, lm2 = t1._state["lm"], t2._state["lm"]
+    for n in lm1:
+        assert torch.equal(lm1[n][0], lm2[n][0]) and torch.equal(lm1[n][1], lm2[n][1])
+    from temporalalignnet_amd.train import lr_multiplier
+    assert t2.current_lr() == pytest.approx(args.lr * lr_multiplier(6, 100, args.epochs, 2))   # lambda(saved iteration), main.py:499
+    t2.train_iteration(batch, 5)
+    assert (t2.batches_seen, t2._resume_bump) == (6, 0)

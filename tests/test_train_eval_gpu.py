@@ -148,26 +148,44 @@ def test_batched_eval_in_bf16_agrees_with_window_by_window_and_is_faster():
 
 
 def test_lr_schedule_lag_matches_reference_lambda_lr():
-    """Replays the reference's LambdaLR usage (train/main.py:495-499,137-139) with torch on a dummy parameter."""
+    """Replays the reference's LambdaLR usage with torch on a dummy parameter: args.iteration starts at 1 (train/main.py:281),
+    lr_scheduler.step(args.iteration) once before training (main.py:499) and after every batch with the pre-increment counter
+    (main.py:138-140); a resume re-enters at main.py:444,499 with the saved counter."""
     import functools
-    from temporalalignnet_amd.train import Trainer, default_args, lr_multiplier
-    p = torch.nn.Parameter(torch.zeros(1))
-    opt = torch.optim.AdamW([p], lr=1e-4)
-    args = default_args(epochs=2)
-    sched = torch.optim.lr_scheduler.LambdaLR(opt, functools.partial(lr_multiplier, iter_per_epoch=1500, epochs=2, warmup=1000))
     import warnings
+    from temporalalignnet_amd.train import Trainer, default_args, lr_multiplier
+    args = default_args(epochs=2)
+    fn = functools.partial(lr_multiplier, iter_per_epoch=1500, epochs=2, warmup=1000)
+
+    def reference_lrs(n_batches, start_iteration=1):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=args.lr)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, fn)
+        it, used = start_iteration, []
+        sched.step(it)                                       # main.py:499
+        for _ in range(n_batches):
+            used.append(opt.param_groups[0]["lr"])           # the optimizer step of this batch
+            sched.step(it)                                   # main.py:138
+            it += 1                                          # main.py:140
+        return used, it
+
     tr = Trainer.__new__(Trainer)
-    tr.args, tr.iter_per_epoch, tr.warmup, tr.iteration = args, 1500, 1000, 0
+    tr.args, tr.iter_per_epoch, tr.warmup, tr.iteration, tr.batches_seen, tr._lr_iter, tr._resume_bump = args, 1500, 1000, 0, 0, None, 0
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        sched.step(0)
-        for it in range(0, 2990, 7):
-            # emulate `it` completed iterations
-            for g_ in opt.param_groups:
-                pass
-            sched.step(max(it - 1, 0)) if it > 0 else None
-            tr.iteration = it + 1
-            assert tr.current_lr() == pytest.approx(opt.param_groups[0]["lr"], rel=1e-12, abs=1e-18)
+        used, it = reference_lrs(2990)
+        for b in range(0, 2990, 7):
+            tr.batches_seen = b
+            assert tr.current_lr() == pytest.approx(used[b], rel=1e-12, abs=1e-18), b
+        assert used[0] == used[1] == pytest.approx(args.lr * 1e-3)       # batches 0 and 1 both run at lambda(1)
+        # resume after 40 batches: saved 'iteration' = 41; the first resumed batch runs one schedule position ahead
+        used_r, _ = reference_lrs(3, start_iteration=41)
+        tr.batches_seen, tr._resume_bump = 40, 1
+        assert tr.current_lr() == pytest.approx(used_r[0], rel=1e-12)
+        tr.batches_seen, tr._resume_bump = 41, 0
+        assert tr.current_lr() == pytest.approx(used_r[1], rel=1e-12)
+        tr.batches_seen = 42
+        assert tr.current_lr() == pytest.approx(used_r[2], rel=1e-12)
 
 
 @pytest.mark.gpu
