@@ -128,6 +128,20 @@ def joint_feature(video, video_padding_mask, lang_with_time, lang_padding_mask, 
     return out[:, :, :T], out[:, :, T:]
 
 
+def sine_position_table(feature_dim=512, num_features=1024, temperature=10000.0):
+    """pos_enc='sine' (tan_model.py:60-62): positions scaled to [0, 2*pi), channel pair i shares the wavelength
+    temperature^(2i/feature_dim); even channels sin, odd channels cos -- model/tfm_model.py:137-149.  Pinned by golden G10."""
+    pos = torch.arange(num_features, dtype=torch.float32)
+    pos = pos / (pos[-1] + 1e-6) * (2.0 * np.pi)
+    idx = torch.arange(feature_dim, dtype=torch.float32)
+    wavelength = temperature ** (2.0 * torch.div(idx, 2, rounding_mode="floor") / feature_dim)
+    ang = pos[:, None] / wavelength[None, :]
+    out = torch.empty(num_features, feature_dim)
+    out[:, 0::2] = ang[:, 0::2].sin()
+    out[:, 1::2] = ang[:, 1::2].cos()
+    return out
+
+
 def _unit(x):
     """x / ||x||_2 over channels, no epsilon -- tan_model.py:116-117,136-137."""
     return x / x.norm(dim=-1, keepdim=True)

@@ -441,9 +441,29 @@ def g10_sine_pos():
     save("g10_sine_pos", corner=t[:6, :10].numpy(), tail=t[-3:, -6:].numpy(), row_sum=t.sum(1).numpy(), col_sum=t.sum(0).numpy())
 
 
+def g11_text_pos_and_sine():
+    """G11: the two constructor branches no other golden reaches: use_text_pos_enc=1 with random_pos_start=1
+    (get_textual_feature_with_time, tan_model.py:212-228; three np.random draws per forward: visual, text, joint) and
+    pos_enc='sine' (the fixed table as a buffer, tan_model.py:60-62).  Every output of TemporalAligner.forward."""
+    batch = synth.make_batch(21, B=3, T=16, n_min=2, n_max=6, video_pad_tail=2)
+    m = make_ref_model(111, 1, 3, True, use_text_pos_enc=1, random_pos_start=1)
+    np.random.seed(321)
+    with torch.no_grad():
+        out = ref_forward(m, batch)
+    save("g11_text_pos_enc", **{k: v.numpy() for k, v in out.items()})
+    m2 = ref_tan.TemporalAligner(num_encoder_layers=2, num_decoder_layers=1, use_alignability_head=0, pos_enc="sine", random_pos_start=0)
+    params = {k: v for k, v in synth.make_params(112, 2, 1, False).items() if k != "temporal_pos_embed"}
+    missing, unexpected = m2.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+    assert not unexpected and missing == ["temporal_pos_embed"], (missing, unexpected)      # the sine table is the model's own buffer
+    with torch.no_grad():
+        out2 = ref_forward(m2, batch)
+    save("g11_sine_forward", **{k: v.numpy() for k, v in out2.items() if k.startswith("logits")})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     table = {"g1": g1_forward_small, "g2": g2_forward_e6d6, "g3": g3_loss_init, "g4": g4_loss_cotrain,
-             "g5": g5_train_steps, "g6": g6_eval_harness, "g7": g7_long_and_interp, "g8": g8_word2vec, "g9": g9_htm_loader, "g10": g10_sine_pos}
+             "g5": g5_train_steps, "g6": g6_eval_harness, "g7": g7_long_and_interp, "g8": g8_word2vec, "g9": g9_htm_loader, "g10": g10_sine_pos,
+             "g11": g11_text_pos_and_sine}
     for w in which:
         table[w]()

@@ -78,6 +78,33 @@ def test_g7_long_sequence_and_eval_entry_points(golden):
 
 
 @gpu
+def test_g11_text_pos_enc_and_sine_goldens(golden):
+    """use_text_pos_enc=1 + random_pos_start=1 (three np.random draws, tan_model.py:163,224,195) and pos_enc='sine'
+    (tan_model.py:60-62) against outputs of the reference itself."""
+    from temporalalignnet_amd.tan_model import TemporalAligner
+    b = synth.make_batch(21, B=3, T=16, n_min=2, n_max=6, video_pad_tail=2)
+    g = golden("g11_text_pos_enc")
+    m = make_model(111, 1, 3, True, use_text_pos_enc=1, random_pos_start=1)
+    np.random.seed(321)
+    with torch.no_grad():
+        out = hip_forward(m, b)
+    assert set(out) == set(g.files)
+    for k in g.files:
+        np.testing.assert_allclose(out[k].cpu().numpy(), g[k], atol=1e-4 if "alignability" in k else 5e-5, err_msg=k)
+    g2 = golden("g11_sine_forward")
+    m2 = TemporalAligner(num_encoder_layers=2, num_decoder_layers=1, use_alignability_head=0, language_model=None, pos_enc="sine",
+                         random_pos_start=0)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_params(112, 2, 1, False).items() if k != "temporal_pos_embed"}
+    missing, unexpected = m2.load_state_dict(sd, strict=False)
+    assert missing == ["temporal_pos_embed"] and not unexpected           # the table is the model's own buffer, as in the reference
+    m2.cuda()
+    with torch.no_grad():
+        out2 = hip_forward(m2, b)
+    for k in g2.files:
+        np.testing.assert_allclose(out2[k].cpu().numpy(), g2[k], atol=5e-5, err_msg=k)
+
+
+@gpu
 @pytest.mark.parametrize("E,D,B,T,vpad", [(1, 1, 4, 16, 3), (2, 3, 3, 32, 0)])
 def test_backward_matches_oracle_autograd(E, D, B, T, vpad):
     """Random linear functional of ALL outputs -> every parameter gradient, vs torch autograd on the CPU oracle."""

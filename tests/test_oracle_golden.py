@@ -55,6 +55,27 @@ def test_g2_forward_e6d6(golden):
         np.testing.assert_allclose(out[k].numpy(), g[k], err_msg=k, **TOL)
 
 
+def test_g11_text_pos_enc_and_sine(golden):
+    """The two constructor branches of tan_model.py:60-62,212-228 (previously unpinned)."""
+    b = synth.make_batch(21, B=3, T=16, n_min=2, n_max=6, video_pad_tail=2)
+    g = golden("g11_text_pos_enc")
+    np.random.seed(321)
+    out = fwd(P(111, 1, 3, True), b, 1, 3, use_text_pos_enc=True, random_pos_start=True)
+    assert set(out) == set(g.files)
+    for k in g.files:
+        np.testing.assert_allclose(out[k].numpy(), g[k], err_msg=k, **TOL)
+    g2 = golden("g11_sine_forward")
+    p = P(112, 2, 1, False)
+    p["temporal_pos_embed"] = tan_ref.sine_position_table(512, 1024)
+    out2 = fwd(p, b, 2, 1, head=False)
+    for k in g2.files:
+        np.testing.assert_allclose(out2[k].numpy(), g2[k], err_msg=k, **TOL)
+    g10 = golden("g10_sine_pos")
+    t = tan_ref.sine_position_table(512, 1024).double()
+    np.testing.assert_allclose(t[:6, :10].numpy(), g10["corner"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(t.sum(0).numpy(), g10["col_sum"], rtol=0, atol=2e-4)
+
+
 def test_g7_long_and_interp(golden):
     g = golden("g7_long_interp")
     b = synth.make_batch(17, B=1, T=256, n_min=8, n_max=8)
