@@ -108,3 +108,59 @@ def test_trainer_with_global_negatives_on_one_rank_equals_local(one_rank_rccl):
     for k in l0:
         assert abs(l0[k] - l1[k]) <= 1e-4 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
     assert (g0 - g1).norm() <= 2e-2 * g0.norm()
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_two_simulated_ranks_match_the_oracle_on_the_concatenated_batch(shared):
+    """the truth for dist_nce.py is the ORACLE's NCE (oracle/loss_ref.nce = train/loss.py:240-275, pinned by
+    goldens G3/G4) on the logits of the concatenated 2*B_local batch -- not another HIP path.  Terms, the normalised loss with
+    global counts, and the feature gradients."""
+    from oracle import loss_ref
+    from temporalalignnet_amd.dist_nce import BlockNCE
+    S, B, T, N, C = 3, 6, 16, 5, 128
+    St = 1 if shared else S
+    R, Mp = B * T, B * N
+    ranks = [_rank_inputs(300 + 10 * r, S, St, B, T, N, C, False) for r in range(2)]
+    # ---- oracle (CPU fp32) on the concatenated batch: cosine logits [2B,S,T,2B,N] / 0.07, block-diagonal targets
+    vn_c = torch.cat([x["vn"] for x in ranks], 1).float().cpu().requires_grad_(True)            # [S, 2R, C]
+    tn_c = torch.cat([x["tn"] for x in ranks], 1).float().cpu().requires_grad_(True)            # [St, 2Mp, C]
+    B2 = 2 * B
+    tn_s = tn_c.expand(S, -1, -1) if shared else tn_c
+    logits = torch.einsum("srk,smk->srm", vn_c, tn_s).view(S, B2, T, B2, N).permute(1, 0, 2, 3, 4) / 0.07
+    tgt_c = torch.cat([x["tgt"] for x in ranks], 0).cpu()                                       # [2B, T, N]
+    keep = ~torch.cat([x["ci"] for x in ranks], 0).bool().cpu().view(B2, N)
+    tgt_cols = loss_ref._block_diag(tgt_c, B2)[:, :, keep].reshape(B2 * T, -1)
+    v_ref, t_ref = loss_ref.nce(logits, tgt_cols, keep)                                         # [S, 2R], [S, M]
+    rows_pos, cols_pos = tgt_cols.sum(-1) > 0, tgt_cols.sum(-2) > 0
+    loss_ref_val = (v_ref[:, rows_pos].mean() + t_ref[:, cols_pos].mean()) / 2
+    d_vn_ref, d_tn_ref = torch.autograd.grad(loss_ref_val, [vn_c, tn_c])
+    # ---- two simulated ranks (collectives by hand, as above)
+    blks = [BlockNCE(x["vn"], x["tgt"], None, B, T, N, shared_text=shared) for x in ranks]
+    tn_all, ci_all = [x["tn"] for x in ranks], [x["ci"] for x in ranks]
+    colsum_all = sum(blk.sweep(tn_all, ci_all, r) for r, blk in enumerate(blks))
+    outs = [blk.finish(colsum_all) for blk in blks]
+    v_sim, t_sim = torch.cat([o[0] for o in outs], 1).cpu(), torch.cat([o[1] for o in outs], 1).cpu()
+    torch.testing.assert_close(v_sim, v_ref.detach(), rtol=2e-3, atol=2e-3)                     # bf16 features, f32 sums
+    torch.testing.assert_close(t_sim[:, keep.view(-1)], t_ref.detach(), rtol=2e-3, atol=2e-3)
+    # global normalisation: each rank divides by the ALL-rank counts, the global loss is the SUM of the rank losses
+    n_rows, n_cols = rows_pos.sum().item(), cols_pos.sum().item()
+    cols_pos_pad = torch.zeros(2 * Mp, dtype=torch.bool)
+    cols_pos_pad[keep.view(-1)] = cols_pos
+    rank_losses, g_v, g_t_blocks = [], [], []
+    for r in range(2):
+        rp, cp = rows_pos[r * R:(r + 1) * R], cols_pos_pad[r * Mp:(r + 1) * Mp]
+        lv = outs[r][0].cpu()[:, rp].sum() / (S * n_rows)
+        lt = outs[r][1].cpu()[:, cp].sum() / (S * n_cols)
+        rank_losses.append((lv + lt) / 2)
+        g_v.append((rp.float() / (2 * S * n_rows)).expand(S, R).contiguous().cuda())
+        g_t_blocks.append((cp.float() / (2 * S * n_cols)).expand(S, Mp).contiguous().cuda())
+    assert abs(sum(rank_losses).item() - loss_ref_val.item()) <= 2e-3 * abs(loss_ref_val.item())
+    g_t_all = torch.stack(g_t_blocks, 0).contiguous()
+    back = [blk.backward(g_v[r], g_t_all) for r, blk in enumerate(blks)]
+    d_vn_sim = torch.cat([b[0] for b in back], 1).float().cpu()
+    d_tn_sim = torch.cat([back[0][1][r] + back[1][1][r] for r in range(2)], 1).float().cpu()
+
+    def close(a, b, what):
+        assert (a - b).norm() <= 3e-2 * b.norm() + 1e-7, (what, float((a - b).norm()), float(b.norm()))
+    close(d_vn_sim, d_vn_ref, "d_vn")
+    close(d_tn_sim, d_tn_ref, "d_tn")
