@@ -116,6 +116,8 @@ int tan_rows_copy(const void* src, void* dst, int G, int R, int C, long src_grp_
 /* out[r][c] = sum_g x[g*R + r][c]  (backward of the broadcast position add) */
 int tan_group_sum(const void* x, void* out, int G, int R, int C, int dtype, void* stream);
 int tan_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
+/* y = x * sigmoid(1.702 x): QuickGELU.forward called on its own (model/tfm_model.py:11-13); in a block it is a GEMM epilogue */
+int tan_quickgelu(const void* x, void* y, long n, int dtype, void* stream);
 /* out[i] += sum_s parts[s*n + i]  (folds split-K partial tiles into an f32 gradient); n % 4 == 0 */
 int tan_reduce_add(const float* parts, float* out, int nparts, long n, void* stream);
 /* Batched bf16 transpose inside one flat buffer: matrix i is src[table[3i] ...] with shape [table[3i+1], table[3i+2]] (row-major;

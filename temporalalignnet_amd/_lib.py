@@ -39,12 +39,38 @@ class GemmDesc(C.Structure):
 _lib = None
 
 
-def declared_symbols() -> list[str]:
-    """Every function name include/tan_hip.h declares."""
+def _header_source() -> str:
     with open(HEADER) as f:
         src = f.read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|long)\s+(tan_[a-z0-9_]+)\s*\(", src)))
+    return re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+
+
+def declared_symbols() -> list[str]:
+    """Every function name include/tan_hip.h declares."""
+    return sorted(set(re.findall(r"\b(?:int|long)\s+(tan_[a-z0-9_]+)\s*\(", _header_source())))
+
+
+_SCALARS = {"int": C.c_int, "long": C.c_long, "float": C.c_float, "double": C.c_double}
+
+
+def declared_prototypes() -> dict:
+    """name -> (restype, [argtypes]) parsed from include/tan_hip.h: every pointer (including `const tan_*_desc*`) is a
+    c_void_p, scalars map one to one.  With argtypes set, a Python int passed for a `long` / `float` / `double` parameter is
+    converted by ctypes instead of relying on the caller to wrap it (ADVICE / VERDICT r1)."""
+    out = {}
+    for ret, name, args in re.findall(r"\b(int|long)\s+(tan_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", _header_source(), flags=re.S):
+        args = " ".join(args.split())
+        types = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    types.append(C.c_void_p)
+                else:
+                    base = [t for t in a.replace("const", " ").replace("unsigned", " ").split()][0]
+                    types.append(_SCALARS[base])
+        out[name] = (_SCALARS[ret], types)
+    return out
 
 
 def lib() -> C.CDLL:
@@ -59,8 +85,10 @@ def lib() -> C.CDLL:
         # (observed: every launch fails with hipErrorNoDevice).  PyTorch is the memory/stream plumbing anyway.
         import torch  # noqa: F401
         _lib = C.CDLL(LIB_PATH)
+        protos = declared_prototypes()
         for name in declared_symbols():
-            getattr(_lib, name).restype = C.c_long if name.endswith("_floats") or name.endswith("_bytes") else C.c_int
+            fn = getattr(_lib, name)
+            fn.restype, fn.argtypes = protos[name]
     return _lib
 
 

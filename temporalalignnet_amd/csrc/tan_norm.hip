@@ -495,6 +495,20 @@ __global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ s, TD*
     }
 }
 
+// QuickGELU.forward (model/tfm_model.py:11-13) stand-alone; inside a block it is the c_fc GEMM's epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void quickgelu_kernel(const T* __restrict__ s, T* __restrict__ d, long n) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            float4 v = ld4(s + i);
+            v.x = quick_gelu_t<T>(v.x); v.y = quick_gelu_t<T>(v.y); v.z = quick_gelu_t<T>(v.z); v.w = quick_gelu_t<T>(v.w);
+            st4(d + i, v);
+        } else {
+            for (long j = i; j < n; ++j) st_f(d + j, quick_gelu_t<T>(ld_f(s + j)));
+        }
+    }
+}
+
 // binary_head (nn.Linear(512,1), tan_model.py:70,147-148): out[r] = <x[r], w> + b   (f32 out)
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
@@ -750,6 +764,17 @@ extern "C" int tan_cast(const void* src, int src_dtype, void* dst, int dst_dtype
         hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, n);
     else if (src_dtype == TAN_BF16 && dst_dtype == TAN_BF16)
         hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+    else return TAN_ERR_BAD_ARG;
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_quickgelu(const void* x, void* y, long n, int dtype, void* stream) {
+    TAN_REQUIRE(x && y && n > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)min((long)4096, (long)cdiv(n, 1024));
+    if (dtype == TAN_F32) hipLaunchKernelGGL((quickgelu_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, n);
+    else if (dtype == TAN_BF16) hipLaunchKernelGGL((quickgelu_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n);
     else return TAN_ERR_BAD_ARG;
     TAN_LAUNCH_CHECK();
     return 0;

@@ -59,3 +59,40 @@ def test_product_never_imports_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+
+
+def test_every_entry_point_gets_argtypes_from_the_header():
+    """`_lib.py` used to set restype only, so every `long` / `float` argument relied on the caller wrapping it."""
+    from temporalalignnet_amd import _lib
+    protos = _lib.declared_prototypes()
+    assert set(protos) == set(_lib.declared_symbols())
+    import ctypes as C
+    assert protos["tan_nce_ws_floats"] == (C.c_long, [C.c_int] * 4)
+    assert protos["tan_adamw_step"][1][5:13] == [C.c_long, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_float]
+    assert protos["tan_encoder_fwd"][1] == [C.c_void_p, C.c_void_p]
+    L = _lib.lib()
+    for name, (res, args) in protos.items():
+        fn = getattr(L, name)
+        assert fn.restype is res and list(fn.argtypes) == args, name
+    # a plain Python int for a `long` parameter now converts (no GPU work: the call is rejected for its NULL pointers)
+    assert L.tan_reduce_add(None, None, 2, 1 << 33, None) == -1
+
+
+def test_reference_import_names_resolve_with_one_sys_path_entry():
+    """`from tan_model import TemporalAligner, TwinTemporalAligner` (train/main.py:21) and
+    `from loss import get_loss, get_mask_from_time, get_text_pos` (main.py:16) must work with ONE sys.path entry."""
+    import importlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from tan_model import TemporalAligner, TwinTemporalAligner\n"
+            "from loss import get_loss, get_mask_from_time, get_text_pos\n"
+            "from tfm_model import TemporalEncoder, ResidualAttentionBlock_Step, QuickGELU, get_position_embedding_sine\n"
+            "from word2vec_model import Word2VecModel, Word2VecTokenizer\n"
+            "import temporalalignnet_amd.tan_model as t\n"
+            "assert TemporalAligner is t.TemporalAligner\n"
+            "print('ok')\n") % os.path.join(root, "dropin")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr

@@ -78,6 +78,40 @@ def test_g7_long_sequence_and_eval_entry_points(golden):
 
 
 @gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-2)])
+def test_tfm_model_classes_run_standalone(dtype, tol):
+    """QuickGELU / ResidualAttentionBlock_Step / TemporalEncoder called on their own keep the reference's signatures and
+    layouts (model/tfm_model.py:11-13,34-38,48-55: [L, B, C] in, (x, ln_1(x)) / list of S tensors out) -- vs the CPU oracle."""
+    from temporalalignnet_amd.tfm_model import QuickGELU, TemporalEncoder
+    torch.manual_seed(3)
+    L, B, C, S = 24, 3, 512, 3
+    enc = TemporalEncoder(C, S, 8)
+    for p_ in enc.parameters():
+        if p_.dim() > 1:
+            torch.nn.init.normal_(p_, std=C ** -0.5)
+        else:
+            torch.nn.init.normal_(p_, mean=1.0 if p_.shape[0] == C and p_.mean().item() > 0.5 else 0.0, std=0.1)
+    p = {f"enc.{k}": v.detach().clone() for k, v in enc.state_dict().items()}
+    x = torch.randn(L, B, C)
+    mask = torch.zeros(B, L, dtype=torch.bool)
+    mask[0, -5:] = True
+    mask[2, -1:] = True
+    enc.cuda()
+    xd = x.cuda().to(dtype)
+    feats = enc(xd, mask.cuda())
+    want = tan_ref.encoder(x.permute(1, 0, 2), mask, p, "enc", S)
+    assert isinstance(feats, list) and len(feats) == S and all(f.shape == (L, B, C) and f.dtype == dtype for f in feats)
+    for got, w in zip(feats, want):
+        assert (got.float().cpu().permute(1, 0, 2) - w).abs().max().item() <= tol * max(1.0, w.abs().max().item())
+    x1, xn = enc.resblocks[0](xd, mask.cuda())
+    w1, wn = tan_ref.block(x.permute(1, 0, 2), mask, p, "enc.resblocks.0")
+    assert (x1.float().cpu().permute(1, 0, 2) - w1).abs().max().item() <= tol * max(1.0, w1.abs().max().item())
+    assert (xn.float().cpu().permute(1, 0, 2) - wn).abs().max().item() <= tol * max(1.0, wn.abs().max().item())
+    g = QuickGELU()(xd)
+    assert (g.float().cpu() - tan_ref.quick_gelu(xd.float().cpu())).abs().max().item() <= (1e-6 if dtype == torch.float32 else 3e-2)
+
+
+@gpu
 def test_g11_text_pos_enc_and_sine_goldens(golden):
     """use_text_pos_enc=1 + random_pos_start=1 (three np.random draws, tan_model.py:163,224,195) and pos_enc='sine'
     (tan_model.py:60-62) against outputs of the reference itself."""
