@@ -37,7 +37,10 @@ GEMM_KIND_NAMES = {0: "gemm_bf16<A:K-contig,B:K-contig> (Linear fwd, dX through 
                    1: "gemm_bf16<A:K-contig,B:K-strided> (d video features = dlogits x text features)",
                    2: "gemm_bf16<A:K-strided,B:K-contig>", 3: "gemm_bf16<A:K-strided,B:K-strided> (dW)",
                    4: "gemm_f32<kc,kc>", 5: "gemm_f32<kc,ks>", 6: "gemm_f32<ks,kc>", 7: "gemm_f32<ks,ks>",
-                   8: "attn_fwd", 9: "attn_bwd", 10: "simnce (logits-free similarity+NCE, fwd stats / bwd dlogits)"}
+                   8: "attn_fwd", 9: "attn_bwd", 10: "simnce (logits-free similarity+NCE, fwd stats / bwd dlogits)",
+                   11: "row-panel fused MLP (opt-in, TAN_PANEL=1)"}
+NKINDS = 12
+FAMILY = list(range(8)) + [10, 11]       # every MFMA GEMM pipeline launch
 
 
 def parse():
@@ -57,6 +60,8 @@ def parse():
     ap.add_argument("--global-negatives", action="store_true", help="row f3: NCE negatives from every rank (W similarity sweeps)")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--timer-every", type=int, default=10, help="HIP-event kernel timer samples every n-th timed step")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra driver-timed configurations (stage 2, len=256) of the N=1 run")
+    ap.add_argument("--extra-steps", type=int, default=10)
     return ap.parse_args()
 
 
@@ -86,50 +91,37 @@ def cpu_baseline(a, args_ns):
                       f"({dt:.2f} s/step)"}
 
 
-def main():
-    a = parse()
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (the driver's own launch line, same flags)
-        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-                                   "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29517"),
-                                   os.path.abspath(__file__)] + sys.argv[1:])
+def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, timer_every):
+    """One configuration: W untimed + K timed steps between barriers; returns the result fields (no printing)."""
     from temporalalignnet_amd import _lib, dist, synth
     from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
-    world, rank, local = dist.init_from_env()
-    if a.gpus != world and rank == 0:
-        print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); reporting n_gpus={world}", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    args_ns = default_args(model="init" if a.stage == 1 else "cotrain", num_encoder_layers=a.layers, num_decoder_layers=a.layers,
-                           loss_threshold=0.0 if a.stage == 1 else 0.5, seq_len=a.seq_len)
+    args_ns = default_args(model="init" if stage == 1 else "cotrain", num_encoder_layers=a.layers, num_decoder_layers=a.layers,
+                           loss_threshold=0.0 if stage == 1 else 0.5, seq_len=seq_len)
     torch.manual_seed(888)
     model = build_model(args_ns, compute_dtype=a.dtype).to(dev)
-    if a.stage == 1:
+    if stage == 1:
         model.random_pos_start = 1
     trainer = Trainer(model, args_ns, iter_per_epoch=2890, warmup=1000,   # 370k videos / 128
                       global_negatives=a.global_negatives)
-    trainer.iteration = 1000                                             # past warm-up: non-zero learning rate
-    dist.broadcast_(trainer.online.flat_parameters())
-    trainer.online._flat.shadow_version = -1          # collectives do not bump the version counter: re-cast the bf16 shadow
-    if a.stage == 2:
+    trainer.batches_seen = 1000                                          # past warm-up: non-zero learning rate
+    trainer.iteration = 1000
+    if stage == 2:
         model._copy_param()
-    batch = to_device_batch(synth.make_batch(888 + rank, B=a.batch, T=a.seq_len, n_min=4, n_max=16), device=dev)
+    batch = to_device_batch(synth.make_batch(888 + rank, B=batch_size, T=seq_len, n_min=4, n_max=16), device=dev)
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):                                              # (the first step broadcasts rank 0's parameters)
         trainer.step(batch)
     L = _lib.lib()
     use_timer = not a.no_kernel_timer
     if use_timer:
-        _lib.check(L.tan_prof_enable(1, 1200 * max(a.steps, 1)), "tan_prof_enable")
+        _lib.check(L.tan_prof_enable(1, 1200 * max(steps, 1)), "tan_prof_enable")
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     sampled = 0
-    for i in range(a.steps):
-        if use_timer:                                  # the event pairs cost ~0.8 ms/step: sample every `timer_every`-th step (2 of 20 by default)
-            on = (i % a.timer_every == 0)
+    for i in range(steps):
+        if use_timer:                                  # the event pairs cost ~0.8 ms/step: sample every `timer_every`-th step
+            on = (i % timer_every == 0)
             L.tan_prof_enable(2 if on else 0, 0)
             sampled += on
         loss = trainer.step(batch)
@@ -141,7 +133,7 @@ def main():
 
     roof = None
     if use_timer:
-        nk = 11
+        nk = NKINDS
         ms, work, cnt = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_long * nk)()
         L.tan_prof_collect(ms, work, cnt, nk)
         # The timed steps run the video and joint stacks on two concurrent HIP streams, so the per-launch durations above
@@ -151,7 +143,7 @@ def main():
         online = trainer.online
         if getattr(online, "overlap_stacks", False):
             online.overlap_stacks = False
-            if a.stage == 2:
+            if stage == 2:
                 model.target.overlap_stacks = False
             trainer.step(batch)
             torch.cuda.synchronize()
@@ -161,49 +153,88 @@ def main():
             torch.cuda.synchronize()
             ms2, work2, cnt2 = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_long * nk)()
             L.tan_prof_collect(ms2, work2, cnt2, nk)
-            fam = [k for k in list(range(8)) + [10] if cnt2[k] > 0]
+            fam = [k for k in FAMILY if cnt2[k] > 0]
             t2, w2, c2 = sum(ms2[k] for k in fam), sum(work2[k] for k in fam), sum(cnt2[k] for k in fam)
             iso = {"achieved": round(w2 / (t2 * 1e-3) / 1e12, 1), "avg_launch_us": round(t2 * 1e3 / c2, 2),
                    "gemm_ms_per_step": round(t2 / 3, 3), "note": "same kernels, stacks serialised on one stream (3 extra steps)"}
             online.overlap_stacks = True
-            if a.stage == 2:
+            if stage == 2:
                 model.target.overlap_stacks = True
         L.tan_prof_enable(0, 0)
         kinds = [{"kernel": GEMM_KIND_NAMES[k], "ms_per_step": ms[k] / sampled, "launches_per_step": round(cnt[k] / sampled, 1),
                   "tflops": (work[k] / (ms[k] * 1e-3) / 1e12) if ms[k] > 0 else 0.0} for k in range(nk) if cnt[k] > 0]
-        gemm = [k for k in list(range(8)) + [10] if cnt[k] > 0]      # every launch of the MFMA GEMM pipeline
+        gemm = [k for k in FAMILY if cnt[k] > 0]      # every launch of the MFMA GEMM pipeline
         if gemm:
             peak = BF16_MFMA_PEAK_TFLOPS if a.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
             tms, twork, tcnt = sum(ms[k] for k in gemm), sum(work[k] for k in gemm), sum(cnt[k] for k in gemm)
             ach = twork / (tms * 1e-3) / 1e12
-            traffic = None      # HBM bytes per launch from the committed PMC passes of this same command (profiles/README.md)
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(pmc) and a.dtype == "bf16" and a.stage == 1 and a.batch == 128 and a.seq_len == 64:
+            # `traffic` (HBM bytes per launch) needs rocprofv3 PMC passes, which cannot run inside this process: null here; the
+            # committed passes of the same command are referenced separately (profiles/README.md), never passed off as in-run data
+            prof = None
+            pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+            if os.path.exists(pmc) and a.dtype == "bf16" and stage == 1 and batch_size == 128 and seq_len == 64:
                 fam = json.load(open(pmc))["mfma_gemm_family"]
-                traffic = round(fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch"])
-            roof = {"bound": "mfma", "kernel": "tal::gemm_glds_kernel + tal::simnce_kernel (one direct-to-LDS MFMA pipeline, all operand layouts)", "achieved": round(ach, 1),
-                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                prof = {"file": "profiles/r02_pmc_traffic.json", "hbm_bytes_per_launch": round(fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch"]),
+                        "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run"}
+            roof = {"bound": "mfma", "kernel": "tal::gemm_glds_kernel + tal::gemm_dw_grouped_kernel + tal::simnce_kernel (one direct-to-LDS MFMA pipeline, all operand layouts)",
+                    "achieved": round(ach, 1),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "traffic_profile": prof,
                     "avg_launch_us": round(tms * 1e3 / tcnt, 2), "launches_per_step": round(tcnt / sampled, 1),
                     "gemm_ms_per_step": round(tms / sampled, 3), "algorithmic_gflop_per_step": round(twork / sampled / 1e9, 1),
-                    "timer": f"HIP events on each launch's own stream, {sampled} of the {a.steps} timed steps (every {a.timer_every}th)",
+                    "step_frac": round(twork / sampled / (elapsed / steps) / 1e12 / peak, 4),
+                    "timer": f"HIP events on each launch's own stream, {sampled} of the {steps} timed steps (every {timer_every}th)",
                     "concurrency": "2 HIP streams (video || joint stack): durations include co-running kernels",
                     "isolated": iso,
                     "by_kernel": [{**x, "ms_per_step": round(x["ms_per_step"], 3), "tflops": round(x["tflops"], 1)} for x in kinds]}
+    res = {"value": round(batch_size * world * steps / elapsed, 1), "unit": "video-seq/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(elapsed / steps * 1e3, 3), "dtype": a.dtype,
+           "config": {"workload": f"E{a.layers}D{a.layers} len={seq_len} {a.dtype} stage-{stage} "
+                                  f"({'init: multi-positive NCE only' if stage == 1 else 'cotrain: EMA + alignability + NCE'}) "
+                                  f"train step (fwd+loss+bwd+AdamW), synthetic HTM-370K-shaped features, N~U[4,16] sentences/video",
+                      "global_batch": batch_size * world, "per_gpu_batch": batch_size, "seq_len": seq_len,
+                      "parallelism": f"dp{world}" + ("+global-negatives" if a.global_negatives else ""),
+                      "final_loss": round(final_loss, 4)},
+           "roofline": roof}
+    del trainer, model, batch
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res, args_ns
 
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (the driver's own launch line, same flags)
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+                                   "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29517"),
+                                   os.path.abspath(__file__)] + sys.argv[1:])
+    from temporalalignnet_amd import dist
+    world, rank, local = dist.init_from_env()
+    if a.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); reporting n_gpus={world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    head, args_ns = run_config(a, world, rank, dev, a.stage, a.batch, a.seq_len, a.steps, a.warmup, a.timer_every)
+    extra = []
+    headline = (a.stage, a.batch, a.seq_len) == (1, 128, 64)
+    if world == 1 and headline and not a.no_extra and a.dtype == "bf16":
+        # BASELINE configs[2] (stage-2 co-training, here on one GPU at the per-GPU batch) and configs[3] (len=256) are
+        # driver-timed too, each with its own roofline; shorter runs (the headline keeps the driver's K / W)
+        for st, bs, sl, tag in ((2, 128, 64, "configs[2] on 1 GPU: E6D6 len=64 stage-2 co-training, B=128"),
+                                (1, 32, 256, "configs[3]: len=256 (joint L=272), B=32")):
+            r, _ = run_config(a, world, rank, dev, st, bs, sl, a.extra_steps, 3, 5)
+            r["name"] = tag
+            extra.append(r)
     if rank == 0:
-        out = {
-            "metric": "video-seq/sec (len=64, E6D6) at 1/2/4/8 MI355X; HTM-Align ROC-AUC parity",
-            "value": round(a.batch * world * a.steps / elapsed, 1), "unit": "video-seq/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"E{a.layers}D{a.layers} len={a.seq_len} {a.dtype} stage-{a.stage} "
-                                   f"({'init: multi-positive NCE only' if a.stage == 1 else 'cotrain: EMA + alignability + NCE'}) "
-                                   f"train step (fwd+loss+bwd+AdamW), synthetic HTM-370K-shaped features, N~U[4,16] sentences/video",
-                       "global_batch": a.batch * world, "per_gpu_batch": a.batch, "seq_len": a.seq_len,
-                       "parallelism": f"dp{world}" + ("+global-negatives" if a.global_negatives else ""),
-                       "final_loss": round(final_loss, 4)},
-            "roofline": roof,
-        }
+        out = {"metric": "video-seq/sec (len=64, E6D6) at 1/2/4/8 MI355X; HTM-Align ROC-AUC parity", "value": head["value"],
+               "unit": head["unit"], "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"], "ms_per_step": head["ms_per_step"],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+               "config": head["config"], "roofline": head["roofline"]}
+        if extra:
+            out["extra"] = extra
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a, args_ns)
     if torch.distributed.is_initialized():

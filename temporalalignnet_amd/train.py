@@ -124,6 +124,11 @@ class Trainer:
         self.ddp_bucket_layers = max(1, int(os.environ.get("TAN_DDP_BUCKET_LAYERS", "2") if ddp_bucket_layers is None
                                             else ddp_bucket_layers))
         self._comm_streams = {}
+        # TAN_DDP_MODE: "buckets" (default) = per-layer-group all-reduces overlapped with backward; "flat" = ONE all-reduce of the whole
+        # flat gradient after backward, what BASELINE.json's north_star literally describes -- an A/B switch for the first
+        # multi-GPU run (no >1-GPU node was available to pick by measurement)
+        self.ddp_mode = os.environ.get("TAN_DDP_MODE", "buckets")
+        self._params_synced = False
 
     # -------------------------------------------------------------- optimizer state
     def _ensure_state(self):
@@ -158,6 +163,20 @@ class Trainer:
         if st is None:
             st = self._comm_streams[device] = torch.cuda.Stream(device=device)
         return st
+
+    def sync_parameters(self, src=0):
+        """Every rank starts from rank `src`'s parameters (what DistributedDataParallel does at construction,
+        end2end/main_nce.py:283): online flat buffer, EMA twin, language model.  Called once, from the first step."""
+        self._params_synced = True
+        if not dist.active():
+            return
+        mods = [self.online] + ([self.model.target] if self.twin else [])
+        for m in mods:
+            dist.broadcast_(m.flat_parameters(), src)
+            m.invalidate_shadow()
+            if m.bert is not None:
+                for p in m.bert.parameters():
+                    dist.broadcast_(p.data, src)
 
     def _lm_params(self):
         lm = self.online.bert
@@ -276,6 +295,8 @@ class Trainer:
         freq = int(getattr(self.args, "backprop_freq", 1))
         if freq <= 1:
             return self.step(batch)
+        if not self._params_synced:
+            self.sync_parameters()
         if not self._accum_open:
             self.zero_grad()
             self._accum_open = True
@@ -322,10 +343,14 @@ class Trainer:
         layers 5,4 runs while layers 3..0 are still being differentiated.  Order of issue is fixed (video buckets last layer
         first, then joint buckets: identical on every rank); the few remaining tensors (embeddings, projections, heads,
         post-LNs) follow at the end in one call."""
+        if not self._params_synced:
+            self.sync_parameters()
         self.zero_grad()
         world = dist.world_size()
         pending, done = [], []
-        if dist.active():
+        if dist.active() and self.ddp_mode == "flat":
+            flat = self.online.flat_grad()
+        elif dist.active():
             flat = self.online.flat_grad()
             comm = self._comm_order_stream(flat.device)
 

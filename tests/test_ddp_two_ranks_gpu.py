@@ -31,17 +31,21 @@ def _setup(seed_batch, kind, layers, bucket):
     return tr, batch
 
 
-def _worker(rank, world, port, out_dir, kind, layers, bucket):
+def _worker(rank, world, port, out_dir, kind, layers, bucket, backend="gloo", mode="buckets"):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    local = rank if backend == "nccl" else 0                # RCCL: one GPU per rank; gloo: both ranks share cuda:0
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local),
+                      TAN_DDP_MODE=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as tdist
     from temporalalignnet_amd import dist
-    torch.cuda.set_device(0)
-    w, r, _ = dist.init_from_env(backend="gloo")
+    torch.cuda.set_device(local)
+    w, r, _ = dist.init_from_env(backend=backend)
     assert (w, r) == (world, rank) and dist.active()
+    torch.manual_seed(1234 + rank)                          # ranks start from DIFFERENT parameters: Trainer.step must broadcast rank 0's
     tr, batch = _setup(100 + rank, kind, layers, bucket)
-    dist.broadcast_(tr.online.flat_parameters())
-    tr.online.invalidate_shadow()
+    if rank == 1:
+        with torch.no_grad():
+            tr.online.flat_parameters().mul_(1.5)
     ld = tr.step(batch)
     torch.cuda.synchronize()
     torch.save({"loss": ld["loss"].item(), "grad": tr.online.flat_grad().cpu(), "param": tr.online._flat.flat.cpu()},
@@ -50,11 +54,20 @@ def _worker(rank, world, port, out_dir, kind, layers, bucket):
     tdist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,layers,bucket", [("init", 2, 1), ("cotrain", 3, 2)])
-def test_two_ranks_equal_one_process_with_both_batches(tmp_path, kind, layers, bucket):
+def _two_gpus():
+    return torch.cuda.is_available() and torch.cuda.device_count() >= 2
+
+
+@pytest.mark.parametrize("kind,layers,bucket,backend,mode", [
+    ("init", 2, 1, "gloo", "buckets"), ("cotrain", 3, 2, "gloo", "buckets"), ("init", 2, 1, "gloo", "flat"),
+    # the same through RCCL over xGMI, one GPU per rank -- runs wherever the box has two GPUs (self-skips on the 1-GPU pool)
+    ("init", 2, 1, "nccl", "buckets"), ("cotrain", 3, 2, "nccl", "buckets"), ("cotrain", 3, 2, "nccl", "flat")])
+def test_two_ranks_equal_one_process_with_both_batches(tmp_path, kind, layers, bucket, backend, mode):
+    if backend == "nccl" and not _two_gpus():
+        pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
     ctx = mp.get_context("spawn")
-    port = 29600 + (os.getpid() + layers) % 1000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), kind, layers, bucket)) for r in range(2)]
+    port = 29600 + (os.getpid() + layers + 7 * len(mode) + 13 * len(backend)) % 1000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), kind, layers, bucket, backend, mode)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

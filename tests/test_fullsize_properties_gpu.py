@@ -103,3 +103,109 @@ def test_bf16_step_tracks_fp32_and_fused_matches_materialised():
     assert cos(g16, g32) > 0.995, cos(g16, g32)
     assert cos(g16f, g16) > 0.999, cos(g16f, g16)
     assert abs(float(g16f.norm() / g16.norm()) - 1.0) < 2e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[2]/[3] at full size (stage 2 and len=256 were only exercised at fixture size)
+
+def _cotrain_setup(dtype, fused, seed_batch=23, perm=None, batch=B, seq=T):
+    """TwinTemporalAligner E6D6 (stage 2: EMA forward, self-labelling, loss threshold, alignability head) + one batch."""
+    from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
+    args = default_args(model="cotrain", num_encoder_layers=E, num_decoder_layers=D, loss_threshold=0.5, seq_len=seq)
+    torch.manual_seed(5)
+    model = build_model(args, compute_dtype=dtype, random_pos_start=0, language_model=None)
+    sd = {f"online.{k}": torch.from_numpy(v) for k, v in synth.make_params(7, E, D, True).items()}
+    sd.update({f"target.{k}": torch.from_numpy(v) for k, v in synth.make_params(8, E, D, True).items()})
+    model.load_state_dict(sd)
+    model.cuda()
+    for p_ in model.target.parameters():
+        p_.requires_grad = False
+    b = synth.make_batch(seed_batch, B=batch, T=seq, n_min=4, n_max=16)
+    if perm is not None:
+        for k in ("video", "padding_mask", "text_embed", "text_padding_mask", "abs_text_pos"):
+            b[k] = b[k][perm]
+        for k in ("start", "end"):
+            b[k] = [b[k][i] for i in perm]
+    tr = Trainer(model, args, fused_loss=fused)
+    return tr, to_device_batch(b)
+
+
+def test_stage2_full_size_permutation_invariance_and_fused_vs_materialised():
+    """E6D6 cotrain at B=128: (i) permuting the videos leaves every loss entry unchanged (self-labelling, thresholds and BCE are
+    per-sentence or batch-symmetric); (ii) the logits-free path equals the materialised reference-layout one; (iii) bf16 tracks fp32."""
+    res = {}
+    perm = np.random.RandomState(1).permutation(B)
+    for name, dtype, fused, pm in (("fp32", "fp32", False, None), ("fp32-perm", "fp32", False, perm), ("bf16", "bf16", False, None),
+                                    ("bf16-fused", "bf16", True, None)):
+        tr, b = _cotrain_setup(dtype, fused, perm=pm)
+        tr.zero_grad()
+        ld = tr.forward_backward(b)
+        res[name] = ({k: v.item() for k, v in ld.items()}, tr.online.flat_grad().clone())
+        del tr, b
+        torch.cuda.empty_cache()
+    keys = ("loss", "loss-dual", "loss-joint", "loss-joint-bce", "loss-total", "confidence-ratio", "alignability_top1")
+    for k in keys:
+        a_, p_ = res["fp32"][0][k], res["fp32-perm"][0][k]
+        assert abs(a_ - p_) <= 2e-5 * max(1.0, abs(a_)), ("perm", k, a_, p_)
+    cos = lambda x, y: float((x * y).sum() / (x.norm() * y.norm()))
+    assert cos(res["fp32"][1], res["fp32-perm"][1]) > 0.99999
+    for k in ("loss", "loss-dual", "loss-joint", "loss-joint-bce"):
+        ref = res["fp32"][0][k]
+        assert abs(res["bf16"][0][k] - ref) < 2e-2 * abs(ref), (k, res["bf16"][0][k], ref)
+        assert abs(res["bf16-fused"][0][k] - res["bf16"][0][k]) < 2e-3 * abs(ref), (k, res["bf16-fused"][0][k], res["bf16"][0][k])
+    assert cos(res["bf16"][1], res["fp32"][1]) > 0.99, cos(res["bf16"][1], res["fp32"][1])
+    assert cos(res["bf16-fused"][1], res["bf16"][1]) > 0.999
+
+
+def test_stage2_full_size_directional_derivative():
+    """<grad, d> of the stage-2 loss (targets, thresholds and BCE labels are constants under no_grad, loss.py:88,277) against
+    central finite differences in fp32, along an ascent direction."""
+    tr, b = _cotrain_setup("fp32", False)
+    flat = tr.online.flat_parameters()
+    tr.zero_grad()
+    tr.forward_backward(b)
+    g = tr.online.flat_grad().clone()
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    d = torch.randn(flat.shape, device="cuda", generator=gen).abs() * g.sign()
+    d = d / d.norm()
+    analytic = float((g.double() * d.double()).sum())
+    h, vals = 1e-2, []
+    for sgn in (1.0, -1.0):
+        with torch.no_grad():
+            flat.add_(d, alpha=sgn * h)
+        tr.zero_grad()
+        vals.append(float(tr.forward_backward(b)["loss"].double()))
+        with torch.no_grad():
+            flat.add_(d, alpha=-sgn * h)
+    numeric = (vals[0] - vals[1]) / (2 * h)
+    # the self-labelled targets can flip under the perturbation (arg-max / quantile selections): a looser bound than stage 1
+    assert abs(numeric - analytic) <= 5e-2 * abs(analytic) + 5e-4, (numeric, analytic)
+
+
+def test_len256_full_size_bf16_tracks_fp32():
+    """BASELINE configs[3]: E6D6, T=256 (joint L = 272: the streamed attention kernels), B=32 -- bf16 step vs fp32 step."""
+    from temporalalignnet_amd.loss import get_loss
+    from temporalalignnet_amd.tan_model import TemporalAligner
+    from temporalalignnet_amd.train import default_args, to_device_batch
+    Bl, Tl = 32, 256
+    b = to_device_batch(synth.make_batch(29, B=Bl, T=Tl, n_min=4, n_max=16))
+    res = {}
+    for dtype, fused in (("fp32", False), ("bf16", True)):
+        m = TemporalAligner(num_encoder_layers=E, num_decoder_layers=D, use_alignability_head=0, language_model=None,
+                            compute_dtype=dtype, random_pos_start=0)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(9, E, D, False).items()})
+        m.cuda()
+        out = m(b["video"], b["text_embed"], b["padding_mask"], b["text_padding_mask"].bool(), b["_tgt_raw"], fused=fused)
+        if fused:
+            out["_fused"].n_text_valid = b["n_text"]
+        l = get_loss(b, b["video"], b["text_embed"], b["padding_mask"], b["text_padding_mask"], out, default_args(model="init", seq_len=Tl),
+                     b["abs_text_pos"])
+        l["loss"].backward()
+        res[dtype] = ({k: v.item() for k, v in l.items()}, m.flat_grad().clone())
+        del m, out, l
+        torch.cuda.empty_cache()
+    for k in ("loss", "loss-dual", "loss-joint"):
+        ref = res["fp32"][0][k]
+        assert abs(res["bf16"][0][k] - ref) < 1e-2 * abs(ref), (k, res["bf16"][0][k], ref)
+    g32, g16 = res["fp32"][1], res["bf16"][1]
+    assert float((g32 * g16).sum() / (g32.norm() * g16.norm())) > 0.99
