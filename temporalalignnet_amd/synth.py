@@ -312,3 +312,33 @@ def write_htm_fixture(root: str, fx: dict):
     with open(paths["holdout"], "w") as f:
         f.writelines(v + "\n" for v in fx["holdout"])
     return paths
+
+
+def yc2_fixture(seed: int = 60, d_video: int = 1024):
+    """Synthetic YouCook2-shaped retrieval fixture (eval/eval_zeroshot_retrieval.py:29-148): a few videos with per-second
+    features [vlen, 1024] and annotated segments {sentence, segment [start, end]} -- short segments (window longer than the
+    segment, :112-115), a >256-s one (windows inside the segment, :116-119) and one touching the end of its video (index
+    clipping, :125).  Returns {'videos': {vid: vlen}, 'clips': [{'vid', 'sentence', 'segment'}]}."""
+    vlens = {"ycA": 180, "ycB": 320, "ycC": 700, "ycD": 96}
+    segs = {"ycA": [(10, 28), (40, 95), (120, 178)], "ycB": [(5, 17), (60, 200), (250, 318)], "ycC": [(30, 340), (400, 470), (600, 699)],
+            "ycD": [(0, 20), (30, 90)]}
+    words = w2v_vocab(40)
+    clips = []
+    for vid in sorted(vlens):
+        for j, (s, e) in enumerate(segs[vid]):
+            idx = randint(seed, f"yc2.words.{vid}.{j}", 0, len(words) - 1, 5)
+            clips.append({"vid": vid, "sentence": " ".join(words[i] for i in idx), "segment": [int(s), int(e)]})
+    return {"videos": vlens, "clips": clips}
+
+
+def yc2_features(vid: str, vlen: int, d_video: int = 1024, seed: int = 61) -> np.ndarray:
+    """Per-second features of a fixture video: a smooth video-specific drift plus noise, so that segments are distinguishable."""
+    base = normal(seed, f"yc2.base.{vid}", (1, d_video), std=0.5)
+    drift = normal(seed, f"yc2.drift.{vid}", (1, d_video), std=0.5)
+    t = (np.arange(vlen, dtype=np.float32) / vlen)[:, None]
+    return np.abs(base + t * drift + normal(seed, f"yc2.noise.{vid}", (vlen, d_video), std=0.3)).astype(np.float32)
+
+
+def yc2_text_embedding(sentence: str, seed: int = 62) -> np.ndarray:
+    """Deterministic stand-in for the language model's pooler_output of one sentence: [512]."""
+    return normal(seed, "yc2.text." + sentence, (512,))

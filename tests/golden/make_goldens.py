@@ -460,10 +460,53 @@ def g11_text_pos_and_sine():
     save("g11_sine_forward", **{k: v.numpy() for k, v in out2.items() if k.startswith("logits")})
 
 
+def g12_retrieval():
+    """G12 (row f4): the reference's own test_retrieval_yc2 + YouCook2_Feature.__getitem__ / _get_video_feature
+    (eval/eval_zeroshot_retrieval.py:82-148,157-256) on the synthetic fixture of synth.yc2_fixture.  The dataset object is built
+    without its __init__ (which reads private paths); its methods run unmodified on feature files written to a temp directory.
+    The tokenizer / language model are a deterministic stand-in (sentence -> synth.yc2_text_embedding)."""
+    import tempfile
+    import eval.eval_zeroshot_retrieval as ref_retr
+    fx = synth.yc2_fixture()
+    tmp = tempfile.mkdtemp(prefix="yc2fx")
+    ds = ref_retr.YouCook2_Feature.__new__(ref_retr.YouCook2_Feature)
+    ds.mode, ds.num_clips, ds.seq_len = "val", 10, -1
+    ds.video_feature_path = tmp
+    ds.vid2path = {vid: f"x/pre/{vid}" for vid in fx["videos"]}
+    ds.vlen_dict = {vid: [vlen, vlen] for vid, vlen in fx["videos"].items()}
+    ds.video_info = fx["clips"]
+    for vid, vlen in fx["videos"].items():
+        torch.save(torch.from_numpy(synth.yc2_features(vid, vlen)), os.path.join(tmp, f"pre_{vid}.pth.tar"))
+    ref_retr.YouCook2_Feature = lambda **kw: ds
+
+    def tokenizer(texts, return_tensors="pt", padding=True):
+        return {"input_ids": torch.tensor([[ord(c) for c in texts[0]]])}
+
+    def lang_model(input_ids):
+        sent = "".join(chr(int(c)) for c in input_ids[0])
+        return {"pooler_output": torch.from_numpy(synth.yc2_text_embedding(sent))[None]}
+
+    m = make_ref_model(113, 2, 1, False, random_pos_start=0)
+    args = types.SimpleNamespace(num_workers=0, tokenizer=tokenizer, seq_len=64, sim="cos")
+    metrics, loc = capture_locals(ref_retr.test_retrieval_yc2, lang_model, m.get_visual_feature, m.get_textual_feature, "cpu", args)
+    save("g12_retrieval", sim=loc["sim"], **{k: np.asarray(v) for k, v in metrics.items()})
+    # the window indices of every clip, straight from the dataset class
+    for i, clip in enumerate(fx["clips"]):
+        item = ds[i]
+        assert item["video"].shape[0] == 10
+    first = ds[0]
+    save("g12_retrieval_windows", **{f"{i}/start_idx": np.asarray(ds[i]["start_idx"]) for i in range(len(fx["clips"]))},
+         **{f"{i}/end_idx": np.asarray(ds[i]["end_idx"]) for i in range(len(fx["clips"]))},
+         **{f"{i}/video_checksum": ds[i]["video"].double().sum(-1).numpy() for i in range(len(fx["clips"]))})
+    # compute_metrics on a matrix with ties and off-diagonal winners
+    x = np.array([[0.9, 0.1, 0.9, 0.0], [0.2, 0.2, 0.1, 0.3], [0.5, 0.6, 0.7, 0.8], [0.0, 0.0, 0.0, 1.0]])
+    save("g12_compute_metrics", x=x, **{k: np.asarray(v) for k, v in ref_retr.compute_metrics(x).items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     table = {"g1": g1_forward_small, "g2": g2_forward_e6d6, "g3": g3_loss_init, "g4": g4_loss_cotrain,
              "g5": g5_train_steps, "g6": g6_eval_harness, "g7": g7_long_and_interp, "g8": g8_word2vec, "g9": g9_htm_loader, "g10": g10_sine_pos,
-             "g11": g11_text_pos_and_sine}
+             "g11": g11_text_pos_and_sine, "g12": g12_retrieval}
     for w in which:
         table[w]()
