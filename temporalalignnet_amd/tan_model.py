@@ -968,11 +968,13 @@ class TemporalAligner(nn.Module):
 
     @torch.no_grad()
     def get_textual_feature(self, lang_embed):
-        """ln_text_init(text_pre_proj(lang)) [B,N,C] (tan_model.py:231-234)."""
+        """ln_text_init(text_pre_proj(lang)) (tan_model.py:231-234): [B,N,C], or any [..., 512] like the reference's Linear +
+        LayerNorm (the retrieval evaluation passes the language model's [1, 512] pooler_output, eval_zeroshot_retrieval.py:190-193)."""
         self._ensure_flat()
-        lang_c = self._prep(lang_embed)
+        lead = lang_embed.shape[:-1]
+        lang_c = self._prep(lang_embed.reshape(1, -1, lang_embed.shape[-1]))
         out, _ = self._text_embed(lang_c, False, 0, None, False)
-        return out.view(*lang_embed.shape[:2], WIDTH).float()
+        return out.view(*lead, WIDTH).float()
 
     @torch.no_grad()
     def get_textual_feature_with_time(self, lang_embed, text_timestamp=None, interpolate_from=None):
