@@ -312,6 +312,7 @@ int tan_linear_wgrad(const void* dy, const void* x, float* gw, long M, int N, in
  *   (kernels here: TN=256,TK=32 for N > 512, TN=512,TK=16 for N == 512).  `table` is DEVICE memory; max_tiles = the largest
  *   N/TN * K/TK of the table. */
 typedef struct tan_pack_entry { long src_off, dst_off; int N, K, TN, TK; } tan_pack_entry;
+int tan_panel_waves(void);   /* waves per row-panel workgroup the library was built for (fragment ownership inside a packed tile) */
 int tan_pack_weights(const void* src, void* dst, const tan_pack_entry* table, int n, int max_tiles, void* stream);
 
 /* tan_mlp_fwd: the MLP half of ResidualAttentionBlock_Step.forward (model/tfm_model.py:23-27,37) for rows % 64 == 0, bf16:

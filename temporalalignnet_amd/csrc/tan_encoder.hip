@@ -137,12 +137,11 @@ extern "C" int tan_linear_wgrad(const void* dy, const void* x, float* gw, long M
 }
 
 // Row-panel path (tan_panel.hip): the MLP half of a block -- LN2, c_fc + QuickGELU, c_proj + residual AND the LayerNorm that
-// consumes the block's output (the next block's ln_1, or the stack's post-LN) -- is ONE launch.  Opt-in (TAN_PANEL=1): stand-alone
-// it matches the four launches it replaces (83 vs 77 us at 8192 rows, 81 vs 91 us at 10240), two stacks side by side it is 9 %
-// ahead, but inside the training step -- where its 128 / 160 one-per-CU workgroups meet the other stream's kernels -- the step
-// is 3 % slower (DESIGN.md section 3.5 has the ablation that explains why).
+// consumes the block's output (the next block's ln_1, or the stack's post-LN) -- is ONE launch (TAN_PANEL=0: the four launches
+// it replaces).  Stand-alone 74 vs 77 us at 8192 rows and 69 vs 87 us at 10240; the two stacks side by side 122 vs 147 us; inside the
+// training step 6.24 / 6.31 vs 6.31 / 6.42 ms (two interleaved rounds on one box).  DESIGN.md section 3.5 has the ablations.
 static int panel_enabled() {
-    static const int on = [] { const char* e = getenv("TAN_PANEL"); return e ? atoi(e) : 0; }();
+    static const int on = [] { const char* e = getenv("TAN_PANEL"); return e ? atoi(e) : 1; }();
     return on;
 }
 

@@ -25,7 +25,10 @@ typedef void __attribute__((address_space(3)))* pn_lptr_t;
 typedef const float __attribute__((address_space(4)))* pn_cfptr_t;     // constant address space: uniform loads become s_load
 
 constexpr int PN_ROWS = 64;        // rows per panel
-constexpr int PN_WAVES = 4;       // one per SIMD: each wave owns the whole 512-entry register file
+#ifndef TAN_PN_WAVES
+#define TAN_PN_WAVES 8
+#endif
+constexpr int PN_WAVES = TAN_PN_WAVES;   // 4: one per SIMD (512 registers each); 8: two per SIMD (the hardware interleaves them)
 
 template <int KD>
 __device__ __forceinline__ int pn_tile_swz(int row) {
@@ -102,6 +105,29 @@ __device__ __forceinline__ void pn_lds_store16_hidden(const char* p, const uint4
     pn_u32x4 d;
     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(uintptr_t)p), "v"(d) : "memory");
+}
+
+// Cooperative copy of a swizzled [64 rows][ROWB bytes] LDS panel to global rows (row stride ld elements): every wave-instruction
+// stores WHOLE rows (1 KiB = two 512-byte rows or one 1-KiB row, lane-contiguous).  The accumulator layout would give 16 bytes per
+// lane at a row stride instead: 64 partial-line writes per instruction, which cost L2 request slots like full lines do and -- VMEM
+// returns being counted in order -- hold up every later weight-load wait of the wave.
+template <int ROWB>
+__device__ __forceinline__ void pn_panel_copy_out(const char* panel, bf16_t* dst, long ld, int wave, int lane) {
+    constexpr int CH = ROWB / 16, RPI = 64 / CH, NI = PN_ROWS / RPI / PN_WAVES;
+#pragma unroll 1
+    for (int i = 0; i < NI; i += 2) {           // two rows-instructions at a time: called where the register file is full
+        uint4 v[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (wave * NI + i + j) * RPI + lane / CH, chunk = lane % CH;
+            v[j] = *reinterpret_cast<const uint4*>(panel + row * ROWB + ((chunk ^ (row & 15)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (wave * NI + i + j) * RPI + lane / CH, chunk = lane % CH;
+            *reinterpret_cast<uint4*>(dst + (long)row * ld + chunk * 8) = v[j];
+        }
+    }
 }
 
 template <int J, int END, typename F>

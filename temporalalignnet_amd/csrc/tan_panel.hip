@@ -65,12 +65,17 @@ struct MlpFwdArgs {
 // by all waves in body(c+1)); the two hidden-panel buffers alternate.
 constexpr int MLP_KDF = 32, MLP_KDP = 16, MLP_TILE = 16384, MLP_TF = 512 / MLP_KDF, MLP_TP = 256 / MLP_KDP;
 constexpr int MLP_D = 8;                 // weight prefetch distance in steps
-constexpr int MLP_XN_OFF = 0, MLP_H_OFF = 65536, MLP_LDS = 131072;
-static_assert(PN_WAVES == 4, "fragment bookkeeping below is written for four waves");
+constexpr int MLP_XN_OFF = 0, MLP_H_OFF = 65536, MLP_PRE_OFF = 131072, MLP_LDS = 163840;   // input panel | hidden x2 | pre-activation
+static_assert(PN_WAVES == 4 || PN_WAVES == 8, "four waves (one per SIMD) or eight (two per SIMD)");
+constexpr int MLP_NBH = 256 / (32 * PN_WAVES);      // 32-feature blocks of a hidden chunk per wave (2 | 1)
+constexpr int MLP_NBO = 512 / (32 * PN_WAVES);      // 32-feature blocks of the output per wave (4 | 2)
+constexpr int MLP_WFR = MLP_NBO;                    // weight fragments per step: c_fc NBH x 2 k steps = c_proj NBO
+constexpr int MLP_HU = 8 * MLP_NBH;                 // epilogue half-units per chunk (16 | 8), dealt over the 16 c_proj steps
+constexpr int MLP_HU_STRIDE = 16 / MLP_HU;
 static_assert(MLP_TF == 16 && MLP_TP == 16 && MLP_TF % MLP_D == 0, "step bookkeeping");
 
 struct MlpXFrags { bf16x8 f[4]; };       // activation fragments of one step: c_fc [k step][row block], c_proj [row block]
-struct MlpWFrags { bf16x8 f[4]; };       // weight fragments of one step: c_fc [feature block][k step], c_proj [feature block]
+struct MlpWFrags { bf16x8 f[MLP_WFR]; };       // weight fragments of one step: c_fc [feature block][k step], c_proj [feature block]
 
 // Activation-fragment addresses.  Chunk c = cJ + hi (cJ = first 16-byte chunk of the k step, even; hi = lane >> 5) of row r sits at
 // slot c ^ (r & 15) = (cJ & ~15) + ((cJ & 15) ^ t) with t = hi ^ (r & 15): the part that depends on the lane takes only EIGHT values
@@ -108,23 +113,23 @@ __device__ __forceinline__ void mlp_load_x_proj(MlpXFrags& F, const MlpXAddr& A,
 }
 
 __device__ __forceinline__ void mlp_load_w(MlpWFrags& W, const char* tile, int wave, int lane) {
-    const char* p = tile + wave * 4096 + lane * 16;
+    const char* p = tile + wave * (MLP_TILE / PN_WAVES) + lane * 16;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) W.f[i] = *reinterpret_cast<const bf16x8*>(p + i * 1024);
+    for (int i = 0; i < MLP_WFR; ++i) W.f[i] = *reinterpret_cast<const bf16x8*>(p + i * 1024);
 }
 
-__device__ __forceinline__ void mlp_mma_fc(const MlpWFrags& W, const MlpXFrags& F, f32x16 (&acc_h)[2][2]) {
+__device__ __forceinline__ void mlp_mma_fc(const MlpWFrags& W, const MlpXFrags& F, f32x16 (&acc_h)[MLP_NBH][2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)          // W.f[2 * nb + i]: hidden features wave*64 + nb*32 .., k step i
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < MLP_NBH; ++nb)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
                 acc_h[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[2 * nb + i], F.f[2 * i + mb], acc_h[nb][mb], 0, 0, 0);
 }
-__device__ __forceinline__ void mlp_mma_proj(const MlpWFrags& W, const MlpXFrags& F, f32x16 (&acc_o)[4][2]) {
+__device__ __forceinline__ void mlp_mma_proj(const MlpWFrags& W, const MlpXFrags& F, f32x16 (&acc_o)[MLP_NBO][2]) {
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)       // W.f[nb]: output features wave*128 + nb*32 .., one k step
+    for (int nb = 0; nb < MLP_NBO; ++nb)       // W.f[nb]: output features wave*128 + nb*32 .., one k step
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) acc_o[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], F.f[mb], acc_o[nb][mb], 0, 0, 0);
 }
@@ -136,20 +141,20 @@ __device__ __forceinline__ void mlp_mma_proj(const MlpWFrags& W, const MlpXFrags
 // s_waitcnt lgkmcnt(0) of a few hundred cycles per half-unit, 128 times per panel.
 struct MlpEpiState { uint32_t pre[4], act[4]; };
 struct MlpBias { float b[16]; };
-template <int UNIT>     // UNIT 0..7 of chunk c; UNIT == 8: unit 0 of chunk c + 1
+template <int UNIT>     // UNIT 0 .. MLP_HU/2 - 1 of chunk c; UNIT == MLP_HU/2: unit 0 of chunk c + 1
 __device__ __forceinline__ void mlp_bias_load(MlpBias& B, const float* b_fc, int c, int wave) {
-    constexpr int u = UNIT & 7, nb = u >> 2, p = u & 1;
-    const int cc = UNIT == 8 ? min(c + 1, 7) : c;
-    pn_cfptr_t bp = (pn_cfptr_t)(uintptr_t)b_fc + cc * 256 + wave * 64 + nb * 32 + 16 * p;
+    constexpr int u = UNIT % (MLP_HU / 2), nb = u >> 2, p = u & 1;
+    const int cc = UNIT == MLP_HU / 2 ? min(c + 1, 7) : c;
+    pn_cfptr_t bp = (pn_cfptr_t)(uintptr_t)b_fc + cc * 256 + wave * (32 * MLP_NBH) + nb * 32 + 16 * p;
 #pragma unroll
     for (int e = 0; e < 16; ++e) B.b[e] = bp[e];
 }
 template <int U>
-__device__ __forceinline__ void mlp_epi_half(MlpEpiState& E, const MlpBias& B, const f32x16 (&acc_h)[2][2], const MlpFwdArgs& a, char* lds,
+__device__ __forceinline__ void mlp_epi_half(MlpEpiState& E, const MlpBias& B, const f32x16 (&acc_h)[MLP_NBH][2], const MlpFwdArgs& a, char* lds,
                                              int c, int hb, long row0, int wave, int lane) {
     constexpr int unit = U >> 1, h = U & 1, nb = unit >> 2, mb = (unit >> 1) & 1, p = unit & 1;
     const int hi = lane >> 5;
-    const int nloc = wave * 64 + nb * 32;                                 // wave-uniform
+    const int nloc = wave * (32 * MLP_NBH) + nb * 32;                     // wave-uniform
     float v[4];
 #pragma unroll
     for (int x2 = 0; x2 < 2; ++x2) {
@@ -158,8 +163,13 @@ __device__ __forceinline__ void mlp_epi_half(MlpEpiState& E, const MlpBias& B, c
         // explicit AGPR reads: left to itself the allocator moves the whole hidden accumulator into VGPRs for this VALU use
         // (64 registers the weight ring needs) and spills the ring
         int ra, rb;
-        asm("v_accvgpr_read_b32 %0, %1" : "=v"(ra) : "a"(acc_h[nb][mb][8 * p + x]));
-        asm("v_accvgpr_read_b32 %0, %1" : "=v"(rb) : "a"(acc_h[nb][mb][8 * p + 4 + x]));
+        if constexpr (PN_WAVES == 4) {
+            asm("v_accvgpr_read_b32 %0, %1" : "=v"(ra) : "a"(acc_h[nb][mb][8 * p + x]));
+            asm("v_accvgpr_read_b32 %0, %1" : "=v"(rb) : "a"(acc_h[nb][mb][8 * p + 4 + x]));
+        } else {
+            ra = __float_as_int(acc_h[nb][mb][8 * p + x]);
+            rb = __float_as_int(acc_h[nb][mb][8 * p + 4 + x]);
+        }
         auto r = __builtin_amdgcn_permlane32_swap(ra, rb, false, false);
         const float blo = hi ? B.b[8 + x] : B.b[x], bhi = hi ? B.b[12 + x] : B.b[4 + x];
         v[x2] = __int_as_float(r[0]) + blo;               // element x
@@ -173,18 +183,17 @@ __device__ __forceinline__ void mlp_epi_half(MlpEpiState& E, const MlpBias& B, c
         const int ch = 2 * p + hi, m = mb * 32 + (lane & 31);
         const uint4 ua = make_uint4(E.act[0], E.act[1], E.act[2], E.act[3]);
         *reinterpret_cast<uint4*>(pn_panel_slot<512>(lds + MLP_H_OFF + hb * 32768, m, (nloc >> 3) + ch)) = ua;
-        const long gi = (row0 + m) * 2048 + c * 256 + nloc + ch * 8;
-        *reinterpret_cast<uint4*>(a.h_pre + gi) = make_uint4(E.pre[0], E.pre[1], E.pre[2], E.pre[3]);
-        *reinterpret_cast<uint4*>(a.h_act + gi) = ua;
+        // the pre-activation goes to its own LDS panel: both leave for HBM as whole rows after the chunk's barrier (body_end)
+        *reinterpret_cast<uint4*>(pn_panel_slot<512>(lds + MLP_PRE_OFF, m, (nloc >> 3) + ch)) = make_uint4(E.pre[0], E.pre[1], E.pre[2], E.pre[3]);
     }
 }
 
 // MODE 0: the kernel.  Timing experiments of tools/lab/mlp_lab.py (results undefined), bit mask: 1 no MFMAs, 2 no weight
 // streaming (loaded once), 4 no activation-fragment reads in the loop, 8 no chunk-epilogue arithmetic / stores
 template <int MODE>
-__global__ __launch_bounds__(256, 1) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
+__global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
     constexpr int TILE = MLP_TILE, D = MLP_D;
-    constexpr int XN_OFF = MLP_XN_OFF;
+    constexpr int XN_OFF = MLP_XN_OFF, H_OFF = MLP_H_OFF;
     __shared__ __attribute__((aligned(1024))) char lds[MLP_LDS];
 
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
@@ -200,14 +209,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
         mlp_load_w(WQ[J], pfc + (long)J * TILE, wave, lane);
     });
 
-    // ---- prologue: LN2 of the panel, 16 rows per wave (two batches of 8), one 16-byte chunk per lane ------------------
+    // ---- prologue: LN2 of the panel, 64 / PN_WAVES rows per wave (batches of 8), one 16-byte chunk per lane ------------
     {
+        constexpr int RPW = PN_ROWS / PN_WAVES;
         const f8 g = ld8f(a.ln_g + lane * 8), b = ld8f(a.ln_b + lane * 8);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < RPW / 8; ++half) {
             f8 v[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = ld8(a.x_mid + (row0 + wave * 16 + half * 8 + r) * 512 + lane * 8);
+            for (int r = 0; r < 8; ++r) v[r] = ld8(a.x_mid + (row0 + wave * RPW + half * 8 + r) * 512 + lane * 8);
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 float s = 0.f;
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = v[r].v[j] * rstd * g.v[j] + b.v[j];
                 const uint4 u = pn_pack8(o);
-                const int m = wave * 16 + half * 8 + r;
+                const int m = wave * RPW + half * 8 + r;
                 *reinterpret_cast<uint4*>(a.xn2 + (row0 + m) * 512 + lane * 8) = u;
                 *reinterpret_cast<uint4*>(pn_panel_slot<1024>(lds + XN_OFF, m, lane)) = u;
                 if (lane == 0) { a.mean2[row0 + m] = mean; a.rstd2[row0 + m] = rstd; }
@@ -231,12 +241,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
     }
     __syncthreads();
 
-    f32x16 acc_o[4][2];      // [feature block of the wave's 128 output features][row block]
+    f32x16 acc_o[MLP_NBO][2];      // [feature block of the wave's output features][row block]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MLP_NBO; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc_zero(acc_o[i][j]);
-    f32x16 acc_h[2][2];      // [feature block of the wave's 64 hidden features][row block]
+    f32x16 acc_h[MLP_NBH][2];      // [feature block of the wave's hidden features][row block]
     MlpXFrags FA, FB;        // activation fragments of the even / odd steps
     MlpEpiState ES;
     MlpBias BA, BB;          // bias values of the even / odd epilogue units
@@ -290,14 +300,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
                                    wave, lane);
                 }
             }
-            if constexpr (EPI) {
-                constexpr int unit = J >> 1;
+            if constexpr (EPI && J % MLP_HU_STRIDE == 0) {
+                constexpr int U = J / MLP_HU_STRIDE, unit = U >> 1;
                 MlpBias& bcur = (unit & 1) ? BB : BA;
                 MlpBias& bnxt = (unit & 1) ? BA : BB;
-                if constexpr ((J & 1) == 0) mlp_bias_load<unit + 1>(bnxt, a.b_fc, c, wave);     // a whole unit ahead
-                if (!(MODE & 8)) mlp_epi_half<J>(ES, bcur, acc_h, a, lds, c, hb, row0, wave, lane);
+                if constexpr ((U & 1) == 0) mlp_bias_load<unit + 1>(bnxt, a.b_fc, c, wave);     // a whole unit ahead
+                if (!(MODE & 8)) mlp_epi_half<U>(ES, bcur, acc_h, a, lds, c, hb, row0, wave, lane);
             }
-            if constexpr (PROJ && EPI) {
+            if constexpr (PROJ && EPI && PN_WAVES == 4) {
                 // in-order issue: eight MFMAs followed by ~55 VALU instructions overlap nothing; deal the epilogue half-unit into
                 // the gaps between the MFMAs (a 32-cycle MFMA hides ~6 single-issue instructions of a lone wave)
 #pragma unroll
@@ -315,13 +325,21 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
     using F_ = std::false_type;
 
     auto body_end = [&](int c) __attribute__((always_inline)) {
-        // hidden chunk c is complete (LDS only: the weight loads stay in flight across the barrier)
+        // hidden chunk c is complete (LDS only: the weight loads stay in flight across the barrier) ...
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        // ... and leaves for HBM (the operands of the weight gradients, and of gelu' in backward) as whole 512-byte rows.  The second
+        // barrier frees the single pre-activation panel for the next chunk's epilogue; the activation panel is double-buffered.
+        if (!(MODE & 8)) {
+            pn_panel_copy_out<512>(lds + MLP_PRE_OFF, a.h_pre + row0 * 2048 + c * 256, 2048, wave, lane);
+            pn_panel_copy_out<512>(lds + H_OFF + (c & 1) * 32768, a.h_act + row0 * 2048 + c * 256, 2048, wave, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
     };
     auto zero_h = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MLP_NBH; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc_zero(acc_h[i][j]);
     };
@@ -345,17 +363,22 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
     proj_phase(8, T_{}, F_{});
     if (MODE & 1) {          // stream-only experiment: keep the loaded fragments alive
 #pragma unroll
-        for (int i = 0; i < D; ++i) asm volatile("" ::"v"(WQ[i].f[0]), "v"(WQ[i].f[1]), "v"(WQ[i].f[2]), "v"(WQ[i].f[3]));
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < MLP_WFR; ++j) asm volatile("" ::"v"(WQ[i].f[j]));
     }
 
-    // ---- epilogue: + bias + residual -> x_out; LayerNorm of the (bf16-rounded) output row -> xn_next ------------------
-    __syncthreads();         // every wave is done with the hidden panels: their space becomes the LayerNorm scratch
-    float* red = reinterpret_cast<float*>(lds + MLP_H_OFF);      // [2][4 waves][64 rows]
-    float xr[4][2][2][8];    // [nb][mb][p][e], rounded like the stored x_out
+    // ---- epilogue: + bias + residual -> x_out; LayerNorm of the (bf16-rounded) output row -> xn_next.  Both leave through LDS
+    // panels as whole 1-KiB rows (pn_panel_copy_out); the input panel's space takes x_out, the hidden panels' space xn_next.
+    __syncthreads();         // every wave is done with the activation panels
+    char* xo_panel = lds + MLP_XN_OFF;
+    char* xn_panel = lds + MLP_H_OFF;
+    float* red = reinterpret_cast<float*>(lds + MLP_PRE_OFF);     // [2][PN_WAVES][64 rows]
+    float xr[MLP_NBO][2][2][8];    // [nb][mb][p][e], rounded like the stored x_out
     float rs[2] = {0.f, 0.f};
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        const int nbase = wave * 128 + nb * 32;
+    for (int nb = 0; nb < MLP_NBO; ++nb) {
+        const int nbase = wave * (32 * MLP_NBO) + nb * 32;
         pn_cfptr_t bp = (pn_cfptr_t)(uintptr_t)(a.b_proj) + nbase;
         uint4 resq[2][2];    // this feature block's residual chunks: four loads in flight
 #pragma unroll
@@ -373,13 +396,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
                 const int ch = 2 * p + hi;
                 float bias[8], res[8];
                 pn_uniform8(bp + 16 * p, bp + 16 * p + 8, hi, bias);
-                const long gi = (row0 + m) * 512 + nbase + ch * 8;
                 pn_unpack8(resq[mb][p], res);
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = o[p][e] + bias[e] + res[e];
                 const uint4 u = pn_pack8(v);
-                *reinterpret_cast<uint4*>(a.x_out + gi) = u;
+                *reinterpret_cast<uint4*>(pn_panel_slot<1024>(xo_panel, m, (nbase >> 3) + ch)) = u;
                 pn_unpack8(u, xr[nb][mb][p]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) rs[mb] += xr[nb][mb][p][e];
@@ -387,13 +409,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
         }
     }
     if (a.xn_next) {
-        float mean[2], rstd[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             const float s = pn_half_sum(rs[mb]);
             if (lane < 32) red[wave * 64 + mb * 32 + lane] = s;
         }
-        __syncthreads();
+    }
+    __syncthreads();
+    pn_panel_copy_out<1024>(xo_panel, a.x_out + row0 * 512, 512, wave, lane);
+    if (a.xn_next) {
+        float mean[2], rstd[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             float s = 0.f;
@@ -402,30 +427,29 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
             mean[mb] = s * (1.0f / 512);
             float q = 0.f;
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
+            for (int nb = 0; nb < MLP_NBO; ++nb)
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { const float d = xr[nb][mb][p][e] - mean[mb]; xr[nb][mb][p][e] = d; q += d * d; }
             q = pn_half_sum(q);
-            if (lane < 32) red[256 + wave * 64 + mb * 32 + lane] = q;
+            if (lane < 32) red[PN_WAVES * 64 + wave * 64 + mb * 32 + lane] = q;
         }
         __syncthreads();
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             float q = 0.f;
 #pragma unroll
-            for (int w = 0; w < PN_WAVES; ++w) q += red[256 + w * 64 + mb * 32 + (lane & 31)];
+            for (int w = 0; w < PN_WAVES; ++w) q += red[PN_WAVES * 64 + w * 64 + mb * 32 + (lane & 31)];
             rstd[mb] = rsqrtf(q * (1.0f / 512) + a.eps);
             const int m = mb * 32 + (lane & 31);
             if (wave == 0 && lane < 32) { a.nmean[row0 + m] = mean[mb]; a.nrstd[row0 + m] = rstd[mb]; }
         }
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < MLP_NBO; ++nb)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const int nu = wave * 128 + nb * 32 + 16 * p;         // wave-uniform: gamma / beta come through scalar loads
-                const int n = nu + 8 * hi;
+                const int nu = wave * (32 * MLP_NBO) + nb * 32 + 16 * p;         // wave-uniform: gamma / beta come through scalar loads
                 pn_cfptr_t gp = (pn_cfptr_t)(uintptr_t)(a.nln_g) + nu;
                 pn_cfptr_t bp = (pn_cfptr_t)(uintptr_t)(a.nln_b) + nu;
                 float g[8], b[8];
@@ -436,15 +460,19 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
                     float y[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) y[e] = xr[nb][mb][p][e] * rstd[mb] * g[e] + b[e];
-                    *reinterpret_cast<uint4*>(a.xn_next + (row0 + mb * 32 + (lane & 31)) * 512 + n) = pn_pack8(y);
+                    *reinterpret_cast<uint4*>(pn_panel_slot<1024>(xn_panel, mb * 32 + (lane & 31), (nu >> 3) + hi)) = pn_pack8(y);
                 }
             }
+        __syncthreads();
+        pn_panel_copy_out<1024>(xn_panel, a.xn_next + row0 * 512, 512, wave, lane);
     }
 }
 
 }  // namespace tal
 
 using namespace tal;
+
+extern "C" int tan_panel_waves(void) { return PN_WAVES; }
 
 extern "C" int tan_pack_weights(const void* src, void* dst, const tan_pack_entry* table, int n, int max_tiles, void* stream) {
     TAN_REQUIRE(src && dst && table && n > 0 && max_tiles > 0);
@@ -470,15 +498,15 @@ extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
     const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0);
     switch (d->variant) {
 #ifdef TAN_PANEL_LAB
-        case 5: hipLaunchKernelGGL((mlp_fwd_panel_kernel<5>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
-        case 2: hipLaunchKernelGGL((mlp_fwd_panel_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
-        case 6: hipLaunchKernelGGL((mlp_fwd_panel_kernel<6>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
-        case 8: hipLaunchKernelGGL((mlp_fwd_panel_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
-        case 10: hipLaunchKernelGGL((mlp_fwd_panel_kernel<10>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
-        case 14: hipLaunchKernelGGL((mlp_fwd_panel_kernel<14>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
-        case 15: hipLaunchKernelGGL((mlp_fwd_panel_kernel<15>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        case 5: hipLaunchKernelGGL((mlp_fwd_panel_kernel<5>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
+        case 2: hipLaunchKernelGGL((mlp_fwd_panel_kernel<2>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
+        case 6: hipLaunchKernelGGL((mlp_fwd_panel_kernel<6>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
+        case 8: hipLaunchKernelGGL((mlp_fwd_panel_kernel<8>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
+        case 10: hipLaunchKernelGGL((mlp_fwd_panel_kernel<10>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
+        case 14: hipLaunchKernelGGL((mlp_fwd_panel_kernel<14>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
+        case 15: hipLaunchKernelGGL((mlp_fwd_panel_kernel<15>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
 #endif
-        default: hipLaunchKernelGGL((mlp_fwd_panel_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        default: hipLaunchKernelGGL((mlp_fwd_panel_kernel<0>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
     }
     prof_end((hipStream_t)stream, rec);
     TAN_LAUNCH_CHECK();

@@ -43,10 +43,11 @@ def test_pack_weights_is_a_permutation_with_the_documented_fragment_layout():
         (p,) = pack([w])
         assert torch.equal(torch.sort(p.view(torch.int16).flatten())[0], torch.sort(w.view(torch.int16).flatten())[0])
         TN, TK = (512, 16) if N == 512 else (256, 32)
-        KS, RB = TK // 16, TN // 128
-        tiles = p.view(N // TN, K // TK, 4, RB, KS, 64, 8)          # [n-block][k-block][wave][row block][k step][lane][8]
-        nb, kb, wv, rb, ks, lane = 0, (K // TK) - 1, 3, RB - 1, KS - 1, 45
-        row = nb * TN + wv * (TN // 4) + rb * 32 + (lane & 31)
+        W = _lib_ops()[0].lib().tan_panel_waves()
+        KS, RB = TK // 16, TN // (32 * W)
+        tiles = p.view(N // TN, K // TK, W, RB, KS, 64, 8)          # [n-block][k-block][wave][row block][k step][lane][8]
+        nb, kb, wv, rb, ks, lane = 0, (K // TK) - 1, W - 1, RB - 1, KS - 1, 45
+        row = nb * TN + wv * (TN // W) + rb * 32 + (lane & 31)
         k = kb * TK + ks * 16 + 8 * (lane >> 5)
         assert torch.equal(tiles[nb, kb, wv, rb, ks, lane], w[row, k:k + 8])
 
