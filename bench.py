@@ -38,7 +38,7 @@ GEMM_KIND_NAMES = {0: "gemm_bf16<A:K-contig,B:K-contig> (Linear fwd, dX through 
                    2: "gemm_bf16<A:K-strided,B:K-contig>", 3: "gemm_bf16<A:K-strided,B:K-strided> (dW)",
                    4: "gemm_f32<kc,kc>", 5: "gemm_f32<kc,ks>", 6: "gemm_f32<ks,kc>", 7: "gemm_f32<ks,ks>",
                    8: "attn_fwd", 9: "attn_bwd", 10: "simnce (logits-free similarity+NCE, fwd stats / bwd dlogits)",
-                   11: "row-panel fused MLP (opt-in, TAN_PANEL=1)"}
+                   11: "row-panel fused MLP forward (LN2 + c_fc + QuickGELU + c_proj + residual + next LN)"}
 NKINDS = 12
 FAMILY = list(range(8)) + [10, 11]       # every MFMA GEMM pipeline launch
 

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libtan_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = (["-DTAN_PANEL_LAB"] if os.environ.get("TAN_PANEL_LAB") else []) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
+FLAGS = (["-DTAN_PANEL_LAB"] if os.environ.get("TAN_PANEL_LAB") else []) + os.environ.get("TAN_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
          "-fgpu-rdc" if False else "-fno-gpu-rdc"]
 
 

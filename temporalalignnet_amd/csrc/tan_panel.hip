@@ -188,8 +188,54 @@ __device__ __forceinline__ void mlp_epi_half(MlpEpiState& E, const MlpBias& B, c
     }
 }
 
+// The side outputs (pre-activation and activation chunk, the operands of backward) leave for HBM ONE row-instruction at a time,
+// spread over BOTH phases of the body that follows the chunk's barrier: the four row-instructions of the pre-activation panel under
+// c_fc(c+1) (the panel is rewritten by the next epilogue), the four of the activation panel under c_proj(c) || epilogue(c+1).  As a burst between two barriers (the first version)
+// the 16 MiB that all CUs store at once take longer to drain than the weight ring covers, and stores retire in order with the
+// ring's loads: 31 us of a 94 us launch (tools/lab/mlp_lab.py, cold buffers).
+struct MlpCopy { uint4 v; uint32_t lds0, voff; };
+// A wave group (waves 4g .. 4g+3) owns hidden features [128 g, 128 g + 128) of a chunk: its half of the two LDS panels is copied by
+// its own waves, one instruction = four half rows (16 lanes x 16 B = 256 B each); wave-in-group wg takes rows 16 wg .. 16 wg + 15.
+__device__ __forceinline__ void mlp_copy_init(MlpCopy& C, int wave, int lane) {
+    static_assert(PN_WAVES == 8, "two wave groups of four");
+    const int g = wave >> 2, row_b = (wave & 3) * 16 + (lane >> 4), chunk = g * 16 + (lane & 15);   // rows row_b + 4 i, i = 0..3
+    C.lds0 = row_b * 512 + ((chunk ^ (row_b & 15)) << 4);
+    C.voff = (row_b * 2048 + chunk * 8) * 2;
+}
+// step J of a 16-step phase moving the group's half of ONE panel (ACT: activation panel of chunk cprev, else the pre-activation
+// panel): row-instruction i = J / 4 is read from LDS at J = 4 i and stored at J = 4 i + 1
+template <int J, bool ACT, bool CM = false>
+__device__ __forceinline__ void mlp_copy_step4(MlpCopy& C, const char* lds, const MlpFwdArgs& a, long row0, int cprev) {
+    constexpr int i = J >> 2;
+    if constexpr ((J & 3) == 0) {
+        const char* panel = ACT ? lds + MLP_H_OFF + (cprev & 1) * 32768 : lds + MLP_PRE_OFF;
+        C.v = *reinterpret_cast<const uint4*>(panel + ((C.lds0 ^ (i << 6)) + i * 2048));      // row & 15 gains 4 i: no carry
+    } else if constexpr ((J & 3) == 1) {
+        if constexpr (CM) {    // lab experiment: chunk-major side outputs [chunk][row][256] (a panel's chunk = 32 KiB contiguous)
+            bf16_t* base = (ACT ? a.h_act : a.h_pre) + (long)cprev * gridDim.x * (64 * 256) + row0 * 256;
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + (C.voff >> 12) * 512 + (C.voff & 511) + i * 2048) = C.v;
+        } else {
+            bf16_t* base = (ACT ? a.h_act : a.h_pre) + row0 * 2048 + cprev * 256;                 // wave-uniform
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + C.voff + i * 16384) = C.v;
+        }
+    }
+}
+// both panels in one 16-step phase (the last one): pair q = J / 2
+template <int J>
+__device__ __forceinline__ void mlp_copy_step8(MlpCopy& C, const char* lds, const MlpFwdArgs& a, long row0, int cprev) {
+    constexpr int q = J >> 1, i = q & 3;
+    if constexpr ((J & 1) == 0) {
+        const char* panel = q < 4 ? lds + MLP_PRE_OFF : lds + MLP_H_OFF + (cprev & 1) * 32768;
+        C.v = *reinterpret_cast<const uint4*>(panel + ((C.lds0 ^ (i << 6)) + i * 2048));
+    } else {
+        bf16_t* base = (q < 4 ? a.h_pre : a.h_act) + row0 * 2048 + cprev * 256;
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + C.voff + i * 16384) = C.v;
+    }
+}
+
 // MODE 0: the kernel.  Timing experiments of tools/lab/mlp_lab.py (results undefined), bit mask: 1 no MFMAs, 2 no weight
-// streaming (loaded once), 4 no activation-fragment reads in the loop, 8 no chunk-epilogue arithmetic / stores
+// streaming (loaded once), 4 no activation-fragment reads in the loop, 8 no chunk-epilogue arithmetic / stores, 16 no side-output copy-out (arithmetic, LDS panel
+// writes and both barriers stay), 32 no chunk-epilogue arithmetic (copy-out stays)
 template <int MODE>
 __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
     constexpr int TILE = MLP_TILE, D = MLP_D;
@@ -197,11 +243,27 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
     __shared__ __attribute__((aligned(1024))) char lds[MLP_LDS];
 
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
+#ifdef TAN_PN_WAVE_PERM     // experiment: which hardware waves share a SIMD?  logical wave = (hw & 1) * 4 + (hw >> 1): group = hw & 1
+    const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = (hw_wave & 1) * 4 + (hw_wave >> 1);
+#else
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
     const long row0 = (long)blockIdx.x * PN_ROWS;
     const char* const pfc = a.pw_fc;
     const char* const ppj = a.pw_proj;
 
+    // First touch of the packed weights (4 MiB, used once per step and stack: cold in every L2).  Streamed cold, every tile's first
+    // miss goes to HBM in the middle of the kernel's own 100 MB of side-output writes and the ring (eight steps) cannot cover that
+    // latency: 97-104 us per launch against 72-77 us with the weights resident in the Infinity Cache (tools/lab/mlp_lab.py, E2/E3).
+    // So the whole set is requested up front, one dword per 128-byte line spread over the first 64 workgroups, while HBM is quiet.
+    if (!(MODE & 256)) {
+        const int L = blockIdx.x * (64 * PN_WAVES) + tid;
+        if (L < 32768) {
+            const char* q = L < 16384 ? pfc + (long)L * 128 : ppj + (long)(L - 16384) * 128;
+            (void)*reinterpret_cast<const volatile uint32_t*>(q);
+        }
+    }
     // the weight stream does not depend on the activations: start it before anything else (ring slots 0..7 = c_fc(0) tiles 0..7)
     MlpWFrags WQ[D];
     pn_static_for<0, D>([&](auto jc) {
@@ -253,22 +315,27 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
     mlp_bias_load<0>(BA, a.b_fc, 0, wave);
     MlpXAddr XA;
     mlp_xaddr_init(XA, lds, lane);
+    MlpCopy CP;
+    mlp_copy_init(CP, wave, lane);
     mlp_load_x_fc<0>(FA, XA);
     __builtin_amdgcn_sched_barrier(0);
 
     // the two 16-step phases; the flags are compile-time so that every step is ONE basic block (the scheduler interleaves the
     // epilogue half-unit with the MFMAs only inside a block)
-    auto fc_phase = [&](int c) __attribute__((always_inline)) {            // c_fc(c)
+    auto fc_phase = [&](int c, auto has_copy) __attribute__((always_inline)) {            // c_fc(c) (|| side outputs of chunk c-1)
+        constexpr bool COPY = decltype(has_copy)::value;
         const int hb = c & 1;
         pn_static_for<0, 16>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
             MlpXFrags& cur = (J & 1) ? FB : FA;
             MlpXFrags& nxt = (J & 1) ? FA : FB;
             if (!(MODE & 4)) {
-                if constexpr (J < 15) mlp_load_x_fc<J + 1>(nxt, XA);
-                else mlp_load_x_proj<0>(nxt, XA, hb ^ 1);      // body(0): reads a not yet written panel, unused
+                if constexpr (J < 15) mlp_load_x_fc<J + 1>(nxt, XA);     // (the next phase's first fragments: after the slot barrier)
             }
             if (!(MODE & 1)) mlp_mma_fc(WQ[J % D], cur, acc_h);
+            if constexpr (COPY) {
+                if (!(MODE & (8 | 16))) mlp_copy_step4<J, false, (MODE & 128) != 0>(CP, lds, a, row0, c - 1);
+            }
             if (!(MODE & 2)) {      // the tile eight steps on: c_fc(c) J+8, else the first half of the next phase that streams
                 const char* src = J + D < 16 ? pfc + (long)(c * 16 + J + D) * TILE
                                              : (c == 0 ? pfc + (long)(16 + J + D - 16) * TILE      // body(0) has no c_proj phase
@@ -293,6 +360,11 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
                     if constexpr (J < 15) mlp_load_x_proj<J + 1>(nxt, XA, hb ^ 1);
                 }
                 if (!(MODE & 1)) mlp_mma_proj(WQ[J % D], cur, acc_o);
+                if constexpr (!EPI) {       // body(8): the side outputs of chunk 7 under c_proj(7)
+                    if (!(MODE & (8 | 16))) mlp_copy_step8<J>(CP, lds, a, row0, 7);
+                } else {                    // the activation panel of chunk c-1 (c_proj(c-1) reads it too; rewritten in body c+1)
+                    if (!(MODE & (8 | 16))) mlp_copy_step4<J, true, (MODE & 128) != 0>(CP, lds, a, row0, c - 1);
+                }
                 if (!(MODE & 2)) {  // c_proj(c-1) J+8, else the first half of the next body's first phase
                     if constexpr (J + D < 16) mlp_load_w(WQ[J % D], ppj + (long)((c - 1) * 16 + J + D) * TILE, wave, lane);
                     else if constexpr (EPI)     // c <= 7: body(c+1) starts with c_fc(c+1), body(8) with c_proj(7)
@@ -305,17 +377,16 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
                 MlpBias& bcur = (unit & 1) ? BB : BA;
                 MlpBias& bnxt = (unit & 1) ? BA : BB;
                 if constexpr ((U & 1) == 0) mlp_bias_load<unit + 1>(bnxt, a.b_fc, c, wave);     // a whole unit ahead
-                if (!(MODE & 8)) mlp_epi_half<U>(ES, bcur, acc_h, a, lds, c, hb, row0, wave, lane);
+                if (!(MODE & (8 | 32))) mlp_epi_half<U>(ES, bcur, acc_h, a, lds, c, hb, row0, wave, lane);
             }
-            if constexpr (PROJ && EPI && PN_WAVES == 4) {
-                // in-order issue: eight MFMAs followed by ~55 VALU instructions overlap nothing; deal the epilogue half-unit into
-                // the gaps between the MFMAs (a 32-cycle MFMA hides ~6 single-issue instructions of a lone wave)
+            if constexpr (PROJ && EPI) {
+                // in-order issue: the step's four MFMAs followed by its ~46 VALU instructions overlap nothing inside the wave (the
+                // matrix pipe runs one MFMA per 32 cycles, the wave sits at the next MFMA's issue); deal the epilogue half-unit
+                // into the gaps so that the wave's own MFMAs execute under its VALU work
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < 4; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x406, 7, 0);        // 7 VALU / SALU / transcendental
-                    if (i < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 weight load
-                    if (i >= 4 && i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 fragment read
+                    __builtin_amdgcn_sched_group_barrier(0x406, 12, 0);       // 12 VALU / SALU / transcendental
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -324,18 +395,28 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
     using T_ = std::true_type;
     using F_ = std::false_type;
 
-    auto body_end = [&](int c) __attribute__((always_inline)) {
-        // hidden chunk c is complete (LDS only: the weight loads stay in flight across the barrier) ...
+    // One barrier per 16-step slot.  The two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run the SAME phase sequence
+    // one slot apart, so that in every slot one wave of a SIMD is in a pure-MFMA c_fc phase while the other interleaves c_proj
+    // MFMAs with the VALU-heavy chunk epilogue and the side-output stores: in lock step (the first version) both waves of a SIMD
+    // did their epilogues at the same time and the matrix pipe idled -- MFMA, epilogue arithmetic and store stalls simply added up
+    // (40 + 22 + 35 us, tools/lab/mlp_lab.py).  Dependencies with the skew: c_proj(c-1) of the early group runs in slot 2c+1 and needs
+    // the late group's epilogue(c-1), slot 2c; the late group's c_proj(c-1), slot 2c+2, needs the early group's, slot 2c-1; a hidden
+    // buffer is rewritten two bodies later (slots 2c+5 / 2c+6), after its last readers (slots 2c+3 / 2c+4).  The pre-activation
+    // panel and the copy-out of both panels are split by group halves, so they never cross groups.  The last phase, c_proj(7), has
+    // to wait for the late group's epilogue(7): the early group idles in slot 16.
+    // lab instrumentation (MODE & 64, xn_next == null): workgroup 0 records the shader clock at phase boundaries into nrstd[]
+    int tick_i = 0;
+    auto tick = [&]() __attribute__((always_inline)) {
+        if (MODE & 64) {
+            const long long t = __builtin_readcyclecounter();
+            if (blockIdx.x == 0 && lane == 0) reinterpret_cast<long long*>(a.nrstd)[wave * 64 + tick_i] = t;
+            ++tick_i;
+        }
+    };
+    auto slot_barrier = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        // ... and leaves for HBM (the operands of the weight gradients, and of gelu' in backward) as whole 512-byte rows.  The second
-        // barrier frees the single pre-activation panel for the next chunk's epilogue; the activation panel is double-buffered.
-        if (!(MODE & 8)) {
-            pn_panel_copy_out<512>(lds + MLP_PRE_OFF, a.h_pre + row0 * 2048 + c * 256, 2048, wave, lane);
-            pn_panel_copy_out<512>(lds + H_OFF + (c & 1) * 32768, a.h_act + row0 * 2048 + c * 256, 2048, wave, lane);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
+        asm volatile("" ::: "memory");
     };
     auto zero_h = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -343,24 +424,35 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc_zero(acc_h[i][j]);
     };
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    tick();
+    if (grp) slot_barrier();
     // body(0) and body(8) are peeled as straight-line code around the loop: as if / else arms INSIDE the loop every extra variant of
     // a phase cost ~300 spilled registers at the joins
     zero_h();
-    fc_phase(0);
-    proj_phase(0, F_{}, T_{});
-    body_end(0);
+    tick(); fc_phase(0, F_{}); tick();
+    slot_barrier();
+    tick(); proj_phase(0, F_{}, T_{}); tick();
+    slot_barrier();
     mlp_load_x_fc<0>(FA, XA);
     __builtin_amdgcn_sched_barrier(0);
     for (int c = 1; c < 8; ++c) {
         zero_h();
-        fc_phase(c);
-        proj_phase(c, T_{}, T_{});
-        body_end(c);
+        tick(); fc_phase(c, T_{}); tick();
+        slot_barrier();
+        mlp_load_x_proj<0>(FA, XA, (c & 1) ^ 1);                    // c_proj(c-1) reads hidden panel (c-1) & 1
+        __builtin_amdgcn_sched_barrier(0);
+        tick(); proj_phase(c, T_{}, T_{}); tick();
+        slot_barrier();
         if (c < 7) mlp_load_x_fc<0>(FA, XA);                        // fragments of the next body's first step
-        else mlp_load_x_proj<0>(FA, XA, 1);                          // body(8): c_proj(7) reads hidden panel 7 & 1
         __builtin_amdgcn_sched_barrier(0);
     }
-    proj_phase(8, T_{}, F_{});
+    slot_barrier();                                                  // (slot of the empty phase "c_fc(8)")
+    mlp_load_x_proj<0>(FA, XA, 1);                                   // c_proj(7) reads hidden panel 7 & 1
+    __builtin_amdgcn_sched_barrier(0);
+    tick(); proj_phase(8, T_{}, F_{}); tick();
+    if (!grp) slot_barrier();
+    tick();
     if (MODE & 1) {          // stream-only experiment: keep the loaded fragments alive
 #pragma unroll
         for (int i = 0; i < D; ++i)
@@ -504,6 +596,13 @@ extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
         case 8: hipLaunchKernelGGL((mlp_fwd_panel_kernel<8>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
         case 10: hipLaunchKernelGGL((mlp_fwd_panel_kernel<10>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
         case 14: hipLaunchKernelGGL((mlp_fwd_panel_kernel<14>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
+        case 16: hipLaunchKernelGGL((mlp_fwd_panel_kernel<16>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
+        case 32: hipLaunchKernelGGL((mlp_fwd_panel_kernel<32>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
+        case 64: hipLaunchKernelGGL((mlp_fwd_panel_kernel<64>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
+        case 80: hipLaunchKernelGGL((mlp_fwd_panel_kernel<80>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
+        case 72: hipLaunchKernelGGL((mlp_fwd_panel_kernel<72>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
+        case 128: hipLaunchKernelGGL((mlp_fwd_panel_kernel<128>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
+        case 256: hipLaunchKernelGGL((mlp_fwd_panel_kernel<256>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
         case 15: hipLaunchKernelGGL((mlp_fwd_panel_kernel<15>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
 #endif
         default: hipLaunchKernelGGL((mlp_fwd_panel_kernel<0>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);

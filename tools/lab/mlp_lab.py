@@ -36,7 +36,7 @@ def pack(mats, variant):
     return outs
 
 
-def run_fused(t, variant, store_h=True, next_ln=True):
+def run_fused(t, variant, store_h=True, next_ln=True, dbg=None):
     d = _lib.MlpDesc()
     d.rows, d.C, d.FF = t["R"], 512, 2048
     d.x_mid = t["x_mid"].data_ptr(); d.ln_g = t["g2"].data_ptr(); d.ln_b = t["b2"].data_ptr()
@@ -49,6 +49,8 @@ def run_fused(t, variant, store_h=True, next_ln=True):
     if next_ln:
         d.nln_g = t["g1"].data_ptr(); d.nln_b = t["b1"].data_ptr(); d.xn_next = t["f_xn1"].data_ptr()
         d.nmean = t["f_mean1"].data_ptr(); d.nrstd = t["f_rstd1"].data_ptr()
+    if dbg is not None:
+        d.nrstd = dbg.data_ptr()
     d.eps = 1e-5; d.variant = variant
     _lib.check(L.tan_mlp_fwd(C.byref(d), ops._stream()), "tan_mlp_fwd")
 
@@ -127,41 +129,118 @@ def check(R=1024):
     return ok
 
 
+def phase_clocks(variant, R=8192):
+    """MODE & 64: per-wave shader-clock stamps at the phase boundaries of workgroup 0 (cold buffers)"""
+    ts = [make(R) for _ in range(6)]
+    dbg = torch.zeros(8 * 64, dtype=torch.int64, device=dev)
+    for i in range(7):
+        run_fused(ts[i % 6], variant, True, False, dbg=dbg)      # next_ln off: nrstd carries the stamps
+    torch.cuda.synchronize()
+    return dbg.cpu().numpy().reshape(8, 64)
+
+
+def print_clocks(variant):
+    st = phase_clocks(variant)
+    t0 = st[:, 0].min()
+    names = ["fc0", "pe0"] + [f"{k}{c}" for c in range(1, 8) for k in ("fc", "pe")] + ["pj7"]
+    print(f"variant {variant}: shader clocks per phase (workgroup 0); start offset / duration per wave")
+    for w in range(8):
+        row = st[w]
+        dur = [int(row[2 + 2 * k] - row[1 + 2 * k]) for k in range(17)]
+        beg = [int(row[1 + 2 * k] - t0) for k in range(17)]
+        print(f" wave {w}: total {int(row[35] - row[0])}  " + " ".join(f"{n}:{b}+{d}" for n, b, d in zip(names, beg, dur)))
+
+
+
 if __name__ == "__main__":
+    if os.environ.get("LAB_CLOCKS"):
+        for v in (int(x) for x in os.environ["LAB_CLOCKS"].split(",")):
+            print_clocks(v)
+        sys.exit(0)
     check(1024)
+    variants = tuple(int(v) for v in os.environ.get("LAB_VARIANTS", "0,16,32,8,5,2,15").split(","))
+    # COLD: six layers' worth of distinct weights and output buffers cycled (as in a stack: nothing is L2 / Infinity-Cache warm)
     for R in (8192, 10240):
-        t = make(R)
+        ts = [make(R) for _ in range(6)]
         fl = 2.0 * R * 512 * 2048 * 2
+        it = [0]
+
+        def cyc(f):
+            def g():
+                f(ts[it[0] % 6]); it[0] += 1
+            return g
+        tu = timeit(cyc(run_unfused), reps=48)
+        print(f"R={R} cold: unfused (LN, fc, proj, LN)       {tu:7.1f} us   {fl / tu / 1e6:6.0f} TF/s", flush=True)
+        for v in variants:
+            tf = timeit(cyc(lambda t: run_fused(t, v, True, True)), reps=48)
+            print(f"R={R} cold: fused v{v:<2d}                        {tf:7.1f} us   {fl / tf / 1e6:6.0f} TF/s", flush=True)
+        if os.environ.get("LAB_E3"):
+            # all cold, but the packed weights are touched (read once: Infinity Cache / one L2) right before the launch
+            wsum = [torch.zeros(1, device=dev) for _ in range(6)]
+
+            def touch(i):
+                for w in ts[i % 6]["pw"]:
+                    wsum[i % 6] += w.view(torch.int16)[::64].sum()       # one element per 128-byte line
+            it4 = [0]
+
+            def g_touch_only():
+                touch(it4[0]); it4[0] += 1
+
+            def g_both():
+                touch(it4[0]); run_fused(ts[it4[0] % 6], 0, True, True); it4[0] += 1
+            t_touch = timeit(g_touch_only, reps=48)
+            t_both = timeit(g_both, reps=48)
+            print(f"R={R} cold + weights touched first: touch {t_touch:6.1f} us, touch + fused v0 {t_both:6.1f} us -> fused alone ~{t_both - t_touch:6.1f} us", flush=True)
+        if os.environ.get("LAB_E2"):
+            # which coldness matters: (a) cycling weights only, (b) cycling activations / outputs only
+            def mix(i, what):
+                t = dict(ts[0])
+                src = ts[i % 6]
+                keys = ("pw", "wfc", "wpj") if what == "w" else [k for k in src if k not in ("pw", "wfc", "wpj", "R")]
+                for k in keys:
+                    t[k] = src[k]
+                return t
+            for what in ("w", "o"):
+                mixed = [mix(i, what) for i in range(6)]
+                it3 = [0]
+
+                def g():
+                    run_fused(mixed[it3[0] % 6], 0, True, True); it3[0] += 1
+                tf = timeit(g, reps=48)
+                print(f"R={R} cold-{what} only: fused v0                 {tf:7.1f} us", flush=True)
+        t = ts[0]
         tu = timeit(lambda: run_unfused(t))
-        print(f"R={R}: unfused (LN, fc, proj, LN)            {tu:7.1f} us   {fl / tu / 1e6:6.0f} TF/s", flush=True)
-        for v in (0, 5, 2, 6, 8, 10, 14, 15):
-            for sh, nl in ((True, True), (True, False)):
-                tf = timeit(lambda: run_fused(t, v, sh, nl))
-                print(f"R={R}: fused v{v} store_h={int(sh)} next_ln={int(nl)}          {tf:7.1f} us   {fl / tf / 1e6:6.0f} TF/s", flush=True)
-    # two panels' worth of work on two streams at once (video + joint stack sizes)
-    ta, tb = make(8192), make(10240)
+        print(f"R={R} warm: unfused (LN, fc, proj, LN)       {tu:7.1f} us   {fl / tu / 1e6:6.0f} TF/s", flush=True)
+        for v in variants:
+            tf = timeit(lambda: run_fused(t, v, True, True))
+            print(f"R={R} warm: fused v{v:<2d}                        {tf:7.1f} us   {fl / tf / 1e6:6.0f} TF/s", flush=True)
+        del ts, t
+        torch.cuda.empty_cache()
+    # two panels' worth of work on two streams at once (video + joint stack sizes), cold
+    tas, tbs = [make(8192) for _ in range(6)], [make(10240) for _ in range(6)]
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    it2 = [0]
 
     def both(fa, fb):
+        i = it2[0] % 6; it2[0] += 1
         with torch.cuda.stream(s1):
-            fa()
+            fa(tas[i])
         with torch.cuda.stream(s2):
-            fb()
+            fb(tbs[i])
 
-    def time_both(fa, fb, reps=30):
+    def time_both(fa, fb, reps=48):
         both(fa, fb); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        s1.wait_stream(torch.cuda.current_stream()); s2.wait_stream(torch.cuda.current_stream())
+        e0.record(); s1.wait_event(e0); s2.wait_event(e0)
         for _ in range(reps):
             both(fa, fb)
         torch.cuda.current_stream().wait_stream(s1); torch.cuda.current_stream().wait_stream(s2)
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / reps
-
     fl2 = 2.0 * (8192 + 10240) * 512 * 2048 * 2
-    tu = time_both(lambda: run_unfused(ta), lambda: run_unfused(tb))
-    print(f"two streams 8192+10240: unfused {tu:7.1f} us {fl2 / tu / 1e6:6.0f} TF/s")
-    for v in (0,):
-        tf = time_both(lambda: run_fused(ta, v), lambda: run_fused(tb, v))
-        print(f"two streams 8192+10240: fused v{v} {tf:7.1f} us {fl2 / tf / 1e6:6.0f} TF/s")
+    tu = time_both(run_unfused, run_unfused)
+    print(f"two streams 8192+10240 cold: unfused  {tu:7.1f} us {fl2 / tu / 1e6:6.0f} TF/s")
+    for v in variants[:4]:
+        tf = time_both(lambda t: run_fused(t, v), lambda t: run_fused(t, v))
+        print(f"two streams 8192+10240 cold: fused v{v:<2d} {tf:7.1f} us {fl2 / tf / 1e6:6.0f} TF/s")
+
