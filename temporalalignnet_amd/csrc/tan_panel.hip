@@ -16,8 +16,11 @@ namespace tal {
 // ------------------------------------------------------------------------------------------------------------------
 // weight packer: table entry e packs the row-major matrix src[e.src_off ..] of shape [N][K] into tiles [TN][TK], tile order
 // (n-block, k-block).  Inside a tile the data is FRAGMENT-MAJOR: wave w (of PN_WAVES) owns rows w*TN/PN_WAVES .. and its MFMA A-operand
-// fragments follow each other, [row block of 32][k step of 16] -> 1 KiB each, lane l's 16 bytes = W[row0 + (l & 31)][k0 + 8 * (l >> 5) ..]
-// -- exactly what one global_load_dwordx4 per lane puts into the fragment registers.
+// fragments follow each other, [row block of 32][k step of 16] -> 1 KiB each, lane l's 16 bytes = W[row0 + f(l & 31)][k0 + 8 * (l >> 5) ..]
+// -- exactly what one global_load_dwordx4 per lane puts into the fragment registers.  f permutes the 32 features of a block over
+// the MFMA's rows, f(rho) = (rho & 3) + 4 (rho >> 3) + 16 ((rho >> 2) & 1): the 32x32 accumulator gives a lane rows
+// (r & 3) + 8 (r >> 2) + 4 (lane >> 5), i.e. with f its 16 registers are the 16 CONSECUTIVE features 16 (lane >> 5) + r of one
+// activation row (swapped orientation, D[feature][row]) -- two 16-byte runs without any cross-lane exchange.
 __global__ __launch_bounds__(256) void pack_tiles_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
                                                          const tan_pack_entry* __restrict__ table) {
     const tan_pack_entry e = table[blockIdx.y];
@@ -31,7 +34,8 @@ __global__ __launch_bounds__(256) void pack_tiles_kernel(const bf16_t* __restric
         for (int s = threadIdx.x; s < slots; s += blockDim.x) {
             const int lane = s & 63, frag = s >> 6;
             const int ks = frag % KS, rb = (frag / KS) % RB, w = frag / (KS * RB);
-            const int row = w * (e.TN / PN_WAVES) + rb * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5);
+            const int rho = lane & 31, f = (rho & 3) + 4 * (rho >> 3) + 16 * ((rho >> 2) & 1);
+            const int row = w * (e.TN / PN_WAVES) + rb * 32 + f, k = ks * 16 + 8 * (lane >> 5);
             *reinterpret_cast<uint4*>(d0 + (long)s * 8) = *reinterpret_cast<const uint4*>(s0 + (long)row * e.K + k);
         }
     }
@@ -66,7 +70,7 @@ struct MlpFwdArgs {
 constexpr int MLP_KDF = 32, MLP_KDP = 16, MLP_TILE = 16384, MLP_TF = 512 / MLP_KDF, MLP_TP = 256 / MLP_KDP;
 constexpr int MLP_D = 8;                 // weight prefetch distance in steps
 constexpr int MLP_XN_OFF = 0, MLP_H_OFF = 65536, MLP_PRE_OFF = 131072, MLP_LDS = 163840;   // input panel | hidden x2 | pre-activation
-static_assert(PN_WAVES == 4 || PN_WAVES == 8, "four waves (one per SIMD) or eight (two per SIMD)");
+static_assert(PN_WAVES == 8, "eight waves: two groups of four, one wave of each per SIMD");
 constexpr int MLP_NBH = 256 / (32 * PN_WAVES);      // 32-feature blocks of a hidden chunk per wave (2 | 1)
 constexpr int MLP_NBO = 512 / (32 * PN_WAVES);      // 32-feature blocks of the output per wave (4 | 2)
 constexpr int MLP_WFR = MLP_NBO;                    // weight fragments per step: c_fc NBH x 2 k steps = c_proj NBO
@@ -134,57 +138,50 @@ __device__ __forceinline__ void mlp_mma_proj(const MlpWFrags& W, const MlpXFrags
         for (int mb = 0; mb < 2; ++mb) acc_o[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], F.f[mb], acc_o[nb][mb], 0, 0, 0);
 }
 
-// Half-unit U (0..15) of the chunk epilogue: unit = U >> 1 = (feature block nb, row block mb, register half p), 8 values per lane;
-// half h = U & 1 finishes elements {2h, 2h+1, 4+2h, 5+2h} (two v_permlane32_swap), the second half stores the 16-byte runs.
-// The 16 bias values a unit needs (b_fc[c*256 + wave*64 + nb*32 + 16p ..]) are wave-uniform: they come through ONE scalar load
-// (s_load_dwordx16) issued a whole unit ahead into the other of two SGPR sets -- used straight after the load they cost an
-// s_waitcnt lgkmcnt(0) of a few hundred cycles per half-unit, 128 times per panel.
-struct MlpEpiState { uint32_t pre[4], act[4]; };
-struct MlpBias { float b[16]; };
-template <int UNIT>     // UNIT 0 .. MLP_HU/2 - 1 of chunk c; UNIT == MLP_HU/2: unit 0 of chunk c + 1
-__device__ __forceinline__ void mlp_bias_load(MlpBias& B, const float* b_fc, int c, int wave) {
-    constexpr int u = UNIT % (MLP_HU / 2), nb = u >> 2, p = u & 1;
-    const int cc = UNIT == MLP_HU / 2 ? min(c + 1, 7) : c;
-    pn_cfptr_t bp = (pn_cfptr_t)(uintptr_t)b_fc + cc * 256 + wave * (32 * MLP_NBH) + nb * 32 + 16 * p;
+// Chunk epilogue, dealt over the 16 steps of the c_proj phase: a lane owns, per row block mb, the 16 consecutive hidden features
+// 16 hi + r of row mb * 32 + (lane & 31) (packer's feature permutation); step J finishes registers 2 (J & 7), 2 (J & 7) + 1 of row
+// block J >> 3 -- one packed bf16 pair of the activation and one of the pre-activation -- and every fourth step stores the two
+// 16-byte runs (activation panel + pre-activation panel).  Three pieces per step, issued between the step's four MFMAs (in-order
+// issue: the wave's own MFMAs then execute under its VALU work, and the quarter-rate v_exp_f32 / v_rcp_f32 results are consumed one
+// MFMA later):  P1 scale, 2 x exp2;  P2 1 + e, 2 x rcp;  P3 x * r, two packs, stores.  The bias is NOT added here: the accumulator
+// of a chunk starts from it (mlp_init_h).
+struct MlpEpiState { float ce[2]; uint32_t pre[4], act[4]; };
+struct MlpBias32 { float b[32]; };       // b_fc[c * 256 + wave * 32 ..]: wave-uniform, through scalar loads
+__device__ __forceinline__ void mlp_bias32_load(MlpBias32& B, const float* b_fc, int c, int wave) {
+    pn_cfptr_t bp = (pn_cfptr_t)(uintptr_t)b_fc + c * 256 + wave * 32;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) B.b[e] = bp[e];
+    for (int e = 0; e < 32; ++e) B.b[e] = bp[e];
 }
-template <int U>
-__device__ __forceinline__ void mlp_epi_half(MlpEpiState& E, const MlpBias& B, const f32x16 (&acc_h)[MLP_NBH][2], const MlpFwdArgs& a, char* lds,
-                                             int c, int hb, long row0, int wave, int lane) {
-    constexpr int unit = U >> 1, h = U & 1, nb = unit >> 2, mb = (unit >> 1) & 1, p = unit & 1;
-    const int hi = lane >> 5;
-    const int nloc = wave * (32 * MLP_NBH) + nb * 32;                     // wave-uniform
-    float v[4];
+__device__ __forceinline__ void mlp_init_h(f32x16 (&acc_h)[MLP_NBH][2], const MlpBias32& B, int hi) {
+    static_assert(MLP_NBH == 1, "eight waves: one 32-feature block of the hidden chunk per wave");
 #pragma unroll
-    for (int x2 = 0; x2 < 2; ++x2) {
-        constexpr int dummy = 0; (void)dummy;
-        const int x = 2 * h + x2;
-        // explicit AGPR reads: left to itself the allocator moves the whole hidden accumulator into VGPRs for this VALU use
-        // (64 registers the weight ring needs) and spills the ring
-        int ra, rb;
-        if constexpr (PN_WAVES == 4) {
-            asm("v_accvgpr_read_b32 %0, %1" : "=v"(ra) : "a"(acc_h[nb][mb][8 * p + x]));
-            asm("v_accvgpr_read_b32 %0, %1" : "=v"(rb) : "a"(acc_h[nb][mb][8 * p + 4 + x]));
-        } else {
-            ra = __float_as_int(acc_h[nb][mb][8 * p + x]);
-            rb = __float_as_int(acc_h[nb][mb][8 * p + 4 + x]);
-        }
-        auto r = __builtin_amdgcn_permlane32_swap(ra, rb, false, false);
-        const float blo = hi ? B.b[8 + x] : B.b[x], bhi = hi ? B.b[12 + x] : B.b[4 + x];
-        v[x2] = __int_as_float(r[0]) + blo;               // element x
-        v[2 + x2] = __int_as_float(r[1]) + bhi;           // element 4 + x
+    for (int r = 0; r < 16; ++r) {
+        const float v = hi ? B.b[16 + r] : B.b[r];
+        acc_h[0][0][r] = v;
+        acc_h[0][1][r] = v;
     }
-    E.pre[h] = f2bf2(v[0], v[1]);
-    E.pre[2 + h] = f2bf2(v[2], v[3]);
-    E.act[h] = f2bf2(quick_gelu_fast(v[0]), quick_gelu_fast(v[1]));
-    E.act[2 + h] = f2bf2(quick_gelu_fast(v[2]), quick_gelu_fast(v[3]));
-    if constexpr (h == 1) {
-        const int ch = 2 * p + hi, m = mb * 32 + (lane & 31);
-        const uint4 ua = make_uint4(E.act[0], E.act[1], E.act[2], E.act[3]);
-        *reinterpret_cast<uint4*>(pn_panel_slot<512>(lds + MLP_H_OFF + hb * 32768, m, (nloc >> 3) + ch)) = ua;
-        // the pre-activation goes to its own LDS panel: both leave for HBM as whole rows after the chunk's barrier (body_end)
-        *reinterpret_cast<uint4*>(pn_panel_slot<512>(lds + MLP_PRE_OFF, m, (nloc >> 3) + ch)) = make_uint4(E.pre[0], E.pre[1], E.pre[2], E.pre[3]);
+}
+template <int J>
+__device__ __forceinline__ void mlp_epi_p1(MlpEpiState& E, const f32x16 (&acc_h)[MLP_NBH][2]) {
+    constexpr int mb = J >> 3, r = 2 * (J & 7);
+    E.ce[0] = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * acc_h[0][mb][r]);
+    E.ce[1] = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * acc_h[0][mb][r + 1]);
+}
+__device__ __forceinline__ void mlp_epi_p2(MlpEpiState& E) {
+    E.ce[0] = __builtin_amdgcn_rcpf(1.0f + E.ce[0]);
+    E.ce[1] = __builtin_amdgcn_rcpf(1.0f + E.ce[1]);
+}
+template <int J>
+__device__ __forceinline__ void mlp_epi_p3(MlpEpiState& E, const f32x16 (&acc_h)[MLP_NBH][2], char* lds, int hb, int wave, int lane) {
+    constexpr int mb = J >> 3, r = 2 * (J & 7), w = J & 3;
+    const float x0 = acc_h[0][mb][r], x1 = acc_h[0][mb][r + 1];
+    E.pre[w] = f2bf2(x0, x1);
+    E.act[w] = f2bf2(x0 * E.ce[0], x1 * E.ce[1]);       // QuickGELU: x * sigmoid(1.702 x)
+    if constexpr (w == 3) {
+        const int ch = (wave * 32 >> 3) + 2 * (lane >> 5) + ((J & 7) >> 2), m = mb * 32 + (lane & 31);
+        *reinterpret_cast<uint4*>(pn_panel_slot<512>(lds + MLP_H_OFF + hb * 32768, m, ch)) = make_uint4(E.act[0], E.act[1], E.act[2], E.act[3]);
+        // the pre-activation goes to its own LDS panel: both leave for HBM as whole half rows under the next phases (mlp_copy_step*)
+        *reinterpret_cast<uint4*>(pn_panel_slot<512>(lds + MLP_PRE_OFF, m, ch)) = make_uint4(E.pre[0], E.pre[1], E.pre[2], E.pre[3]);
     }
 }
 
@@ -311,8 +308,9 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
     f32x16 acc_h[MLP_NBH][2];      // [feature block of the wave's hidden features][row block]
     MlpXFrags FA, FB;        // activation fragments of the even / odd steps
     MlpEpiState ES;
-    MlpBias BA, BB;          // bias values of the even / odd epilogue units
-    mlp_bias_load<0>(BA, a.b_fc, 0, wave);
+    MlpBias32 B32;           // bias of the next chunk: loaded before a slot barrier, consumed right after it (mlp_init_h)
+    mlp_bias32_load(B32, a.b_fc, 0, wave);
+    static_assert(MLP_NBO == 2 && MLP_WFR == 2, "eight waves");
     MlpXAddr XA;
     mlp_xaddr_init(XA, lds, lane);
     MlpCopy CP;
@@ -345,48 +343,52 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-    auto proj_phase = [&](int c, auto has_proj, auto has_epi) __attribute__((always_inline)) {   // c_proj(c-1) MFMAs || epilogue(c) half-units
+    auto proj_phase = [&](int c, auto has_proj, auto has_epi) __attribute__((always_inline)) {   // c_proj(c-1) MFMAs || epilogue(c)
         constexpr bool PROJ = decltype(has_proj)::value, EPI = decltype(has_epi)::value;
+        constexpr bool ARITH = EPI && !(MODE & (8 | 32));
         const int hb = c & 1;
-        if constexpr (EPI) {        // MFMA result -> v_accvgpr_read inside asm: the hazard pad the compiler cannot see (c_fc's last MFMAs)
-            asm volatile("s_nop 15\n\ts_nop 15");
-        }
         pn_static_for<0, 16>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
             MlpXFrags& cur = (J & 1) ? FB : FA;
             MlpXFrags& nxt = (J & 1) ? FA : FB;
+            MlpWFrags& W = WQ[J % D];
             if constexpr (PROJ) {
                 if (!(MODE & 4)) {
                     if constexpr (J < 15) mlp_load_x_proj<J + 1>(nxt, XA, hb ^ 1);
                 }
-                if (!(MODE & 1)) mlp_mma_proj(WQ[J % D], cur, acc_o);
                 if constexpr (!EPI) {       // body(8): the side outputs of chunk 7 under c_proj(7)
                     if (!(MODE & (8 | 16))) mlp_copy_step8<J>(CP, lds, a, row0, 7);
                 } else {                    // the activation panel of chunk c-1 (c_proj(c-1) reads it too; rewritten in body c+1)
                     if (!(MODE & (8 | 16))) mlp_copy_step4<J, true, (MODE & 128) != 0>(CP, lds, a, row0, c - 1);
                 }
+            }
+            // c_proj: W.f[nb] = output features wave*64 + nb*32 .., one k step; the epilogue pieces sit between the MFMAs.  Neither
+            // the MFMAs nor the arithmetic have side effects, so sched_barrier alone does not keep them apart (instruction selection
+            // linearises pure nodes freely): empty asm statements tie each piece's results to the accumulator the NEXT MFMA
+            // continues (written four MFMAs ago: no hazard padding), which orders piece -> asm -> MFMA -> next piece.
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PROJ) { if (!(MODE & 1)) acc_o[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[0], cur.f[0], acc_o[0][0], 0, 0, 0); }
+            if constexpr (ARITH) {
+                mlp_epi_p1<J>(ES, acc_h);
+                asm volatile("" : "+v"(acc_o[0][1]), "+v"(ES.ce[0]), "+v"(ES.ce[1]));
+            }
+            if constexpr (PROJ) { if (!(MODE & 1)) acc_o[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[0], cur.f[1], acc_o[0][1], 0, 0, 0); }
+            if constexpr (ARITH) {
+                mlp_epi_p2(ES);
+                asm volatile("" : "+v"(acc_o[1][0]), "+v"(ES.ce[0]), "+v"(ES.ce[1]));
+            }
+            if constexpr (PROJ) { if (!(MODE & 1)) acc_o[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[1], cur.f[0], acc_o[1][0], 0, 0, 0); }
+            if constexpr (ARITH) {
+                mlp_epi_p3<J>(ES, acc_h, lds, hb, wave, lane);
+                asm volatile("" : "+v"(acc_o[1][1]), "+v"(ES.pre[J & 3]), "+v"(ES.act[J & 3]));
+            }
+            if constexpr (PROJ) {
+                if (!(MODE & 1)) acc_o[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[1], cur.f[1], acc_o[1][1], 0, 0, 0);
                 if (!(MODE & 2)) {  // c_proj(c-1) J+8, else the first half of the next body's first phase
-                    if constexpr (J + D < 16) mlp_load_w(WQ[J % D], ppj + (long)((c - 1) * 16 + J + D) * TILE, wave, lane);
+                    if constexpr (J + D < 16) mlp_load_w(W, ppj + (long)((c - 1) * 16 + J + D) * TILE, wave, lane);
                     else if constexpr (EPI)     // c <= 7: body(c+1) starts with c_fc(c+1), body(8) with c_proj(7)
-                        mlp_load_w(WQ[J % D], c < 7 ? pfc + (long)((c + 1) * 16 + J + D - 16) * TILE : ppj + (long)(7 * 16 + J + D - 16) * TILE,
+                        mlp_load_w(W, c < 7 ? pfc + (long)((c + 1) * 16 + J + D - 16) * TILE : ppj + (long)(7 * 16 + J + D - 16) * TILE,
                                    wave, lane);
-                }
-            }
-            if constexpr (EPI && J % MLP_HU_STRIDE == 0) {
-                constexpr int U = J / MLP_HU_STRIDE, unit = U >> 1;
-                MlpBias& bcur = (unit & 1) ? BB : BA;
-                MlpBias& bnxt = (unit & 1) ? BA : BB;
-                if constexpr ((U & 1) == 0) mlp_bias_load<unit + 1>(bnxt, a.b_fc, c, wave);     // a whole unit ahead
-                if (!(MODE & (8 | 32))) mlp_epi_half<U>(ES, bcur, acc_h, a, lds, c, hb, row0, wave, lane);
-            }
-            if constexpr (PROJ && EPI) {
-                // in-order issue: the step's four MFMAs followed by its ~46 VALU instructions overlap nothing inside the wave (the
-                // matrix pipe runs one MFMA per 32 cycles, the wave sits at the next MFMA's issue); deal the epilogue half-unit
-                // into the gaps so that the wave's own MFMAs execute under its VALU work
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x406, 12, 0);       // 12 VALU / SALU / transcendental
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -418,31 +420,27 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    auto zero_h = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < MLP_NBH; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc_zero(acc_h[i][j]);
-    };
     const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
     tick();
     if (grp) slot_barrier();
     // body(0) and body(8) are peeled as straight-line code around the loop: as if / else arms INSIDE the loop every extra variant of
     // a phase cost ~300 spilled registers at the joins
-    zero_h();
+    mlp_init_h(acc_h, B32, hi);
     tick(); fc_phase(0, F_{}); tick();
     slot_barrier();
     tick(); proj_phase(0, F_{}, T_{}); tick();
+    mlp_bias32_load(B32, a.b_fc, 1, wave);
     slot_barrier();
     mlp_load_x_fc<0>(FA, XA);
     __builtin_amdgcn_sched_barrier(0);
     for (int c = 1; c < 8; ++c) {
-        zero_h();
+        mlp_init_h(acc_h, B32, hi);
         tick(); fc_phase(c, T_{}); tick();
         slot_barrier();
         mlp_load_x_proj<0>(FA, XA, (c & 1) ^ 1);                    // c_proj(c-1) reads hidden panel (c-1) & 1
         __builtin_amdgcn_sched_barrier(0);
         tick(); proj_phase(c, T_{}, T_{}); tick();
+        mlp_bias32_load(B32, a.b_fc, min(c + 1, 7), wave);
         slot_barrier();
         if (c < 7) mlp_load_x_fc<0>(FA, XA);                        // fragments of the next body's first step
         __builtin_amdgcn_sched_barrier(0);
@@ -477,21 +475,19 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int p = 0; p < 2; ++p)
-                resq[mb][p] = *reinterpret_cast<const uint4*>(a.x_mid + (row0 + mb * 32 + (lane & 31)) * 512 + nbase + (2 * p + hi) * 8);
+                resq[mb][p] = *reinterpret_cast<const uint4*>(a.x_mid + (row0 + mb * 32 + (lane & 31)) * 512 + nbase + (2 * hi + p) * 8);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
-            float o[2][8];
-            pn_rows_from_acc(acc_o[nb][mb], o);
-            const int m = mb * 32 + (lane & 31);
+            const int m = mb * 32 + (lane & 31);       // the lane's registers: features nbase + 16 hi + r of row m
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const int ch = 2 * p + hi;
+                const int ch = 2 * hi + p;
                 float bias[8], res[8];
-                pn_uniform8(bp + 16 * p, bp + 16 * p + 8, hi, bias);
+                pn_uniform8(bp + 8 * p, bp + 16 + 8 * p, hi, bias);
                 pn_unpack8(resq[mb][p], res);
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = o[p][e] + bias[e] + res[e];
+                for (int e = 0; e < 8; ++e) v[e] = acc_o[nb][mb][8 * p + e] + bias[e] + res[e];
                 const uint4 u = pn_pack8(v);
                 *reinterpret_cast<uint4*>(pn_panel_slot<1024>(xo_panel, m, (nbase >> 3) + ch)) = u;
                 pn_unpack8(u, xr[nb][mb][p]);
@@ -541,18 +537,18 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
         for (int nb = 0; nb < MLP_NBO; ++nb)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const int nu = wave * (32 * MLP_NBO) + nb * 32 + 16 * p;         // wave-uniform: gamma / beta come through scalar loads
+                const int nu = wave * (32 * MLP_NBO) + nb * 32 + 8 * p;          // wave-uniform: gamma / beta come through scalar loads
                 pn_cfptr_t gp = (pn_cfptr_t)(uintptr_t)(a.nln_g) + nu;
                 pn_cfptr_t bp = (pn_cfptr_t)(uintptr_t)(a.nln_b) + nu;
                 float g[8], b[8];
-                pn_uniform8(gp, gp + 8, hi, g);
-                pn_uniform8(bp, bp + 8, hi, b);
+                pn_uniform8(gp, gp + 16, hi, g);
+                pn_uniform8(bp, bp + 16, hi, b);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
                     float y[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) y[e] = xr[nb][mb][p][e] * rstd[mb] * g[e] + b[e];
-                    *reinterpret_cast<uint4*>(pn_panel_slot<1024>(xn_panel, mb * 32 + (lane & 31), (nu >> 3) + hi)) = pn_pack8(y);
+                    *reinterpret_cast<uint4*>(pn_panel_slot<1024>(xn_panel, mb * 32 + (lane & 31), (nu >> 3) + 2 * hi)) = pn_pack8(y);
                 }
             }
         __syncthreads();

@@ -47,7 +47,8 @@ def test_pack_weights_is_a_permutation_with_the_documented_fragment_layout():
         KS, RB = TK // 16, TN // (32 * W)
         tiles = p.view(N // TN, K // TK, W, RB, KS, 64, 8)          # [n-block][k-block][wave][row block][k step][lane][8]
         nb, kb, wv, rb, ks, lane = 0, (K // TK) - 1, W - 1, RB - 1, KS - 1, 45
-        row = nb * TN + wv * (TN // W) + rb * 32 + (lane & 31)
+        rho = lane & 31                                              # MFMA row -> feature of the 32-row block (see tan_panel.hip)
+        row = nb * TN + wv * (TN // W) + rb * 32 + (rho & 3) + 4 * (rho >> 3) + 16 * ((rho >> 2) & 1)
         k = kb * TK + ks * 16 + 8 * (lane >> 5)
         assert torch.equal(tiles[nb, kb, wv, rb, ks, lane], w[row, k:k + 8])
 

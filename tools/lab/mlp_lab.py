@@ -191,6 +191,37 @@ if __name__ == "__main__":
             t_touch = timeit(g_touch_only, reps=48)
             t_both = timeit(g_both, reps=48)
             print(f"R={R} cold + weights touched first: touch {t_touch:6.1f} us, touch + fused v0 {t_both:6.1f} us -> fused alone ~{t_both - t_touch:6.1f} us", flush=True)
+        if os.environ.get("LAB_E4"):
+            # the UNFUSED quartet: which coldness costs its 20 us (weights: 4 MB, activations / outputs: ~150 MB)?
+            def mixu(i, what):
+                t = dict(ts[0])
+                src = ts[i % 6]
+                keys = ("wfc", "wpj") if what == "w" else [k for k in src if k not in ("pw", "wfc", "wpj", "R")]
+                for k in keys:
+                    t[k] = src[k]
+                return t
+            for what in ("w", "o"):
+                mixed = [mixu(i, what) for i in range(6)]
+                it5 = [0]
+
+                def gu():
+                    run_unfused(mixed[it5[0] % 6]); it5[0] += 1
+                tf = timeit(gu, reps=48)
+                print(f"R={R} cold-{what} only: unfused                  {tf:7.1f} us", flush=True)
+            for nm, (M_, N_, K_) in {"fc": (R, 2048, 512), "proj": (R, 512, 2048)}.items():
+                for what in ("warm", "w", "o", "all"):
+                    it6 = [0]
+
+                    def gg():
+                        i = it6[0] % 6; it6[0] += 1
+                        tw = ts[i if what in ("w", "all") else 0]
+                        to = ts[i if what in ("o", "all") else 0]
+                        if nm == "fc":
+                            ops.gemm(to["u_xn2"], tw["wfc"], to["u_hact"], M=R, N=2048, K=512, bias=tw["bfc"], act=ops.ACT_QUICKGELU, aux=to["u_hpre"])
+                        else:
+                            ops.gemm(to["u_hact"], tw["wpj"], to["u_xout"], M=R, N=512, K=2048, bias=tw["bpj"], residual=to["x_mid"])
+                    tf = timeit(gg, reps=48)
+                    print(f"R={R} gemm {nm:4s} cold={what:4s}  {tf:7.1f} us", flush=True)
         if os.environ.get("LAB_E2"):
             # which coldness matters: (a) cycling weights only, (b) cycling activations / outputs only
             def mix(i, what):
