@@ -336,6 +336,26 @@ typedef struct tan_mlp_desc {
 } tan_mlp_desc;
 int tan_mlp_fwd(const tan_mlp_desc* d, void* stream);
 
+/* Backward of the same branch in ONE launch (replaces, in tan_encoder_bwd: the c_proj dX GEMM with its quickgelu' epilogue and
+ * bias column sums, the c_fc dX GEMM, and the ln_2 backward kernel; reference: autograd of model/tfm_model.py:23-27,37,44):
+ *   dh  = (dx W_proj) o quickgelu'(h_pre)                  -> dh [rows, FF] bf16 (operand of the c_fc weight gradient)
+ *   dx2 = dx + LayerNorm-backward(dh W_fc; x_mid, mean2, rstd2, ln_g)      -> dx2 [rows, C] bf16
+ *   g_b_fc += colsum(dh), g_ln_g += colsum(dxn o xhat), g_ln_b += colsum(dxn), g_b_out += colsum(dx2)     (f32 atomics)
+ * pwt_proj = tan_pack_weights image of W_proj^T [2048][512] (TN=256,TK=32), pwt_fc = of W_fc^T [512][2048] (TN=512,TK=16).
+ * rows % 64 == 0, C = 512, FF = 2048, bf16 only.                                                                             */
+typedef struct tan_mlp_bwd_desc {
+    long rows; int C, FF;
+    const void* dx;                          /* [rows, C] gradient w.r.t. the block's output (also the residual gradient) */
+    const void* h_pre;                       /* [rows, FF] pre-activation saved by the forward */
+    const void* x_mid;                       /* [rows, C] the branch's input (ln_2 input) */
+    const float *mean2, *rstd2, *ln_g;
+    const void *pwt_proj, *pwt_fc;
+    void* dh;                                /* out [rows, FF] */
+    void* dx2;                               /* out [rows, C] */
+    float *g_b_fc, *g_ln_g, *g_ln_b, *g_b_out;   /* accumulated */
+} tan_mlp_bwd_desc;
+int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,6 +126,17 @@ class MlpDesc(C.Structure):
     ]
 
 
+class MlpBwdDesc(C.Structure):
+    _fields_ = [
+        ("rows", C.c_long), ("C", C.c_int), ("FF", C.c_int),
+        ("dx", C.c_void_p), ("h_pre", C.c_void_p), ("x_mid", C.c_void_p),
+        ("mean2", C.c_void_p), ("rstd2", C.c_void_p), ("ln_g", C.c_void_p),
+        ("pwt_proj", C.c_void_p), ("pwt_fc", C.c_void_p),
+        ("dh", C.c_void_p), ("dx2", C.c_void_p),
+        ("g_b_fc", C.c_void_p), ("g_ln_g", C.c_void_p), ("g_ln_b", C.c_void_p), ("g_b_out", C.c_void_p),
+    ]
+
+
 class EncoderDesc(C.Structure):
     _fields_ = [
         ("dtype", C.c_int), ("B", C.c_int), ("L", C.c_int), ("C", C.c_int), ("H", C.c_int), ("layers", C.c_int),

@@ -140,6 +140,10 @@ extern "C" int tan_linear_wgrad(const void* dy, const void* x, float* gw, long M
 // consumes the block's output (the next block's ln_1, or the stack's post-LN) -- is ONE launch (TAN_PANEL=0: the four launches
 // it replaces).  Stand-alone 74 vs 77 us at 8192 rows and 69 vs 87 us at 10240; the two stacks side by side 122 vs 147 us; inside the
 // training step 6.24 / 6.31 vs 6.31 / 6.42 ms (two interleaved rounds on one box).  DESIGN.md section 3.5 has the ablations.
+static int panel_bwd_enabled() {
+    static const int v = [] { const char* e = getenv("TAN_PANEL_BWD"); return e ? atoi(e) : 1; }();
+    return v;
+}
 static int panel_enabled() {
     static const int on = [] { const char* e = getenv("TAN_PANEL"); return e ? atoi(e) : 1; }();
     return on;
@@ -219,11 +223,24 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         // ---- MLP branch: x_out = x_mid + c_proj(quickgelu(c_fc(LN2(x_mid))))
         const bool grouped = grouped_enabled() != 0;       // the four dW GEMMs after the dX chain, in one launch
         if (!grouped) CK(linear_bwd_w(dt, dx, b.h_act, p.g_w_proj, R, C, 4 * C, e->dw_ws, e->dw_ws_floats, st));
-        CK(linear_bwd_x(dt, dx, p.w_proj, p.wt_proj, e->scr_dh, R, C, 4 * C, TAN_ACT_QUICKGELU_GRAD, b.h_pre, nullptr, p.g_b_fc, st));
-        if (!grouped) CK(linear_bwd_w(dt, e->scr_dh, b.xn2, p.g_w_fc, R, 4 * C, C, e->dw_ws, e->dw_ws_floats, st));
-        CK(linear_bwd_x(dt, e->scr_dh, p.w_fc, p.wt_fc, e->scr_dxn, R, 4 * C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
-        CK(tan_layernorm_bwd(e->scr_dxn, b.x_mid, p.ln2_g, b.mean2, b.rstd2, dx, dx2, p.g_ln2_g, p.g_ln2_b, p.g_b_out, e->ln_ws, R, C,
-                             dt, st));
+        if (panel_bwd_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0 && p.wtp_fc && p.wtp_proj) {
+            // one launch: dh = (dx W_proj) o quickgelu'(h_pre), dxn = dh W_fc, LN2 backward + residual -> dx2, four parameter
+            // gradients that are column sums (tan_panel.hip)
+            tan_mlp_bwd_desc m{};
+            m.rows = R; m.C = C; m.FF = 4 * C;
+            m.dx = dx; m.h_pre = b.h_pre; m.x_mid = b.x_mid; m.mean2 = b.mean2; m.rstd2 = b.rstd2; m.ln_g = p.ln2_g;
+            m.pwt_proj = p.wtp_proj; m.pwt_fc = p.wtp_fc;
+            m.dh = e->scr_dh; m.dx2 = dx2;
+            m.g_b_fc = p.g_b_fc; m.g_ln_g = p.g_ln2_g; m.g_ln_b = p.g_ln2_b; m.g_b_out = p.g_b_out;
+            CK(tan_mlp_bwd(&m, st));
+            if (!grouped) CK(linear_bwd_w(dt, e->scr_dh, b.xn2, p.g_w_fc, R, 4 * C, C, e->dw_ws, e->dw_ws_floats, st));
+        } else {
+            CK(linear_bwd_x(dt, dx, p.w_proj, p.wt_proj, e->scr_dh, R, C, 4 * C, TAN_ACT_QUICKGELU_GRAD, b.h_pre, nullptr, p.g_b_fc, st));
+            if (!grouped) CK(linear_bwd_w(dt, e->scr_dh, b.xn2, p.g_w_fc, R, 4 * C, C, e->dw_ws, e->dw_ws_floats, st));
+            CK(linear_bwd_x(dt, e->scr_dh, p.w_fc, p.wt_fc, e->scr_dxn, R, 4 * C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
+            CK(tan_layernorm_bwd(e->scr_dxn, b.x_mid, p.ln2_g, b.mean2, b.rstd2, dx, dx2, p.g_ln2_g, p.g_ln2_b, p.g_b_out, e->ln_ws, R, C,
+                                 dt, st));
+        }
         // ---- attention branch: x_mid = x_in + out_proj(attn(LN1(x_in)))
         if (!grouped) CK(linear_bwd_w(dt, dx2, b.attn_o, p.g_w_out, R, C, C, e->dw_ws, e->dw_ws_floats, st));
         CK(linear_bwd_x(dt, dx2, p.w_out, p.wt_out, e->scr_do, R, C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));

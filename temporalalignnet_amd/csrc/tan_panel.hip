@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void pack_tiles_kernel(const bf16_t* __restric
 
 // ------------------------------------------------------------------------------------------------------------------
 struct MlpFwdArgs {
+    static constexpr bool bwd = false;
     const bf16_t* x_mid; const float* ln_g; const float* ln_b;
     const char* pw_fc; const char* pw_proj;
     const float* b_fc; const float* b_proj;
@@ -50,6 +51,22 @@ struct MlpFwdArgs {
     bf16_t* h_pre; bf16_t* h_act; bf16_t* x_out;
     const float* nln_g; const float* nln_b; bf16_t* xn_next; float* nmean; float* nrstd;
     float eps;
+};
+// Backward of the same branch, same schedule with the roles of the two weights exchanged (tan_mlp_bwd):
+//   dh_c = (dx W_proj[:, c]) o quickgelu'(h_pre_c)      "c_fc-like": K = 512 over the resident dx panel, packed W_proj^T tiles
+//   dxn += dh_c W_fc[c, :]                             "c_proj-like": K = 256 per chunk, packed W_fc^T tiles
+//   dx2 = dx + LN2-backward(dxn; x_mid, mean2, rstd2, gamma)
+// dh leaves as the side output (operand of the c_fc weight gradient); the four bias / LayerNorm parameter gradients are column
+// sums over the panel's rows, added to the f32 gradients with atomics.
+struct MlpBwdArgs {
+    static constexpr bool bwd = true;
+    const bf16_t* dx; const bf16_t* h_pre; const bf16_t* x_mid;
+    const float* mean2; const float* rstd2; const float* ln_g;
+    const char* pw_fc;          // packed W_proj^T [2048][512]  (tiles [256][32])
+    const char* pw_proj;        // packed W_fc^T   [512][2048]  (tiles [512][16])
+    bf16_t* h_act;              // dh out [rows][2048] (the "activation" side output of the shared schedule)
+    bf16_t* dx2;
+    float* g_b_fc; float* g_ln_g; float* g_ln_b; float* g_b_out;
 };
 
 // Tiles are 16 KiB: c_fc [256 features][32 k], c_proj [512 features][16 k].  A weight fragment is consumed by exactly ONE wave
@@ -68,7 +85,10 @@ struct MlpFwdArgs {
 // LDS and re-loads the ring slot it just consumed.  One barrier per body hands hidden chunk c over (written by all waves, read
 // by all waves in body(c+1)); the two hidden-panel buffers alternate.
 constexpr int MLP_KDF = 32, MLP_KDP = 16, MLP_TILE = 16384, MLP_TF = 512 / MLP_KDF, MLP_TP = 256 / MLP_KDP;
-constexpr int MLP_D = 8;                 // weight prefetch distance in steps
+#ifndef TAN_MLP_D
+#define TAN_MLP_D 4
+#endif
+constexpr int MLP_D = TAN_MLP_D;                 // weight prefetch distance in steps (4: as fast as 8 once the weights are requested up front, 32 registers less)
 constexpr int MLP_XN_OFF = 0, MLP_H_OFF = 65536, MLP_PRE_OFF = 131072, MLP_LDS = 163840;   // input panel | hidden x2 | pre-activation
 static_assert(PN_WAVES == 8, "eight waves: two groups of four, one wave of each per SIMD");
 constexpr int MLP_NBH = 256 / (32 * PN_WAVES);      // 32-feature blocks of a hidden chunk per wave (2 | 1)
@@ -185,6 +205,61 @@ __device__ __forceinline__ void mlp_epi_p3(MlpEpiState& E, const f32x16 (&acc_h)
     }
 }
 
+// ---- backward chunk epilogue: dh = acc o quickgelu'(h_pre), step J = row block J & 1, register pair q = J >> 1 (both row blocks of
+// a feature pair in adjacent steps: their sum is the lane's share of the c_fc bias gradient).  The pre-activations come straight
+// from HBM in the accumulator's layout (16 consecutive features of a row = two 16-byte loads per row block), issued under the
+// c_fc-like phase of the same chunk.
+struct MlpHPre { uint4 q[2][2]; };       // [row block][8-feature half]
+struct MlpBwdEpi { float x[2], ce[2], cs[2], colacc; uint32_t w[2][4]; };
+template <int MB, int HALF>
+__device__ __forceinline__ void mlp_hpre_load(MlpHPre& H, const bf16_t* h_pre, long row0, int c, int wave, int lane) {
+    H.q[MB][HALF] = *reinterpret_cast<const uint4*>(h_pre + (row0 + MB * 32 + (lane & 31)) * 2048 + c * 256 + wave * 32 + 16 * (lane >> 5) + 8 * HALF);
+}
+__device__ __forceinline__ float pn_half32_sum(float v) {      // sum over the 32 lanes that share lane >> 5, in every one of them
+    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);     // row_half_mirror
+    v += dpp_move<0x140>(v);     // row_mirror
+    auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+    return __int_as_float(r16[0]) + __int_as_float(r16[1]);
+}
+template <int J>
+__device__ __forceinline__ void mlp_bepi_p1(MlpBwdEpi& E, const MlpHPre& H) {
+    constexpr int mb = J & 1, q = J >> 1;
+    const uint4 u = H.q[mb][q >> 2];
+    const uint32_t wd = (q & 3) == 0 ? u.x : (q & 3) == 1 ? u.y : (q & 3) == 2 ? u.z : u.w;
+    E.x[0] = __uint_as_float(wd << 16);
+    E.x[1] = __uint_as_float(wd & 0xffff0000u);
+    E.ce[0] = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * E.x[0]);
+    E.ce[1] = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * E.x[1]);
+}
+__device__ __forceinline__ void mlp_bepi_p2(MlpBwdEpi& E) {
+    E.ce[0] = __builtin_amdgcn_rcpf(1.0f + E.ce[0]);       // s = sigmoid(1.702 x)
+    E.ce[1] = __builtin_amdgcn_rcpf(1.0f + E.ce[1]);
+}
+template <int J>
+__device__ __forceinline__ void mlp_bepi_p3(MlpBwdEpi& E, const f32x16 (&acc_h)[MLP_NBH][2], char* lds, int hb, int wave, int lane) {
+    constexpr int mb = J & 1, q = J >> 1;
+    float d[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float sg = E.ce[i], t = 1.702f * E.x[i] * sg;
+        d[i] = acc_h[0][mb][2 * q + i] * fmaf(t, 1.0f - sg, sg);      // quickgelu'(x) = s + 1.702 x s (1 - s)
+    }
+    E.w[mb][q & 3] = f2bf2(d[0], d[1]);
+    if constexpr (mb == 0) {
+        E.cs[0] = d[0]; E.cs[1] = d[1];
+    } else {
+        const float r0 = pn_half32_sum(E.cs[0] + d[0]), r1 = pn_half32_sum(E.cs[1] + d[1]);
+        // lane (l & 31) = f keeps the total of the wave's feature 16 hi + f: one atomic per chunk (mlp_bwd flush), no branch here
+        E.colacc = (lane & 31) == 2 * q ? r0 : ((lane & 31) == 2 * q + 1 ? r1 : E.colacc);
+    }
+    if constexpr ((q & 3) == 3) {
+        const int ch = (wave * 32 >> 3) + 2 * (lane >> 5) + (q >> 2), m = mb * 32 + (lane & 31);
+        *reinterpret_cast<uint4*>(pn_panel_slot<512>(lds + MLP_H_OFF + hb * 32768, m, ch)) = make_uint4(E.w[mb][0], E.w[mb][1], E.w[mb][2], E.w[mb][3]);
+    }
+}
+
 // The side outputs (pre-activation and activation chunk, the operands of backward) leave for HBM ONE row-instruction at a time,
 // spread over BOTH phases of the body that follows the chunk's barrier: the four row-instructions of the pre-activation panel under
 // c_fc(c+1) (the panel is rewritten by the next epilogue), the four of the activation panel under c_proj(c) || epilogue(c+1).  As a burst between two barriers (the first version)
@@ -202,39 +277,41 @@ __device__ __forceinline__ void mlp_copy_init(MlpCopy& C, int wave, int lane) {
 // step J of a 16-step phase moving the group's half of ONE panel (ACT: activation panel of chunk cprev, else the pre-activation
 // panel): row-instruction i = J / 4 is read from LDS at J = 4 i and stored at J = 4 i + 1
 template <int J, bool ACT, bool CM = false>
-__device__ __forceinline__ void mlp_copy_step4(MlpCopy& C, const char* lds, const MlpFwdArgs& a, long row0, int cprev) {
+__device__ __forceinline__ void mlp_copy_step4(MlpCopy& C, const char* lds, bf16_t* dst, long row0, int cprev) {
     constexpr int i = J >> 2;
     if constexpr ((J & 3) == 0) {
         const char* panel = ACT ? lds + MLP_H_OFF + (cprev & 1) * 32768 : lds + MLP_PRE_OFF;
         C.v = *reinterpret_cast<const uint4*>(panel + ((C.lds0 ^ (i << 6)) + i * 2048));      // row & 15 gains 4 i: no carry
     } else if constexpr ((J & 3) == 1) {
         if constexpr (CM) {    // lab experiment: chunk-major side outputs [chunk][row][256] (a panel's chunk = 32 KiB contiguous)
-            bf16_t* base = (ACT ? a.h_act : a.h_pre) + (long)cprev * gridDim.x * (64 * 256) + row0 * 256;
+            bf16_t* base = dst + (long)cprev * gridDim.x * (64 * 256) + row0 * 256;
             *reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + (C.voff >> 12) * 512 + (C.voff & 511) + i * 2048) = C.v;
         } else {
-            bf16_t* base = (ACT ? a.h_act : a.h_pre) + row0 * 2048 + cprev * 256;                 // wave-uniform
+            bf16_t* base = dst + row0 * 2048 + cprev * 256;                 // wave-uniform
             *reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + C.voff + i * 16384) = C.v;
         }
     }
 }
 // both panels in one 16-step phase (the last one): pair q = J / 2
 template <int J>
-__device__ __forceinline__ void mlp_copy_step8(MlpCopy& C, const char* lds, const MlpFwdArgs& a, long row0, int cprev) {
+__device__ __forceinline__ void mlp_copy_step8(MlpCopy& C, const char* lds, bf16_t* dst_pre, bf16_t* dst_act, long row0, int cprev) {
     constexpr int q = J >> 1, i = q & 3;
     if constexpr ((J & 1) == 0) {
         const char* panel = q < 4 ? lds + MLP_PRE_OFF : lds + MLP_H_OFF + (cprev & 1) * 32768;
         C.v = *reinterpret_cast<const uint4*>(panel + ((C.lds0 ^ (i << 6)) + i * 2048));
     } else {
-        bf16_t* base = (q < 4 ? a.h_pre : a.h_act) + row0 * 2048 + cprev * 256;
+        bf16_t* base = (q < 4 ? dst_pre : dst_act) + row0 * 2048 + cprev * 256;
         *reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + C.voff + i * 16384) = C.v;
     }
 }
 
 // MODE 0: the kernel.  Timing experiments of tools/lab/mlp_lab.py (results undefined), bit mask: 1 no MFMAs, 2 no weight
-// streaming (loaded once), 4 no activation-fragment reads in the loop, 8 no chunk-epilogue arithmetic / stores, 16 no side-output copy-out (arithmetic, LDS panel
-// writes and both barriers stay), 32 no chunk-epilogue arithmetic (copy-out stays)
-template <int MODE>
-__global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_kernel(MlpFwdArgs a) {
+// streaming (loaded once), 4 no activation-fragment reads in the loop, 16 no side-output copy-out (arithmetic, LDS panel writes and barriers stay), 64 phase clocks
+// into nrstd[], 256 no up-front touch of the weights.  (Variants that drop the epilogue arithmetic also drop the c_fc MFMAs -- dead code --
+// and measure nothing useful: removed.)
+template <int MODE, typename ArgsT>
+__global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(ArgsT a) {
+    constexpr bool BWD = ArgsT::bwd;
     constexpr int TILE = MLP_TILE, D = MLP_D;
     constexpr int XN_OFF = MLP_XN_OFF, H_OFF = MLP_H_OFF;
     __shared__ __attribute__((aligned(1024))) char lds[MLP_LDS];
@@ -268,7 +345,16 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
         mlp_load_w(WQ[J], pfc + (long)J * TILE, wave, lane);
     });
 
-    // ---- prologue: LN2 of the panel, 64 / PN_WAVES rows per wave (batches of 8), one 16-byte chunk per lane ------------
+    // ---- prologue.  Forward: LN2 of the panel, 64 / PN_WAVES rows per wave (batches of 8), one 16-byte chunk per lane.  Backward:
+    // the dx panel as it is.
+    if constexpr (BWD) {
+        constexpr int RPW = PN_ROWS / PN_WAVES;
+        uint4 v[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) v[r] = *reinterpret_cast<const uint4*>(a.dx + (row0 + wave * RPW + r) * 512 + lane * 8);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) *reinterpret_cast<uint4*>(pn_panel_slot<1024>(lds + XN_OFF, wave * RPW + r, lane)) = v[r];
+    } else
     {
         constexpr int RPW = PN_ROWS / PN_WAVES;
         const f8 g = ld8f(a.ln_g + lane * 8), b = ld8f(a.ln_b + lane * 8);
@@ -309,7 +395,10 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
     MlpXFrags FA, FB;        // activation fragments of the even / odd steps
     MlpEpiState ES;
     MlpBias32 B32;           // bias of the next chunk: loaded before a slot barrier, consumed right after it (mlp_init_h)
-    mlp_bias32_load(B32, a.b_fc, 0, wave);
+    MlpHPre HP;              // backward: pre-activations of the chunk in the accumulator layout
+    MlpBwdEpi BE;
+    if constexpr (BWD) BE.colacc = 0.f;
+    else mlp_bias32_load(B32, a.b_fc, 0, wave);
     static_assert(MLP_NBO == 2 && MLP_WFR == 2, "eight waves");
     MlpXAddr XA;
     mlp_xaddr_init(XA, lds, lane);
@@ -331,8 +420,13 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
                 if constexpr (J < 15) mlp_load_x_fc<J + 1>(nxt, XA);     // (the next phase's first fragments: after the slot barrier)
             }
             if (!(MODE & 1)) mlp_mma_fc(WQ[J % D], cur, acc_h);
-            if constexpr (COPY) {
-                if (!(MODE & (8 | 16))) mlp_copy_step4<J, false, (MODE & 128) != 0>(CP, lds, a, row0, c - 1);
+            if constexpr (BWD) {        // pre-activations of THIS chunk, consumed by the epilogue a phase later
+                if constexpr (J == 2) mlp_hpre_load<0, 0>(HP, a.h_pre, row0, c, wave, lane);
+                if constexpr (J == 6) mlp_hpre_load<1, 0>(HP, a.h_pre, row0, c, wave, lane);
+                if constexpr (J == 10) mlp_hpre_load<0, 1>(HP, a.h_pre, row0, c, wave, lane);
+                if constexpr (J == 14) mlp_hpre_load<1, 1>(HP, a.h_pre, row0, c, wave, lane);
+            } else if constexpr (COPY) {
+                if (!(MODE & (8 | 16))) mlp_copy_step4<J, false, (MODE & 128) != 0>(CP, lds, a.h_pre, row0, c - 1);
             }
             if (!(MODE & 2)) {      // the tile eight steps on: c_fc(c) J+8, else the first half of the next phase that streams
                 const char* src = J + D < 16 ? pfc + (long)(c * 16 + J + D) * TILE
@@ -356,10 +450,10 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
                 if (!(MODE & 4)) {
                     if constexpr (J < 15) mlp_load_x_proj<J + 1>(nxt, XA, hb ^ 1);
                 }
-                if constexpr (!EPI) {       // body(8): the side outputs of chunk 7 under c_proj(7)
-                    if (!(MODE & (8 | 16))) mlp_copy_step8<J>(CP, lds, a, row0, 7);
+                if constexpr (!EPI && !BWD) {       // body(8): the side outputs of chunk 7 under c_proj(7)
+                    if (!(MODE & (8 | 16))) mlp_copy_step8<J>(CP, lds, a.h_pre, a.h_act, row0, 7);
                 } else {                    // the activation panel of chunk c-1 (c_proj(c-1) reads it too; rewritten in body c+1)
-                    if (!(MODE & (8 | 16))) mlp_copy_step4<J, true, (MODE & 128) != 0>(CP, lds, a, row0, c - 1);
+                    if (!(MODE & (8 | 16))) mlp_copy_step4<J, true, (MODE & 128) != 0>(CP, lds, a.h_act, row0, c - 1);
                 }
             }
             // c_proj: W.f[nb] = output features wave*64 + nb*32 .., one k step; the epilogue pieces sit between the MFMAs.  Neither
@@ -368,17 +462,26 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
             // continues (written four MFMAs ago: no hazard padding), which orders piece -> asm -> MFMA -> next piece.
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (PROJ) { if (!(MODE & 1)) acc_o[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[0], cur.f[0], acc_o[0][0], 0, 0, 0); }
-            if constexpr (ARITH) {
+            if constexpr (ARITH && BWD) {
+                mlp_bepi_p1<J>(BE, HP);
+                asm volatile("" : "+v"(acc_o[0][1]), "+v"(BE.ce[0]), "+v"(BE.ce[1]));
+            } else if constexpr (ARITH) {
                 mlp_epi_p1<J>(ES, acc_h);
                 asm volatile("" : "+v"(acc_o[0][1]), "+v"(ES.ce[0]), "+v"(ES.ce[1]));
             }
             if constexpr (PROJ) { if (!(MODE & 1)) acc_o[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[0], cur.f[1], acc_o[0][1], 0, 0, 0); }
-            if constexpr (ARITH) {
+            if constexpr (ARITH && BWD) {
+                mlp_bepi_p2(BE);
+                asm volatile("" : "+v"(acc_o[1][0]), "+v"(BE.ce[0]), "+v"(BE.ce[1]));
+            } else if constexpr (ARITH) {
                 mlp_epi_p2(ES);
                 asm volatile("" : "+v"(acc_o[1][0]), "+v"(ES.ce[0]), "+v"(ES.ce[1]));
             }
             if constexpr (PROJ) { if (!(MODE & 1)) acc_o[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[1], cur.f[0], acc_o[1][0], 0, 0, 0); }
-            if constexpr (ARITH) {
+            if constexpr (ARITH && BWD) {
+                mlp_bepi_p3<J>(BE, acc_h, lds, hb, wave, lane);
+                asm volatile("" : "+v"(acc_o[1][1]), "+v"(BE.w[J & 1][(J >> 1) & 3]), "+v"(BE.colacc));
+            } else if constexpr (ARITH) {
                 mlp_epi_p3<J>(ES, acc_h, lds, hb, wave, lane);
                 asm volatile("" : "+v"(acc_o[1][1]), "+v"(ES.pre[J & 3]), "+v"(ES.act[J & 3]));
             }
@@ -409,7 +512,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
     // lab instrumentation (MODE & 64, xn_next == null): workgroup 0 records the shader clock at phase boundaries into nrstd[]
     int tick_i = 0;
     auto tick = [&]() __attribute__((always_inline)) {
-        if (MODE & 64) {
+        if constexpr ((MODE & 64) != 0 && !BWD) {
             const long long t = __builtin_readcyclecounter();
             if (blockIdx.x == 0 && lane == 0) reinterpret_cast<long long*>(a.nrstd)[wave * 64 + tick_i] = t;
             ++tick_i;
@@ -421,26 +524,41 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
         asm volatile("" ::: "memory");
     };
     const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    auto start_h = [&]() __attribute__((always_inline)) {       // a chunk's accumulator starts from the bias (forward) / zero
+        if constexpr (BWD) {
+            acc_zero(acc_h[0][0]);
+            acc_zero(acc_h[0][1]);
+        } else {
+            mlp_init_h(acc_h, B32, hi);
+        }
+    };
+    auto after_epi = [&](int c) __attribute__((always_inline)) {   // after the epilogue of chunk c, before the slot barrier
+        if constexpr (BWD) {       // c_fc bias gradient: lanes 0-15 of each half hold the column sums of the wave's 32 features
+            if ((lane & 31) < 16) unsafeAtomicAdd(a.g_b_fc + c * 256 + wave * 32 + 16 * hi + (lane & 31), BE.colacc);
+        } else {
+            mlp_bias32_load(B32, a.b_fc, min(c + 1, 7), wave);
+        }
+    };
     tick();
     if (grp) slot_barrier();
     // body(0) and body(8) are peeled as straight-line code around the loop: as if / else arms INSIDE the loop every extra variant of
     // a phase cost ~300 spilled registers at the joins
-    mlp_init_h(acc_h, B32, hi);
+    start_h();
     tick(); fc_phase(0, F_{}); tick();
     slot_barrier();
     tick(); proj_phase(0, F_{}, T_{}); tick();
-    mlp_bias32_load(B32, a.b_fc, 1, wave);
+    after_epi(0);
     slot_barrier();
     mlp_load_x_fc<0>(FA, XA);
     __builtin_amdgcn_sched_barrier(0);
     for (int c = 1; c < 8; ++c) {
-        mlp_init_h(acc_h, B32, hi);
+        start_h();
         tick(); fc_phase(c, T_{}); tick();
         slot_barrier();
         mlp_load_x_proj<0>(FA, XA, (c & 1) ^ 1);                    // c_proj(c-1) reads hidden panel (c-1) & 1
         __builtin_amdgcn_sched_barrier(0);
         tick(); proj_phase(c, T_{}, T_{}); tick();
-        mlp_bias32_load(B32, a.b_fc, min(c + 1, 7), wave);
+        after_epi(c);
         slot_barrier();
         if (c < 7) mlp_load_x_fc<0>(FA, XA);                        // fragments of the next body's first step
         __builtin_amdgcn_sched_barrier(0);
@@ -458,9 +576,10 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
             for (int j = 0; j < MLP_WFR; ++j) asm volatile("" ::"v"(WQ[i].f[j]));
     }
 
+    __syncthreads();         // every wave is done with the activation panels
+    if constexpr (!BWD) {
     // ---- epilogue: + bias + residual -> x_out; LayerNorm of the (bf16-rounded) output row -> xn_next.  Both leave through LDS
     // panels as whole 1-KiB rows (pn_panel_copy_out); the input panel's space takes x_out, the hidden panels' space xn_next.
-    __syncthreads();         // every wave is done with the activation panels
     char* xo_panel = lds + MLP_XN_OFF;
     char* xn_panel = lds + MLP_H_OFF;
     float* red = reinterpret_cast<float*>(lds + MLP_PRE_OFF);     // [2][PN_WAVES][64 rows]
@@ -554,6 +673,121 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_fwd_panel_ker
         __syncthreads();
         pn_panel_copy_out<1024>(xn_panel, a.xn_next + row0 * 512, 512, wave, lane);
     }
+
+    } else {
+        // ---- backward epilogue: LayerNorm-2 backward of dxn (the f32 accumulator) + the residual gradient -> dx2; column sums
+        // over the panel's rows -> g_ln_g, g_ln_b, g_b_out.  A lane owns rows mb * 32 + (lane & 31) and features nbase + 16 hi + r
+        // (two 8-feature chunks per feature block and row block); its dx values sit in the input panel at the slots its dx2 values
+        // take, so the panel is updated in place and leaves as whole rows.
+        char* xo_panel = lds + MLP_XN_OFF;
+        float* red = reinterpret_cast<float*>(lds + MLP_PRE_OFF);     // [2][PN_WAVES][64 rows]
+        float mean[2], rstd[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            mean[mb] = a.mean2[row0 + mb * 32 + (lane & 31)];
+            rstd[mb] = a.rstd2[row0 + mb * 32 + (lane & 31)];
+        }
+        uint4 xq[MLP_NBO][2][2];       // x_mid chunks, kept packed for the second pass
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+        float cg = 0.f, cb = 0.f;      // lane (l & 31) = 16 nb + r: column sums of feature nbase(nb) + 16 hi + r
+#pragma unroll
+        for (int nb = 0; nb < MLP_NBO; ++nb) {
+            const int nbase = wave * (32 * MLP_NBO) + nb * 32;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    xq[nb][mb][p] = *reinterpret_cast<const uint4*>(a.x_mid + (row0 + mb * 32 + (lane & 31)) * 512 + nbase + (2 * hi + p) * 8);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                pn_cfptr_t gp = (pn_cfptr_t)(uintptr_t)(a.ln_g) + nbase + 8 * p;
+                float gam[8];
+                pn_uniform8(gp, gp + 16, hi, gam);
+                float dg[8], db[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { dg[e] = 0.f; db[e] = 0.f; }
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    float xv[8];
+                    pn_unpack8(xq[nb][mb][p], xv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xh = (xv[e] - mean[mb]) * rstd[mb], dy = acc_o[nb][mb][8 * p + e], g = dy * gam[e];
+                        s1[mb] += g;
+                        s2[mb] += g * xh;
+                        dg[e] += dy * xh;
+                        db[e] += dy;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float tg = pn_half32_sum(dg[e]), tb = pn_half32_sum(db[e]);
+                    const bool mine = (lane & 31) == 16 * nb + 8 * p + e;
+                    cg = mine ? tg : cg;
+                    cb = mine ? tb : cb;
+                }
+            }
+        }
+        {
+            const int n = wave * (32 * MLP_NBO) + ((lane & 31) >> 4) * 32 + 16 * hi + (lane & 15);
+            unsafeAtomicAdd(a.g_ln_g + n, cg);
+            unsafeAtomicAdd(a.g_ln_b + n, cb);
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const float t1 = pn_half_sum(s1[mb]), t2 = pn_half_sum(s2[mb]);
+            if (lane < 32) { red[wave * 64 + mb * 32 + lane] = t1; red[PN_WAVES * 64 + wave * 64 + mb * 32 + lane] = t2; }
+        }
+        __syncthreads();
+        float m1[2], m2[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < PN_WAVES; ++w) { t1 += red[w * 64 + mb * 32 + (lane & 31)]; t2 += red[PN_WAVES * 64 + w * 64 + mb * 32 + (lane & 31)]; }
+            m1[mb] = t1 * (1.0f / 512);
+            m2[mb] = t2 * (1.0f / 512);
+        }
+        float co = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < MLP_NBO; ++nb) {
+            const int nbase = wave * (32 * MLP_NBO) + nb * 32;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                pn_cfptr_t gp = (pn_cfptr_t)(uintptr_t)(a.ln_g) + nbase + 8 * p;
+                float gam[8], ds[8];
+                pn_uniform8(gp, gp + 16, hi, gam);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ds[e] = 0.f;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const int m = mb * 32 + (lane & 31), ch = (nbase >> 3) + 2 * hi + p;
+                    uint4* slot = reinterpret_cast<uint4*>(pn_panel_slot<1024>(xo_panel, m, ch));
+                    float xv[8], rv[8], o[8];
+                    pn_unpack8(xq[nb][mb][p], xv);
+                    pn_unpack8(*slot, rv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xh = (xv[e] - mean[mb]) * rstd[mb], g = acc_o[nb][mb][8 * p + e] * gam[e];
+                        o[e] = rstd[mb] * (g - m1[mb] - xh * m2[mb]) + rv[e];
+                        ds[e] += o[e];
+                    }
+                    *slot = pn_pack8(o);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = pn_half32_sum(ds[e]);
+                    co = (lane & 31) == 16 * nb + 8 * p + e ? t : co;
+                }
+            }
+        }
+        {
+            const int n = wave * (32 * MLP_NBO) + ((lane & 31) >> 4) * 32 + 16 * hi + (lane & 15);
+            unsafeAtomicAdd(a.g_b_out + n, co);
+        }
+        __syncthreads();
+        pn_panel_copy_out<1024>(xo_panel, a.dx2 + row0 * 512, 512, wave, lane);
+    }
 }
 
 }  // namespace tal
@@ -584,25 +818,36 @@ extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
     a.eps = d->eps;
     const dim3 grid((unsigned)(d->rows / PN_ROWS));
     const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0);
+#define TAN_MLP_LAUNCH(M) hipLaunchKernelGGL((mlp_panel_kernel<M, MlpFwdArgs>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a)
     switch (d->variant) {
 #ifdef TAN_PANEL_LAB
-        case 5: hipLaunchKernelGGL((mlp_fwd_panel_kernel<5>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
-        case 2: hipLaunchKernelGGL((mlp_fwd_panel_kernel<2>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
-        case 6: hipLaunchKernelGGL((mlp_fwd_panel_kernel<6>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
-        case 8: hipLaunchKernelGGL((mlp_fwd_panel_kernel<8>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
-        case 10: hipLaunchKernelGGL((mlp_fwd_panel_kernel<10>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
-        case 14: hipLaunchKernelGGL((mlp_fwd_panel_kernel<14>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
-        case 16: hipLaunchKernelGGL((mlp_fwd_panel_kernel<16>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
-        case 32: hipLaunchKernelGGL((mlp_fwd_panel_kernel<32>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
-        case 64: hipLaunchKernelGGL((mlp_fwd_panel_kernel<64>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
-        case 80: hipLaunchKernelGGL((mlp_fwd_panel_kernel<80>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
-        case 72: hipLaunchKernelGGL((mlp_fwd_panel_kernel<72>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
-        case 128: hipLaunchKernelGGL((mlp_fwd_panel_kernel<128>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
-        case 256: hipLaunchKernelGGL((mlp_fwd_panel_kernel<256>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
-        case 15: hipLaunchKernelGGL((mlp_fwd_panel_kernel<15>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a); break;
+        case 2: TAN_MLP_LAUNCH(2); break;
+        case 16: TAN_MLP_LAUNCH(16); break;
+        case 64: TAN_MLP_LAUNCH(64); break;
+        case 80: TAN_MLP_LAUNCH(80); break;
+        case 256: TAN_MLP_LAUNCH(256); break;
 #endif
-        default: hipLaunchKernelGGL((mlp_fwd_panel_kernel<0>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
+        default: TAN_MLP_LAUNCH(0);
     }
+#undef TAN_MLP_LAUNCH
+    prof_end((hipStream_t)stream, rec);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream) {
+    TAN_REQUIRE(d && d->rows > 0 && d->rows % PN_ROWS == 0 && d->C == 512 && d->FF == 2048);
+    TAN_REQUIRE(d->dx && d->h_pre && d->x_mid && d->mean2 && d->rstd2 && d->ln_g && d->pwt_proj && d->pwt_fc && d->dh && d->dx2);
+    TAN_REQUIRE(d->g_b_fc && d->g_ln_g && d->g_ln_b && d->g_b_out);
+    MlpBwdArgs a;
+    a.dx = (const bf16_t*)d->dx; a.h_pre = (const bf16_t*)d->h_pre; a.x_mid = (const bf16_t*)d->x_mid;
+    a.mean2 = d->mean2; a.rstd2 = d->rstd2; a.ln_g = d->ln_g;
+    a.pw_fc = (const char*)d->pwt_proj; a.pw_proj = (const char*)d->pwt_fc;
+    a.h_act = (bf16_t*)d->dh; a.dx2 = (bf16_t*)d->dx2;
+    a.g_b_fc = d->g_b_fc; a.g_ln_g = d->g_ln_g; a.g_ln_b = d->g_ln_b; a.g_b_out = d->g_b_out;
+    const dim3 grid((unsigned)(d->rows / PN_ROWS));
+    const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0);
+    hipLaunchKernelGGL((mlp_panel_kernel<0, MlpBwdArgs>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
     prof_end((hipStream_t)stream, rec);
     TAN_LAUNCH_CHECK();
     return 0;

@@ -90,7 +90,7 @@ class _Flat:
 
             def table(transposed):
                 ents, mx = [], 0
-                for n in names:
+                for n in (names if not transposed else [n for n in names if ".mlp.c_" in n]):
                     o, _, (N, K) = self.off[n]
                     if transposed:
                         N, K = K, N
@@ -121,6 +121,19 @@ class _Flat:
             ops.cast(self.flat, self.shadow)
             self.shadow_version = self.flat._version
             self.shadow_epoch += 1
+
+    def sync_shadow_tp(self):
+        """Packed images of the TRANSPOSED MLP weights (row-panel backward): tan_pack_weights over `shadow_t`, same offsets."""
+        if self.shadow is None or self.shadow_t is None:
+            return None
+        if self.shadow_tp is None:
+            self.shadow_tp = torch.zeros(self.total, dtype=torch.bfloat16, device=self.shadow.device)
+        if self.shadow_tp_epoch != self.shadow_t_epoch:
+            tab, n, mx = self._pack_tables()[1]
+            _lib.check(_lib.lib().tan_pack_weights(_vp(self.shadow_t), _vp(self.shadow_tp), _vp(tab), C.c_int(n), C.c_int(mx),
+                                                   ops._stream()), "tan_pack_weights")
+            self.shadow_tp_epoch = self.shadow_t_epoch
+        return self.shadow_tp
 
     def sync_shadow_t(self):
         """(Re)build the transposed copies of every 2-D `...resblocks.*` weight from the bf16 shadow: one batched launch."""
@@ -399,8 +412,9 @@ class TemporalAligner(nn.Module):
         wbuf = f.shadow if self.compute_dtype == torch.bfloat16 else f.flat
         wt = f.shadow_t if (self.compute_dtype == torch.bfloat16 and self.transposed_dx) else None
         wp = f.shadow_p if (self.compute_dtype == torch.bfloat16 and self.panel_kernels) else None
+        wtp = f.shadow_tp if (wt is not None and wp is not None) else None
         sig = (f.flat.data_ptr(), f.grad.data_ptr(), wbuf.data_ptr(), wt.data_ptr() if wt is not None else 0,
-               wp.data_ptr() if wp is not None else 0)
+               wp.data_ptr() if wp is not None else 0, wtp.data_ptr() if wtp is not None else 0)
         hit = self._lp_cache.get((prefix, layers))
         if hit is not None and hit[0] == sig:
             return hit[1]
@@ -417,6 +431,8 @@ class TemporalAligner(nn.Module):
                 setattr(arr[i], "g_" + k, f.ptr(f.grad, base + v))
                 setattr(arr[i], "wt_" + k[2:], f.ptr(wt, base + v) if wt is not None else None)
                 setattr(arr[i], "wp_" + k[2:], f.ptr(wp, base + v) if wp is not None else None)
+                if k in ("w_fc", "w_proj"):
+                    setattr(arr[i], "wtp_" + k[2:], f.ptr(wtp, base + v) if wtp is not None else None)
             for k, v in fm.items():
                 setattr(arr[i], k, f.ptr(f.flat, base + v))
                 setattr(arr[i], "g_" + k, f.ptr(f.grad, base + v))
@@ -863,6 +879,8 @@ class TemporalAligner(nn.Module):
         d_xj = torch.empty(B * L, Cw, dtype=cd, device=dev) if any_j else None
         if cd == torch.bfloat16 and self.transposed_dx:
             self._flat.sync_shadow_t()         # W^T copies for the dX GEMMs, rebuilt once per optimizer step (main stream)
+            if self.panel_kernels:
+                self._flat.sync_shadow_tp()    # their packed images (MLP weights) for the row-panel backward
         main, side = torch.cuda.current_stream(), self._side_stream(dev)
         if any_j and any_v and side is not None:
             # joint stack backward on the side stream (issued by the helper thread), video stack backward on the main stream

@@ -113,3 +113,64 @@ def test_mlp_fwd_rejects_what_it_cannot_do():
     d = _lib.MlpDesc()
     d.rows, d.C, d.FF = 100, 512, 2048       # not a multiple of 64 rows, and nothing bound
     assert _lib.lib().tan_mlp_fwd(C.byref(d), ops._stream()) == -1
+
+
+@pytest.mark.parametrize("R", [64, 640, 1024])
+def test_mlp_bwd_matches_the_fp32_backward_of_the_branch(R):
+    """tan_mlp_bwd = autograd of x_out = x_mid + c_proj(quickgelu(c_fc(LN2(x_mid)))) w.r.t. x_mid, b_fc, ln_2 and (through dx2's
+    column sums) the attention out-projection bias; dh is the operand of the c_fc weight gradient.  Reference: fp32 math on the same
+    bf16 tensors, rounded where the kernel rounds (dh to bf16 before the second GEMM)."""
+    _lib, ops = _lib_ops()
+    torch.manual_seed(100 + R)
+    bf = torch.bfloat16
+    x_mid = (torch.randn(R, 512, device="cuda") * 1.5).to(bf)
+    dx = (torch.randn(R, 512, device="cuda") * 0.02).to(bf)
+    wfc = (torch.randn(2048, 512, device="cuda") * 1024 ** -0.5).to(bf)
+    wpj = (torch.randn(512, 2048, device="cuda") * 0.03).to(bf)
+    bfc = torch.randn(2048, device="cuda") * 0.1
+    g2, b2 = 1 + 0.1 * torch.randn(512, device="cuda"), 0.1 * torch.randn(512, device="cuda")
+    x = x_mid.float()
+    mean2, rstd2 = x.mean(-1), (x.var(-1, unbiased=False) + 1e-5).rsqrt()
+    xhat = (x - mean2[:, None]) * rstd2[:, None]
+    xn2 = (xhat * g2 + b2).to(bf)
+    h_pre = (xn2.float() @ wfc.float().T + bfc).to(bf)
+    # packed images of the TRANSPOSED weights: W_proj^T [2048][512] (c_fc-like tiles), W_fc^T [512][2048] (c_proj-like tiles)
+    pwt_proj, pwt_fc = pack([wpj.T.contiguous(), wfc.T.contiguous()])
+    dh = torch.zeros(R, 2048, device="cuda", dtype=bf)
+    dx2 = torch.zeros(R, 512, device="cuda", dtype=bf)
+    g_b_fc = torch.full((2048,), 0.5, device="cuda")            # accumulated INTO: start from something
+    g_ln_g, g_ln_b, g_b_out = (torch.full((512,), v, device="cuda") for v in (0.25, -0.5, 1.0))
+    d = _lib.MlpBwdDesc()
+    d.rows, d.C, d.FF = R, 512, 2048
+    d.dx, d.h_pre, d.x_mid = dx.data_ptr(), h_pre.data_ptr(), x_mid.data_ptr()
+    d.mean2, d.rstd2, d.ln_g = mean2.data_ptr(), rstd2.data_ptr(), g2.data_ptr()
+    d.pwt_proj, d.pwt_fc = pwt_proj.data_ptr(), pwt_fc.data_ptr()
+    d.dh, d.dx2 = dh.data_ptr(), dx2.data_ptr()
+    d.g_b_fc, d.g_ln_g, d.g_ln_b, d.g_b_out = g_b_fc.data_ptr(), g_ln_g.data_ptr(), g_ln_b.data_ptr(), g_b_out.data_ptr()
+    _lib.check(_lib.lib().tan_mlp_bwd(C.byref(d), ops._stream()), "tan_mlp_bwd")
+    torch.cuda.synchronize()
+    hp = h_pre.float()
+    sg = torch.sigmoid(1.702 * hp)
+    r_dh = (dx.float() @ wpj.float()) * (sg + 1.702 * hp * sg * (1 - sg))
+    r_dxn = r_dh.to(bf).float() @ wfc.float()
+    g = r_dxn * g2
+    r_dx2 = rstd2[:, None] * (g - g.mean(-1, keepdim=True) - xhat * (g * xhat).mean(-1, keepdim=True)) + dx.float()
+
+    def close(got, ref, what, rel):
+        err = (got.float() - ref).abs().max().item()
+        assert err <= rel * ref.abs().max().item() + 1e-7, (what, err, ref.abs().max().item())
+    close(dh, r_dh, "dh", 2.0 ** -7)
+    close(dx2, r_dx2, "dx2", 2.0 ** -7)
+    close(g_b_fc - 0.5, r_dh.sum(0), "g_b_fc", 2e-3)
+    close(g_ln_g - 0.25, (r_dxn * xhat).sum(0), "g_ln_g", 2e-3)
+    close(g_ln_b + 0.5, r_dxn.sum(0), "g_ln_b", 2e-3)
+    close(g_b_out - 1.0, r_dx2.sum(0), "g_b_out", 2e-3)
+
+
+def test_mlp_bwd_rejects_what_it_cannot_do():
+    _lib, ops = _lib_ops()
+    d = _lib.MlpBwdDesc()
+    d.rows, d.C, d.FF = 128, 512, 2048       # nothing bound
+    assert _lib.lib().tan_mlp_bwd(C.byref(d), ops._stream()) == -1
+    d.rows = 100
+    assert _lib.lib().tan_mlp_bwd(C.byref(d), ops._stream()) == -1
