@@ -38,7 +38,7 @@ GEMM_KIND_NAMES = {0: "gemm_bf16<A:K-contig,B:K-contig> (Linear fwd, dX through 
                    2: "gemm_bf16<A:K-strided,B:K-contig>", 3: "gemm_bf16<A:K-strided,B:K-strided> (dW)",
                    4: "gemm_f32<kc,kc>", 5: "gemm_f32<kc,ks>", 6: "gemm_f32<ks,kc>", 7: "gemm_f32<ks,ks>",
                    8: "attn_fwd", 9: "attn_bwd", 10: "simnce (logits-free similarity+NCE, fwd stats / bwd dlogits)",
-                   11: "row-panel fused MLP forward (LN2 + c_fc + QuickGELU + c_proj + residual + next LN)"}
+                   11: "row-panel fused MLP, forward (LN2 + c_fc + QuickGELU + c_proj + residual + next LN) and backward (both dX GEMMs + quickgelu' + LN2 backward)"}
 NKINDS = 12
 FAMILY = list(range(8)) + [10, 11]       # every MFMA GEMM pipeline launch
 
@@ -176,7 +176,7 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
                 fam = json.load(open(pmc))["mfma_gemm_family"]
                 prof = {"file": "profiles/r02_pmc_traffic.json", "hbm_bytes_per_launch": round(fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch"]),
                         "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run"}
-            roof = {"bound": "mfma", "kernel": "tal::gemm_glds_kernel + tal::gemm_dw_grouped_kernel + tal::simnce_kernel (one direct-to-LDS MFMA pipeline, all operand layouts)",
+            roof = {"bound": "mfma", "kernel": "tal::gemm_glds_kernel + tal::gemm_dw_grouped_kernel + tal::simnce_kernel (one direct-to-LDS MFMA pipeline, all operand layouts) + tal::mlp_panel_kernel (row-panel fused MLP, forward and backward)",
                     "achieved": round(ach, 1),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "traffic_profile": prof,
                     "avg_launch_us": round(tms * 1e3 / tcnt, 2), "launches_per_step": round(tcnt / sampled, 1),

@@ -66,7 +66,7 @@ int linear_bwd_w(int dt, const void* dy, const void* x, float* gw, long M, int N
     d.A = dy; d.lda = N; d.B = x; d.ldb = K; d.ldc = K;
     d.alpha = 1.0f;
     const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
-    static const long target = [] { const char* e = getenv("TAN_DW_TARGET_WGS"); long v = e ? atol(e) : 0; return v > 0 ? v : (long)TAN_DW_TARGET_WGS; }();
+    const long target = TAN_DW_TARGET_WGS;
     long want = (target + tiles - 1) / tiles;   // workgroups per dW GEMM (the other stack co-runs on a 2nd stream)
     const long max_split = (M + 255) / 256;
     if (want > max_split) want = max_split;

@@ -650,33 +650,15 @@ int gemm_dw_grouped(int nprob, const void* const* dy, const void* const* x, floa
     return 0;
 }
 
-static int use_four_stage(const tan_gemm_desc* d, const GemmArgs2& a) {
-    static int forced = -2;
-    if (forced == -2) { const char* e = getenv("TAN_GEMM_STAGES"); forced = e ? atoi(e) : -1; }
-    if (forced == 2) return 0;
-    if (forced == 4) return 1;
-    // K-contiguous x K-contiguous: stand-alone (tools/gemm_shapes.py, 100 reps) the deeper prefetch wins 6-12 % when a CU holds
-    // ONE workgroup (the N=512 outputs: 11.3 vs 12.0 us at K=512, 25.0 vs 28.3 us at K=2048) -- but inside the training step,
-    // where two stacks' kernels share the CUs and hide each other's DMA latency, it LOSES 2.4 % of the whole step (7.21 vs
-    // 7.04 ms, three interleaved A/B rounds), so it is off by default (TAN_GEMM_KC4=1: the stand-alone rule, =2: K >= 1024 only)
-    const long wgs = (long)cdiv(d->M, GBM) * cdiv(d->N, GBN) * d->batch * d->split_k;
-    // K-strided x K-strided (dW, hand-issued transposing reads in both kernels): three tiles in flight are worth 3-9 % once the
-    // K-slice is long (tools/gemm_shapes.py: dW c_fc 35.7 -> 33.8 us, c_proj 35.8 -> 33.3 us at 8192 rows)
-    static int ks4 = -1;
-    if (ks4 < 0) { const char* e = getenv("TAN_GEMM_KS4"); ks4 = e ? atoi(e) : 1; }
-    if (!d->a_kc && !d->b_kc) return ks4 && a.kchunk >= 1024;
-    static int kc4 = -1;
-    if (kc4 < 0) { const char* e = getenv("TAN_GEMM_KC4"); kc4 = e ? atoi(e) : 0; }
-    return kc4 && d->a_kc && d->b_kc && wgs <= 384 && a.kchunk >= (kc4 == 2 ? 1024 : 128);
-}
+// The 4-stage / K-step-32 pipeline (three tiles in flight) pays for the K-strided x K-strided weight-gradient GEMMs once the K
+// slice is long (dW c_fc 35.7 -> 33.8 us, c_proj 35.8 -> 33.3 us at 8192 rows).  For K-contiguous operands it won 6-12 % stand-alone
+// on the N=512 outputs and LOST 2.4 % of the training step: that instantiation was removed in round 2.
+static int use_four_stage(const tan_gemm_desc* d, const GemmArgs2& a) { return !d->a_kc && !d->b_kc && a.kchunk >= 1024; }
 
 template <typename TC>
 static int launch2(const tan_gemm_desc* d, const GemmArgs2& a, dim3 grid, hipStream_t st) {
     if (use_four_stage(d, a)) {
-        if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_glds4_kernel<TC, true, true>), grid, dim3(256), 0, st, a);
-        else if (d->a_kc && !d->b_kc) hipLaunchKernelGGL((gemm_glds4_kernel<TC, true, false>), grid, dim3(256), 0, st, a);
-        else if (!d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_glds4_kernel<TC, false, true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gemm_glds4_kernel<TC, false, false>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gemm_glds4_kernel<TC, false, false>), grid, dim3(256), 0, st, a);
         TAN_LAUNCH_CHECK();
         return 0;
     }
@@ -708,8 +690,7 @@ int gemm_glds_try(const tan_gemm_desc* d, hipStream_t st) {
     a.vec_epi = !d->accumulate && d->N % 8 == 0 && al16(d->C, d->ldc) && al16(d->residual, d->ldr) && al16(d->aux, d->ldaux) &&
                 ((d->sC * oe) % 16 == 0);
     a.colsum = a.vec_epi ? d->colsum : nullptr;
-    static const int plane_xcd = [] { const char* e = getenv("TAN_GEMM_PLANE_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
-    a.plane_xcd = plane_xcd;
+    a.plane_xcd = 1;
     dim3 grid(cdiv(d->N, GBN), cdiv(d->M, GBM), d->batch * d->split_k);
     if (d->colsum && !a.vec_epi) {            // cannot fuse: run the GEMM, caller adds a separate column-sum pass
         int rc = d->out_dtype == TAN_F32 ? launch2<float>(d, a, grid, st) : launch2<bf16_t>(d, a, grid, st);

@@ -305,6 +305,10 @@ __device__ __forceinline__ void mlp_copy_step8(MlpCopy& C, const char* lds, bf16
     }
 }
 
+#ifdef TAN_PANEL_LAB
+__device__ long long* g_panel_dbg = nullptr;      // tools/lab: phase clocks of workgroup 0 (tan_panel_lab_set_dbg)
+#endif
+
 // MODE 0: the kernel.  Timing experiments of tools/lab/mlp_lab.py (results undefined), bit mask: 1 no MFMAs, 2 no weight
 // streaming (loaded once), 4 no activation-fragment reads in the loop, 16 no side-output copy-out (arithmetic, LDS panel writes and barriers stay), 64 phase clocks
 // into nrstd[], 256 no up-front touch of the weights.  (Variants that drop the epilogue arithmetic also drop the c_fc MFMAs -- dead code --
@@ -509,14 +513,16 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     // buffer is rewritten two bodies later (slots 2c+5 / 2c+6), after its last readers (slots 2c+3 / 2c+4).  The pre-activation
     // panel and the copy-out of both panels are split by group halves, so they never cross groups.  The last phase, c_proj(7), has
     // to wait for the late group's epilogue(7): the early group idles in slot 16.
-    // lab instrumentation (MODE & 64, xn_next == null): workgroup 0 records the shader clock at phase boundaries into nrstd[]
+    // lab instrumentation (MODE & 64): workgroup 0 records the shader clock at phase boundaries
     int tick_i = 0;
     auto tick = [&]() __attribute__((always_inline)) {
-        if constexpr ((MODE & 64) != 0 && !BWD) {
+#ifdef TAN_PANEL_LAB
+        if constexpr ((MODE & 64) != 0) {
             const long long t = __builtin_readcyclecounter();
-            if (blockIdx.x == 0 && lane == 0) reinterpret_cast<long long*>(a.nrstd)[wave * 64 + tick_i] = t;
+            if (blockIdx.x == 0 && lane == 0 && g_panel_dbg) g_panel_dbg[wave * 64 + tick_i] = t;
             ++tick_i;
         }
+#endif
     };
     auto slot_barrier = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -847,8 +853,19 @@ extern "C" int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream) {
     a.g_b_fc = d->g_b_fc; a.g_ln_g = d->g_ln_g; a.g_ln_b = d->g_ln_b; a.g_b_out = d->g_b_out;
     const dim3 grid((unsigned)(d->rows / PN_ROWS));
     const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0);
+#ifdef TAN_PANEL_LAB
+    if (getenv("TAN_PANEL_LAB_CLOCKS")) hipLaunchKernelGGL((mlp_panel_kernel<64, MlpBwdArgs>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
+    else
+#endif
     hipLaunchKernelGGL((mlp_panel_kernel<0, MlpBwdArgs>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
     prof_end((hipStream_t)stream, rec);
     TAN_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef TAN_PANEL_LAB
+extern "C" int tan_panel_lab_set_dbg(void* p) {
+    long long* q = (long long*)p;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_panel_dbg), &q, sizeof(q));
+}
+#endif

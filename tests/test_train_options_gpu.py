@@ -66,9 +66,15 @@ def test_gradient_accumulation_follows_the_reference_loop():
     tb.zero_grad(); tb.forward_backward(batches[0]); tb._lr_iter = 0; tb.optimizer_step()
     tb.zero_grad(); tb.forward_backward(batches[1]); tb.forward_backward(batches[2]); tb._lr_iter = 2; tb.optimizer_step()
     assert ta.iteration == tb.iteration == 2 and ta.batches_seen == 3
-    torch.testing.assert_close(ta.online.flat_parameters(), tb.online.flat_parameters(), rtol=1e-5, atol=5e-5)   # Adam on near-zero gradients: f32-atomic noise is a few % of one lr-sized (2e-4) update
+    # Same arithmetic, different order of the f32 atomics that gather bias / LayerNorm gradients: Adam turns that noise, on
+    # parameters whose gradient is ~0, into a fraction of one lr-sized (2e-4) update for a handful of elements -- bounded per
+    # element by half an update, and invisible on average.
+    diff = (ta.online.flat_parameters() - tb.online.flat_parameters()).abs()
+    assert diff.max().item() <= 1e-4, diff.max().item()
+    assert diff.mean().item() <= 2e-7 and (diff > 2e-5).float().mean().item() < 1e-4, (diff.mean().item(), (diff > 2e-5).float().mean().item())
     # and it differs from stepping three times
     tc, _ = _trainer(model="init", backprop_freq=1)
     for b in batches:
         tc.step(b)
-    assert (tc.online.flat_parameters() - ta.online.flat_parameters()).abs().max() > 1e-4
+    d3 = (tc.online.flat_parameters() - ta.online.flat_parameters()).abs()
+    assert d3.max() > 1e-4 and d3.mean().item() > 50 * max(diff.mean().item(), 1e-9)

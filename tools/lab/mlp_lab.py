@@ -129,12 +129,71 @@ def check(R=1024):
     return ok
 
 
+def make_bwd(t):
+    """backward inputs for the tensors of make(): dx, packed transposes, gradient accumulators, outputs"""
+    R = t["R"]
+    bf = torch.bfloat16
+    t["dx"] = (torch.randn(R, 512, device=dev) * 0.02).to(bf)
+    t["pwt"] = pack([t["wpj"].T.contiguous(), t["wfc"].T.contiguous()], 0)
+    t["dh"] = torch.zeros(R, 2048, device=dev, dtype=bf)
+    t["dx2"] = torch.zeros(R, 512, device=dev, dtype=bf)
+    t["dxn"] = torch.zeros(R, 512, device=dev, dtype=bf)
+    for k, n in (("g_b_fc", 2048), ("g_ln_g", 512), ("g_ln_b", 512), ("g_b_out", 512)):
+        t[k] = torch.zeros(n, device=dev)
+    t["ln_ws"] = torch.zeros(4 * 1024 * 512, device=dev)
+    return t
+
+
+def run_bwd(t):
+    d = _lib.MlpBwdDesc()
+    d.rows, d.C, d.FF = t["R"], 512, 2048
+    d.dx, d.h_pre, d.x_mid = t["dx"].data_ptr(), t["f_hpre"].data_ptr(), t["x_mid"].data_ptr()
+    d.mean2, d.rstd2, d.ln_g = t["f_mean2"].data_ptr(), t["f_rstd2"].data_ptr(), t["g2"].data_ptr()
+    d.pwt_proj, d.pwt_fc = t["pwt"][0].data_ptr(), t["pwt"][1].data_ptr()
+    d.dh, d.dx2 = t["dh"].data_ptr(), t["dx2"].data_ptr()
+    d.g_b_fc, d.g_ln_g, d.g_ln_b, d.g_b_out = (t[k].data_ptr() for k in ("g_b_fc", "g_ln_g", "g_ln_b", "g_b_out"))
+    _lib.check(L.tan_mlp_bwd(C.byref(d), ops._stream()), "tan_mlp_bwd")
+
+
+def bwd_main():
+    for R in (8192, 10240):
+        ts = [make_bwd(make(R)) for _ in range(6)]
+        for t in ts:
+            run_fused(t, 0)            # h_pre, mean2, rstd2 of the forward
+        fl = 2.0 * R * 512 * 2048 * 2
+        it = [0]
+
+        def g():
+            run_bwd(ts[it[0] % 6]); it[0] += 1
+        tb = timeit(g, reps=48)
+        print(f"R={R} cold: fused backward                  {tb:7.1f} us   {fl / tb / 1e6:6.0f} TF/s", flush=True)
+        t = ts[0]
+        tb = timeit(lambda: run_bwd(t))
+        print(f"R={R} warm: fused backward                  {tb:7.1f} us   {fl / tb / 1e6:6.0f} TF/s", flush=True)
+        if R == 8192 and os.environ.get("TAN_PANEL_LAB_CLOCKS"):
+            dbg = torch.zeros(8 * 64, dtype=torch.int64, device=dev)
+            assert L.tan_panel_lab_set_dbg(C.c_void_p(dbg.data_ptr())) == 0
+            for i in range(7):
+                run_bwd(ts[i % 6])
+            torch.cuda.synchronize()
+            st = dbg.cpu().numpy().reshape(8, 64)
+            t0 = st[:, 0].min()
+            names = ["fc0", "pe0"] + [f"{k}{c}" for c in range(1, 8) for k in ("fc", "pe")] + ["pj7"]
+            for w in (0, 4):
+                row = st[w]
+                print(f" wave {w}: total {int(row[35] - row[0])}  " + " ".join(
+                    f"{n}:{int(row[1 + 2 * k] - t0)}+{int(row[2 + 2 * k] - row[1 + 2 * k])}" for k, n in enumerate(names)))
+        del ts, t
+        torch.cuda.empty_cache()
+
+
 def phase_clocks(variant, R=8192):
     """MODE & 64: per-wave shader-clock stamps at the phase boundaries of workgroup 0 (cold buffers)"""
     ts = [make(R) for _ in range(6)]
     dbg = torch.zeros(8 * 64, dtype=torch.int64, device=dev)
+    assert L.tan_panel_lab_set_dbg(C.c_void_p(dbg.data_ptr())) == 0
     for i in range(7):
-        run_fused(ts[i % 6], variant, True, False, dbg=dbg)      # next_ln off: nrstd carries the stamps
+        run_fused(ts[i % 6], variant, True, True)
     torch.cuda.synchronize()
     return dbg.cpu().numpy().reshape(8, 64)
 
@@ -153,6 +212,9 @@ def print_clocks(variant):
 
 
 if __name__ == "__main__":
+    if os.environ.get("LAB_BWD"):
+        bwd_main()
+        sys.exit(0)
     if os.environ.get("LAB_CLOCKS"):
         for v in (int(x) for x in os.environ["LAB_CLOCKS"].split(",")):
             print_clocks(v)
