@@ -305,6 +305,143 @@ __device__ __forceinline__ void mlp_copy_step8(MlpCopy& C, const char* lds, bf16
     }
 }
 
+// LayerNorm backward of a panel whose upstream gradient dy sits in the f32 accumulators (+ an optional bf16 gradient `dadd` joining
+// it), plus the residual gradient that sits in the LDS panel at MLP_XN_OFF: out = dres + LN-backward(dy; x, mean, rstd, gamma),
+// written back into the same panel slots (every slot is owned by one lane) and left there for pn_panel_copy_out; the parameter
+// gradients that are column sums over the panel's rows go to the f32 gradients with one atomic per column.
+struct PnLnBwd {
+    const bf16_t* x; const float* mean; const float* rstd; const float* gamma;
+    const bf16_t* dadd;                 // optional [rows][512]: added to dy first (the deep-supervision gradient of this LayerNorm's output)
+    float* g_gamma; float* g_beta; float* g_colsum;      // g_colsum optional: column sums of the OUTPUT
+};
+__device__ __forceinline__ void pn_ln_bwd_epilogue(f32x16 (&acc_o)[MLP_NBO][2], char* lds, const PnLnBwd& P, long row0, int wave, int lane) {
+    const int hi = lane >> 5;
+    if (P.dadd) {
+#pragma unroll
+        for (int nb = 0; nb < MLP_NBO; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    float dv[8];
+                    pn_unpack8(*reinterpret_cast<const uint4*>(P.dadd + (row0 + mb * 32 + (lane & 31)) * 512 + wave * (32 * MLP_NBO) + nb * 32 + (2 * hi + p) * 8), dv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc_o[nb][mb][8 * p + e] += dv[e];
+                }
+    }
+    // ---- backward epilogue: LayerNorm-2 backward of dxn (the f32 accumulator) + the residual gradient -> dx2; column sums
+    // over the panel's rows -> g_ln_g, g_ln_b, g_b_out.  A lane owns rows mb * 32 + (lane & 31) and features nbase + 16 hi + r
+    // (two 8-feature chunks per feature block and row block); its dx values sit in the input panel at the slots its dx2 values
+    // take, so the panel is updated in place and leaves as whole rows.
+    char* xo_panel = lds + MLP_XN_OFF;
+    float* red = reinterpret_cast<float*>(lds + MLP_PRE_OFF);     // [2][PN_WAVES][64 rows]
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        mean[mb] = P.mean[row0 + mb * 32 + (lane & 31)];
+        rstd[mb] = P.rstd[row0 + mb * 32 + (lane & 31)];
+    }
+    uint4 xq[MLP_NBO][2][2];       // x_mid chunks, kept packed for the second pass
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    float cg = 0.f, cb = 0.f;      // lane (l & 31) = 16 nb + r: column sums of feature nbase(nb) + 16 hi + r
+#pragma unroll
+    for (int nb = 0; nb < MLP_NBO; ++nb) {
+        const int nbase = wave * (32 * MLP_NBO) + nb * 32;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                xq[nb][mb][p] = *reinterpret_cast<const uint4*>(P.x + (row0 + mb * 32 + (lane & 31)) * 512 + nbase + (2 * hi + p) * 8);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            pn_cfptr_t gp = (pn_cfptr_t)(uintptr_t)(P.gamma) + nbase + 8 * p;
+            float gam[8];
+            pn_uniform8(gp, gp + 16, hi, gam);
+            float dg[8], db[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { dg[e] = 0.f; db[e] = 0.f; }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                float xv[8];
+                pn_unpack8(xq[nb][mb][p], xv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (xv[e] - mean[mb]) * rstd[mb], dy = acc_o[nb][mb][8 * p + e], g = dy * gam[e];
+                    s1[mb] += g;
+                    s2[mb] += g * xh;
+                    dg[e] += dy * xh;
+                    db[e] += dy;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float tg = pn_half32_sum(dg[e]), tb = pn_half32_sum(db[e]);
+                const bool mine = (lane & 31) == 16 * nb + 8 * p + e;
+                cg = mine ? tg : cg;
+                cb = mine ? tb : cb;
+            }
+        }
+    }
+    {
+        const int n = wave * (32 * MLP_NBO) + ((lane & 31) >> 4) * 32 + 16 * hi + (lane & 15);
+        unsafeAtomicAdd(P.g_gamma + n, cg);
+        unsafeAtomicAdd(P.g_beta + n, cb);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const float t1 = pn_half_sum(s1[mb]), t2 = pn_half_sum(s2[mb]);
+        if (lane < 32) { red[wave * 64 + mb * 32 + lane] = t1; red[PN_WAVES * 64 + wave * 64 + mb * 32 + lane] = t2; }
+    }
+    __syncthreads();
+    float m1[2], m2[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < PN_WAVES; ++w) { t1 += red[w * 64 + mb * 32 + (lane & 31)]; t2 += red[PN_WAVES * 64 + w * 64 + mb * 32 + (lane & 31)]; }
+        m1[mb] = t1 * (1.0f / 512);
+        m2[mb] = t2 * (1.0f / 512);
+    }
+    float co = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < MLP_NBO; ++nb) {
+        const int nbase = wave * (32 * MLP_NBO) + nb * 32;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            pn_cfptr_t gp = (pn_cfptr_t)(uintptr_t)(P.gamma) + nbase + 8 * p;
+            float gam[8], ds[8];
+            pn_uniform8(gp, gp + 16, hi, gam);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ds[e] = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int m = mb * 32 + (lane & 31), ch = (nbase >> 3) + 2 * hi + p;
+                uint4* slot = reinterpret_cast<uint4*>(pn_panel_slot<1024>(xo_panel, m, ch));
+                float xv[8], rv[8], o[8];
+                pn_unpack8(xq[nb][mb][p], xv);
+                pn_unpack8(*slot, rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (xv[e] - mean[mb]) * rstd[mb], g = acc_o[nb][mb][8 * p + e] * gam[e];
+                    o[e] = rstd[mb] * (g - m1[mb] - xh * m2[mb]) + rv[e];
+                    ds[e] += o[e];
+                }
+                *slot = pn_pack8(o);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = pn_half32_sum(ds[e]);
+                co = (lane & 31) == 16 * nb + 8 * p + e ? t : co;
+            }
+        }
+    }
+    if (P.g_colsum) {
+        const int n = wave * (32 * MLP_NBO) + ((lane & 31) >> 4) * 32 + 16 * hi + (lane & 15);
+        unsafeAtomicAdd(P.g_colsum + n, co);
+    }
+    __syncthreads();
+}
+
 #ifdef TAN_PANEL_LAB
 __device__ long long* g_panel_dbg = nullptr;      // tools/lab: phase clocks of workgroup 0 (tan_panel_lab_set_dbg)
 #endif
@@ -681,120 +818,14 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     }
 
     } else {
-        // ---- backward epilogue: LayerNorm-2 backward of dxn (the f32 accumulator) + the residual gradient -> dx2; column sums
-        // over the panel's rows -> g_ln_g, g_ln_b, g_b_out.  A lane owns rows mb * 32 + (lane & 31) and features nbase + 16 hi + r
-        // (two 8-feature chunks per feature block and row block); its dx values sit in the input panel at the slots its dx2 values
-        // take, so the panel is updated in place and leaves as whole rows.
-        char* xo_panel = lds + MLP_XN_OFF;
-        float* red = reinterpret_cast<float*>(lds + MLP_PRE_OFF);     // [2][PN_WAVES][64 rows]
-        float mean[2], rstd[2];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            mean[mb] = a.mean2[row0 + mb * 32 + (lane & 31)];
-            rstd[mb] = a.rstd2[row0 + mb * 32 + (lane & 31)];
-        }
-        uint4 xq[MLP_NBO][2][2];       // x_mid chunks, kept packed for the second pass
-        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-        float cg = 0.f, cb = 0.f;      // lane (l & 31) = 16 nb + r: column sums of feature nbase(nb) + 16 hi + r
-#pragma unroll
-        for (int nb = 0; nb < MLP_NBO; ++nb) {
-            const int nbase = wave * (32 * MLP_NBO) + nb * 32;
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-                    xq[nb][mb][p] = *reinterpret_cast<const uint4*>(a.x_mid + (row0 + mb * 32 + (lane & 31)) * 512 + nbase + (2 * hi + p) * 8);
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                pn_cfptr_t gp = (pn_cfptr_t)(uintptr_t)(a.ln_g) + nbase + 8 * p;
-                float gam[8];
-                pn_uniform8(gp, gp + 16, hi, gam);
-                float dg[8], db[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { dg[e] = 0.f; db[e] = 0.f; }
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
-                    float xv[8];
-                    pn_unpack8(xq[nb][mb][p], xv);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float xh = (xv[e] - mean[mb]) * rstd[mb], dy = acc_o[nb][mb][8 * p + e], g = dy * gam[e];
-                        s1[mb] += g;
-                        s2[mb] += g * xh;
-                        dg[e] += dy * xh;
-                        db[e] += dy;
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float tg = pn_half32_sum(dg[e]), tb = pn_half32_sum(db[e]);
-                    const bool mine = (lane & 31) == 16 * nb + 8 * p + e;
-                    cg = mine ? tg : cg;
-                    cb = mine ? tb : cb;
-                }
-            }
-        }
-        {
-            const int n = wave * (32 * MLP_NBO) + ((lane & 31) >> 4) * 32 + 16 * hi + (lane & 15);
-            unsafeAtomicAdd(a.g_ln_g + n, cg);
-            unsafeAtomicAdd(a.g_ln_b + n, cb);
-        }
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            const float t1 = pn_half_sum(s1[mb]), t2 = pn_half_sum(s2[mb]);
-            if (lane < 32) { red[wave * 64 + mb * 32 + lane] = t1; red[PN_WAVES * 64 + wave * 64 + mb * 32 + lane] = t2; }
-        }
-        __syncthreads();
-        float m1[2], m2[2];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < PN_WAVES; ++w) { t1 += red[w * 64 + mb * 32 + (lane & 31)]; t2 += red[PN_WAVES * 64 + w * 64 + mb * 32 + (lane & 31)]; }
-            m1[mb] = t1 * (1.0f / 512);
-            m2[mb] = t2 * (1.0f / 512);
-        }
-        float co = 0.f;
-#pragma unroll
-        for (int nb = 0; nb < MLP_NBO; ++nb) {
-            const int nbase = wave * (32 * MLP_NBO) + nb * 32;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                pn_cfptr_t gp = (pn_cfptr_t)(uintptr_t)(a.ln_g) + nbase + 8 * p;
-                float gam[8], ds[8];
-                pn_uniform8(gp, gp + 16, hi, gam);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ds[e] = 0.f;
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
-                    const int m = mb * 32 + (lane & 31), ch = (nbase >> 3) + 2 * hi + p;
-                    uint4* slot = reinterpret_cast<uint4*>(pn_panel_slot<1024>(xo_panel, m, ch));
-                    float xv[8], rv[8], o[8];
-                    pn_unpack8(xq[nb][mb][p], xv);
-                    pn_unpack8(*slot, rv);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float xh = (xv[e] - mean[mb]) * rstd[mb], g = acc_o[nb][mb][8 * p + e] * gam[e];
-                        o[e] = rstd[mb] * (g - m1[mb] - xh * m2[mb]) + rv[e];
-                        ds[e] += o[e];
-                    }
-                    *slot = pn_pack8(o);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float t = pn_half32_sum(ds[e]);
-                    co = (lane & 31) == 16 * nb + 8 * p + e ? t : co;
-                }
-            }
-        }
-        {
-            const int n = wave * (32 * MLP_NBO) + ((lane & 31) >> 4) * 32 + 16 * hi + (lane & 15);
-            unsafeAtomicAdd(a.g_b_out + n, co);
-        }
-        __syncthreads();
-        pn_panel_copy_out<1024>(xo_panel, a.dx2 + row0 * 512, 512, wave, lane);
+        PnLnBwd P;
+        P.x = a.x_mid; P.mean = a.mean2; P.rstd = a.rstd2; P.gamma = a.ln_g; P.dadd = nullptr;
+        P.g_gamma = a.g_ln_g; P.g_beta = a.g_ln_b; P.g_colsum = a.g_b_out;
+        pn_ln_bwd_epilogue(acc_o, lds, P, row0, wave, lane);
+        pn_panel_copy_out<1024>(lds + MLP_XN_OFF, a.dx2 + row0 * 512, 512, wave, lane);
     }
 }
+
 
 }  // namespace tal
 
@@ -862,6 +893,7 @@ extern "C" int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream) {
     TAN_LAUNCH_CHECK();
     return 0;
 }
+
 
 #ifdef TAN_PANEL_LAB
 extern "C" int tan_panel_lab_set_dbg(void* p) {
