@@ -84,13 +84,13 @@ class _Flat:
         self.shadow_p, self.shadow_tp, self.pack_table, self.shadow_p_epoch, self.shadow_tp_epoch = None, None, None, -1, -1
 
     def _pack_tables(self):
-        """device tables of tan_pack_entry for the encoder Linear weights ([out, in]) and for their transposes ([in, out])"""
+        """device tables of tan_pack_entry for the MLP weights of every block ([out, in]) and for their transposes ([in, out])"""
         if self.pack_table is None:
             names = [n for n in self.names if ".resblocks." in n and len(self.off[n][2]) == 2]
 
             def table(transposed):
                 ents, mx = [], 0
-                for n in (names if not transposed else [n for n in names if ".mlp.c_" in n]):
+                for n in [n for n in names if ".mlp.c_" in n]:          # only the MLP weights have row-panel consumers
                     o, _, (N, K) = self.off[n]
                     if transposed:
                         N, K = K, N
@@ -430,7 +430,8 @@ class TemporalAligner(nn.Module):
                 setattr(arr[i], k, f.ptr(wbuf, base + v))
                 setattr(arr[i], "g_" + k, f.ptr(f.grad, base + v))
                 setattr(arr[i], "wt_" + k[2:], f.ptr(wt, base + v) if wt is not None else None)
-                setattr(arr[i], "wp_" + k[2:], f.ptr(wp, base + v) if wp is not None else None)
+                if k in ("w_fc", "w_proj"):
+                    setattr(arr[i], "wp_" + k[2:], f.ptr(wp, base + v) if wp is not None else None)
                 if k in ("w_fc", "w_proj"):
                     setattr(arr[i], "wtp_" + k[2:], f.ptr(wtp, base + v) if wtp is not None else None)
             for k, v in fm.items():
