@@ -105,6 +105,14 @@ int tan_l2norm_fwd(const void* x, void* y, float* inv_norm, long rows, int C, in
                    int dtype, void* stream);
 int tan_l2norm_bwd(const void* dy, const void* y, const float* inv_norm, void* dx, long rows, int C, int grp,
                    int dst_grp_rows, int dst_off, int dtype, void* stream);
+/* The same for up to 8 deep-supervision stages in ONE launch (tan_model.py:116-117,136-137 run per stage of the [B,S,T,C]
+ * features): stage s reads / scatters to its own buffer xs->p[s] / dxs->p[s]; y, dy [nstage][rows][C] and inv_norm
+ * [nstage][rows] are stage-major contiguous.                                                                             */
+typedef struct tan_ptr8 { const void* p[8]; } tan_ptr8;
+int tan_l2norm_fwd_multi(const tan_ptr8* xs, void* y, float* inv_norm, int nstage, long rows, int C, int grp,
+                         int src_grp_rows, int src_off, int dtype, void* stream);
+int tan_l2norm_bwd_multi(const void* dy, const void* y, const float* inv_norm, const tan_ptr8* dxs, int nstage, long rows,
+                         int C, int grp, int dst_grp_rows, int dst_off, int dtype, void* stream);
 
 /* ---- small HBM-bound helpers ----------------------------------------------------------------------------- */
 /* out[c] += sum_r x[r][c]  (nn.Linear bias gradients) */

@@ -114,6 +114,10 @@ class PackEntry(C.Structure):
     _fields_ = [("src_off", C.c_long), ("dst_off", C.c_long), ("N", C.c_int), ("K", C.c_int), ("TN", C.c_int), ("TK", C.c_int)]
 
 
+class Ptr8(C.Structure):
+    _fields_ = [("p", C.c_void_p * 8)]
+
+
 class MlpDesc(C.Structure):
     _fields_ = [
         ("rows", C.c_long), ("C", C.c_int), ("FF", C.c_int),

@@ -285,13 +285,18 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize(const float* __restrict__
 // ------------------------------------------------------------------------------------------------------
 // L2 normalisation over channels (no epsilon): tan_model.py:116-117,136-137.  Rows may be gathered from
 // / scattered to a grouped layout: src row = (r / grp) * src_grp_rows + src_off + r % grp.
+// blockIdx.y = stage: the deep-supervision stages are separate buffers (xs.p[stage]); outputs are stage-major contiguous.
+struct L2nPtrs { const void* p[8]; };
 template <typename T, int NCH>
-__global__ __launch_bounds__(256) void l2n_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ inv_o,
+__global__ __launch_bounds__(256) void l2n_fwd_kernel(L2nPtrs xs, T* __restrict__ y, float* __restrict__ inv_o,
                                                       long rows, int grp, int src_grp_rows, int src_off) {
     constexpr int C = NCH * 256;
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (r >= rows) return;
+    const T* __restrict__ x = (const T*)xs.p[blockIdx.y];
+    y += (long)blockIdx.y * rows * C;
+    if (inv_o) inv_o += (long)blockIdx.y * rows;
     const long sr = (r / grp) * src_grp_rows + src_off + r % grp;
     float4 v[NCH];
     float q = 0.f;
@@ -310,12 +315,16 @@ __global__ __launch_bounds__(256) void l2n_fwd_kernel(const T* __restrict__ x, T
 // dx = (dy - y * <y, dy>) * inv_norm, scattered back to the grouped layout (plain store)
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void l2n_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
-                                                      const float* __restrict__ inv_i, T* __restrict__ dx, long rows,
+                                                      const float* __restrict__ inv_i, L2nPtrs dxs, long rows,
                                                       int grp, int dst_grp_rows, int dst_off) {
     constexpr int C = NCH * 256;
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (r >= rows) return;
+    T* __restrict__ dx = (T*)dxs.p[blockIdx.y];
+    dy += (long)blockIdx.y * rows * C;
+    y += (long)blockIdx.y * rows * C;
+    inv_i += (long)blockIdx.y * rows;
     const long dr = (r / grp) * dst_grp_rows + dst_off + r % grp;
     float4 d[NCH], yv[NCH];
     float dot = 0.f;
@@ -666,25 +675,44 @@ extern "C" int tan_layernorm_bwd(const void* dy, const void* x, const float* gam
     return 0;
 }
 
+extern "C" int tan_l2norm_fwd_multi(const tan_ptr8* xs, void* y, float* inv_norm, int nstage, long rows, int C, int grp,
+                                    int src_grp_rows, int src_off, int dtype, void* stream) {
+    TAN_REQUIRE(xs && y && nstage >= 1 && nstage <= 8 && rows > 0 && grp > 0);
+    L2nPtrs ps{};
+    for (int i = 0; i < nstage; ++i) { TAN_REQUIRE(xs->p[i]); ps.p[i] = xs->p[i]; }
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, DISPATCH_NCH(C, hipLaunchKernelGGL((l2n_fwd_kernel<T, NCH>), dim3(cdiv(rows, ROWS_PER_BLOCK), nstage), dim3(256), 0,
+                                                         st, ps, (T*)y, inv_norm, rows, grp, src_grp_rows, src_off)));
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int tan_l2norm_fwd(const void* x, void* y, float* inv_norm, long rows, int C, int grp, int src_grp_rows,
                               int src_off, int dtype, void* stream) {
-    TAN_REQUIRE(x && y && rows > 0 && grp > 0);
+    TAN_REQUIRE(x);
+    tan_ptr8 xs{};
+    xs.p[0] = x;
+    return tan_l2norm_fwd_multi(&xs, y, inv_norm, 1, rows, C, grp, src_grp_rows, src_off, dtype, stream);
+}
+
+extern "C" int tan_l2norm_bwd_multi(const void* dy, const void* y, const float* inv_norm, const tan_ptr8* dxs, int nstage, long rows,
+                                    int C, int grp, int dst_grp_rows, int dst_off, int dtype, void* stream) {
+    TAN_REQUIRE(dy && y && inv_norm && dxs && nstage >= 1 && nstage <= 8 && rows > 0 && grp > 0);
+    L2nPtrs ps{};
+    for (int i = 0; i < nstage; ++i) { TAN_REQUIRE(dxs->p[i]); ps.p[i] = dxs->p[i]; }
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T(dtype, DISPATCH_NCH(C, hipLaunchKernelGGL((l2n_fwd_kernel<T, NCH>), dim3(cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0,
-                                                         st, (const T*)x, (T*)y, inv_norm, rows, grp, src_grp_rows, src_off)));
+    DISPATCH_T(dtype, DISPATCH_NCH(C, hipLaunchKernelGGL((l2n_bwd_kernel<T, NCH>), dim3(cdiv(rows, ROWS_PER_BLOCK), nstage), dim3(256), 0,
+                                                         st, (const T*)dy, (const T*)y, inv_norm, ps, rows, grp, dst_grp_rows, dst_off)));
     TAN_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int tan_l2norm_bwd(const void* dy, const void* y, const float* inv_norm, void* dx, long rows, int C, int grp,
                               int dst_grp_rows, int dst_off, int dtype, void* stream) {
-    TAN_REQUIRE(dy && y && inv_norm && dx && rows > 0 && grp > 0);
-    hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T(dtype, DISPATCH_NCH(C, hipLaunchKernelGGL((l2n_bwd_kernel<T, NCH>), dim3(cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0,
-                                                         st, (const T*)dy, (const T*)y, inv_norm, (T*)dx, rows, grp,
-                                                         dst_grp_rows, dst_off)));
-    TAN_LAUNCH_CHECK();
-    return 0;
+    TAN_REQUIRE(dx);
+    tan_ptr8 ds{};
+    ds.p[0] = dx;
+    return tan_l2norm_bwd_multi(dy, y, inv_norm, &ds, 1, rows, C, grp, dst_grp_rows, dst_off, dtype, stream);
 }
 
 extern "C" int tan_colsum_acc(const void* x, float* out, long rows, int C, int dtype, void* stream) {

@@ -108,6 +108,34 @@ def l2norm_bwd(dy, y, inv_norm, dx, rows, Cc, grp=None, dst_grp_rows=None, dst_o
     return dx
 
 
+def _ptr8(tensors):
+    if not 1 <= len(tensors) <= 8:
+        raise ValueError(f"1..8 stage buffers, got {len(tensors)}")
+    t = _lib.Ptr8()
+    for i, x in enumerate(tensors):
+        t.p[i] = x.data_ptr()
+    return t
+
+
+def l2norm_fwd_multi(xs, y, inv_norm, rows, Cc, grp=None, src_grp_rows=None, src_off=0):
+    """all stages of one feature family in one launch: xs = list of per-stage buffers, y [S, rows, C], inv_norm [S * rows] or None"""
+    grp = rows if grp is None else grp
+    t = _ptr8(xs)
+    _lib.check(_lib.lib().tan_l2norm_fwd_multi(C.byref(t), _ptr(y), _f32(inv_norm), C.c_int(len(xs)), C.c_long(rows), C.c_int(Cc),
+                                                C.c_int(grp), C.c_int(src_grp_rows if src_grp_rows is not None else grp),
+                                                C.c_int(src_off), _dt(y), _stream()), "tan_l2norm_fwd_multi")
+    return y
+
+
+def l2norm_bwd_multi(dy, y, inv_norm, dxs, rows, Cc, grp=None, dst_grp_rows=None, dst_off=0):
+    grp = rows if grp is None else grp
+    t = _ptr8(dxs)
+    _lib.check(_lib.lib().tan_l2norm_bwd_multi(_ptr(dy), _ptr(y), _f32(inv_norm), C.byref(t), C.c_int(len(dxs)), C.c_long(rows),
+                                                C.c_int(Cc), C.c_int(grp), C.c_int(dst_grp_rows if dst_grp_rows is not None else grp),
+                                                C.c_int(dst_off), _dt(y), _stream()), "tan_l2norm_bwd_multi")
+
+
+
 def colsum_acc(x, out, rows, Cc):
     _lib.check(_lib.lib().tan_colsum_acc(_ptr(x), _f32(out), C.c_long(rows), C.c_int(Cc), _dt(x), _stream()), "tan_colsum_acc")
     return out

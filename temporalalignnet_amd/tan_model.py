@@ -725,31 +725,39 @@ class TemporalAligner(nn.Module):
             lang_t, sv_text_t = self._text_embed(lang_c, True, p_t, itp, keep)
         else:
             lang_t, sv_text_t = lang_raw, None
-        # the two stacks are independent (tan_model.py:108-134): the joint stack runs on a side HIP stream next to the video
-        # stack, which fills the CUs left idle by each other's small kernels (attention, LayerNorm) and launch gaps
-        main, side = torch.cuda.current_stream(), self._side_stream(dev)
-        if side is not None:
-            side.wait_stream(main)
-            fut = self._on_side(side, lambda: self._run_joint_stack(x0j, lang_t, vmask_u8, tmask_u8, B, T, N))
-            ev = self._run_video_stack(x0, vmask_u8, B, T)
-            ej = fut.result()
-            main.wait_stream(side)
-        else:
-            ev = self._run_video_stack(x0, vmask_u8, B, T)
-            ej = self._run_joint_stack(x0j, lang_t, vmask_u8, tmask_u8, B, T, N)
         R, Mp, L = B * T, B * N, T + N
-        # L2-normalised features (tan_model.py:116-117,136-137)
+        # L2-normalised features (tan_model.py:116-117,136-137): all stages of a family in one launch, each family right behind the
+        # stack that feeds it and on that stack's stream -- 19 per-stage launches after the join sat on the critical path before
         vn_d = torch.empty(Se, R, Cw, dtype=cd, device=dev)
         vn_j = torch.empty(Sd, R, Cw, dtype=cd, device=dev)
         tn_d = torch.empty(Mp, Cw, dtype=cd, device=dev)
         tn_j = torch.empty(Sd, Mp, Cw, dtype=cd, device=dev)
         inv = _Blocks(torch.float32, dev, {"vd": Se * R, "vj": Sd * R, "td": Mp, "tj": Sd * Mp})
-        for s in range(Se):
-            ops.l2norm_fwd(ev.stage(s), vn_d[s], inv["vd"][s * R:(s + 1) * R], R, Cw)
-        ops.l2norm_fwd(lang_raw, tn_d, inv["td"], Mp, Cw)
-        for s in range(Sd):
-            ops.l2norm_fwd(ej.stage(s), vn_j[s], inv["vj"][s * R:(s + 1) * R], R, Cw, T, L, 0)
-            ops.l2norm_fwd(ej.stage(s), tn_j[s], inv["tj"][s * Mp:(s + 1) * Mp], Mp, Cw, N, L, T)
+
+        def video_side():
+            ev_ = self._run_video_stack(x0, vmask_u8, B, T)
+            ops.l2norm_fwd_multi([ev_.stage(s) for s in range(Se)], vn_d, inv["vd"], R, Cw)
+            ops.l2norm_fwd(lang_raw, tn_d, inv["td"], Mp, Cw)
+            return ev_
+
+        def joint_side():
+            ej_ = self._run_joint_stack(x0j, lang_t, vmask_u8, tmask_u8, B, T, N)
+            stages = [ej_.stage(s) for s in range(Sd)]
+            ops.l2norm_fwd_multi(stages, vn_j, inv["vj"], R, Cw, T, L, 0)
+            ops.l2norm_fwd_multi(stages, tn_j, inv["tj"], Mp, Cw, N, L, T)
+            return ej_
+        # the two stacks are independent (tan_model.py:108-134): the joint stack runs on a side HIP stream next to the video
+        # stack, which fills the CUs left idle by each other's small kernels (attention, LayerNorm) and launch gaps
+        main, side = torch.cuda.current_stream(), self._side_stream(dev)
+        if side is not None:
+            side.wait_stream(main)
+            fut = self._on_side(side, joint_side)
+            ev = video_side()
+            ej = fut.result()
+            main.wait_stream(side)
+        else:
+            ev = video_side()
+            ej = joint_side()
         if opts.get("fused"):
             # logits-free mode: hand the unit features to get_loss (tan_simnce_* never materialises [S,R,Mp])
             # (fresh view objects: the returned tensors must not be the objects kept in `run`, see _AlignerFn.forward)
@@ -832,9 +840,10 @@ class TemporalAligner(nn.Module):
             gt = g_tn.contiguous().view(Mp, Cw).to(cd)
             d_tn_d = gt if d_tn_d is None else d_tn_d + gt
         if d_vn_d is not None:
+            dst_all = torch.empty(Se, R, Cw, dtype=cd, device=dev)
             for s in range(Se):
-                dst_v[s] = torch.empty(R, Cw, dtype=cd, device=dev)
-                ops.l2norm_bwd(d_vn_d[s], run["vn_d"][s], inv["vd"][s * R:(s + 1) * R], dst_v[s], R, Cw)
+                dst_v[s] = dst_all[s]
+            ops.l2norm_bwd_multi(d_vn_d, run["vn_d"], inv["vd"], dst_v, R, Cw)
         if d_tn_d is not None:
             ops.l2norm_bwd(d_tn_d, run["tn_d"], inv["td"], d_lang_raw, Mp, Cw)
             have_lang_raw = True
@@ -852,10 +861,11 @@ class TemporalAligner(nn.Module):
             d_vn_j = g_vnj.contiguous().to(cd) if g_vnj is not None else torch.zeros(Sd, R, Cw, dtype=cd, device=dev)
             d_tn_j = g_tnj.contiguous().to(cd) if g_tnj is not None else torch.zeros(Sd, Mp, Cw, dtype=cd, device=dev)
         if d_vn_j is not None:
+            dst_all = torch.empty(Sd, B * L, Cw, dtype=cd, device=dev)
             for s in range(Sd):
-                dst_j[s] = torch.empty(B * L, Cw, dtype=cd, device=dev)
-                ops.l2norm_bwd(d_vn_j[s], run["vn_j"][s], inv["vj"][s * R:(s + 1) * R], dst_j[s], R, Cw, T, L, 0)
-                ops.l2norm_bwd(d_tn_j[s], run["tn_j"][s], inv["tj"][s * Mp:(s + 1) * Mp], dst_j[s], Mp, Cw, N, L, T)
+                dst_j[s] = dst_all[s]
+            ops.l2norm_bwd_multi(d_vn_j, run["vn_j"], inv["vj"], dst_j, R, Cw, T, L, 0)
+            ops.l2norm_bwd_multi(d_tn_j, run["tn_j"], inv["tj"], dst_j, Mp, Cw, N, L, T)
         # ---- alignability heads (tan_model.py:147-148)
         if self.use_alignability_head and (g_ad is not None or g_aj is not None):
             w = self._f("binary_head.weight").view(-1)
