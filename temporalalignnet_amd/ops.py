@@ -30,7 +30,9 @@ def _ptr(t):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw handle of torch's CURRENT stream on the current device; the public torch.cuda.current_stream() builds a Stream
+    # object through three Python layers (~3 us) and this is called once per launch (~120 times per training step)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def gemm(A, B, C_out, *, M, N, K, a_kc=True, b_kc=True, lda=None, ldb=None, ldc=None, bias=None, residual=None,
