@@ -204,11 +204,14 @@ int tan_masked_quantile(const float* x, const unsigned char* invalid, int n, flo
  *   TAN_SIM_SWEEP  the tile sweep (fwd: row sums += valid columns, column sums of this block -> colsum; bwd: d logits)
  *   TAN_SIM_ACC_ROWS  with SWEEP: keep accumulating into rowsum instead of zeroing it first
  *   TAN_SIM_DIAG   same-video blocks: positives + padded-frame quirk (only the block that holds the rows' own sentences)
- *   TAN_SIM_TERMS  (fwd) v_terms / t_terms from the final sums                                                            */
+ *   TAN_SIM_TERMS  (fwd) v_terms / t_terms from the final sums
+ *   TAN_SIM_DIAG_KEEP  (bwd, with DIAG) `ws` still holds the same-video blocks tan_simnce_fwd computed for these features: do
+ *                  not recompute them                                                                                      */
 #define TAN_SIM_SWEEP 1
 #define TAN_SIM_DIAG 2
 #define TAN_SIM_TERMS 4
 #define TAN_SIM_ACC_ROWS 8
+#define TAN_SIM_DIAG_KEEP 16
 long tan_simnce_ws_floats(int S, int B, int T, int N);
 int tan_simnce_max_cols(void);   /* most text columns (B*N, or Mc when compacted) one sweep accepts: callers fall back to tan_nce_* above it */
 int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,

@@ -299,8 +299,40 @@ static int simnce_common(SimArgs& a, int S, int B, int T, int N, int C) {
     return 0;
 }
 
-// same-video cosine blocks diag[s,b,t,n] = <vn[s,b*T+t], tn[s,b*N+n]> through the ordinary GEMM (batch = S*B... per stage)
+// same-video cosine blocks diag[s,b,t,n] = <vn[s,b*T+t], tn[s,b*N+n]>, C = 512: one workgroup per (video, stage), the N sentence
+// features in LDS, a wave per frame row with 8 channels per lane and a DPP reduction per (frame, sentence).  S*B*T*N*C MACs =
+// 0.4 G at B = 128: the 128 x 128-tile GEMM this replaces spent 73 us on it (one launch, 768 mostly-padding tiles) or 6 x 9 us
+// (shared text features: one launch per stage) on the critical loss chain.
+__global__ __launch_bounds__(256) void simnce_blocks_kernel(const bf16_t* __restrict__ V, const bf16_t* __restrict__ tn_blocks,
+                                                            long tb_stage_stride, float* __restrict__ diag, int B, int T, int N, long R) {
+    constexpr int C = 512;
+    extern __shared__ __attribute__((aligned(16))) char sm[];            // [N][C] bf16
+    const int b = blockIdx.x, s = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bf16_t* tb = tn_blocks + (long)s * tb_stage_stride + (long)b * N * C;
+    for (int i = threadIdx.x; i < N * (C / 8); i += 256) reinterpret_cast<uint4*>(sm)[i] = reinterpret_cast<const uint4*>(tb)[i];
+    __syncthreads();
+    float* out = diag + ((long)s * B + b) * T * N;
+    for (int t = wave; t < T; t += 4) {
+        const f8 v = ld8(V + ((long)s * R + (long)b * T + t) * C + lane * 8);
+        for (int n = 0; n < N; ++n) {
+            const f8 w = ld8(reinterpret_cast<const bf16_t*>(sm) + n * C + lane * 8);
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d = fmaf(v.v[j], w.v[j], d);
+            d = wave_sum(d);
+            if (lane == 0) out[t * N + n] = d;
+        }
+    }
+}
+
+// (other channel counts: through the ordinary GEMM, batch = S*B, or per stage when the text features are shared)
 static int simnce_diag_blocks(const SimArgs& a, const bf16_t* tn_blocks, long tb_stage_stride, float* diag, hipStream_t st) {
+    if (a.C == 512 && a.N * 1024 <= 64 * 1024 && (((uintptr_t)a.V | (uintptr_t)tn_blocks) % 16) == 0 && tb_stage_stride % 8 == 0) {
+        hipLaunchKernelGGL(simnce_blocks_kernel, dim3(a.B, a.S), dim3(256), (size_t)a.N * 1024, st, a.V, tn_blocks, tb_stage_stride, diag,
+                           a.B, a.T, a.N, (long)a.R);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : (int)e;
+    }
     // per-stage text features laid out back to back: (stage, video) is ONE batch index for all three operands
     const bool one_launch = tb_stage_stride == (long)a.B * a.N * a.C;
     for (int s = 0; s < (one_launch ? 1 : a.S); ++s) {
@@ -393,7 +425,7 @@ extern "C" int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_st
         TAN_LAUNCH_CHECK();
     }
     if (phases & TAN_SIM_DIAG) {
-        if ((rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;
+        if (!(phases & TAN_SIM_DIAG_KEEP) && (rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;
         hipLaunchKernelGGL((simnce_diag_kernel<true>), dim3(B, S), dim3(256), 0, st, diag, tgt, col_invalid, row_leak, (float*)rowsum,
                            (float*)colsum, (float*)possum_v, (float*)possum_t, g_v, g_t, (bf16_t*)dl, B, T, N, colmap, a.Mp);
     }

@@ -264,7 +264,7 @@ class _FusedNCEFn(torch.autograd.Function):
                                                 _p(row_leak), _p(rowsum), _p(colsum), _p(possum_v), _p(possum_t), _p(g_v),
                                                 _p(g_t), _p(dl), _p(ws), C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N),
                                                 C.c_int(Cw), _p(tn) if compact else None, C.c_long(0 if shared else Mp * Cw),
-                                                _p(colmap), C.c_int(Mc), C.c_int(0), ops._stream()), "tan_simnce_bwd_dl")
+                                                _p(colmap), C.c_int(Mc), C.c_int(1 | 2 | 16), ops._stream()), "tan_simnce_bwd_dl")   # SWEEP | DIAG | DIAG_KEEP: `ws` still holds the forward's same-video blocks
         d_vn = torch.empty_like(vn)
         ops.gemm(dl, tn_run, d_vn, M=R, N=Cw, K=Mc, a_kc=True, b_kc=False, lda=Mc, ldb=Cw, batch=S, sA=R * Mc,
                  sB=0 if shared else Mc * Cw, sC=R * Cw)
