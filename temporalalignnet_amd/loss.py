@@ -291,6 +291,45 @@ def _side_stream(dev):
     return st
 
 
+def prepare_inputs(input_data, video_padding_mask, text_padding_mask, T, N, dev, args, n_text_valid=None, want_compaction=False):
+    """Everything get_loss derives from the BATCH alone (train/loss.py:58-70,236-237): pad masks in the kernels' formats, the
+    start/end target, and -- when no self-labelling rewrites the target -- the positive row / column masks and the text-column
+    compaction.  ~20 tiny launches that do not depend on the model: the training driver issues them on a side stream next to the
+    forward (`Trainer.forward_backward`), get_loss computes them itself otherwise."""
+    B = text_padding_mask.shape[0]
+    tpad = text_padding_mask.to(dev).bool()
+    tpad_u8 = tpad.to(torch.uint8).contiguous()
+    vpad_u8 = video_padding_mask.to(dev).bool().to(torch.uint8).contiguous()
+    valid = (~tpad).view(B * N)
+    prep = {"tpad": tpad, "tpad_u8": tpad_u8, "vpad_u8": vpad_u8, "valid": valid, "valid_f": valid.float()}
+    tgt_raw = input_data.get("_tgt_raw") if isinstance(input_data, dict) else None
+    if tgt_raw is None:
+        tgt_raw, _, _ = get_mask_from_time(input_data["start"], input_data["end"], T, N, device=dev)   # [B,N,T] bool
+    prep["tgt_raw"] = tgt_raw
+    if not args.learn_agreement:
+        prep["tgt"] = tgt_raw.permute(0, 2, 1).float().contiguous()                                   # [B,T,N]
+        prep["rows_pos"], prep["cols_pos"] = _pos_masks(prep["tgt"], tpad_u8, B, T, N)
+    if want_compaction:
+        prep["nv"], prep["nv_for"] = compaction_prep(tpad_u8.view(B * N), n_text_valid), n_text_valid
+    return prep
+
+
+def prepare_inputs_async(input_data, video_padding_mask, text_padding_mask, T, N, dev, args, n_text_valid=None, want_compaction=False):
+    """prepare_inputs on the loss side stream; the result carries the event and the tensor list get_loss joins on."""
+    main, side = torch.cuda.current_stream(), _side_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        prep = prepare_inputs(input_data, video_padding_mask, text_padding_mask, T, N, dev, args, n_text_valid, want_compaction)
+        prep["_event"] = side.record_event()
+    flat = []
+    for v in prep.values():
+        for x in (v if isinstance(v, (tuple, list)) else (v,)):
+            if torch.is_tensor(x) and x.is_cuda:
+                flat.append(x)
+    prep["_tensors"] = flat
+    return prep
+
+
 def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding_mask, logits, args, abs_text_pos=None,
              return_aux=False):
     """Reference signature (train/loss.py:55-57); returns the reference's loss_dict ('loss' carries the graph)."""
@@ -309,17 +348,17 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
         blk_d, blk_j = _Blocks.of_logits(lg_d.detach(), B, T, N), _Blocks.of_logits(lg_j.detach(), B, T, N)
     else:
         blk_d = blk_j = None                        # built lazily from the features below
-    tpad = text_padding_mask.to(dev).bool()
-    tpad_u8 = tpad.to(torch.uint8).contiguous()
-    vpad = video_padding_mask.to(dev).bool()
-    vpad_u8 = vpad.to(torch.uint8).contiguous()
-    valid = (~tpad).view(Mp)
-    valid_f = valid.float()
+    prep = input_data.get("_loss_prep") if isinstance(input_data, dict) else None
+    if prep is not None:             # computed ahead by the training driver on a side stream (prepare_inputs): join it here
+        main = torch.cuda.current_stream()
+        main.wait_event(prep["_event"])
+        for v in prep["_tensors"]:
+            v.record_stream(main)
+    else:
+        prep = prepare_inputs(input_data, video_padding_mask, text_padding_mask, T, N, dev, args)
+    tpad, tpad_u8, vpad_u8, valid, valid_f, tgt_raw = (prep[k] for k in ("tpad", "tpad_u8", "vpad_u8", "valid", "valid_f", "tgt_raw"))
     out, aux = {}, {}
 
-    tgt_raw = input_data.get("_tgt_raw") if isinstance(input_data, dict) else None
-    if tgt_raw is None:
-        tgt_raw, _, _ = get_mask_from_time(input_data["start"], input_data["end"], T, N, device=dev)   # [B,N,T] bool
     row_leak = None
     if args.learn_agreement:
         with torch.no_grad():
@@ -354,10 +393,9 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
             aux.update(max_position_joint=J["max_pos"], max_position_dual=D["max_pos"], max_logits_joint=J["max_logit"],
                        max_logits_dual=D["max_logit"], joint_self_tgt=J["tgt"], dual_self_tgt=D["tgt"], iou=iou,
                        confidence_mask=conf, agreement_tgt=tgt)
+        rows_pos, cols_pos = _pos_masks(tgt, tpad_u8, B, T, N)                                        # loss.py:236-237
     else:
-        tgt = tgt_raw.permute(0, 2, 1).float().contiguous()                                           # [B,T,N]
-
-    rows_pos, cols_pos = _pos_masks(tgt, tpad_u8, B, T, N)                                            # loss.py:236-237
+        tgt, rows_pos, cols_pos = prep["tgt"], prep["rows_pos"], prep["cols_pos"]                     # [B,T,N]; loss.py:236-237
 
     nce_counts = None            # global (all-rank) mask sums in global-negatives mode, else the tail kernel counts locally
     ci = tpad_u8.view(Mp)
@@ -372,7 +410,8 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
         nce_counts = global_counts(rows_pos, cols_pos)
     else:
         # host-side count of real sentences (no sync), or None: padded text columns are then skipped by both sweeps
-        nv = compaction_prep(ci, getattr(fused, "n_text_valid", None))
+        n_text_valid = getattr(fused, "n_text_valid", None)
+        nv = prep["nv"] if ("nv" in prep and prep["nv_for"] == n_text_valid) else compaction_prep(ci, n_text_valid)
         # The dual and joint similarity sweeps are independent until the final mean: the joint one runs on a second HIP
         # stream (each sweep alone fills 75 % of the workgroup slots).  autograd replays a node's backward on the stream its
         # forward ran on and synchronises producer/consumer streams itself, so the two backward chains (d-logits + the two

@@ -230,6 +230,15 @@ class Trainer:
                 if self.global_negatives:
                     raise _lib.TanHipError(f"global_negatives: {Bn}x{Nn} text columns per rank exceed the fused sweep's limit")
                 fused = False
+        if batch["video"].is_cuda and os.environ.get("TAN_LOSS_STREAMS", "1") != "0":
+            # what get_loss derives from the batch alone (masks, targets, column compaction: ~20 tiny launches) runs on the loss
+            # side stream next to the forward instead of between the stacks and the similarity sweeps
+            from .loss import prepare_inputs_async
+            batch = dict(batch)
+            Tn, Nn = batch["video"].shape[1], batch["text_embed"].shape[1]
+            batch["_loss_prep"] = prepare_inputs_async(batch, batch["padding_mask"], batch["text_padding_mask"], Tn, Nn,
+                                                       batch["video"].device, a, batch.get("n_text"),
+                                                       want_compaction=bool(fused) and not self.global_negatives)
         logits = m(batch["video"], batch["text_embed"], video_padding_mask=batch["padding_mask"],
                    lang_padding_mask=batch["text_padding_mask"].bool(), text_timestamp=batch.get("_tgt_raw"),
                    abs_text_pos=batch.get("abs_text_pos"), fused=fused)
