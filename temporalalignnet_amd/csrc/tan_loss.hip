@@ -362,18 +362,33 @@ __global__ __launch_bounds__(1024) void nce_tail_fwd_kernel(const float* __restr
                                                             float* __restrict__ counts, const float* __restrict__ counts_in) {
     __shared__ float red[16];
     float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // sum v_d, t_d, v_j, t_j, n_r, n_c
-    for (long r = threadIdx.x; r < R; r += 1024) {
-        const float m = rmask[r];
-        a[4] += m;
-        for (int s = 0; s < Sd; ++s) a[0] += v_d[(long)s * R + r] * m;
-        for (int s = 0; s < Sj; ++s) a[2] += v_j[(long)s * R + r] * m;
-    }
-    for (long c = threadIdx.x; c < M; c += 1024) {
-        const float m = cmask[c];
-        a[5] += m;
-        for (int s = 0; s < Sd; ++s) a[1] += t_d[(long)s * M + c] * m;
-        for (int s = 0; s < Sj; ++s) a[3] += t_j[(long)s * M + c] * m;
-    }
+    // one block (deterministic sums); eight rows per thread with their loads issued together -- row by row, each of the
+    // Sd + Sj dependent-looking loads paid a full memory latency (36 us for 8192 rows x 12 stages on the loss's critical path)
+    constexpr int U = 8;
+    auto masked_sums = [&](const float* __restrict__ xd, const float* __restrict__ xj, const float* __restrict__ mask, long n, float& sd,
+                           float& sj, float& cnt) {
+        for (long r0 = threadIdx.x; r0 < n; r0 += 1024 * U) {
+            float m[U];
+            long rr[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const long r = r0 + (long)k * 1024;
+                rr[k] = r < n ? r : n - 1;
+                m[k] = r < n ? mask[rr[k]] : 0.f;
+                cnt += m[k];
+            }
+            for (int st = 0; st < Sd; ++st) {
+#pragma unroll
+                for (int k = 0; k < U; ++k) sd += xd[(long)st * n + rr[k]] * m[k];
+            }
+            for (int st = 0; st < Sj; ++st) {
+#pragma unroll
+                for (int k = 0; k < U; ++k) sj += xj[(long)st * n + rr[k]] * m[k];
+            }
+        }
+    };
+    masked_sums(v_d, v_j, rmask, R, a[0], a[2], a[4]);
+    masked_sums(t_d, t_j, cmask, M, a[1], a[3], a[5]);
     float tot[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) tot[i] = block_sum_1024(a[i], red);

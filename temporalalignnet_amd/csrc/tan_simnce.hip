@@ -204,7 +204,8 @@ __global__ void simnce_col_finalize(const float* __restrict__ colpart, float* __
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= SM) return;
     float s = 0.f;
-    for (int k = 0; k < npanel; ++k) s += colpart[(long)k * SM + i];
+#pragma unroll 16
+    for (int k = 0; k < npanel; ++k) s += colpart[(long)k * SM + i];      // (independent loads: sixteen in flight)
     colsum[i] = s;
 }
 
@@ -382,7 +383,7 @@ extern "C" int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_strid
         hipLaunchKernelGGL((simnce_kernel<0>), dim3(npanel, S), dim3(256), 0, st, a);
         prof_end(st, prec);
         TAN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(simnce_col_finalize, dim3(cdiv(SM, 256)), dim3(256), 0, st, a.colpart, colsum, npanel, SM);
+        hipLaunchKernelGGL(simnce_col_finalize, dim3(cdiv(SM, 64)), dim3(64), 0, st, a.colpart, colsum, npanel, SM);
     }
     if (phases & TAN_SIM_DIAG) {
         if ((rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;
