@@ -579,7 +579,7 @@ class TemporalAligner(nn.Module):
         ops.layernorm_bwd(d_x0, sv["proj"], self._f("ln_video_init.weight"), sv["mean"], sv["rstd"], d_proj,
                           self._g("ln_video_init.weight"), self._g("ln_video_init.bias"))
         ops.gemm(d_proj, video_c, self._g("video_pre_proj.weight"), M=WIDTH, N=Dv, K=R, a_kc=False, b_kc=False,
-                 lda=WIDTH, ldb=Dv, accumulate=True, split_k=max(1, min(32, R // 256)))
+                 lda=WIDTH, ldb=Dv, accumulate=True, split_k=max(1, min(32, R // 1024)))      # K-slices >= 1024 rows: the 4-stage K-strided kernel
         d_pos = torch.empty(T, WIDTH, dtype=cd, device=dev)
         ops.group_sum(d_x0, d_pos, B, T, WIDTH)
         self._pos_ln_bwd(sv["pos"], d_pos)
