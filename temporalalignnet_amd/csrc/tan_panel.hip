@@ -85,6 +85,9 @@ struct MlpBwdArgs {
 // LDS and re-loads the ring slot it just consumed.  One barrier per body hands hidden chunk c over (written by all waves, read
 // by all waves in body(c+1)); the two hidden-panel buffers alternate.
 constexpr int MLP_KDF = 32, MLP_KDP = 16, MLP_TILE = 16384, MLP_TF = 512 / MLP_KDF, MLP_TP = 256 / MLP_KDP;
+#ifndef TAN_HPRE_STEP
+#define TAN_HPRE_STEP 2
+#endif
 #ifndef TAN_MLP_D
 #define TAN_MLP_D 4
 #endif
@@ -210,7 +213,7 @@ __device__ __forceinline__ void mlp_epi_p3(MlpEpiState& E, const f32x16 (&acc_h)
 // from HBM in the accumulator's layout (16 consecutive features of a row = two 16-byte loads per row block), issued under the
 // c_fc-like phase of the same chunk.
 struct MlpHPre { uint4 q[2][2]; };       // [row block][8-feature half]
-struct MlpBwdEpi { float x[2], ce[2], cs[2], colacc; uint32_t w[2][4]; };
+struct MlpBwdEpi { float x[2], ce[2], cs[16]; uint32_t w[2][4]; };
 template <int MB, int HALF>
 __device__ __forceinline__ void mlp_hpre_load(MlpHPre& H, const bf16_t* h_pre, long row0, int c, int wave, int lane) {
     H.q[MB][HALF] = *reinterpret_cast<const uint4*>(h_pre + (row0 + MB * 32 + (lane & 31)) * 2048 + c * 256 + wave * 32 + 16 * (lane >> 5) + 8 * HALF);
@@ -222,6 +225,34 @@ __device__ __forceinline__ float pn_half32_sum(float v) {      // sum over the 3
     v += dpp_move<0x140>(v);     // row_mirror
     auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
     return __int_as_float(r16[0]) + __int_as_float(r16[1]);
+}
+// Sums of 16 per-lane values over the 32 lanes that share lane >> 5, 38 instructions instead of 16 x 6: every level adds the
+// partner lane's value for two values at once and keeps one of them per lane (v_permlane16_swap does both in one go for the
+// lanes 16 apart; then row_ror:8, row_half_mirror, quad_perm [1,0,3,2], and a last quad_perm [2,3,0,1] add).  Lane l ends up
+// with the total of value index ((l >> 4) & 1) | ((l >> 3) & 1) << 1 | ((l >> 2) & 1) << 2 | (l & 1) << 3 (lanes l and l ^ 2 hold the same).
+__device__ __forceinline__ float pn_colsum16(const float (&v)[16], int lane) {
+    float w[8], u[4], y[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v[2 * i]), __float_as_int(v[2 * i + 1]), false, false);
+        w[i] = __int_as_float(r[0]) + __int_as_float(r[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float t0 = w[2 * j] + dpp_move<0x128>(w[2 * j]), t1 = w[2 * j + 1] + dpp_move<0x128>(w[2 * j + 1]);     // row_ror:8
+        u[j] = (lane & 8) ? t1 : t0;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float x0 = u[2 * k] + dpp_move<0x141>(u[2 * k]), x1 = u[2 * k + 1] + dpp_move<0x141>(u[2 * k + 1]);      // row_half_mirror
+        y[k] = (lane & 4) ? x1 : x0;
+    }
+    const float z0 = y[0] + dpp_move<0xB1>(y[0]), z1 = y[1] + dpp_move<0xB1>(y[1]);                                   // quad_perm [1,0,3,2]
+    const float zz = (lane & 1) ? z1 : z0;
+    return zz + dpp_move<0x4E>(zz);                                                                                  // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ int pn_colsum16_index(int lane) {
+    return ((lane >> 4) & 1) | (((lane >> 3) & 1) << 1) | (((lane >> 2) & 1) << 2) | ((lane & 1) << 3);
 }
 template <int J>
 __device__ __forceinline__ void mlp_bepi_p1(MlpBwdEpi& E, const MlpHPre& H) {
@@ -240,19 +271,18 @@ __device__ __forceinline__ void mlp_bepi_p2(MlpBwdEpi& E) {
 template <int J>
 __device__ __forceinline__ void mlp_bepi_p3(MlpBwdEpi& E, const f32x16 (&acc_h)[MLP_NBH][2], char* lds, int hb, int wave, int lane) {
     constexpr int mb = J & 1, q = J >> 1;
-    float d[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float sg = E.ce[i], t = 1.702f * E.x[i] * sg;
-        d[i] = acc_h[0][mb][2 * q + i] * fmaf(t, 1.0f - sg, sg);      // quickgelu'(x) = s + 1.702 x s (1 - s)
-    }
+    // quickgelu'(x) = s + 1.702 x s (1 - s), two values per packed-f32 instruction (v_pk_mul_f32 / v_pk_fma_f32)
+    typedef float pn_f2 __attribute__((ext_vector_type(2)));
+    const pn_f2 xx = {E.x[0], E.x[1]}, sg = {E.ce[0], E.ce[1]}, av = {acc_h[0][mb][2 * q], acc_h[0][mb][2 * q + 1]};
+    const pn_f2 t = (xx * 1.702f) * sg;
+    const pn_f2 dd = av * (t * (1.0f - sg) + sg);
+    const float d[2] = {dd[0], dd[1]};
     E.w[mb][q & 3] = f2bf2(d[0], d[1]);
+    // the lane's share of the c_fc bias gradient (two rows per feature); reduced over the 32 lanes once per chunk (pn_colsum16)
     if constexpr (mb == 0) {
-        E.cs[0] = d[0]; E.cs[1] = d[1];
+        E.cs[2 * q] = d[0]; E.cs[2 * q + 1] = d[1];
     } else {
-        const float r0 = pn_half32_sum(E.cs[0] + d[0]), r1 = pn_half32_sum(E.cs[1] + d[1]);
-        // lane (l & 31) = f keeps the total of the wave's feature 16 hi + f: one atomic per chunk (mlp_bwd flush), no branch here
-        E.colacc = (lane & 31) == 2 * q ? r0 : ((lane & 31) == 2 * q + 1 ? r1 : E.colacc);
+        E.cs[2 * q] += d[0]; E.cs[2 * q + 1] += d[1];
     }
     if constexpr ((q & 3) == 3) {
         const int ch = (wave * 32 >> 3) + 2 * (lane >> 5) + (q >> 2), m = mb * 32 + (lane & 31);
@@ -538,8 +568,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     MlpBias32 B32;           // bias of the next chunk: loaded before a slot barrier, consumed right after it (mlp_init_h)
     MlpHPre HP;              // backward: pre-activations of the chunk in the accumulator layout
     MlpBwdEpi BE;
-    if constexpr (BWD) BE.colacc = 0.f;
-    else mlp_bias32_load(B32, a.b_fc, 0, wave);
+    if constexpr (!BWD) mlp_bias32_load(B32, a.b_fc, 0, wave);
     static_assert(MLP_NBO == 2 && MLP_WFR == 2, "eight waves");
     MlpXAddr XA;
     mlp_xaddr_init(XA, lds, lane);
@@ -562,10 +591,14 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
             }
             if (!(MODE & 1)) mlp_mma_fc(WQ[J % D], cur, acc_h);
             if constexpr (BWD) {        // pre-activations of THIS chunk, consumed by the epilogue a phase later
-                if constexpr (J == 2) mlp_hpre_load<0, 0>(HP, a.h_pre, row0, c, wave, lane);
-                if constexpr (J == 6) mlp_hpre_load<1, 0>(HP, a.h_pre, row0, c, wave, lane);
-                if constexpr (J == 10) mlp_hpre_load<0, 1>(HP, a.h_pre, row0, c, wave, lane);
-                if constexpr (J == 14) mlp_hpre_load<1, 1>(HP, a.h_pre, row0, c, wave, lane);
+                // all four together: each is a cold HBM read in the in-order vmcnt queue in front of the weight ring, and the
+                // ring stalls once per batch of them, not once per load
+                if constexpr (J == TAN_HPRE_STEP) {
+                    mlp_hpre_load<0, 0>(HP, a.h_pre, row0, c, wave, lane);
+                    mlp_hpre_load<1, 0>(HP, a.h_pre, row0, c, wave, lane);
+                    mlp_hpre_load<0, 1>(HP, a.h_pre, row0, c, wave, lane);
+                    mlp_hpre_load<1, 1>(HP, a.h_pre, row0, c, wave, lane);
+                }
             } else if constexpr (COPY) {
                 if (!(MODE & (8 | 16))) mlp_copy_step4<J, false, (MODE & 128) != 0>(CP, lds, a.h_pre, row0, c - 1);
             }
@@ -621,7 +654,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
             if constexpr (PROJ) { if (!(MODE & 1)) acc_o[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[1], cur.f[0], acc_o[1][0], 0, 0, 0); }
             if constexpr (ARITH && BWD) {
                 mlp_bepi_p3<J>(BE, acc_h, lds, hb, wave, lane);
-                asm volatile("" : "+v"(acc_o[1][1]), "+v"(BE.w[J & 1][(J >> 1) & 3]), "+v"(BE.colacc));
+                asm volatile("" : "+v"(acc_o[1][1]), "+v"(BE.w[J & 1][(J >> 1) & 3]), "+v"(BE.cs[2 * (J >> 1)]), "+v"(BE.cs[2 * (J >> 1) + 1]));
             } else if constexpr (ARITH) {
                 mlp_epi_p3<J>(ES, acc_h, lds, hb, wave, lane);
                 asm volatile("" : "+v"(acc_o[1][1]), "+v"(ES.pre[J & 3]), "+v"(ES.act[J & 3]));
@@ -676,8 +709,9 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
         }
     };
     auto after_epi = [&](int c) __attribute__((always_inline)) {   // after the epilogue of chunk c, before the slot barrier
-        if constexpr (BWD) {       // c_fc bias gradient: lanes 0-15 of each half hold the column sums of the wave's 32 features
-            if ((lane & 31) < 16) unsafeAtomicAdd(a.g_b_fc + c * 256 + wave * 32 + 16 * hi + (lane & 31), BE.colacc);
+        if constexpr (BWD) {       // c_fc bias gradient: column sums of the wave's 32 features over the panel's 64 rows
+            const float tot = pn_colsum16(BE.cs, lane);
+            if (!(lane & 2)) unsafeAtomicAdd(a.g_b_fc + c * 256 + wave * 32 + 16 * hi + pn_colsum16_index(lane), tot);
         } else {
             mlp_bias32_load(B32, a.b_fc, min(c + 1, 7), wave);
         }
