@@ -226,34 +226,6 @@ __device__ __forceinline__ float pn_half32_sum(float v) {      // sum over the 3
     auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
     return __int_as_float(r16[0]) + __int_as_float(r16[1]);
 }
-// Sums of 16 per-lane values over the 32 lanes that share lane >> 5, 38 instructions instead of 16 x 6: every level adds the
-// partner lane's value for two values at once and keeps one of them per lane (v_permlane16_swap does both in one go for the
-// lanes 16 apart; then row_ror:8, row_half_mirror, quad_perm [1,0,3,2], and a last quad_perm [2,3,0,1] add).  Lane l ends up
-// with the total of value index ((l >> 4) & 1) | ((l >> 3) & 1) << 1 | ((l >> 2) & 1) << 2 | (l & 1) << 3 (lanes l and l ^ 2 hold the same).
-__device__ __forceinline__ float pn_colsum16(const float (&v)[16], int lane) {
-    float w[8], u[4], y[2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v[2 * i]), __float_as_int(v[2 * i + 1]), false, false);
-        w[i] = __int_as_float(r[0]) + __int_as_float(r[1]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float t0 = w[2 * j] + dpp_move<0x128>(w[2 * j]), t1 = w[2 * j + 1] + dpp_move<0x128>(w[2 * j + 1]);     // row_ror:8
-        u[j] = (lane & 8) ? t1 : t0;
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const float x0 = u[2 * k] + dpp_move<0x141>(u[2 * k]), x1 = u[2 * k + 1] + dpp_move<0x141>(u[2 * k + 1]);      // row_half_mirror
-        y[k] = (lane & 4) ? x1 : x0;
-    }
-    const float z0 = y[0] + dpp_move<0xB1>(y[0]), z1 = y[1] + dpp_move<0xB1>(y[1]);                                   // quad_perm [1,0,3,2]
-    const float zz = (lane & 1) ? z1 : z0;
-    return zz + dpp_move<0x4E>(zz);                                                                                  // quad_perm [2,3,0,1]
-}
-__device__ __forceinline__ int pn_colsum16_index(int lane) {
-    return ((lane >> 4) & 1) | (((lane >> 3) & 1) << 1) | (((lane >> 2) & 1) << 2) | ((lane & 1) << 3);
-}
 template <int J>
 __device__ __forceinline__ void mlp_bepi_p1(MlpBwdEpi& E, const MlpHPre& H) {
     constexpr int mb = J & 1, q = J >> 1;

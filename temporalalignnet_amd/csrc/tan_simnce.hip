@@ -307,29 +307,43 @@ static int simnce_common(SimArgs& a, int S, int B, int T, int N, int C) {
 __global__ __launch_bounds__(256) void simnce_blocks_kernel(const bf16_t* __restrict__ V, const bf16_t* __restrict__ tn_blocks,
                                                             long tb_stage_stride, float* __restrict__ diag, int B, int T, int N, long R) {
     constexpr int C = 512;
-    extern __shared__ __attribute__((aligned(16))) char sm[];            // [N][C] bf16
+    extern __shared__ __attribute__((aligned(16))) char sm[];            // [N rounded up to 16][C] bf16, zero rows past N
     const int b = blockIdx.x, s = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Np = (N + 15) & ~15;
     const bf16_t* tb = tn_blocks + (long)s * tb_stage_stride + (long)b * N * C;
-    for (int i = threadIdx.x; i < N * (C / 8); i += 256) reinterpret_cast<uint4*>(sm)[i] = reinterpret_cast<const uint4*>(tb)[i];
+    for (int i = threadIdx.x; i < Np * (C / 8); i += 256)
+        reinterpret_cast<uint4*>(sm)[i] = i < N * (C / 8) ? reinterpret_cast<const uint4*>(tb)[i] : make_uint4(0, 0, 0, 0);
     __syncthreads();
     float* out = diag + ((long)s * B + b) * T * N;
-    for (int t = wave; t < T; t += 4) {
+    // blockIdx.z: 64 frame rows, 16 per wave; 16 sentences at a time: per-lane partial dots, one butterfly reduction for all 16
+    for (int i = 0; i < 16; ++i) {
+        const int t = blockIdx.z * 64 + wave * 16 + i;
+        if (t >= T) break;                                               // wave-uniform
         const f8 v = ld8(V + ((long)s * R + (long)b * T + t) * C + lane * 8);
-        for (int n = 0; n < N; ++n) {
-            const f8 w = ld8(reinterpret_cast<const bf16_t*>(sm) + n * C + lane * 8);
-            float d = 0.f;
+        for (int n0 = 0; n0 < Np; n0 += 16) {
+            float p[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d = fmaf(v.v[j], w.v[j], d);
-            d = wave_sum(d);
-            if (lane == 0) out[t * N + n] = d;
+            for (int n = 0; n < 16; ++n) {
+                const f8 w = ld8(reinterpret_cast<const bf16_t*>(sm) + (n0 + n) * C + lane * 8);
+                float d = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d = fmaf(v.v[j], w.v[j], d);
+                p[n] = d;
+            }
+            float tot = pn_colsum16(p, lane);                            // sums over each 32-lane half ...
+            auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_int(tot), __float_as_int(tot), false, false);
+            tot = __int_as_float(r32[0]) + __int_as_float(r32[1]);       // ... and over both
+            const int n = n0 + pn_colsum16_index(lane);
+            if (lane < 32 && !(lane & 2) && n < N) out[t * N + n] = tot;
         }
     }
 }
 
 // (other channel counts: through the ordinary GEMM, batch = S*B, or per stage when the text features are shared)
 static int simnce_diag_blocks(const SimArgs& a, const bf16_t* tn_blocks, long tb_stage_stride, float* diag, hipStream_t st) {
-    if (a.C == 512 && a.N * 1024 <= 64 * 1024 && (((uintptr_t)a.V | (uintptr_t)tn_blocks) % 16) == 0 && tb_stage_stride % 8 == 0) {
-        hipLaunchKernelGGL(simnce_blocks_kernel, dim3(a.B, a.S), dim3(256), (size_t)a.N * 1024, st, a.V, tn_blocks, tb_stage_stride, diag,
+    const int Np = (a.N + 15) & ~15;
+    if (a.C == 512 && Np * 1024 <= 64 * 1024 && (((uintptr_t)a.V | (uintptr_t)tn_blocks) % 16) == 0 && tb_stage_stride % 8 == 0) {
+        hipLaunchKernelGGL(simnce_blocks_kernel, dim3(a.B, a.S, cdiv(a.T, 64)), dim3(256), (size_t)Np * 1024, st, a.V, tn_blocks, tb_stage_stride, diag,
                            a.B, a.T, a.N, (long)a.R);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : (int)e;
