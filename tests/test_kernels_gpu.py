@@ -77,6 +77,33 @@ def test_l2norm_grouped(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_l2norm_multi_equals_one_launch_per_stage(dtype):
+    """tan_l2norm_fwd/bwd_multi: S stage buffers in one launch == S single launches, bit for bit (same kernel, blockIdx.y = stage)."""
+    from temporalalignnet_amd import ops
+    S, B, T, N, C = 3, 3, 5, 4, 512
+    L = T + N
+    xs = [rnd((B * L, C), dtype, 20 + s) for s in range(S)]
+    for grp, off in ((T, 0), (N, T)):
+        rows = B * grp
+        y1, y2 = (torch.empty(S, rows, C, device="cuda", dtype=dtype) for _ in range(2))
+        i1, i2 = (torch.empty(S * rows, device="cuda") for _ in range(2))
+        for s in range(S):
+            ops.l2norm_fwd(xs[s], y1[s], i1[s * rows:(s + 1) * rows], rows, C, grp, L, off)
+        ops.l2norm_fwd_multi(xs, y2, i2, rows, C, grp, L, off)
+        assert torch.equal(y1, y2) and torch.equal(i1, i2)
+        dy = rnd((S, rows, C), dtype, 30)
+        d1 = [torch.zeros(B * L, C, device="cuda", dtype=dtype) for _ in range(S)]
+        d2 = [torch.zeros(B * L, C, device="cuda", dtype=dtype) for _ in range(S)]
+        for s in range(S):
+            ops.l2norm_bwd(dy[s], y1[s], i1[s * rows:(s + 1) * rows], d1[s], rows, C, grp, L, off)
+        ops.l2norm_bwd_multi(dy, y2, i2, d2, rows, C, grp, L, off)
+        for a, b in zip(d1, d2):
+            assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        ops.l2norm_fwd_multi([xs[0]] * 9, y2, i2, rows, C, grp, L, off)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_small_helpers(dtype):
     from temporalalignnet_amd import ops
     rows, C = 300, 1536
