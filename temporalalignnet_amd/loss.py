@@ -150,6 +150,7 @@ class FusedSim:
         self.vn_d, self.tn_d, self.vn_j, self.tn_j, self.B, self.T, self.N = vn_d, tn_d, vn_j, tn_j, B, T, N
         self.n_text_valid = None      # host-side count of real (unpadded) sentences when the caller knows it: enables column compaction
         self.global_negatives = False # row f3: sentences of every data-parallel rank are negatives (dist_nce.py)
+        self.join_event = None        # forward(fused="defer"): the joint features are complete after this event (side stream)
 
     def diag_blocks(self, which):
         """[B,T,N] f32 last-stage same-video cosine logits (all that self-labelling / thresholding read of the B^2 tensor)."""
@@ -343,6 +344,11 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
     B, T, _ = video_seq.shape
     N = text_embed.shape[1]
     R, Mp = B * T, B * N
+    join_ev = getattr(fused, "join_event", None) if fused is not None else None
+    two_streams = os.environ.get("TAN_LOSS_STREAMS", "1") != "0"
+    if join_ev is not None and (args.learn_agreement or getattr(fused, "global_negatives", False) or not two_streams):
+        torch.cuda.current_stream().wait_event(join_ev)      # these paths read the joint features on this stream right away
+        join_ev = None
     if fused is None:
         lg_d, lg_j = _stage_major(logits["logits_dual"]), _stage_major(logits["logits_joint"])
         blk_d, blk_j = _Blocks.of_logits(lg_d.detach(), B, T, N), _Blocks.of_logits(lg_j.detach(), B, T, N)
@@ -420,6 +426,8 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
         side = _side_stream(dev) if os.environ.get("TAN_LOSS_STREAMS", "1") != "0" else None
         if side is not None:
             side.wait_stream(main)
+            if join_ev is not None:          # deferred join of the forward: only the joint sweep waits for the joint stack
+                side.wait_event(join_ev)
             with torch.cuda.stream(side):
                 v_j, t_j = _FusedNCEFn.apply(fused.vn_j, fused.tn_j, tgt, ci, row_leak, B, T, N, nv)
             v_d, t_d = _FusedNCEFn.apply(fused.vn_d, fused.tn_d, tgt, ci, row_leak, B, T, N, nv)

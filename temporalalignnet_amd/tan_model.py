@@ -764,7 +764,12 @@ class TemporalAligner(nn.Module):
             fut = self._on_side(side, joint_side)
             ev = video_side()
             ej = fut.result()
-            main.wait_stream(side)
+            if opts.get("defer_join") and not self.use_alignability_head:
+                # the caller (get_loss) joins: the dual similarity sweep only needs the video stack and starts under the joint
+                # stack's tail; whoever touches the joint features first waits for this event
+                self._join_event = side.record_event()
+            else:
+                main.wait_stream(side)
         else:
             ev = video_side()
             ej = joint_side()
@@ -968,17 +973,21 @@ class TemporalAligner(nn.Module):
         runs the logits-free similarity+NCE kernels; 'logits_dual' / 'logits_joint' are absent."""
         self._ensure_flat()
         f = self._flat
+        defer = fused == "defer"        # (training driver only) leave the join of the two stack streams to get_loss
         fused = bool(fused) and self.compute_dtype == torch.bfloat16
         needs_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in f.params) or lang_embed.requires_grad)
+        self._join_event = None
         outs = _AlignerFn.apply(self, video_embed, lang_embed, self._mask_u8(video_padding_mask),
                                 self._mask_u8(lang_padding_mask),
-                                {"interpolate_from": interpolate_from, "needs_grad": needs_grad, "fused": fused}, *f.params)
+                                {"interpolate_from": interpolate_from, "needs_grad": needs_grad, "fused": fused,
+                                 "defer_join": defer and fused}, *f.params)
         B, T, N = video_embed.shape[0], video_embed.shape[1], lang_embed.shape[1]
         if fused:
             from .loss import FusedSim
             Se = self.num_encoder_layers
             out = {"_fused": FusedSim(outs[0].permute(1, 0, 2, 3).reshape(Se, B * T, WIDTH), outs[1].reshape(1, B * N, WIDTH),
                                       outs[2], outs[3], B, T, N)}
+            out["_fused"].join_event, self._join_event = self._join_event, None
             nxt = 4
             if self.return_dual_feature:
                 out["dual_feature_video"], out["dual_feature_text"] = outs[0], outs[1]

@@ -241,7 +241,8 @@ class Trainer:
                                                        want_compaction=bool(fused) and not self.global_negatives)
         logits = m(batch["video"], batch["text_embed"], video_padding_mask=batch["padding_mask"],
                    lang_padding_mask=batch["text_padding_mask"].bool(), text_timestamp=batch.get("_tgt_raw"),
-                   abs_text_pos=batch.get("abs_text_pos"), fused=fused)
+                   abs_text_pos=batch.get("abs_text_pos"),
+                   fused="defer" if (fused and not a.learn_agreement and not self.global_negatives) else fused)
         if "_fused" in logits and batch.get("n_text") is not None:
             logits["_fused"].n_text_valid = batch["n_text"]        # padded text columns are skipped by the similarity sweep
         if self.global_negatives:
