@@ -70,6 +70,17 @@ def allreduce_sum_(flat_grad: torch.Tensor, async_op: bool = False):
     return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
+def all_gather_cat(x: torch.Tensor) -> torch.Tensor:
+    """The ranks' equally-shaped tensors concatenated along dim 0 in rank order (= the order of the videos in the global
+    batch); the tensor itself when no collective has to run."""
+    if not _active():
+        return x
+    x = x.contiguous()
+    parts = [torch.empty_like(x) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, x)
+    return torch.cat(parts, 0)
+
+
 def broadcast_(flat: torch.Tensor, src: int = 0):
     if _active():
         dist.broadcast(flat, src=src)

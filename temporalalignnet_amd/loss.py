@@ -135,6 +135,25 @@ def _quantile(x, invalid_u8, q):
     return out
 
 
+def _quantile_global(x, invalid_u8, q):
+    """_quantile over the sentences of EVERY rank (global-negatives mode: the reference computes these statistics over the
+    whole batch, loss.py:191-194,286,315-320): all-gather of the per-sentence values and pad flags, then the same kernel; beyond
+    its 8192 values a sort with at::lerp's rounding, still without a host sync."""
+    from . import dist as _dist
+    xg, ig = _dist.all_gather_cat(x), _dist.all_gather_cat(invalid_u8)
+    if xg.numel() <= 8192:
+        return _quantile(xg, ig, q)
+    inf = torch.full_like(xg, float("inf"))
+    xs = torch.where(ig != 0, inf, xg).sort().values
+    n = (ig == 0).sum()
+    pos = q * (n - 1).to(torch.float32)
+    lo = pos.floor().long().clamp(min=0)
+    hi = torch.minimum(lo + 1, (n - 1).clamp(min=0))
+    w = pos - lo.to(torch.float32)
+    a, b = xs[lo], xs[hi]
+    return torch.where(w < 0.5, a + w * (b - a), b - (b - a) * (1 - w)).view(1)
+
+
 def _diag_max(blk, row_leak, B, T, N):
     out = torch.empty(B * N, device=blk.tensor.device)
     _lib.check(_lib.lib().tan_diag_max(blk.ptr, C.c_long(blk.sb), C.c_long(blk.st), _p(row_leak), _p(out), C.c_int(B), C.c_int(T),
@@ -382,8 +401,9 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
             dur = tgt_raw.sum(-1).float().clamp(min=1.0).masked_fill(tpad, 0.0).contiguous()         # loss.py:113-115
             J = _selflabel(src_j, vpad_u8, tpad_u8, dur, B, T, N)
             D = _selflabel(src_d, vpad_u8, tpad_u8, dur, B, T, N)
-            q_j = _quantile(J["max_logit"].view(-1), tpad_u8.view(-1), 0.3)                           # loss.py:191-194
-            q_d = _quantile(D["max_logit"].view(-1), tpad_u8.view(-1), 0.3)
+            quant = _quantile_global if getattr(fused, "global_negatives", False) else _quantile
+            q_j = quant(J["max_logit"].view(-1), tpad_u8.view(-1), 0.3)                               # loss.py:191-194
+            q_d = quant(D["max_logit"].view(-1), tpad_u8.view(-1), 0.3)
             tgt = torch.empty(B, T, N, device=dev)
             iou = torch.empty(B, N, device=dev)
             conf = torch.empty(B, N, dtype=torch.uint8, device=dev)
@@ -446,15 +466,23 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
                 blk_j, blk_d = _Blocks.of_diag(fused.diag_blocks("joint")), _Blocks.of_diag(fused.diag_blocks("dual"))
             md = _diag_max(blk_d, row_leak, B, T, N)                                                  # loss.py:280
             mj = _diag_max(blk_j, row_leak, B, T, N)                                                  # loss.py:283
-            n_valid = valid_f.sum()
+            glob_stats = nce_counts is not None      # global negatives: batch statistics over the sentences of every rank
+            quant = _quantile_global if glob_stats else _quantile
+
+            def gsum(x):
+                if glob_stats:
+                    from . import dist as _dist
+                    _dist.allreduce_sum_(x)
+                return x
+            n_valid = gsum(valid_f.sum())
 
             def zscore(x):
-                mean = (x * valid_f).sum() / n_valid
-                var = (((x - mean) ** 2) * valid_f).sum() / (n_valid - 1)
+                mean = gsum((x * valid_f).sum()) / n_valid
+                var = gsum((((x - mean) ** 2) * valid_f).sum()) / (n_valid - 1)
                 return (x - mean) / var.sqrt()
 
             metric = -(zscore(md) + zscore(mj))
-            th = _quantile(metric, tpad_u8.view(-1), float(args.loss_threshold))                      # loss.py:286
+            th = quant(metric, tpad_u8.view(-1), float(args.loss_threshold))                          # loss.py:286
             th_mask = (metric <= th) & valid
             th_f = th_mask.float()
             tgt_valid = tgt * (~tpad)[:, None, :].float()
@@ -469,13 +497,13 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
             if glob:
                 from .dist_nce import global_counts
                 th_counts = global_counts(rows_pos_th, th_f)
-            pair_th = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos_th, th_f, th_counts)   # (the thresholds themselves stay rank-local)
+            pair_th = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos_th, th_f, th_counts)
             loss_dual_th, loss_joint_th = pair_th[0], pair_th[1]
             out["loss-dual"], out["loss-joint"] = loss_dual_th.detach(), loss_joint_th.detach()
         if args.use_alignability_head:
             with torch.no_grad():
-                med_d = _quantile(md, tpad_u8.view(-1), 0.5)                                          # loss.py:315-320
-                med_j = _quantile(mj, tpad_u8.view(-1), 0.5)
+                med_d = quant(md, tpad_u8.view(-1), 0.5)                                              # loss.py:315-320
+                med_j = quant(mj, tpad_u8.view(-1), 0.5)
                 lab = torch.full_like(metric, 2.0)
                 lab = lab.masked_fill((md > med_d) & (mj > med_j), 1.0)
                 lab = lab.masked_fill((md < med_d) & (mj < med_j), 0.0)

@@ -112,18 +112,23 @@ def _slice(batch, lo, hi):
     return {k: (v[lo:hi] if isinstance(v, (np.ndarray, list)) else v) for k, v in batch.items()}
 
 
-def _gn_setup(global_negatives):
+def _gn_setup(global_negatives, kind="init"):
     from temporalalignnet_amd import synth
     from temporalalignnet_amd.train import Trainer, build_model, default_args
-    args = default_args(model="init", num_encoder_layers=2, num_decoder_layers=2)
+    extra = dict(loss_threshold=0.5) if kind == "cotrain" else {}
+    args = default_args(model=kind, num_encoder_layers=2, num_decoder_layers=3 if kind == "cotrain" else 2, **extra)
     torch.manual_seed(0)
     model = build_model(args, compute_dtype="bf16", random_pos_start=0).cuda()
+    if kind == "cotrain":
+        model._copy_param()
+        for p_ in model.target.parameters():
+            p_.requires_grad = False
     tr = Trainer(model, args, global_negatives=global_negatives, ddp_bucket_layers=1)
     tr.iteration = 2000
     return tr, synth.make_batch(300, B=GB, T=32, n_min=3, n_max=7)
 
 
-def _gn_worker(rank, world, port, out_dir):
+def _gn_worker(rank, world, port, out_dir, kind="init"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     import torch.distributed as tdist
@@ -131,7 +136,7 @@ def _gn_worker(rank, world, port, out_dir):
     from temporalalignnet_amd.train import to_device_batch
     torch.cuda.set_device(0)
     dist.init_from_env(backend="gloo")
-    tr, full = _gn_setup(True)
+    tr, full = _gn_setup(True, kind)
     lo, hi = dist.shard_range(GB, world, rank)
     ld = tr.step(to_device_batch(_slice(full, lo, hi)))
     torch.cuda.synchronize()
@@ -140,11 +145,14 @@ def _gn_worker(rank, world, port, out_dir):
     tdist.destroy_process_group()
 
 
-def test_two_ranks_with_global_negatives_equal_one_process_on_the_whole_batch(tmp_path):
+@pytest.mark.parametrize("kind", ["init", "cotrain"])
+def test_two_ranks_with_global_negatives_equal_one_process_on_the_whole_batch(tmp_path, kind):
+    """Stage 1: the NCE over every rank's sentences.  Stage 2 (cotrain, loss_threshold, alignability head) adds the BATCH statistics
+    of loss.py:191-194,281-286,315-320 -- quantiles, z-scores, medians -- which in this mode run over the sentences of all ranks."""
     from temporalalignnet_amd.train import to_device_batch
     ctx = mp.get_context("spawn")
-    port = 29700 + os.getpid() % 1000
-    procs = [ctx.Process(target=_gn_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    port = 29700 + os.getpid() % 1000 + (50 if kind == "cotrain" else 0)
+    procs = [ctx.Process(target=_gn_worker, args=(r, 2, port, str(tmp_path), kind)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -152,7 +160,7 @@ def test_two_ranks_with_global_negatives_equal_one_process_on_the_whole_batch(tm
         assert p.exitcode == 0
     r0, r1 = (torch.load(tmp_path / f"gn{r}.pt") for r in range(2))
     assert torch.equal(r0["grad"], r1["grad"])
-    tr, full = _gn_setup(False)                               # local negatives on the WHOLE batch = the global semantics
+    tr, full = _gn_setup(False, kind)                         # local negatives on the WHOLE batch = the global semantics
     tr.zero_grad()
     loss = tr.forward_backward(to_device_batch(full))["loss"].item()
     g = tr.online.flat_grad().cpu()
