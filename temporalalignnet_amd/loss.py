@@ -413,7 +413,7 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
                                                 _p(iou), _p(conf), C.c_int(B), C.c_int(T), C.c_int(N), ops._stream()),
                        "tan_agreement")
             out["confidence-ratio"] = (conf.view(Mp).float() * valid_f).sum() / valid_f.sum()
-            out["iou-threshold"] = torch.tensor(0.5, device=dev)
+            out["iou-threshold"] = torch.full((), 0.5, device=dev)       # (torch.tensor(x, device=...) is a SYNCHRONOUS host-to-device copy)
             if not cotrain:      # reference in-place quirk: the -6e4 fills leak into the online logits (loss.py:96-101)
                 row_leak = vpad_u8.view(R)
             aux.update(max_position_joint=J["max_pos"], max_position_dual=D["max_pos"], max_logits_joint=J["max_logit"],

@@ -1,12 +1,18 @@
-"""Does the host run ahead of the GPU across steps?  Per-step host time of 40 un-synchronised steps (then one sync)."""
+"""Does the host run ahead of the GPU across steps?  Per-step host time of 40 un-synchronised steps (then one sync).
+env: B (batch, default 128), KIND (init | cotrain)."""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from temporalalignnet_amd import synth
 from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
-args = default_args(model="init")
-model = build_model(args, compute_dtype="bf16").cuda(); model.random_pos_start = 1
-tr = Trainer(model, args, iter_per_epoch=2890, warmup=1000); tr.iteration = 1000
+KIND = os.environ.get("KIND", "init")
+args = default_args(model=KIND, **({"loss_threshold": 0.5} if KIND == "cotrain" else {}))
+model = build_model(args, compute_dtype="bf16").cuda()
+if KIND == "cotrain":
+    model._copy_param()
+    for p in model.target.parameters():
+        p.requires_grad = False
+tr = Trainer(model, args, iter_per_epoch=2890, warmup=1000); tr.batches_seen = 1000
 b = to_device_batch(synth.make_batch(888, B=int(os.environ.get("B", 128)), T=64, n_min=4, n_max=16))
 for _ in range(5): tr.step(b)
 torch.cuda.synchronize()
