@@ -377,10 +377,12 @@ __global__ __launch_bounds__(1024) void nce_tail_fwd_kernel(const float* __restr
                 m[k] = r < n ? mask[rr[k]] : 0.f;
                 cnt += m[k];
             }
-            for (int st = 0; st < Sd; ++st) {
+#pragma unroll 6
+            for (int st = 0; st < Sd; ++st) {          // (unrolled by the usual stage count: 48 loads in flight per thread)
 #pragma unroll
                 for (int k = 0; k < U; ++k) sd += xd[(long)st * n + rr[k]] * m[k];
             }
+#pragma unroll 6
             for (int st = 0; st < Sj; ++st) {
 #pragma unroll
                 for (int k = 0; k < U; ++k) sj += xj[(long)st * n + rr[k]] * m[k];

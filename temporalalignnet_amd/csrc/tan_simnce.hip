@@ -300,50 +300,43 @@ static int simnce_common(SimArgs& a, int S, int B, int T, int N, int C) {
     return 0;
 }
 
-// same-video cosine blocks diag[s,b,t,n] = <vn[s,b*T+t], tn[s,b*N+n]>, C = 512: one workgroup per (video, stage), the N sentence
-// features in LDS, a wave per frame row with 8 channels per lane and a DPP reduction per (frame, sentence).  S*B*T*N*C MACs =
-// 0.4 G at B = 128: the 128 x 128-tile GEMM this replaces spent 73 us on it (one launch, 768 mostly-padding tiles) or 6 x 9 us
-// (shared text features: one launch per stage) on the critical loss chain.
+// same-video cosine blocks diag[s,b,t,n] = <vn[s,b*T+t], tn[s,b*N+n]>, C = 512: one WAVE per 32 frame rows of a (video, stage),
+// both MFMA operands straight from global memory in fragment layout (rows K-contiguous: a lane's 8 channels are one 16-byte load),
+// 32 k-steps, the 32 x 32 result stored for the N real sentences.  S*B*T*N*C MACs = 0.4 G at B = 128: the 128 x 128-tile GEMM this
+// replaces spent 73 us on it (one launch, 768 mostly-padding tiles) or 6 x 9 us (shared text features: one launch per stage), a
+// VALU dot-product version 47 us, on the critical chain of the loss.
 __global__ __launch_bounds__(256) void simnce_blocks_kernel(const bf16_t* __restrict__ V, const bf16_t* __restrict__ tn_blocks,
                                                             long tb_stage_stride, float* __restrict__ diag, int B, int T, int N, long R) {
     constexpr int C = 512;
-    extern __shared__ __attribute__((aligned(16))) char sm[];            // [N rounded up to 16][C] bf16, zero rows past N
     const int b = blockIdx.x, s = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int Np = (N + 15) & ~15;
-    const bf16_t* tb = tn_blocks + (long)s * tb_stage_stride + (long)b * N * C;
-    for (int i = threadIdx.x; i < Np * (C / 8); i += 256)
-        reinterpret_cast<uint4*>(sm)[i] = i < N * (C / 8) ? reinterpret_cast<const uint4*>(tb)[i] : make_uint4(0, 0, 0, 0);
-    __syncthreads();
+    const int t0 = (blockIdx.z * 4 + wave) * 32;
+    if (t0 >= T) return;
+    const int hi8 = 8 * (lane >> 5);
+    const bf16_t* arow = V + ((long)s * R + (long)b * T + min(t0 + (lane & 31), T - 1)) * C + hi8;
     float* out = diag + ((long)s * B + b) * T * N;
-    // blockIdx.z: 64 frame rows, 16 per wave; 16 sentences at a time: per-lane partial dots, one butterfly reduction for all 16
-    for (int i = 0; i < 16; ++i) {
-        const int t = blockIdx.z * 64 + wave * 16 + i;
-        if (t >= T) break;                                               // wave-uniform
-        const f8 v = ld8(V + ((long)s * R + (long)b * T + t) * C + lane * 8);
-        for (int n0 = 0; n0 < Np; n0 += 16) {
-            float p[16];
+    for (int n0 = 0; n0 < N; n0 += 32) {
+        const bf16_t* brow = tn_blocks + (long)s * tb_stage_stride + ((long)b * N + min(n0 + (lane & 31), N - 1)) * C + hi8;
+        f32x16 acc;
+        acc_zero(acc);
+#pragma unroll 8
+        for (int ks = 0; ks < C; ks += 16) {
+            const bf16x8 fa = *reinterpret_cast<const bf16x8*>(arow + ks);
+            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(brow + ks);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+        }
+        const int n = n0 + acc_col(lane);
 #pragma unroll
-            for (int n = 0; n < 16; ++n) {
-                const f8 w = ld8(reinterpret_cast<const bf16_t*>(sm) + (n0 + n) * C + lane * 8);
-                float d = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) d = fmaf(v.v[j], w.v[j], d);
-                p[n] = d;
-            }
-            float tot = pn_colsum16(p, lane);                            // sums over each 32-lane half ...
-            auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_int(tot), __float_as_int(tot), false, false);
-            tot = __int_as_float(r32[0]) + __int_as_float(r32[1]);       // ... and over both
-            const int n = n0 + pn_colsum16_index(lane);
-            if (lane < 32 && !(lane & 2) && n < N) out[t * N + n] = tot;
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + acc_row(r, lane);
+            if (t < T && n < N) out[t * N + n] = acc[r];
         }
     }
 }
 
 // (other channel counts: through the ordinary GEMM, batch = S*B, or per stage when the text features are shared)
 static int simnce_diag_blocks(const SimArgs& a, const bf16_t* tn_blocks, long tb_stage_stride, float* diag, hipStream_t st) {
-    const int Np = (a.N + 15) & ~15;
-    if (a.C == 512 && Np * 1024 <= 64 * 1024 && (((uintptr_t)a.V | (uintptr_t)tn_blocks) % 16) == 0 && tb_stage_stride % 8 == 0) {
-        hipLaunchKernelGGL(simnce_blocks_kernel, dim3(a.B, a.S, cdiv(a.T, 64)), dim3(256), (size_t)Np * 1024, st, a.V, tn_blocks, tb_stage_stride, diag,
+    if (a.C == 512 && (((uintptr_t)a.V | (uintptr_t)tn_blocks) % 16) == 0 && tb_stage_stride % 8 == 0) {
+        hipLaunchKernelGGL(simnce_blocks_kernel, dim3(a.B, a.S, cdiv(a.T, 128)), dim3(256), 0, st, a.V, tn_blocks, tb_stage_stride, diag,
                            a.B, a.T, a.N, (long)a.R);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : (int)e;
