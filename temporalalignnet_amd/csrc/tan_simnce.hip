@@ -228,30 +228,39 @@ __global__ __launch_bounds__(256) void simnce_diag_kernel(const float* __restric
     const float* blk = diag + ((long)s * B + b) * T * N;
     const float* tg = tgt + (long)b * T * N;
     if (!DL) {
-        for (int t = threadIdx.x; t < T; t += 256) {
+        // every thread takes entries of the T x N block; row / column sums meet in LDS (f32 atomics, like the sweep's column sums).
+        // One thread per row with a serial loop over the sentences, then one per sentence over the rows, left 3/4 (then 15/16) of the
+        // block idle behind chains of dependent loads: 31 us on the loss's critical chain.
+        extern __shared__ float dsm[];
+        float* accR = dsm; float* lostR = dsm + T; float* accC = dsm + 2 * T; float* lostC = accC + N;
+        for (int i = threadIdx.x; i < 2 * (T + N); i += 256) dsm[i] = 0.f;
+        __syncthreads();
+        for (int i = threadIdx.x; i < T * N; i += 256) {
+            const int t = i / N, k = i - t * N;
+            const int cc = colmap ? colmap[b * N + k] : b * N + k;
             const bool leak = row_leak && row_leak[b * T + t];
-            float acc = 0.f, lost = 0.f;
-            for (int k = 0; k < N; ++k) {
-                const float e = __expf((blk[t * N + k] - 1.0f) * inv_tau);
-                const int cc = colmap ? colmap[b * N + k] : b * N + k;
-                const bool valid = cc >= 0 && !col_invalid[cc];
-                if (leak) { if (valid) lost += e; }
-                else if (tg[t * N + k] != 0.f && valid) acc += e;
+            const bool pos = tg[i] != 0.f;
+            if (!leak && !pos) continue;
+            const float e = __expf((blk[i] - 1.0f) * inv_tau);
+            const bool valid = cc >= 0 && !col_invalid[cc];
+            if (leak) {
+                if (valid) atomicAdd(&lostR[t], e);
+                if (cc >= 0) atomicAdd(&lostC[k], e);
+            } else {
+                if (valid) atomicAdd(&accR[t], e);
+                if (cc >= 0) atomicAdd(&accC[k], e);
             }
-            possum_v[(long)s * R + b * T + t] = acc;
-            if (leak) rowsum[(long)s * R + b * T + t] -= lost;
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < T; t += 256) {
+            possum_v[(long)s * R + b * T + t] = accR[t];
+            if (row_leak && row_leak[b * T + t]) rowsum[(long)s * R + b * T + t] -= lostR[t];
         }
         for (int k = threadIdx.x; k < N; k += 256) {
             const int cc = colmap ? colmap[b * N + k] : b * N + k;
             if (cc < 0) continue;
-            float acc = 0.f, lost = 0.f;
-            for (int t = 0; t < T; ++t) {
-                const float e = __expf((blk[t * N + k] - 1.0f) * inv_tau);
-                if (row_leak && row_leak[b * T + t]) lost += e;
-                else if (tg[t * N + k] != 0.f) acc += e;
-            }
-            possum_t[(long)s * Mp + cc] = acc;
-            if (lost != 0.f) colsum[(long)s * Mp + cc] -= lost;
+            possum_t[(long)s * Mp + cc] = accC[k];
+            if (lostC[k] != 0.f) colsum[(long)s * Mp + cc] -= lostC[k];
         }
     } else {
         for (int i = threadIdx.x; i < T * N; i += 256) {
@@ -394,7 +403,7 @@ extern "C" int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_strid
     }
     if (phases & TAN_SIM_DIAG) {
         if ((rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;
-        hipLaunchKernelGGL((simnce_diag_kernel<false>), dim3(B, S), dim3(256), 0, st, diag, tgt, col_invalid, row_leak, rowsum, colsum,
+        hipLaunchKernelGGL((simnce_diag_kernel<false>), dim3(B, S), dim3(256), sizeof(float) * 2 * (size_t)(T + N), st, diag, tgt, col_invalid, row_leak, rowsum, colsum,
                            possum_v, possum_t, (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, B, T, N, colmap, a.Mp);
     }
     if (phases & TAN_SIM_TERMS) {
