@@ -263,20 +263,38 @@ __global__ __launch_bounds__(256) void simnce_diag_kernel(const float* __restric
             if (lostC[k] != 0.f) colsum[(long)s * Mp + cc] -= lostC[k];
         }
     } else {
-        for (int i = threadIdx.x; i < T * N; i += 256) {
-            const int t = i / N, k = i - t * N;
-            const int cc = colmap ? colmap[b * N + k] : b * N + k;
-            if (cc < 0) continue;
-            const long r = (long)s * R + b * T + t, c = (long)s * Mp + cc;
-            bf16_t* out = dl + r * Mp + cc;
-            if (row_leak && row_leak[b * T + t]) { *out = 0; continue; }
-            if (tg[i] == 0.f) continue;
-            const float e = __expf((blk[i] - 1.0f) * inv_tau);
-            const bool valid = !col_invalid[cc];
-            float corr = 0.f;
-            if (valid && possum_v[r] > 0.f) corr += g_v[r] / possum_v[r];
-            if (possum_t[c] > 0.f) corr += g_t[c] / possum_t[c];
-            *out = f2bf(bf2f(*out) - e * corr * inv_tau);
+        // four entries per thread with every load issued before the first use (clamped addresses, predicated stores): entry by
+        // entry, each of the ~10 loads behind its own branch paid a full memory latency (27 us per launch)
+        constexpr int U = 4;
+        for (int i0 = threadIdx.x; i0 < T * N; i0 += 256 * U) {
+            int cc[U]; long r[U], c[U]; bool in[U], leak[U];
+            float tgv[U], bl[U], pv[U], gv[U], pt[U], gt[U]; unsigned char inval[U]; bf16_t cur[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int i = min(i0 + j * 256, T * N - 1);
+                const int t = i / N, k = i - t * N;
+                const int m = colmap ? colmap[b * N + k] : b * N + k;
+                in[j] = i0 + j * 256 < T * N && m >= 0;
+                cc[j] = max(m, 0);
+                r[j] = (long)s * R + b * T + t;
+                c[j] = (long)s * Mp + cc[j];
+                leak[j] = row_leak && row_leak[b * T + t];
+                tgv[j] = tg[i]; bl[j] = blk[i]; inval[j] = col_invalid[cc[j]];
+                pv[j] = possum_v[r[j]]; gv[j] = g_v[r[j]]; pt[j] = possum_t[c[j]]; gt[j] = g_t[c[j]];
+                cur[j] = dl[r[j] * Mp + cc[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                if (!in[j]) continue;
+                bf16_t* out = dl + r[j] * Mp + cc[j];
+                if (leak[j]) { *out = 0; continue; }
+                if (tgv[j] == 0.f) continue;
+                const float e = __expf((bl[j] - 1.0f) * inv_tau);
+                float corr = 0.f;
+                if (!inval[j] && pv[j] > 0.f) corr += gv[j] / pv[j];
+                if (pt[j] > 0.f) corr += gt[j] / pt[j];
+                *out = f2bf(bf2f(cur[j]) - e * corr * inv_tau);
+            }
         }
     }
 }
