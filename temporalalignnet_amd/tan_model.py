@@ -582,7 +582,37 @@ class TemporalAligner(nn.Module):
         ops.layernorm_fwd(proj, self._f("ln_video_init.weight"), self._f("ln_video_init.bias"), x0, mean, rstd, pos_c, T)
         return x0, {"proj": proj, "mean": mean, "rstd": rstd, "pos": pos_saved, "video_c": video_c}
 
-    def _video_embed_bwd(self, sv, d_x0):
+    def _video_embed_repos(self, sv, pos_start, interpolate_from, keep):
+        """The video embedding of `sv` again with another position offset: ln_video_init(proj) + ln_position_init(pos')."""
+        proj = sv["proj"]
+        R, (B, T, _) = proj.shape[0], sv["video_c"].shape
+        cd, dev = proj.dtype, proj.device
+        pos_c, pos_saved = self._pos_ln("temporal_pos_embed", T, pos_start, interpolate_from, cd, keep)
+        x0 = torch.empty(R, WIDTH, dtype=cd, device=dev)
+        ops.layernorm_fwd(proj, self._f("ln_video_init.weight"), self._f("ln_video_init.bias"), x0,
+                          torch.empty(R, device=dev), torch.empty(R, device=dev), pos_c, T)
+        return x0, {"pos": pos_saved, "repos_of": sv}
+
+    def _video_embed_bwd_pair(self, sv, d_x0, have_x0, sv_j, d_x0j):
+        """Backward of a video embedding used twice with two position offsets (dual path `d_x0`, joint path `d_x0j`): the position
+        tables get their own row sums; the LayerNorm backward is linear in its upstream gradient and both uses share input and
+        statistics, so ONE LayerNorm backward and ONE weight-gradient GEMM run on the sum of the two gradients."""
+        B, T, _ = sv["video_c"].shape
+        cd, dev = d_x0j.dtype, d_x0j.device
+        for saved, d in ((sv["pos"], d_x0 if have_x0 else None), (sv_j["pos"], d_x0j)):
+            if d is None:
+                continue
+            d_pos = torch.empty(T, WIDTH, dtype=cd, device=dev)
+            ops.group_sum(d, d_pos, B, T, WIDTH)
+            self._pos_ln_bwd(saved, d_pos)
+        if have_x0:
+            ops.rows_copy(d_x0j, d_x0, B, T, WIDTH, T, 0, T, 0, accumulate=True)
+            d_sum = d_x0
+        else:
+            d_sum = d_x0j
+        self._video_embed_bwd(sv, d_sum, pos_too=False)
+
+    def _video_embed_bwd(self, sv, d_x0, pos_too=True):
         video_c = sv["video_c"]
         B, T, Dv = video_c.shape
         R, cd, dev = B * T, d_x0.dtype, d_x0.device
@@ -591,9 +621,10 @@ class TemporalAligner(nn.Module):
                           self._g("ln_video_init.weight"), self._g("ln_video_init.bias"))
         ops.gemm(d_proj, video_c, self._g("video_pre_proj.weight"), M=WIDTH, N=Dv, K=R, a_kc=False, b_kc=False,
                  lda=WIDTH, ldb=Dv, accumulate=True, split_k=max(1, min(32, R // 1024)))      # K-slices >= 1024 rows: the 4-stage K-strided kernel
-        d_pos = torch.empty(T, WIDTH, dtype=cd, device=dev)
-        ops.group_sum(d_x0, d_pos, B, T, WIDTH)
-        self._pos_ln_bwd(sv["pos"], d_pos)
+        if pos_too:
+            d_pos = torch.empty(T, WIDTH, dtype=cd, device=dev)
+            ops.group_sum(d_x0, d_pos, B, T, WIDTH)
+            self._pos_ln_bwd(sv["pos"], d_pos)
 
     def _text_embed(self, lang_c, with_time, pos_start, interpolate_from, keep):
         """ln_text_init(text_pre_proj(lang)) (+ ln_position_init(text_pos))  (tan_model.py:231-234 / 212-228)."""
@@ -737,8 +768,9 @@ class TemporalAligner(nn.Module):
         p_t = self._draw(N, itp) if self.use_text_pos_enc else 0
         p_j = self._draw(T, itp)
         x0, sv_video = self._video_embed(video_c, p_v, itp, keep)
-        if p_j != p_v:      # random_pos_start=1 draws independent offsets for the dual and joint paths
-            x0j, sv_video_j = self._video_embed(video_c, p_j, itp, keep)
+        if p_j != p_v:      # random_pos_start=1 draws independent offsets for the dual and joint paths: same projection and
+            #                 LayerNorm input, another slice of the position table (one GEMM, not two; see _video_embed_bwd_pair)
+            x0j, sv_video_j = self._video_embed_repos(sv_video, p_j, itp, keep)
         else:
             x0j, sv_video_j = x0, None
         lang_raw, sv_text = self._text_embed(lang_c, False, 0, None, keep)
@@ -957,10 +989,10 @@ class TemporalAligner(nn.Module):
                 ops.rows_copy(d_xj, d_lang_t, B, N, Cw, L, T, N, 0)
         # ---- embeddings
         d_lang = None
-        if any_v or (any_j and run["sv_video_j"] is None):
-            self._video_embed_bwd(run["sv_video"], d_x0)
         if any_j and run["sv_video_j"] is not None:
-            self._video_embed_bwd(run["sv_video_j"], d_x0j)
+            self._video_embed_bwd_pair(run["sv_video"], d_x0, any_v, run["sv_video_j"], d_x0j)
+        elif any_v or any_j:
+            self._video_embed_bwd(run["sv_video"], d_x0)
         if have_lang_raw:
             d_lang = self._text_embed_bwd(run["sv_text"], d_lang_raw, need_d_lang)
         if d_lang_t is not None:
