@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--global-negatives", action="store_true", help="row f3: NCE negatives from every rank (W similarity sweeps)")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--timer-every", type=int, default=10, help="HIP-event kernel timer samples every n-th timed step")
+    ap.add_argument("--timer-every", type=int, default=20, help="HIP-event kernel timer samples one timed step in n (the middle one)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra driver-timed configurations (stage 2, len=256) of the N=1 run")
     ap.add_argument("--extra-steps", type=int, default=10)
     return ap.parse_args()
@@ -120,8 +120,9 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
     t0 = time.perf_counter()
     sampled = 0
     for i in range(steps):
-        if use_timer:                                  # the event pairs cost ~0.8 ms/step: sample every `timer_every`-th step
-            on = (i % timer_every == 0)
+        if use_timer:                                  # ~200 timing events cost 1-1.7 ms in the step they bracket: one step in
+            every = min(timer_every, steps)            # `timer_every` is sampled, the middle one (the host is ahead of the GPU there)
+            on = (i % every == every // 2)
             L.tan_prof_enable(2 if on else 0, 0)
             sampled += on
         loss = trainer.step(batch)
@@ -182,7 +183,7 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
                     "avg_launch_us": round(tms * 1e3 / tcnt, 2), "launches_per_step": round(tcnt / sampled, 1),
                     "gemm_ms_per_step": round(tms / sampled, 3), "algorithmic_gflop_per_step": round(twork / sampled / 1e9, 1),
                     "step_frac": round(twork / sampled / (elapsed / steps) / 1e12 / peak, 4),
-                    "timer": f"HIP events on each launch's own stream, {sampled} of the {steps} timed steps (every {timer_every}th)",
+                    "timer": f"HIP events on each launch's own stream, {sampled} of the {steps} timed steps (one in {min(timer_every, steps)})",
                     "concurrency": "2 HIP streams (video || joint stack): durations include co-running kernels",
                     "isolated": iso,
                     "by_kernel": [{**x, "ms_per_step": round(x["ms_per_step"], 3), "tflops": round(x["tflops"], 1)} for x in kinds]}
