@@ -150,6 +150,10 @@ int tan_attn_fwd(const void* qkv, const unsigned char* key_padding_mask, void* o
                  int dtype, void* stream);
 int tan_attn_bwd(const void* qkv, const unsigned char* key_padding_mask, const void* o, const float* lse,
                  const void* d_o, void* dqkv, int B, int L, int H, int dtype, void* stream);
+/* the same, and g_b_qkv [3C] f32 += column sums of dqkv (the in_proj bias gradient of nn.MultiheadAttention): summed in
+ * the backward kernel from the rows it is about to store when L <= 128 (bf16), by tan_colsum_acc over dqkv otherwise    */
+int tan_attn_bwd_bias(const void* qkv, const unsigned char* key_padding_mask, const void* o, const float* lse,
+                      const void* d_o, void* dqkv, float* g_b_qkv, int B, int L, int H, int dtype, void* stream);
 
 /* ---- loss side (train/loss.py:get_loss) -------------------------------------------------------------------
  * logits: raw cosines, stage-major [S, R=B*T, Mp=B*N] f32 (the reference's [B,S,T,B,N] is a permuted view).

@@ -65,6 +65,7 @@ struct AttnArgs {
     const void* qkv; const unsigned char* keypad; void* o; float* lse;
     const void* d_o; void* dqkv;
     int B, L, H, Lpad;
+    float* gbias;          // [3C] f32 or null: += column sums of dqkv (the in_proj bias gradient), short bf16 backward only
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -605,6 +606,20 @@ __global__ __launch_bounds__(64 * NKB, 2) void attn_bwd_short_kernel(AttnArgs a)
         rows_to_global(Qi, k0, lane, out, ld, 0, L);
         rows_to_global(Ki, k0, lane, out + C, ld, 0, L);
         rows_to_global(Vi, k0, lane, out + 2 * C, ld, 0, L);
+        if (a.gbias) {
+            // in_proj bias gradient: column sums of the 32 rows this wave parked (the bf16 values tan_colsum_acc would read
+            // back from dqkv; rows past L hold exact zeros), one lane per head feature
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) {
+                const int row = k0 + r, off = row * 128 + (((lane >> 3) ^ img_swz(row)) << 4) + (lane & 7) * 2;
+                s0 += bf2f(*reinterpret_cast<const bf16_t*>(Qi + off));
+                s1 += bf2f(*reinterpret_cast<const bf16_t*>(Ki + off));
+                s2 += bf2f(*reinterpret_cast<const bf16_t*>(Vi + off));
+            }
+            float* g = a.gbias + h * DH + lane;
+            unsafeAtomicAdd(g, s0); unsafeAtomicAdd(g + C, s1); unsafeAtomicAdd(g + 2 * C, s2);
+        }
     }
 }
 
@@ -947,10 +962,18 @@ extern "C" int tan_attn_fwd(const void* qkv, const unsigned char* key_padding_ma
     return 0;
 }
 
-extern "C" int tan_attn_bwd(const void* qkv, const unsigned char* key_padding_mask, const void* o, const float* lse,
-                            const void* d_o, void* dqkv, int B, int L, int H, int dtype, void* stream) {
+// TAN_ATTN_BIAS_FUSED=0: the in_proj bias gradient by tan_colsum_acc over dqkv for every path (A/B measurements)
+static bool bias_fused() {
+    static const int v = [] { const char* e = getenv("TAN_ATTN_BIAS_FUSED"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+
+static int attn_bwd_impl(const void* qkv, const unsigned char* key_padding_mask, const void* o, const float* lse,
+                         const void* d_o, void* dqkv, float* g_b_qkv, int B, int L, int H, int dtype, void* stream) {
     TAN_REQUIRE(qkv && o && lse && d_o && dqkv && B > 0 && L > 0 && H > 0);
     AttnArgs a{};
+    const bool fuse = g_b_qkv && short_path(dtype, L) && bias_fused();
+    a.gbias = fuse ? g_b_qkv : nullptr;
     a.qkv = qkv; a.keypad = key_padding_mask; a.o = (void*)o; a.lse = (float*)lse; a.d_o = d_o; a.dqkv = dqkv;
     a.B = B; a.L = L; a.H = H; a.Lpad = (L + 63) / 64 * 64;
     dim3 grid(a.Lpad / 64, H, B);
@@ -978,5 +1001,17 @@ extern "C" int tan_attn_bwd(const void* qkv, const unsigned char* key_padding_ma
     } else return TAN_ERR_BAD_ARG;
     prof_end(st, rec);
     TAN_LAUNCH_CHECK();
+    if (g_b_qkv && !fuse) return tan_colsum_acc(dqkv, g_b_qkv, (long)B * L, 3 * H * DH, dtype, stream);
     return 0;
+}
+
+extern "C" int tan_attn_bwd(const void* qkv, const unsigned char* key_padding_mask, const void* o, const float* lse,
+                            const void* d_o, void* dqkv, int B, int L, int H, int dtype, void* stream) {
+    return attn_bwd_impl(qkv, key_padding_mask, o, lse, d_o, dqkv, nullptr, B, L, H, dtype, stream);
+}
+
+extern "C" int tan_attn_bwd_bias(const void* qkv, const unsigned char* key_padding_mask, const void* o, const float* lse,
+                                 const void* d_o, void* dqkv, float* g_b_qkv, int B, int L, int H, int dtype, void* stream) {
+    TAN_REQUIRE(g_b_qkv);
+    return attn_bwd_impl(qkv, key_padding_mask, o, lse, d_o, dqkv, g_b_qkv, B, L, H, dtype, stream);
 }

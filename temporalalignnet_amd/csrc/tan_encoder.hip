@@ -244,8 +244,7 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         // ---- attention branch: x_mid = x_in + out_proj(attn(LN1(x_in)))
         if (!grouped) CK(linear_bwd_w(dt, dx2, b.attn_o, p.g_w_out, R, C, C, e->dw_ws, e->dw_ws_floats, st));
         CK(linear_bwd_x(dt, dx2, p.w_out, p.wt_out, e->scr_do, R, C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
-        CK(tan_attn_bwd(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->scr_do, e->scr_dqkv, e->B, e->L, H, dt, st));
-        CK(tan_colsum_acc(e->scr_dqkv, p.g_b_qkv, R, 3 * C, dt, st));
+        CK(tan_attn_bwd_bias(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->scr_do, e->scr_dqkv, p.g_b_qkv, e->B, e->L, H, dt, st));
         if (!grouped) CK(linear_bwd_w(dt, e->scr_dqkv, b.xn1, p.g_w_qkv, R, 3 * C, C, e->dw_ws, e->dw_ws_floats, st));
         // stage i-1 IS this layer's xn1: its gradient joins here
         const void* dstage = i >= 1 ? e->d_stage[i - 1] : nullptr;

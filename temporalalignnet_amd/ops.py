@@ -200,7 +200,13 @@ def attn_fwd(qkv, keypad_u8, o, lse, B, L, H):
     return o
 
 
-def attn_bwd(qkv, keypad_u8, o, lse, d_o, dqkv, B, L, H):
+def attn_bwd(qkv, keypad_u8, o, lse, d_o, dqkv, B, L, H, g_b_qkv=None):
+    """g_b_qkv [3C] f32: += the column sums of dqkv (in_proj bias gradient), by the same call."""
+    if g_b_qkv is not None:
+        _lib.check(_lib.lib().tan_attn_bwd_bias(_ptr(qkv), _ptr(keypad_u8), _ptr(o), _f32(lse), _ptr(d_o), _ptr(dqkv),
+                                                 _f32(g_b_qkv), C.c_int(B), C.c_int(L), C.c_int(H), _dt(qkv), _stream()),
+                   "tan_attn_bwd_bias")
+        return dqkv
     _lib.check(_lib.lib().tan_attn_bwd(_ptr(qkv), _ptr(keypad_u8), _ptr(o), _f32(lse), _ptr(d_o), _ptr(dqkv), C.c_int(B),
                                         C.c_int(L), C.c_int(H), _dt(qkv), _stream()), "tan_attn_bwd")
     return dqkv

@@ -210,6 +210,14 @@ def test_attention_fwd_bwd(dtype, B, L, pad):
     dqkv = torch.full_like(qkv, float("nan"))
     ops.attn_bwd(qkv, keypad, o, lse, d_o, dqkv, B, L, H)
     close(dqkv, qr.grad, 1e-4 if dtype == torch.float32 else 1e-1)
+    # the entry that also accumulates the in_proj bias gradient: same dqkv, g += its column sums (of the stored values)
+    dqkv2 = torch.full_like(qkv, float("nan"))
+    g0 = rnd((3 * C,), torch.float32, 22)
+    g = g0.clone()
+    ops.attn_bwd(qkv, keypad, o, lse, d_o, dqkv2, B, L, H, g_b_qkv=g)
+    assert torch.equal(dqkv2, dqkv)
+    want = dqkv.double().sum(0)
+    close(g - g0, want, 1e-4 * (1.0 + want.abs().max().item()))
 
 
 def test_transpose_batch():
