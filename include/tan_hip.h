@@ -318,6 +318,11 @@ int tan_encoder_bwd(const tan_encoder_desc* e, void* stream);
  * slices <= 32) they are written as partial tiles and folded by tan_reduce_add, otherwise accumulated with f32 atomics. */
 int tan_linear_wgrad(const void* dy, const void* x, float* gw, long M, int N, int K, float* ws, long ws_floats, int dtype,
                      void* stream);
+/* The weight gradients of up to four Linear layers over the same M rows (the in_proj, out_proj, c_fc and c_proj of one
+ * ResidualAttentionBlock, tfm_model.py:17-27) in ONE launch: gw[i][N[i],K[i]] += dy[i][M,N[i]]^T x[i][M,K[i]].  This is the call
+ * tan_encoder_bwd makes per block; not eligible groups (f32, ragged M) run tan_linear_wgrad one by one.               */
+int tan_linear_wgrad_group(int n, const void* const* dy, const void* const* x, float* const* gw, const int* N, const int* K,
+                           long M, float* ws, long ws_floats, int dtype, void* stream);
 
 /* ---- row-panel fused kernels: one launch per half block ("fused layer") ------------------------
  * A workgroup owns a 64-row panel of the residual stream and keeps it in LDS while the weights stream past it from L2; the

@@ -22,6 +22,8 @@
 namespace tal {
 int gemm_dw_grouped(int nprob, const void* const* dy, const void* const* x, float* const* parts, const int* Ms, const int* Ns,
                     long rows, int split, int accumulate, hipStream_t st);      // tan_gemm_glds.hip
+int gemm_dw256_grouped(int nprob, const void* const* dy, const void* const* x, float* const* gw, const int* Ms, const int* Ns,
+                       long rows, int split, hipStream_t st);                   // tan_gemm_glds.hip
 }
 
 using namespace tal;
@@ -100,7 +102,30 @@ int grouped_enabled() {
     return on;
 }
 
+// TAN_DW256 = K slices of the 256 x 256-tile kernel (gemm_dw256_kernel; default 2, 0 = the 128 x 128 kernel below): slices > 1
+// add into the gradient with f32 atomics (no partial planes, no fold launches on the backward chain)
+int dw256_split() {
+    static const int v = [] { const char* e = getenv("TAN_DW256"); return e ? atoi(e) : 2; }();
+    return v < 0 ? 0 : v;
+}
+
 int linear_bwd_w_group(int dt, const DwItem* it, int n, long M, float* ws, long ws_floats, void* st) {
+    if (const int s256 = dt == TAN_BF16 ? dw256_split() : 0) {
+        bool ok = M % 128 == 0 && M / 128 >= s256;
+        for (int i = 0; i < n; ++i) ok = ok && it[i].N % 256 == 0 && it[i].K % 256 == 0;
+        if (ok) {
+            const void* dy[4]; const void* x[4]; float* gw[4]; int Ms[4], Ns[4];
+            double work = 0;
+            for (int i = 0; i < n; ++i) {
+                dy[i] = it[i].dy; x[i] = it[i].x; gw[i] = it[i].gw; Ms[i] = it[i].N; Ns[i] = it[i].K;
+                work += 2.0 * M * it[i].N * (double)it[i].K;
+            }
+            const int rec = prof_begin((hipStream_t)st, TAN_PROF_GEMM_BF16 + 3, work);
+            const int rc = gemm_dw256_grouped(n, dy, x, gw, Ms, Ns, M, s256, (hipStream_t)st);
+            prof_end((hipStream_t)st, rec);
+            if (rc != -2) return rc;
+        }
+    }
     int split = grouped_enabled();
     while (split > 1 && (M % split != 0 || (M / split) % 64 != 0)) --split;
     long need = 0;
@@ -129,6 +154,14 @@ int linear_bwd_w_group(int dt, const DwItem* it, int n, long M, float* ws, long 
 }
 
 }  // namespace
+
+extern "C" int tan_linear_wgrad_group(int n, const void* const* dy, const void* const* x, float* const* gw, const int* N, const int* K,
+                                      long M, float* ws, long ws_floats, int dtype, void* stream) {
+    TAN_REQUIRE(n >= 1 && n <= 4 && dy && x && gw && N && K && M > 0);
+    DwItem it[4];
+    for (int i = 0; i < n; ++i) { TAN_REQUIRE(dy[i] && x[i] && gw[i] && N[i] > 0 && K[i] > 0); it[i] = DwItem{dy[i], x[i], gw[i], N[i], K[i]}; }
+    return linear_bwd_w_group(dtype, it, n, M, ws, ws_floats, stream);
+}
 
 extern "C" int tan_linear_wgrad(const void* dy, const void* x, float* gw, long M, int N, int K, float* ws, long ws_floats,
                                 int dtype, void* stream) {

@@ -650,6 +650,201 @@ int gemm_dw_grouped(int nprob, const void* const* dy, const void* const* x, floa
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 256 x 256 block tiles for the grouped weight gradient: four waves, 128 x 128 per wave (16 accumulator tiles = 256 AGPRs),
+// K cut in TWO slices (96 workgroups for the four Linear layers of a block) that add into the f32 gradient with atomics.
+// Why: the weight-gradient kernels are bound by what a CU can pull through its vector-memory path -- the 128 x 128 kernel above
+// and this one both move ~50 GB/s per CU with the LDS-DMA (measured with the MFMAs ablated: 162 us of DMA alone for 48
+// workgroups x 8192 rows, 176 us with the MFMAs) -- so the lever is bytes per FLOP: a 256 x 256 tile stages 32 KiB per 32 K-rows
+// for 32 MFMAs per wave, half of the 128 x 128 tile's bytes per FLOP (and half its LDS fragment bytes: 8 KiB per 16 MFMAs).
+// Stand-alone the two kernels tie (86 us for 8192 rows); inside the training step this one runs the same 122 us on HALF the CUs
+// (96 instead of 192), and the other stack's kernels speed up by what it leaves them: 5.46 -> 5.33 ms per step (ABBA x2).
+// Three slices: 5.43; four (planes + folds or atomics): 5.45-5.54; one (48 workgroups): 5.78.
+// LDS: four 32-KiB stages [A rows 0-127][A rows 128-255][B 0-127][B 128-255], each an 8-KiB [32 k][256 B] image exactly as
+// stage_tile4<false> writes it; three stages in flight behind the one being read.  One barrier per stage, placed BETWEEN the two
+// 16-deep steps: when a wave's reads of step 1 have landed it has finished with the stage, so behind that barrier the stage
+// is free for the DMA of tile t+4 and tile t+1 (complete: counted vmcnt) may be read.
+constexpr int D256_STAGE = 4 * T4_BYTES;
+struct TrStep4 { TrFrag f[8]; };          // a[0..3] = f[0..3], b[0..3] = f[4..7]
+
+// hipcc orders (pure) MFMA builtins freely around asm statements -- it sinks the 16 MFMAs of a step below the wait for the NEXT
+// step's fragments and the barrier -- and it issues a stage's eight LDS-DMA loads and sixteen fragment reads in one burst.  With
+// one wave per SIMD and the four waves in lock step behind a barrier that is fatal: the vector-memory front end takes ~16
+// cycles per 1-KiB DMA instruction and a wave cannot reach its MFMAs before ITS loads are accepted, so all four waves queue
+// there (~450 cycles of a 1024-cycle stage, measured by ablation), then all four multiply while the memory path idles.  Every
+// instruction of the main loop is therefore volatile asm, executed in source order: one fragment read behind each of the first
+// eight MFMAs of a step, one DMA load behind every fourth MFMA, accumulators pinned to AGPRs ("+a").
+// The hazard recognizer does not look inside asm: `s_nop 1` covers "VALU wrote a source VGPR (the register allocator's copies of
+// fragment halves) -> MFMA reads it" (2 wait states; it issues while the matrix pipe is still busy with the previous MFMA).
+__device__ __forceinline__ void tr_wait256(TrStep4& s) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(s.f[0].lo), "+v"(s.f[0].hi), "+v"(s.f[1].lo), "+v"(s.f[1].hi), "+v"(s.f[2].lo), "+v"(s.f[2].hi),
+                   "+v"(s.f[3].lo), "+v"(s.f[3].hi), "+v"(s.f[4].lo), "+v"(s.f[4].hi), "+v"(s.f[5].lo), "+v"(s.f[5].hi),
+                   "+v"(s.f[6].lo), "+v"(s.f[6].hi), "+v"(s.f[7].lo), "+v"(s.f[7].hi));
+}
+__device__ __forceinline__ void mma256(f32x16& c, const TrFrag& a, const TrFrag& b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(tr_frag(a)), "v"(tr_frag(b)));
+}
+// one 1-KiB LDS-DMA load (M0 = destination, written and restored in the statement that uses it).  Scalar tile base + a per-lane
+// 32-bit offset that never changes: a VALU pointer increment behind the load would have to wait until the queued load has read its
+// address registers -- with the four waves' loads colliding at the vector-memory front end that stalled each wave ~50 cycles per load
+__device__ __forceinline__ void dma256(unsigned voff, const char* base, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(base) : "memory");
+}
+
+__global__ __launch_bounds__(256) void gemm_dw256_kernel(GroupedDwArgs ga) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];          // 4 * D256_STAGE = 128 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int T = gridDim.x;
+    int t;
+    {
+        const int id = blockIdx.x, xcd = id & 7, q = T >> 3, r = T & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    int p = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p += (i + 1 < ga.nprob && t >= ga.tile_end[i]) ? 1 : 0;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const int t0 = p ? ga.tile_end[p - 1] : 0;
+    const int M = ga.M[p], N = ga.N[p];
+    const int ntn = N / 256;
+    const int lt = t - t0, n0 = (lt % ntn) * 256, m0 = (lt / ntn) * 256;
+    const int split = blockIdx.y;
+    // K slices in groups of 128 rows (four stages), the first K/128 % slices of them one group longer
+    const int groups = ga.K / 128, gbase = groups / (int)gridDim.y, grem = groups % (int)gridDim.y;
+    const int kbeg = 128 * (split * gbase + min(split, grem));
+    const int nt = 4 * (gbase + (split < grem ? 1 : 0));
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc_zero(acc[i][j]);
+    // per-lane fragment addresses inside stage 0 / stage 2 (the 16-bit offset field of ds_read reaches two stages)
+    unsigned f_lo[8], f_hi[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f_lo[i] = tr_lane_addr(lds + wm * T4_BYTES, i * 32, lane);
+        f_lo[4 + i] = tr_lane_addr(lds + (2 + wn) * T4_BYTES, i * 32, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f_hi[i] = f_lo[i] + 2 * D256_STAGE;
+    // the eight 1-KiB pieces this thread's wave loads per stage: u = 2 * (A rows 0-127 | A 128-255 | B 0-127 | B 128-255) + piece
+    unsigned voff[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int h = u >> 1, piece = wave * 2 + (u & 1);
+        const int k = piece * 4 + (lane >> 4), slot = lane & 15, chunk = slot ^ ((k & 3) << 2);
+        voff[u] = (unsigned)(k * (h < 2 ? M : N) + 128 * (h & 1) + chunk * 8) * 2u;
+    }
+    const char* baseA = (const char*)(ga.A[p] + (long)kbeg * M + m0);       // the K tile to load next
+    const char* baseB = (const char*)(ga.B[p] + (long)kbeg * N + n0);
+    const unsigned lds0 = (unsigned)(uintptr_t)lds + (unsigned)wave * 2048u;
+    const long strideA = 64L * M, strideB = 64L * N;          // 32 k-rows, in bytes
+
+#define D2_DST(S_, U_) (lds0 + (S_) * D256_STAGE + ((U_) >> 1) * T4_BYTES + ((U_) & 1) * 1024)
+#define D2_READ(S_, STEP_, DST_, M_)                                                                           \
+    {                                                                                                          \
+        if ((S_) < 2) tr_issue<((S_) & 1) * D256_STAGE + (STEP_) * 4096>(DST_.f[M_], f_lo[M_]);                \
+        else          tr_issue<((S_) & 1) * D256_STAGE + (STEP_) * 4096>(DST_.f[M_], f_hi[M_]);                \
+    }
+    // Stage CUR holds tile T_ (landed; s0 = its step-0 fragments, in flight or landed).  PRV / NXT = (CUR -+ 1) & 3.
+    // Step 0: 16 MFMAs on s0; behind them the step-1 fragments and the second half of tile T_+3's loads (into stage PRV, free since
+    // the previous barrier).  Then the one barrier of the stage: every wave has READ all of stage CUR (its step-1 fragments have
+    // landed) and tile T_+1 is complete (own loads counted, vmcnt: tiles T_+2, T_+3 may be in flight).  Step 1: 16 MFMAs on s1;
+    // behind them the step-0 fragments of stage NXT and the first half of tile T_+4's loads (into stage CUR).
+#define D2_STAGE(T_, PRV, CUR, NXT)                                                                            \
+    {                                                                                                          \
+        tr_wait256(s0);                                                                                        \
+        _Pragma("unroll") for (int m_ = 0; m_ < 16; ++m_) {                                                    \
+            mma256(acc[m_ >> 2][m_ & 3], s0.f[m_ >> 2], s0.f[4 + (m_ & 3)]);                                   \
+            if (m_ < 8) D2_READ(CUR, 1, s1, (m_ == 0 ? 0 : m_ < 5 ? m_ + 3 : m_ - 4))                          \
+            if ((m_ & 3) == 3) dma256(voff[4 + (m_ >> 2)], baseB, D2_DST(PRV, 4 + (m_ >> 2)));                         \
+        }                                                                                                      \
+        baseB += ((T_) + 4 < nt) ? strideB : 0L;                                                               \
+        tr_wait256(s1);                                                                                        \
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                                      \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        _Pragma("unroll") for (int m_ = 0; m_ < 16; ++m_) {                                                    \
+            mma256(acc[m_ >> 2][m_ & 3], s1.f[m_ >> 2], s1.f[4 + (m_ & 3)]);                                   \
+            if (m_ < 8) D2_READ(NXT, 0, s0, (m_ == 0 ? 0 : m_ < 5 ? m_ + 3 : m_ - 4))                          \
+            if ((m_ & 3) == 3) dma256(voff[m_ >> 2], baseA, D2_DST(CUR, m_ >> 2));                                     \
+        }                                                                                                      \
+        baseA += ((T_) + 5 < nt) ? strideA : 0L;                                                               \
+    }
+    TrStep4 s0, s1;
+    // prologue: tiles 0, 1, 2 and the first half of tile 3
+#pragma unroll
+    for (int tl = 0; tl < 3; ++tl) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dma256(voff[u], u < 4 ? baseA : baseB, D2_DST(tl, u));
+        baseA += strideA; baseB += strideB;              // nt >= 4
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dma256(voff[u], baseA, D2_DST(3, u));
+    baseA += (4 < nt) ? strideA : 0L;
+    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) D2_READ(0, 0, s0, m)
+    for (int tt = 0; tt < nt; tt += 4) {
+        D2_STAGE(tt, 3, 0, 1)
+        D2_STAGE(tt + 1, 0, 1, 2)
+        D2_STAGE(tt + 2, 1, 2, 3)
+        D2_STAGE(tt + 3, 2, 3, 0)
+    }
+#undef D2_STAGE
+#undef D2_READ
+#undef D2_ADV
+#undef D2_DST
+    tr_wait256(s0);                      // the read-ahead of a tile past the end: landed, unused
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");     // + the last MFMA's result before the AGPR reads
+
+    float* C = ga.C[p] + (long)(m0 + wm * 128) * N + n0 + wn * 128 + acc_col(lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* row = C + (long)(i * 32 + acc_row(r, lane)) * N;
+            if (ga.accumulate == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) unsafeAtomicAdd(row + j * 32, acc[i][j][r]);
+            } else {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = row[j * 32];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) row[j * 32] = v[j] + acc[i][j][r];
+            }
+        }
+}
+
+// host side: gw_p += dy_p^T x_p; returns -2 when the group is not eligible
+int gemm_dw256_grouped(int nprob, const void* const* dy, const void* const* x, float* const* gw, const int* Ms, const int* Ns,
+                       long rows, int split, hipStream_t st) {
+    if (nprob < 1 || nprob > 4 || split < 1 || rows % 128 != 0 || rows / 128 < split) return -2;
+    GroupedDwArgs ga{};
+    int tiles = 0;
+    for (int p = 0; p < nprob; ++p) {
+        if (Ms[p] % 256 || Ns[p] % 256 || ((uintptr_t)dy[p] | (uintptr_t)x[p] | (uintptr_t)gw[p]) % 16) return -2;
+        ga.A[p] = (const bf16_t*)dy[p]; ga.B[p] = (const bf16_t*)x[p]; ga.C[p] = gw[p];
+        ga.M[p] = Ms[p]; ga.N[p] = Ns[p];
+        tiles += (Ms[p] / 256) * (Ns[p] / 256);
+        ga.tile_end[p] = tiles;
+    }
+    for (int p = nprob; p < 4; ++p) { ga.tile_end[p] = tiles; ga.A[p] = ga.A[0]; ga.B[p] = ga.B[0]; ga.C[p] = ga.C[0]; ga.M[p] = ga.M[0]; ga.N[p] = ga.N[0]; }
+    ga.nprob = nprob; ga.K = (int)rows; ga.accumulate = split == 1 ? 1 : 2;       // 1: one slice, plain read-add-write; 2: atomics
+    static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_dw256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * D256_STAGE);
+    if (attr != hipSuccess) return (int)attr;
+    hipLaunchKernelGGL(gemm_dw256_kernel, dim3(tiles, split), dim3(256), 4 * D256_STAGE, st, ga);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
 // The 4-stage / K-step-32 pipeline (three tiles in flight) pays for the K-strided x K-strided weight-gradient GEMMs once the K
 // slice is long (dW c_fc 35.7 -> 33.8 us, c_proj 35.8 -> 33.3 us at 8192 rows).  For K-contiguous operands it won 6-12 % stand-alone
 // on the N=512 outputs and LOST 2.4 % of the training step: that instantiation was removed in round 2.

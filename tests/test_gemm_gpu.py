@@ -167,3 +167,29 @@ def test_gemm_random_configurations():
                 want = pre
         err = (out.double() - want).abs().max().item()
         assert err < tol * (want.abs().max().item() + 1.0), (case, M, N, K, a_kc, b_kc, batch, mode, err)
+
+
+@pytest.mark.parametrize("rows", [8192, 10240, 384, 1024 + 64, 200])
+@pytest.mark.parametrize("shapes", [[(1536, 512), (512, 512), (2048, 512), (512, 2048)], [(256, 768)], [(1536, 512), (40, 72)]])
+def test_linear_wgrad_group(rows, shapes):
+    """tan_linear_wgrad_group: gw_i += dy_i^T x_i for the Linear layers of one block in one call.  rows % 128 == 0 with every
+    N, K a multiple of 256 takes the 256 x 256-tile kernel (two K slices adding with atomics, or slices of unequal length when
+    rows / 128 is odd); everything else the 128 x 128 grouped kernel or the one-by-one path.  gw starts non-zero: it is +=."""
+    import ctypes as C
+    from temporalalignnet_amd import ops, _lib
+    n = len(shapes)
+    dys = [_mk((rows, N), torch.bfloat16, 30 + i) * 0.5 for i, (N, K) in enumerate(shapes)]
+    xs = [_mk((rows, K), torch.bfloat16, 40 + i) for i, (N, K) in enumerate(shapes)]
+    g0 = [_mk((N, K), torch.float32, 50 + i) for i, (N, K) in enumerate(shapes)]
+    gws = [g.clone() for g in g0]
+    ws = torch.empty(4 * sum(N * K for N, K in shapes), device="cuda")
+    arr_p, arr_i = C.c_void_p * n, C.c_int * n
+    rc = _lib.lib().tan_linear_wgrad_group(n, arr_p(*[d.data_ptr() for d in dys]), arr_p(*[x.data_ptr() for x in xs]),
+                                           arr_p(*[g.data_ptr() for g in gws]), arr_i(*[N for N, K in shapes]),
+                                           arr_i(*[K for N, K in shapes]), C.c_long(rows), C.c_void_p(ws.data_ptr()),
+                                           C.c_long(ws.numel()), _lib.TAN_BF16, ops._stream())
+    assert rc == 0
+    for g, g_init, d, x in zip(gws, g0, dys, xs):
+        want = g_init.double() + d.double().t() @ x.double()
+        err = (g.double() - want).abs().max().item()
+        assert err < 2e-5 * max(1.0, want.abs().max().item()), err
