@@ -695,15 +695,25 @@ __device__ __forceinline__ void dma256(unsigned voff, const char* base, unsigned
 }
 
 __global__ __launch_bounds__(256) void gemm_dw256_kernel(GroupedDwArgs ga) {
-    extern __shared__ __attribute__((aligned(1024))) char lds[];          // 4 * D256_STAGE = 128 KiB
+    constexpr int NST = 4;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];          // NST * D256_STAGE = 128 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int T = gridDim.x;
-    int t;
-    {
+    // Workgroup -> (tile, K slice).  ga.kchunk = S > 0 (S | 8): a 1-D grid, XCD x = id % 8 works slice x / (8/S) and a contiguous
+    // run of tiles (column tile fastest), so the workgroups that share operand columns of the SAME K rows sit behind one L2 --
+    // a CU pulls ~20 B/clk of L2 misses (what bounds this kernel) and several times that of L2 hits.
+    int t, split, nsplit;
+    if (ga.kchunk > 0) {
+        nsplit = ga.kchunk;
+        const int id = blockIdx.x, xcd = id & 7, per = 8 / nsplit, T = (int)gridDim.x / nsplit, run = T / per;
+        split = xcd / per;
+        t = (xcd % per) * run + (id >> 3);
+    } else {
+        const int T = gridDim.x;
         const int id = blockIdx.x, xcd = id & 7, q = T >> 3, r = T & 7;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        split = blockIdx.y; nsplit = gridDim.y;
     }
     int p = 0;
 #pragma unroll
@@ -713,9 +723,8 @@ __global__ __launch_bounds__(256) void gemm_dw256_kernel(GroupedDwArgs ga) {
     const int M = ga.M[p], N = ga.N[p];
     const int ntn = N / 256;
     const int lt = t - t0, n0 = (lt % ntn) * 256, m0 = (lt / ntn) * 256;
-    const int split = blockIdx.y;
     // K slices in groups of 128 rows (four stages), the first K/128 % slices of them one group longer
-    const int groups = ga.K / 128, gbase = groups / (int)gridDim.y, grem = groups % (int)gridDim.y;
+    const int groups = ga.K / 128, gbase = groups / nsplit, grem = groups % nsplit;
     const int kbeg = 128 * (split * gbase + min(split, grem));
     const int nt = 4 * (gbase + (split < grem ? 1 : 0));
 
@@ -725,14 +734,14 @@ __global__ __launch_bounds__(256) void gemm_dw256_kernel(GroupedDwArgs ga) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc_zero(acc[i][j]);
     // per-lane fragment addresses inside stage 0 / stage 2 (the 16-bit offset field of ds_read reaches two stages)
-    unsigned f_lo[8], f_hi[8];
+    unsigned f_lo[8], f_hi[8], f_top[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         f_lo[i] = tr_lane_addr(lds + wm * T4_BYTES, i * 32, lane);
         f_lo[4 + i] = tr_lane_addr(lds + (2 + wn) * T4_BYTES, i * 32, lane);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) f_hi[i] = f_lo[i] + 2 * D256_STAGE;
+    for (int i = 0; i < 8; ++i) { f_hi[i] = f_lo[i] + 2 * D256_STAGE; f_top[i] = f_lo[i] + 4 * D256_STAGE; }
     // the eight 1-KiB pieces this thread's wave loads per stage: u = 2 * (A rows 0-127 | A 128-255 | B 0-127 | B 128-255) + piece
     unsigned voff[8];
 #pragma unroll
@@ -749,14 +758,15 @@ __global__ __launch_bounds__(256) void gemm_dw256_kernel(GroupedDwArgs ga) {
 #define D2_DST(S_, U_) (lds0 + (S_) * D256_STAGE + ((U_) >> 1) * T4_BYTES + ((U_) & 1) * 1024)
 #define D2_READ(S_, STEP_, DST_, M_)                                                                           \
     {                                                                                                          \
-        if ((S_) < 2) tr_issue<((S_) & 1) * D256_STAGE + (STEP_) * 4096>(DST_.f[M_], f_lo[M_]);                \
-        else          tr_issue<((S_) & 1) * D256_STAGE + (STEP_) * 4096>(DST_.f[M_], f_hi[M_]);                \
+        if ((S_) < 2)      tr_issue<((S_) & 1) * D256_STAGE + (STEP_) * 4096>(DST_.f[M_], f_lo[M_]);           \
+        else if ((S_) < 4) tr_issue<((S_) & 1) * D256_STAGE + (STEP_) * 4096>(DST_.f[M_], f_hi[M_]);           \
+        else               tr_issue<((S_) & 1) * D256_STAGE + (STEP_) * 4096>(DST_.f[M_], f_top[M_]);          \
     }
-    // Stage CUR holds tile T_ (landed; s0 = its step-0 fragments, in flight or landed).  PRV / NXT = (CUR -+ 1) & 3.
-    // Step 0: 16 MFMAs on s0; behind them the step-1 fragments and the second half of tile T_+3's loads (into stage PRV, free since
-    // the previous barrier).  Then the one barrier of the stage: every wave has READ all of stage CUR (its step-1 fragments have
-    // landed) and tile T_+1 is complete (own loads counted, vmcnt: tiles T_+2, T_+3 may be in flight).  Step 1: 16 MFMAs on s1;
-    // behind them the step-0 fragments of stage NXT and the first half of tile T_+4's loads (into stage CUR).
+    // Stage CUR holds tile T_ (landed; s0 = its step-0 fragments, in flight or landed).  PRV / NXT = (CUR -+ 1) mod NST.
+    // Step 0: 16 MFMAs on s0; behind them the step-1 fragments and the second half of tile T_+NST-1's loads (into stage PRV, free
+    // since the previous barrier).  Then the one barrier of the stage: every wave has READ all of stage CUR (its step-1 fragments
+    // have landed) and tile T_+1 is complete (own loads counted, vmcnt: tiles T_+2 .. T_+NST-1 may be in flight).  Step 1: 16 MFMAs
+    // on s1; behind them the step-0 fragments of stage NXT and the first half of tile T_+NST's loads (into stage CUR).
 #define D2_STAGE(T_, PRV, CUR, NXT)                                                                            \
     {                                                                                                          \
         tr_wait256(s0);                                                                                        \
@@ -765,33 +775,36 @@ __global__ __launch_bounds__(256) void gemm_dw256_kernel(GroupedDwArgs ga) {
             if (m_ < 8) D2_READ(CUR, 1, s1, (m_ == 0 ? 0 : m_ < 5 ? m_ + 3 : m_ - 4))                          \
             if ((m_ & 3) == 3) dma256(voff[4 + (m_ >> 2)], baseB, D2_DST(PRV, 4 + (m_ >> 2)));                         \
         }                                                                                                      \
-        baseB += ((T_) + 4 < nt) ? strideB : 0L;                                                               \
+        baseB += ((T_) + NST < nt) ? strideB : 0L;                                                             \
         tr_wait256(s1);                                                                                        \
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                                      \
+        if (NST == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                        \
+        else          asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                                        \
         __builtin_amdgcn_s_barrier();                                                                          \
         _Pragma("unroll") for (int m_ = 0; m_ < 16; ++m_) {                                                    \
             mma256(acc[m_ >> 2][m_ & 3], s1.f[m_ >> 2], s1.f[4 + (m_ & 3)]);                                   \
             if (m_ < 8) D2_READ(NXT, 0, s0, (m_ == 0 ? 0 : m_ < 5 ? m_ + 3 : m_ - 4))                          \
             if ((m_ & 3) == 3) dma256(voff[m_ >> 2], baseA, D2_DST(CUR, m_ >> 2));                                     \
         }                                                                                                      \
-        baseA += ((T_) + 5 < nt) ? strideA : 0L;                                                               \
+        baseA += ((T_) + NST + 1 < nt) ? strideA : 0L;                                                         \
     }
     TrStep4 s0, s1;
-    // prologue: tiles 0, 1, 2 and the first half of tile 3
+    // prologue: tiles 0 .. NST-2 and the first half of tile NST-1 (nt >= 4)
 #pragma unroll
-    for (int tl = 0; tl < 3; ++tl) {
+    for (int tl = 0; tl < NST - 1; ++tl) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) dma256(voff[u], u < 4 ? baseA : baseB, D2_DST(tl, u));
-        baseA += strideA; baseB += strideB;              // nt >= 4
+        baseA += (tl + 1 < nt) ? strideA : 0L;
+        baseB += (tl + 1 < nt) ? strideB : 0L;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) dma256(voff[u], baseA, D2_DST(3, u));
-    baseA += (4 < nt) ? strideA : 0L;
-    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    for (int u = 0; u < 4; ++u) dma256(voff[u], baseA, D2_DST(NST - 1, u));
+    baseA += (NST < nt) ? strideA : 0L;
+    if (NST == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else          asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int m = 0; m < 8; ++m) D2_READ(0, 0, s0, m)
-    for (int tt = 0; tt < nt; tt += 4) {
+    for (int tt = 0; tt < nt; tt += 4) {           // nt % 4 == 0
         D2_STAGE(tt, 3, 0, 1)
         D2_STAGE(tt + 1, 0, 1, 2)
         D2_STAGE(tt + 2, 1, 2, 3)
@@ -840,7 +853,10 @@ int gemm_dw256_grouped(int nprob, const void* const* dy, const void* const* x, f
     ga.nprob = nprob; ga.K = (int)rows; ga.accumulate = split == 1 ? 1 : 2;       // 1: one slice, plain read-add-write; 2: atomics
     static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_dw256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * D256_STAGE);
     if (attr != hipSuccess) return (int)attr;
-    hipLaunchKernelGGL(gemm_dw256_kernel, dim3(tiles, split), dim3(256), 4 * D256_STAGE, st, ga);
+    static const int xmap = [] { const char* e = getenv("TAN_DW256_XCD"); return e ? atoi(e) : 1; }();
+    ga.kchunk = (xmap && 8 % split == 0 && tiles % (8 / split) == 0) ? split : 0;        // slices pinned to XCD groups
+    if (ga.kchunk) hipLaunchKernelGGL(gemm_dw256_kernel, dim3(tiles * split), dim3(256), 4 * D256_STAGE, st, ga);
+    else hipLaunchKernelGGL(gemm_dw256_kernel, dim3(tiles, split), dim3(256), 4 * D256_STAGE, st, ga);
     TAN_LAUNCH_CHECK();
     return 0;
 }
