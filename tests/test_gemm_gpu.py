@@ -193,3 +193,18 @@ def test_linear_wgrad_group(rows, shapes):
         want = g_init.double() + d.double().t() @ x.double()
         err = (g.double() - want).abs().max().item()
         assert err < 2e-5 * max(1.0, want.abs().max().item()), err
+
+
+@pytest.mark.parametrize("M,N,K", [(1280, 512, 49152), (512, 512, 24576 + 128), (1280, 512, 49152 + 64)])
+def test_gemm_long_contraction_accumulate(M, N, K):
+    """C[M,N] (f32) += A[K,M]^T B[K,N], bf16, K = S*B*T rows: the text-feature gradient of the similarity loss (K slices adding
+    with atomics into a non-zero C)."""
+    from temporalalignnet_amd import ops
+    A = _mk((K, M), torch.bfloat16, 60) * 0.25
+    B = _mk((K, N), torch.bfloat16, 61) * 0.25
+    C0 = _mk((M, N), torch.float32, 62)
+    C = C0.clone()
+    ops.gemm(A, B, C, M=M, N=N, K=K, a_kc=False, b_kc=False, lda=M, ldb=N, accumulate=True, split_k=8)
+    ref = C0.double() + A.double().t() @ B.double()
+    err = (C.double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
