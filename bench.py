@@ -177,7 +177,7 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
                 fam = json.load(open(pmc))["mfma_gemm_family"]
                 prof = {"file": "profiles/r02_pmc_traffic.json", "hbm_bytes_per_launch": round(fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch"]),
                         "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run"}
-            roof = {"bound": "mfma", "kernel": "tal::gemm_glds_kernel + tal::gemm_dw256_kernel + tal::simnce_kernel (one direct-to-LDS MFMA pipeline, all operand layouts) + tal::mlp_panel_kernel (row-panel fused MLP, forward and backward)",
+            roof = {"bound": "mfma", "kernel": "tal::gemm_glds_kernel + tal::gemm_dw256_kernel + tal::simnce_res_kernel (direct-to-LDS MFMA pipelines, all operand layouts) + tal::mlp_panel_kernel (row-panel fused MLP, forward and backward)",
                     "achieved": round(ach, 1),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "traffic_profile": prof,
                     "avg_launch_us": round(tms * 1e3 / tcnt, 2), "launches_per_step": round(tcnt / sampled, 1),

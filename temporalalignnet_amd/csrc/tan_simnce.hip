@@ -199,6 +199,173 @@ __global__ __launch_bounds__(256, 2) void simnce_kernel(SimArgs a) {
     }
 }
 
+// ---- the same sweep with the frame panel RESIDENT in the LDS (C = 512) ---------------------------------------------------------
+// simnce_kernel re-stages its 128 x 512 frame panel for every column tile: 2.5 MB of L2->LDS traffic per workgroup, and the 48
+// panels an XCD works on at once (6 MB) do not fit its 4-MB L2 next to the text features -- rocprofv3 counted ~500 MB of HBM reads
+// per launch for 52 MB of operands.  Here the panel's eight 16-KiB K tiles are staged ONCE (128 KiB) and stay; EIGHT waves share
+// them: two groups of four (each the 2 x 2 wave grid of simnce_kernel) take the even / the odd column tiles, each streaming its
+// text tile through its own 2 x 8 KiB double buffer in 32-deep K steps -- 128 + 32 = 160 KiB, the whole LDS of a CU, two waves per
+// SIMD as with two resident workgroups of the re-staging kernel.  (Four waves per CU -- the panel + one 2 x 16 KiB text buffer --
+// were measured first: 234 / 224 us vs 184 / 157 us per launch; one compiler-scheduled wave per SIMD cannot cover its own stalls.
+// Cutting each panel's columns over two workgroups, 768 shorter items instead of 384 = a round and a half: 235 us, 5.34 vs 5.25 ms.)
+// Measured: HBM reads 502 -> 62 MB (statistics sweep) and 514 -> 83 MB (dlogits sweep) per launch; 177 / 182 us per launch in the
+// step (re-staging kernel: 167 / 157 us), the step itself 5.243 vs 5.256 ms (ABBA x2) -- the sweep was never HBM-bound, its loop
+// (a `vmcnt(0)` + barrier per K step, compiler-ordered) is.
+// Column sums: the 128 columns of a tile are final when the tile is done (a column tile is visited once per workgroup), so the two
+// row-waves store their halves straight to colpart rows (2 * panel + wm): no LDS accumulators, no atomics.
+constexpr int S_T32 = 128 * 32 * 2;   // 8 KiB text tile of a 32-deep K step
+
+// [128 rows][4 x 16-B slots], slot = chunk ^ ((row >> 2) & 3): 512 pieces of 16 B, two per thread of a four-wave group
+__device__ __forceinline__ void s_stage32(const bf16_t* __restrict__ P, long ld, int outer0, int OUT, int k0, char* lds_tile, int gw,
+                                          int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int piece = gw * 2 + i;
+        const int row = piece * 16 + (lane >> 2), slot = lane & 3;
+        const int chunk = slot ^ ((row >> 2) & 3);
+        const int gr = min(outer0 + row, OUT - 1);
+        __builtin_amdgcn_global_load_lds((sgptr_t)(P + (long)gr * ld + k0 + chunk * 8), (slptr_t)(lds_tile + piece * 1024), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ bf16x8 s_frag32(const char* lds_tile, int o0, int ks, int lane) {
+    const int row = o0 + (lane & 31), chunk = (ks >> 3) + (lane >> 5);
+    return *reinterpret_cast<const bf16x8*>(lds_tile + row * 64 + (chunk ^ ((row >> 2) & 3)) * 16);
+}
+
+template <int MODE>
+__device__ __forceinline__ void tile_done_res(const TileCtx& c, f32x16 (&acc)[2][2], float (&rowacc)[2][16], float* colrow, int ct) {
+    const int c0 = ct * 128, R = c.R, Mp = c.Mp, lane = c.lane;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = c0 + c.wn * 64 + j * 32 + acc_col(lane);
+        const bool col_ok = col < Mp;
+        const bool col_valid = col_ok && !c.col_invalid[min(col, Mp - 1)];
+        float csum = 0.f, bc = 0.f;
+        if (MODE == 1) {
+            const long idx = (long)c.s * Mp + min(col, Mp - 1);
+            const float gt = c.g_t[idx], cs = c.colsum[idx];
+            bc = col_ok ? gt / cs * c.inv_tau : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c.m0 + c.wm * 64 + i * 32 + acc_row(r, lane);
+                float e = __expf((acc[i][j][r] - 1.0f) * c.inv_tau);
+                if (!col_ok || row >= R) e = 0.f;
+                if (MODE == 0) {
+                    if (col_valid) rowacc[i][r] += e;
+                    csum += e;
+                } else {
+                    const float g = e * ((col_valid ? rowacc[i][r] : 0.f) + bc);
+                    if (col_ok && row < R) c.dl[((long)c.s * R + row) * Mp + col] = f2bf(g);
+                }
+            }
+        if (MODE == 0) {
+            csum += __shfl_xor(csum, 32, 64);
+            if (lane < 32 && col_ok) colrow[col] = csum;
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void simnce_res_kernel(SimArgs a) {
+    __shared__ __attribute__((aligned(1024))) char lds[8 * S_TILE + 4 * S_T32];      // [8 frame K tiles][group][2 text tiles]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, gw = wave & 3, wm = gw >> 1, wn = gw & 1;
+    const int npanel = gridDim.x;
+    int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const int nwg = gridDim.x * gridDim.y, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    }
+    const int s = wg / npanel, panel = wg - s * npanel, m0 = panel * 128;
+    const int R = a.R, Mp = a.Mp, Cw = a.C, nS = a.S;
+    const bf16_t* V = a.V + (long)s * R * Cw;
+    const bf16_t* Tt = a.Tt + (long)s * a.t_stage_stride;
+    const int nct = (Mp + 127) / 128, niter = (nct + 1) / 2;
+    const float inv_tau = 1.0f / S_TAU;
+    char* tbuf = lds + 8 * S_TILE + grp * 2 * S_T32;
+
+    float rowacc[2][16];      // MODE_STATS: running row sums (this group's column tiles); MODE_DL: gv/rowsum/tau
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            rowacc[i][r] = 0.f;
+            if (MODE == 1) {
+                const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+                const long idx = (long)s * R + min(row, R - 1);
+                const float gv = a.g_v[idx], rs = a.rowsum[idx];
+                rowacc[i][r] = row < R ? gv / rs * inv_tau : 0.f;
+            }
+        }
+    TileCtx c;
+    c.col_invalid = a.col_invalid; c.colsum = a.colsum; c.g_t = a.g_t; c.dl = a.dl;
+    c.R = R; c.Mp = Mp; c.s = s; c.m0 = m0; c.wm = wm; c.wn = wn; c.lane = lane; c.inv_tau = inv_tau;
+    float* colrow = MODE == 0 ? a.colpart + ((long)(2 * panel + wm) * nS + s) * Mp : nullptr;
+
+    f32x16 acc[2][2];
+    // one 32-deep K step of this group's column tile ct_ (wave-uniform `live_`: the odd group idles through a last lone tile)
+#define SIMR_KSTEP(KT, CUR, NXT)                                                                                           \
+    {                                                                                                                      \
+        const int kt_ = (KT);                                                                                              \
+        const int ct2 = kt_ < 15 ? ct_ : ct_ + 2, kt2 = kt_ < 15 ? kt_ + 1 : 0;                                            \
+        if (ct2 < nct) s_stage32(Tt, Cw, ct2 * 128, Mp, kt2 * 32, tbuf + (NXT) * S_T32, gw, lane);                         \
+        if (kt_ == 0) {                                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]); \
+        }                                                                                                                  \
+        if (live_) {                                                                                                       \
+            const char* vt_ = lds + (kt_ >> 1) * S_TILE;                                                                   \
+            _Pragma("unroll") for (int ks = 0; ks < 32; ks += 16) {                                                        \
+                bf16x8 af[2], bfr[2];                                                                                      \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) af[i] = s_frag(vt_, wm * 64 + i * 32, (kt_ & 1) * 32 + ks, lane); \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) bfr[j] = s_frag32(tbuf + (CUR) * S_T32, wn * 64 + j * 32, ks, lane); \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);                \
+            }                                                                                                              \
+            if (kt_ == 15) tile_done_res<MODE>(c, acc, rowacc, colrow, ct_);                                               \
+        }                                                                                                                  \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                   \
+        __syncthreads();                                                                                                   \
+    }
+
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) s_stage(V, Cw, m0, R, (grp * 4 + kt) * 64, lds + (grp * 4 + kt) * S_TILE, gw, lane);
+    if (grp < nct) s_stage32(Tt, Cw, grp * 128, Mp, 0, tbuf, gw, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+        const int ct_ = 2 * it + grp;
+        const bool live_ = ct_ < nct;
+        for (int kt = 0; kt < 16; kt += 2) {
+            SIMR_KSTEP(kt, 0, 1)
+            SIMR_KSTEP(kt + 1, 1, 0)
+        }
+    }
+#undef SIMR_KSTEP
+
+    if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = rowacc[i][r];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+                if ((lane & 31) == 0 && row < R) unsafeAtomicAdd(a.rowsum + (long)s * R + row, v);
+            }
+    }
+}
+
+// TAN_SIM_RES=0: the re-staging kernel for every shape (A/B measurements)
+static bool res_enabled(const SimArgs& a) {
+    static const int v = [] { const char* e = getenv("TAN_SIM_RES"); return e ? atoi(e) : 1; }();
+    return v != 0 && a.C == 512;
+}
+
 // colsum[s,c] = sum over row panels of colpart
 __global__ void simnce_col_finalize(const float* __restrict__ colpart, float* __restrict__ colsum, int npanel, long SM) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -317,7 +484,7 @@ extern "C" int tan_simnce_max_cols(void) { return S_MAXCOLS; }
 
 extern "C" long tan_simnce_ws_floats(int S, int B, int T, int N) {
     const long R = (long)B * T, Mp = (long)B * N;
-    return (long)cdiv(R, 128) * S * Mp + (long)S * B * T * N;     // column partials + same-video blocks
+    return 2 * (long)cdiv(R, 128) * S * Mp + (long)S * B * T * N;     // column partials (two per row panel) + same-video blocks
 }
 
 static int simnce_common(SimArgs& a, int S, int B, int T, int N, int C) {
@@ -402,7 +569,7 @@ extern "C" int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_strid
     if (rc) return rc;
     const int npanel = cdiv(a.R, 128);
     a.colpart = ws;
-    float* diag = ws + (long)npanel * S * a.Mp;          // sized for the padded column count
+    float* diag = ws + 2 * (long)npanel * S * a.Mp;      // sized for the padded column count
     if (colmap) a.Mp = Mc;
     else { tn_blocks = tn; tb_stage_stride = t_stage_stride; }
     if (a.Mp > S_MAXCOLS) return TAN_ERR_BAD_ARG;        // columns of the sweep (compacted or not): one LDS accumulator each
@@ -414,10 +581,12 @@ extern "C" int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_strid
             if (e != hipSuccess) return (int)e;
         }
         const int prec = prof_begin(st, TAN_PROF_SIMNCE, 2.0 * S * a.R * (double)a.Mp * C);
-        hipLaunchKernelGGL((simnce_kernel<0>), dim3(npanel, S), dim3(256), 0, st, a);
+        const bool res = res_enabled(a);
+        if (res) hipLaunchKernelGGL((simnce_res_kernel<0>), dim3(npanel, S), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((simnce_kernel<0>), dim3(npanel, S), dim3(256), 0, st, a);
         prof_end(st, prec);
         TAN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(simnce_col_finalize, dim3(cdiv(SM, 64)), dim3(64), 0, st, a.colpart, colsum, npanel, SM);
+        hipLaunchKernelGGL(simnce_col_finalize, dim3(cdiv(SM, 64)), dim3(64), 0, st, a.colpart, colsum, res ? 2 * npanel : npanel, SM);
     }
     if (phases & TAN_SIM_DIAG) {
         if ((rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;
@@ -449,13 +618,14 @@ extern "C" int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_st
     int rc = simnce_common(a, S, B, T, N, C);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    float* diag = ws + (long)cdiv(a.R, 128) * S * a.Mp;
+    float* diag = ws + 2 * (long)cdiv(a.R, 128) * S * a.Mp;
     if (colmap) a.Mp = Mc;
     else { tn_blocks = tn; tb_stage_stride = t_stage_stride; }
     if (a.Mp > S_MAXCOLS) return TAN_ERR_BAD_ARG;        // columns of the sweep (compacted or not): one LDS accumulator each
     if (phases & TAN_SIM_SWEEP) {
         const int prec = prof_begin(st, TAN_PROF_SIMNCE, 2.0 * S * a.R * (double)a.Mp * C);
-        hipLaunchKernelGGL((simnce_kernel<1>), dim3(cdiv(a.R, 128), S), dim3(256), 0, st, a);
+        if (res_enabled(a)) hipLaunchKernelGGL((simnce_res_kernel<1>), dim3(cdiv(a.R, 128), S), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((simnce_kernel<1>), dim3(cdiv(a.R, 128), S), dim3(256), 0, st, a);
         prof_end(st, prec);
         TAN_LAUNCH_CHECK();
     }
