@@ -36,6 +36,9 @@ struct SimArgs {
     const float *g_v, *g_t;            // [S, R], [S, Mp]   (MODE_DL in)
     bf16_t* dl;                        // [S, R, Mp]        (MODE_DL out)
     int S, B, T, N, C, R, Mp;
+    // simnce_res_kernel<1> with the same-video corrections as its tail (instead of a simnce_diag_kernel<true> launch):
+    const float* diag;                 // [S, B, T, N] same-video cosines, or null: no corrections in the sweep kernel
+    const int* colmap;                 // padded column b*N+k -> column of the sweep, or -1; null: identity
 };
 
 // K-contiguous 128-row operand tile, same image as tan_gemm_glds.hip (slot = chunk ^ ((row >> 1) & 7))
@@ -358,8 +361,40 @@ __global__ __launch_bounds__(512) void simnce_res_kernel(SimArgs a) {
                 if ((lane & 31) == 0 && row < R) unsafeAtomicAdd(a.rowsum + (long)s * R + row, v);
             }
     }
+    if (MODE == 1 && a.diag) {
+        // Same-video corrections (simnce_diag_kernel<true>'s arithmetic) on the 128 rows this workgroup has just written, as the
+        // kernel's tail: a separate launch of 768 small blocks queued behind the other sweep's whole-CU workgroups for 50 us on the
+        // loss's critical chain.  The stores above are this workgroup's own: drained and fenced, they are visible to its loads.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int T = a.T, N = a.N;
+        const int nrow = min(128, R - m0);
+        for (int i = tid; i < nrow * N; i += 512) {
+            const int lr = i / N, k = i - lr * N, row = m0 + lr;
+            const int b = row / T, t = row - b * T;
+            const int m = a.colmap ? a.colmap[b * N + k] : b * N + k;
+            if (m < 0) continue;
+            bf16_t* out = a.dl + ((long)s * R + row) * Mp + m;
+            if (a.row_leak && a.row_leak[row]) { *out = 0; continue; }
+            if (a.tgt[((long)b * T + t) * N + k] == 0.f) continue;
+            const long ri = (long)s * R + row, ci = (long)s * Mp + m;
+            const float e = __expf((a.diag[(((long)s * a.B + b) * T + t) * N + k] - 1.0f) * inv_tau);
+            const float pv = a.possum_v[ri], pt = a.possum_t[ci];
+            float corr = 0.f;
+            if (!a.col_invalid[m] && pv > 0.f) corr += a.g_v[ri] / pv;
+            if (pt > 0.f) corr += a.g_t[ci] / pt;
+            *out = f2bf(bf2f(*out) - e * corr * inv_tau);
+        }
+    }
 }
 
+// TAN_SIM_INLINE_DIAG=0: the dlogits sweep followed by simnce_diag_kernel<true> (A/B measurements)
+static bool inline_diag_enabled() {
+    static const int v = [] { const char* e = getenv("TAN_SIM_INLINE_DIAG"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
 // TAN_SIM_RES=0: the re-staging kernel for every shape (A/B measurements)
 static bool res_enabled(const SimArgs& a) {
     static const int v = [] { const char* e = getenv("TAN_SIM_RES"); return e ? atoi(e) : 1; }();
@@ -623,9 +658,15 @@ extern "C" int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_st
     else { tn_blocks = tn; tb_stage_stride = t_stage_stride; }
     if (a.Mp > S_MAXCOLS) return TAN_ERR_BAD_ARG;        // columns of the sweep (compacted or not): one LDS accumulator each
     if (phases & TAN_SIM_SWEEP) {
+        const bool res = res_enabled(a);
+        const bool tail = res && inline_diag_enabled() && (phases & TAN_SIM_DIAG);      // corrections as the sweep kernel's tail
+        if (tail && !(phases & TAN_SIM_DIAG_KEEP) && (rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;
         const int prec = prof_begin(st, TAN_PROF_SIMNCE, 2.0 * S * a.R * (double)a.Mp * C);
-        if (res_enabled(a)) hipLaunchKernelGGL((simnce_res_kernel<1>), dim3(cdiv(a.R, 128), S), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((simnce_kernel<1>), dim3(cdiv(a.R, 128), S), dim3(256), 0, st, a);
+        if (res) {
+            a.diag = tail ? diag : nullptr; a.colmap = colmap;
+            hipLaunchKernelGGL((simnce_res_kernel<1>), dim3(cdiv(a.R, 128), S), dim3(512), 0, st, a);
+            if (tail) phases &= ~TAN_SIM_DIAG;
+        } else hipLaunchKernelGGL((simnce_kernel<1>), dim3(cdiv(a.R, 128), S), dim3(256), 0, st, a);
         prof_end(st, prec);
         TAN_LAUNCH_CHECK();
     }
