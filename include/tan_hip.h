@@ -227,6 +227,21 @@ int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_stride, const
                       const float* possum_t, const float* g_v, const float* g_t, void* dl, float* ws, int S, int B, int T, int N,
                       int C, const void* tn_blocks, long tb_stage_stride, const int* colmap, int Mc, int phases, void* stream);
 
+/* The same pair with the exponentials KEPT: tan_simnce_fwd_keep also stores e = exp((cos - 1)/tau) of every (frame, sentence) pair of
+ * the sweep as bf16 [S,R,Mp] (Mp = Mc when compacted); tan_simnce_bwd_dl_kept turns them into d loss/d logits with one element-wise
+ * pass (2 x S*R*Mp*2 bytes of HBM traffic) instead of a second 2*S*R*Mp*C-FLOP sweep.  tan_simnce_keeps(C) != 0 says whether the
+ * pair is available for C channels (the LDS-resident sweep: C = 512); all other arguments as above.                          */
+int tan_simnce_keeps(int C);
+int tan_simnce_fwd_keep(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
+                        const unsigned char* row_leak, float* rowsum, float* colsum, float* possum_v, float* possum_t,
+                        float* v_terms, float* t_terms, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks,
+                        long tb_stage_stride, const int* colmap, int Mc, int phases, void* e_keep, void* stream);
+int tan_simnce_bwd_dl_kept(const void* e_keep, const void* vn, const void* tn, long t_stage_stride, const float* tgt,
+                           const unsigned char* col_invalid, const unsigned char* row_leak, const float* rowsum, const float* colsum,
+                           const float* possum_v, const float* possum_t, const float* g_v, const float* g_t, void* dl, float* ws,
+                           int S, int B, int T, int N, int C, const void* tn_blocks, long tb_stage_stride, const int* colmap, int Mc,
+                           int phases, void* stream);
+
 /* NCE tail (loss.py:236-237,254-275).  tan_pos_masks: rows_pos[b*T+t] = 1 if frame t of video b has a positive among its
  * unpadded sentences, cols_pos[b*N+k] = 1 if sentence k is unpadded and has a positive frame (tgt [B,T,N] f32, text_pad [B,N]).
  * tan_nce_tail_fwd: out2[0] = (mean(v_d | rows_mask) + mean(t_d | cols_mask)) / 2 and out2[1] the same for the joint terms,

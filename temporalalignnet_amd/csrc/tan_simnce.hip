@@ -36,6 +36,7 @@ struct SimArgs {
     const float *g_v, *g_t;            // [S, R], [S, Mp]   (MODE_DL in)
     bf16_t* dl;                        // [S, R, Mp]        (MODE_DL out)
     int S, B, T, N, C, R, Mp;
+    bf16_t* ekeep;                     // [S, R, Mp] or null: simnce_res_kernel<0> also stores every e = exp((cos - 1)/tau) (bf16)
     // simnce_res_kernel<1> with the same-video corrections as its tail (instead of a simnce_diag_kernel<true> launch):
     const float* diag;                 // [S, B, T, N] same-video cosines, or null: no corrections in the sweep kernel
     const int* colmap;                 // padded column b*N+k -> column of the sweep, or -1; null: identity
@@ -259,6 +260,7 @@ __device__ __forceinline__ void tile_done_res(const TileCtx& c, f32x16 (&acc)[2]
                 if (MODE == 0) {
                     if (col_valid) rowacc[i][r] += e;
                     csum += e;
+                    if (c.dl && col_ok && row < R) c.dl[((long)c.s * R + row) * Mp + col] = f2bf(e);      // kept for the backward
                 } else {
                     const float g = e * ((col_valid ? rowacc[i][r] : 0.f) + bc);
                     if (col_ok && row < R) c.dl[((long)c.s * R + row) * Mp + col] = f2bf(g);
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(512) void simnce_res_kernel(SimArgs a) {
     c.col_invalid = a.col_invalid; c.colsum = a.colsum; c.g_t = a.g_t; c.dl = a.dl;
     c.R = R; c.Mp = Mp; c.s = s; c.m0 = m0; c.wm = wm; c.wn = wn; c.lane = lane; c.inv_tau = inv_tau;
     float* colrow = MODE == 0 ? a.colpart + ((long)(2 * panel + wm) * nS + s) * Mp : nullptr;
+    if (MODE == 0) c.dl = a.ekeep;
 
     f32x16 acc[2][2];
     // one 32-deep K step of this group's column tile ct_ (wave-uniform `live_`: the odd group idles through a last lone tile)
@@ -387,6 +390,75 @@ __global__ __launch_bounds__(512) void simnce_res_kernel(SimArgs a) {
             if (pt > 0.f) corr += a.g_t[ci] / pt;
             *out = f2bf(bf2f(*out) - e * corr * inv_tau);
         }
+    }
+}
+
+// d loss / d logits from the exponentials the statistics sweep kept (bf16 [S, R, Mp]) instead of a second sweep: an element-wise
+// pass, dl = e * (g_v/rowsum [valid column] + g_t/colsum) / tau, 8 rows per block, then the same-video corrections on those rows
+// (simnce_diag_kernel<true>'s arithmetic).  2 x 126 MB of HBM traffic (~65 us) against a 64-GFLOP recomputation (~180 us).
+__global__ __launch_bounds__(256) void simnce_dl_kept_kernel(SimArgs a) {
+    constexpr int ROWS = 8;
+    const int s = blockIdx.y, r0 = blockIdx.x * ROWS, tid = threadIdx.x;
+    const int R = a.R, Mp = a.Mp, T = a.T, N = a.N;
+    const float inv_tau = 1.0f / S_TAU;
+    const int nrow = min(ROWS, R - r0);
+    float rf[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const long ri = (long)s * R + min(r0 + i, R - 1);
+        rf[i] = a.g_v[ri] / a.rowsum[ri] * inv_tau;
+    }
+    for (int c0 = tid * 8; c0 < Mp; c0 += 256 * 8) {
+        float cf[8]; bool cv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = min(c0 + j, Mp - 1);
+            const long ci = (long)s * Mp + col;
+            cf[j] = a.g_t[ci] / a.colsum[ci] * inv_tau;
+            cv[j] = !a.col_invalid[col];
+        }
+        const bool vec = c0 + 8 <= Mp && (Mp & 7) == 0;
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            if (i >= nrow) break;
+            const long base = ((long)s * R + r0 + i) * Mp + c0;
+            if (vec) {
+                const uint4 u = *reinterpret_cast<const uint4*>(a.ekeep + base);
+                const unsigned w[4] = {u.x, u.y, u.z, u.w};
+                unsigned o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float e0 = __uint_as_float(w[q] << 16), e1 = __uint_as_float(w[q] & 0xffff0000u);
+                    const float g0 = e0 * ((cv[2 * q] ? rf[i] : 0.f) + cf[2 * q]);
+                    const float g1 = e1 * ((cv[2 * q + 1] ? rf[i] : 0.f) + cf[2 * q + 1]);
+                    o[q] = f2bf2(g0, g1);
+                }
+                *reinterpret_cast<uint4*>(a.dl + base) = make_uint4(o[0], o[1], o[2], o[3]);
+            } else {
+                for (int j = 0; j < 8 && c0 + j < Mp; ++j)
+                    a.dl[base + j] = f2bf(bf2f(a.ekeep[base + j]) * ((cv[j] ? rf[i] : 0.f) + cf[j]));
+            }
+        }
+    }
+    if (!a.diag) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int i = tid; i < nrow * N; i += 256) {
+        const int lr = i / N, k = i - lr * N, row = r0 + lr;
+        const int b = row / T, t = row - b * T;
+        const int m = a.colmap ? a.colmap[b * N + k] : b * N + k;
+        if (m < 0) continue;
+        bf16_t* out = a.dl + ((long)s * R + row) * Mp + m;
+        if (a.row_leak && a.row_leak[row]) { *out = 0; continue; }
+        if (a.tgt[((long)b * T + t) * N + k] == 0.f) continue;
+        const long ri = (long)s * R + row, ci = (long)s * Mp + m;
+        const float e = __expf((a.diag[(((long)s * a.B + b) * T + t) * N + k] - 1.0f) * inv_tau);
+        const float pv = a.possum_v[ri], pt = a.possum_t[ci];
+        float corr = 0.f;
+        if (!a.col_invalid[m] && pv > 0.f) corr += a.g_v[ri] / pv;
+        if (pt > 0.f) corr += a.g_t[ci] / pt;
+        *out = f2bf(bf2f(*out) - e * corr * inv_tau);
     }
 }
 
@@ -589,10 +661,10 @@ static int simnce_diag_blocks(const SimArgs& a, const bf16_t* tn_blocks, long tb
 }
 
 // v_terms / t_terms of loss.py:240-253 straight from unit features (no logits); sums are kept for tan_simnce_bwd_dl.
-extern "C" int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
-                              const unsigned char* row_leak, float* rowsum, float* colsum, float* possum_v, float* possum_t,
-                              float* v_terms, float* t_terms, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks,
-                              long tb_stage_stride, const int* colmap, int Mc, int phases, void* stream) {
+static int simnce_fwd_impl(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
+                           const unsigned char* row_leak, float* rowsum, float* colsum, float* possum_v, float* possum_t,
+                           float* v_terms, float* t_terms, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks,
+                           long tb_stage_stride, const int* colmap, int Mc, int phases, void* ekeep, void* stream) {
     TAN_REQUIRE(vn && tn && tgt && col_invalid && rowsum && colsum && possum_v && possum_t && v_terms && t_terms && ws);
     TAN_REQUIRE(!colmap || (tn_blocks && Mc > 0 && Mc <= B * N));
     if (phases == 0) phases = TAN_SIM_SWEEP | TAN_SIM_DIAG | TAN_SIM_TERMS;
@@ -617,6 +689,8 @@ extern "C" int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_strid
         }
         const int prec = prof_begin(st, TAN_PROF_SIMNCE, 2.0 * S * a.R * (double)a.Mp * C);
         const bool res = res_enabled(a);
+        if (ekeep && !res) return TAN_ERR_BAD_ARG;          // tan_simnce_keeps() said no
+        a.ekeep = (bf16_t*)ekeep;
         if (res) hipLaunchKernelGGL((simnce_res_kernel<0>), dim3(npanel, S), dim3(512), 0, st, a);
         else hipLaunchKernelGGL((simnce_kernel<0>), dim3(npanel, S), dim3(256), 0, st, a);
         prof_end(st, prec);
@@ -636,12 +710,36 @@ extern "C" int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_strid
     return 0;
 }
 
+extern "C" int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
+                              const unsigned char* row_leak, float* rowsum, float* colsum, float* possum_v, float* possum_t,
+                              float* v_terms, float* t_terms, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks,
+                              long tb_stage_stride, const int* colmap, int Mc, int phases, void* stream) {
+    return simnce_fwd_impl(vn, tn, t_stage_stride, tgt, col_invalid, row_leak, rowsum, colsum, possum_v, possum_t, v_terms, t_terms, ws,
+                           S, B, T, N, C, tn_blocks, tb_stage_stride, colmap, Mc, phases, nullptr, stream);
+}
+
+// 1 when tan_simnce_fwd_keep / tan_simnce_bwd_dl_kept are available for this channel count (TAN_SIM_KEEP_E=0: never)
+extern "C" int tan_simnce_keeps(int C) {
+    static const int v = [] { const char* e = getenv("TAN_SIM_KEEP_E"); return e ? atoi(e) : 1; }();
+    SimArgs a{}; a.C = C;
+    return v != 0 && res_enabled(a) ? 1 : 0;
+}
+
+extern "C" int tan_simnce_fwd_keep(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
+                                   const unsigned char* row_leak, float* rowsum, float* colsum, float* possum_v, float* possum_t,
+                                   float* v_terms, float* t_terms, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks,
+                                   long tb_stage_stride, const int* colmap, int Mc, int phases, void* e_keep, void* stream) {
+    TAN_REQUIRE(e_keep);
+    return simnce_fwd_impl(vn, tn, t_stage_stride, tgt, col_invalid, row_leak, rowsum, colsum, possum_v, possum_t, v_terms, t_terms, ws,
+                           S, B, T, N, C, tn_blocks, tb_stage_stride, colmap, Mc, phases, e_keep, stream);
+}
+
 // d loss / d logits [S, R, Mp] in bf16 from upstream g_v [S,R], g_t [S,Mp] (recomputes every logit tile); ws as in fwd
-extern "C" int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_stride, const float* tgt,
-                                 const unsigned char* col_invalid, const unsigned char* row_leak, const float* rowsum,
-                                 const float* colsum, const float* possum_v, const float* possum_t, const float* g_v, const float* g_t,
-                                 void* dl, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks, long tb_stage_stride,
-                                 const int* colmap, int Mc, int phases, void* stream) {
+static int simnce_bwd_impl(const void* vn, const void* tn, long t_stage_stride, const float* tgt,
+                           const unsigned char* col_invalid, const unsigned char* row_leak, const float* rowsum,
+                           const float* colsum, const float* possum_v, const float* possum_t, const float* g_v, const float* g_t,
+                           void* dl, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks, long tb_stage_stride,
+                           const int* colmap, int Mc, int phases, const void* ekeep, void* stream) {
     TAN_REQUIRE(vn && tn && tgt && col_invalid && rowsum && colsum && possum_v && possum_t && g_v && g_t && dl && ws);
     TAN_REQUIRE(!colmap || (tn_blocks && Mc > 0 && Mc <= B * N));
     if (phases == 0) phases = TAN_SIM_SWEEP | TAN_SIM_DIAG;
@@ -657,6 +755,14 @@ extern "C" int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_st
     if (colmap) a.Mp = Mc;
     else { tn_blocks = tn; tb_stage_stride = t_stage_stride; }
     if (a.Mp > S_MAXCOLS) return TAN_ERR_BAD_ARG;        // columns of the sweep (compacted or not): one LDS accumulator each
+    if (ekeep && (phases & TAN_SIM_SWEEP)) {        // the statistics sweep kept its exponentials: one element-wise pass, corrections as its tail
+        const bool tail = (phases & TAN_SIM_DIAG) != 0;
+        if (tail && !(phases & TAN_SIM_DIAG_KEEP) && (rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;
+        a.ekeep = (bf16_t*)ekeep; a.diag = tail ? diag : nullptr; a.colmap = colmap;
+        hipLaunchKernelGGL(simnce_dl_kept_kernel, dim3(cdiv(a.R, 8), S), dim3(256), 0, st, a);
+        TAN_LAUNCH_CHECK();
+        return 0;
+    }
     if (phases & TAN_SIM_SWEEP) {
         const bool res = res_enabled(a);
         const bool tail = res && inline_diag_enabled() && (phases & TAN_SIM_DIAG);      // corrections as the sweep kernel's tail
@@ -677,4 +783,23 @@ extern "C" int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_st
     }
     TAN_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_stride, const float* tgt,
+                                 const unsigned char* col_invalid, const unsigned char* row_leak, const float* rowsum,
+                                 const float* colsum, const float* possum_v, const float* possum_t, const float* g_v, const float* g_t,
+                                 void* dl, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks, long tb_stage_stride,
+                                 const int* colmap, int Mc, int phases, void* stream) {
+    return simnce_bwd_impl(vn, tn, t_stage_stride, tgt, col_invalid, row_leak, rowsum, colsum, possum_v, possum_t, g_v, g_t, dl, ws,
+                           S, B, T, N, C, tn_blocks, tb_stage_stride, colmap, Mc, phases, nullptr, stream);
+}
+
+extern "C" int tan_simnce_bwd_dl_kept(const void* e_keep, const void* vn, const void* tn, long t_stage_stride, const float* tgt,
+                                      const unsigned char* col_invalid, const unsigned char* row_leak, const float* rowsum,
+                                      const float* colsum, const float* possum_v, const float* possum_t, const float* g_v,
+                                      const float* g_t, void* dl, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks,
+                                      long tb_stage_stride, const int* colmap, int Mc, int phases, void* stream) {
+    TAN_REQUIRE(e_keep);
+    return simnce_bwd_impl(vn, tn, t_stage_stride, tgt, col_invalid, row_leak, rowsum, colsum, possum_v, possum_t, g_v, g_t, dl, ws,
+                           S, B, T, N, C, tn_blocks, tb_stage_stride, colmap, Mc, phases, e_keep, stream);
 }

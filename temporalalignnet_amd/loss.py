@@ -257,21 +257,28 @@ class _FusedNCEFn(torch.autograd.Function):
         v_terms, t_run = torch.empty(S, R, device=dev), torch.empty(S, Mc, device=dev)
         L = _lib.lib()
         ws = torch.empty(L.tan_simnce_ws_floats(C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N)), device=dev)
-        _lib.check(L.tan_simnce_fwd(_p(vn), _p(tn_run), C.c_long(0 if shared else Mc * Cw), _p(tgt), _p(ci_run), _p(row_leak),
-                                    _p(rowsum), _p(colsum), _p(possum_v), _p(possum_t), _p(v_terms), _p(t_run), _p(ws),
-                                    C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N), C.c_int(Cw), _p(tn) if compact else None,
-                                    C.c_long(0 if shared else Mp * Cw), _p(colmap), C.c_int(Mc), C.c_int(0), ops._stream()), "tan_simnce_fwd")
+        # the sweep can keep its exponentials (bf16 [S,R,Mc]) so that the backward is an element-wise pass instead of a second sweep
+        want_bwd = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]           # (not the no-grad sweeps of the EMA target)
+        ekeep = torch.empty(S, R, Mc, dtype=torch.bfloat16, device=dev) if want_bwd and L.tan_simnce_keeps(C.c_int(Cw)) else None
+        fwd_args = (_p(vn), _p(tn_run), C.c_long(0 if shared else Mc * Cw), _p(tgt), _p(ci_run), _p(row_leak),
+                    _p(rowsum), _p(colsum), _p(possum_v), _p(possum_t), _p(v_terms), _p(t_run), _p(ws),
+                    C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N), C.c_int(Cw), _p(tn) if compact else None,
+                    C.c_long(0 if shared else Mp * Cw), _p(colmap), C.c_int(Mc), C.c_int(0))
+        if ekeep is not None:
+            _lib.check(L.tan_simnce_fwd_keep(*fwd_args, _p(ekeep), ops._stream()), "tan_simnce_fwd_keep")
+        else:
+            _lib.check(L.tan_simnce_fwd(*fwd_args, ops._stream()), "tan_simnce_fwd")
         if compact:
             t_terms = torch.zeros(S, Mp, device=dev).index_copy_(1, idx, t_run)
         else:
             t_terms = t_run
-        ctx.saved = (vn, tn, tn_run, tgt, ci_run, row_leak, rowsum, colsum, possum_v, possum_t, ws, idx, colmap)
+        ctx.saved = (vn, tn, tn_run, tgt, ci_run, row_leak, rowsum, colsum, possum_v, possum_t, ws, idx, colmap, ekeep)
         ctx.dims = (S, B, T, N, Cw, shared, Mc)
         return v_terms, t_terms
 
     @staticmethod
     def backward(ctx, g_v, g_t):
-        vn, tn, tn_run, tgt, ci_run, row_leak, rowsum, colsum, possum_v, possum_t, ws, idx, colmap = ctx.saved
+        vn, tn, tn_run, tgt, ci_run, row_leak, rowsum, colsum, possum_v, possum_t, ws, idx, colmap, ekeep = ctx.saved
         S, B, T, N, Cw, shared, Mc = ctx.dims
         R, Mp, dev = B * T, B * N, vn.device
         compact = idx is not None
@@ -280,11 +287,15 @@ class _FusedNCEFn(torch.autograd.Function):
         if compact:
             g_t = g_t.index_select(1, idx).contiguous()
         dl = torch.empty(S, R, Mc, dtype=torch.bfloat16, device=dev)
-        _lib.check(_lib.lib().tan_simnce_bwd_dl(_p(vn), _p(tn_run), C.c_long(0 if shared else Mc * Cw), _p(tgt), _p(ci_run),
-                                                _p(row_leak), _p(rowsum), _p(colsum), _p(possum_v), _p(possum_t), _p(g_v),
-                                                _p(g_t), _p(dl), _p(ws), C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N),
-                                                C.c_int(Cw), _p(tn) if compact else None, C.c_long(0 if shared else Mp * Cw),
-                                                _p(colmap), C.c_int(Mc), C.c_int(1 | 2 | 16), ops._stream()), "tan_simnce_bwd_dl")   # SWEEP | DIAG | DIAG_KEEP: `ws` still holds the forward's same-video blocks
+        bwd_args = (_p(vn), _p(tn_run), C.c_long(0 if shared else Mc * Cw), _p(tgt), _p(ci_run),
+                    _p(row_leak), _p(rowsum), _p(colsum), _p(possum_v), _p(possum_t), _p(g_v),
+                    _p(g_t), _p(dl), _p(ws), C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N),
+                    C.c_int(Cw), _p(tn) if compact else None, C.c_long(0 if shared else Mp * Cw),
+                    _p(colmap), C.c_int(Mc), C.c_int(1 | 2 | 16), ops._stream())      # SWEEP | DIAG | DIAG_KEEP: `ws` still holds the forward's same-video blocks
+        if ekeep is not None:
+            _lib.check(_lib.lib().tan_simnce_bwd_dl_kept(_p(ekeep), *bwd_args), "tan_simnce_bwd_dl_kept")
+        else:
+            _lib.check(_lib.lib().tan_simnce_bwd_dl(*bwd_args), "tan_simnce_bwd_dl")
         d_vn = torch.empty_like(vn)
         ops.gemm(dl, tn_run, d_vn, M=R, N=Cw, K=Mc, a_kc=True, b_kc=False, lda=Mc, ldb=Cw, batch=S, sA=R * Mc,
                  sB=0 if shared else Mc * Cw, sC=R * Cw)
