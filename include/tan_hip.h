@@ -228,10 +228,12 @@ int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_stride, const
                       int C, const void* tn_blocks, long tb_stage_stride, const int* colmap, int Mc, int phases, void* stream);
 
 /* The same pair with the exponentials KEPT: tan_simnce_fwd_keep also stores e = exp((cos - 1)/tau) of every (frame, sentence) pair of
- * the sweep as bf16 [S,R,Mp] (Mp = Mc when compacted); tan_simnce_bwd_dl_kept turns them into d loss/d logits with one element-wise
+ * the sweep as bf16, S * ceil(R/128) * ceil(Mp/128) tiles of 128 x 128 in the sweep's accumulator order (Mp = Mc when compacted:
+ * tan_simnce_keep_elems() elements); tan_simnce_bwd_dl_kept turns them into d loss/d logits with one element-wise
  * pass (2 x S*R*Mp*2 bytes of HBM traffic) instead of a second 2*S*R*Mp*C-FLOP sweep.  tan_simnce_keeps(C) != 0 says whether the
  * pair is available for C channels (the LDS-resident sweep: C = 512); all other arguments as above.                          */
 int tan_simnce_keeps(int C);
+long tan_simnce_keep_elems(int S, int R, int Mp);
 int tan_simnce_fwd_keep(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
                         const unsigned char* row_leak, float* rowsum, float* colsum, float* possum_v, float* possum_t,
                         float* v_terms, float* t_terms, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks,

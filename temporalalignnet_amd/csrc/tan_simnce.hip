@@ -244,7 +244,7 @@ __device__ __forceinline__ void tile_done_res(const TileCtx& c, f32x16 (&acc)[2]
         const int col = c0 + c.wn * 64 + j * 32 + acc_col(lane);
         const bool col_ok = col < Mp;
         const bool col_valid = col_ok && !c.col_invalid[min(col, Mp - 1)];
-        float csum = 0.f, bc = 0.f;
+        float csum = 0.f, bc = 0.f, e_prev = 0.f;
         if (MODE == 1) {
             const long idx = (long)c.s * Mp + min(col, Mp - 1);
             const float gt = c.g_t[idx], cs = c.colsum[idx];
@@ -260,7 +260,13 @@ __device__ __forceinline__ void tile_done_res(const TileCtx& c, f32x16 (&acc)[2]
                 if (MODE == 0) {
                     if (col_valid) rowacc[i][r] += e;
                     csum += e;
-                    if (c.dl && col_ok && row < R) c.dl[((long)c.s * R + row) * Mp + col] = f2bf(e);      // kept for the backward
+                    // kept for the backward, in ACCUMULATOR order [i][j][r/2][lane] (two rows per dword): every store instruction
+                    // writes 256 contiguous bytes.  Row-major 2-byte stores (64-byte pieces of lines) cost the sweep +110 us and
+                    // 200 MB of read-modify-write traffic; simnce_dl_kept_kernel does the transposition, where the LDS is free.
+                    if (c.dl) {
+                        if (r & 1) reinterpret_cast<unsigned*>(c.dl)[((i * 2 + j) * 8 + (r >> 1)) * 64 + lane] = f2bf2(e_prev, e);
+                        e_prev = e;
+                    }
                 } else {
                     const float g = e * ((col_valid ? rowacc[i][r] : 0.f) + bc);
                     if (col_ok && row < R) c.dl[((long)c.s * R + row) * Mp + col] = f2bf(g);
@@ -310,7 +316,6 @@ __global__ __launch_bounds__(512) void simnce_res_kernel(SimArgs a) {
     c.col_invalid = a.col_invalid; c.colsum = a.colsum; c.g_t = a.g_t; c.dl = a.dl;
     c.R = R; c.Mp = Mp; c.s = s; c.m0 = m0; c.wm = wm; c.wn = wn; c.lane = lane; c.inv_tau = inv_tau;
     float* colrow = MODE == 0 ? a.colpart + ((long)(2 * panel + wm) * nS + s) * Mp : nullptr;
-    if (MODE == 0) c.dl = a.ekeep;
 
     f32x16 acc[2][2];
     // one 32-deep K step of this group's column tile ct_ (wave-uniform `live_`: the odd group idles through a last lone tile)
@@ -331,7 +336,10 @@ __global__ __launch_bounds__(512) void simnce_res_kernel(SimArgs a) {
                 _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);                \
             }                                                                                                              \
-            if (kt_ == 15) tile_done_res<MODE>(c, acc, rowacc, colrow, ct_);                                               \
+            if (kt_ == 15) {                                                                                               \
+                if (MODE == 0 && a.ekeep) c.dl = a.ekeep + ((((long)s * npanel + panel) * nct + ct_) * 4 + gw) * 4096;    \
+                tile_done_res<MODE>(c, acc, rowacc, colrow, ct_);                                                          \
+            }                                                                                                              \
         }                                                                                                                  \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                   \
         __syncthreads();                                                                                                   \
@@ -393,72 +401,80 @@ __global__ __launch_bounds__(512) void simnce_res_kernel(SimArgs a) {
     }
 }
 
-// d loss / d logits from the exponentials the statistics sweep kept (bf16 [S, R, Mp]) instead of a second sweep: an element-wise
-// pass, dl = e * (g_v/rowsum [valid column] + g_t/colsum) / tau, 8 rows per block, then the same-video corrections on those rows
-// (simnce_diag_kernel<true>'s arithmetic).  2 x 126 MB of HBM traffic (~65 us) against a 64-GFLOP recomputation (~180 us).
-__global__ __launch_bounds__(256) void simnce_dl_kept_kernel(SimArgs a) {
-    constexpr int ROWS = 8;
-    const int s = blockIdx.y, r0 = blockIdx.x * ROWS, tid = threadIdx.x;
-    const int R = a.R, Mp = a.Mp, T = a.T, N = a.N;
+// d loss / d logits from the exponentials the statistics sweep kept instead of a second sweep: dl = e * (g_v/rowsum [valid column] +
+// g_t/colsum) / tau.  One block per 128 x 128 tile (stage, row panel, column tile): the four wave tiles are read in the accumulator
+// order the sweep stored them in (1 KiB per instruction), scaled, parked row-major in the LDS, the same-video corrections
+// (simnce_diag_kernel<true>'s arithmetic) applied there, and the tile stored with 16-byte row-contiguous vectors.  2 x 126 MB of HBM
+// traffic against a 64-GFLOP recomputation (~180 us in the step).
+__global__ __launch_bounds__(256) void simnce_dl_kept_kernel(SimArgs a, int npanel, int nct) {
+    constexpr int LD = 136;                                   // bf16 per LDS row (128 + 8: 16-byte aligned, off the bank period)
+    __shared__ __attribute__((aligned(16))) bf16_t tile[128 * LD];
+    __shared__ float rf[128], cf[128];
+    __shared__ unsigned char cv[128];
+    __shared__ int crange[2];                                 // sweep columns that hold sentences of this panel's videos: [min, max]
+    const int tid = threadIdx.x, s = blockIdx.y;
+    const int panel = blockIdx.x / nct, ct = blockIdx.x - panel * nct;
+    const int R = a.R, Mp = a.Mp, T = a.T, N = a.N, m0 = panel * 128, c0 = ct * 128;
     const float inv_tau = 1.0f / S_TAU;
-    const int nrow = min(ROWS, R - r0);
-    float rf[ROWS];
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-        const long ri = (long)s * R + min(r0 + i, R - 1);
-        rf[i] = a.g_v[ri] / a.rowsum[ri] * inv_tau;
-    }
-    for (int c0 = tid * 8; c0 < Mp; c0 += 256 * 8) {
-        float cf[8]; bool cv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int col = min(c0 + j, Mp - 1);
-            const long ci = (long)s * Mp + col;
-            cf[j] = a.g_t[ci] / a.colsum[ci] * inv_tau;
-            cv[j] = !a.col_invalid[col];
-        }
-        const bool vec = c0 + 8 <= Mp && (Mp & 7) == 0;
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) {
-            if (i >= nrow) break;
-            const long base = ((long)s * R + r0 + i) * Mp + c0;
-            if (vec) {
-                const uint4 u = *reinterpret_cast<const uint4*>(a.ekeep + base);
-                const unsigned w[4] = {u.x, u.y, u.z, u.w};
-                unsigned o[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float e0 = __uint_as_float(w[q] << 16), e1 = __uint_as_float(w[q] & 0xffff0000u);
-                    const float g0 = e0 * ((cv[2 * q] ? rf[i] : 0.f) + cf[2 * q]);
-                    const float g1 = e1 * ((cv[2 * q + 1] ? rf[i] : 0.f) + cf[2 * q + 1]);
-                    o[q] = f2bf2(g0, g1);
-                }
-                *reinterpret_cast<uint4*>(a.dl + base) = make_uint4(o[0], o[1], o[2], o[3]);
-            } else {
-                for (int j = 0; j < 8 && c0 + j < Mp; ++j)
-                    a.dl[base + j] = f2bf(bf2f(a.ekeep[base + j]) * ((cv[j] ? rf[i] : 0.f) + cf[j]));
-            }
-        }
-    }
-    if (!a.diag) return;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (tid == 0) { crange[0] = 0x7fffffff; crange[1] = -1; }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (int i = tid; i < nrow * N; i += 256) {
-        const int lr = i / N, k = i - lr * N, row = r0 + lr;
-        const int b = row / T, t = row - b * T;
-        const int m = a.colmap ? a.colmap[b * N + k] : b * N + k;
-        if (m < 0) continue;
-        bf16_t* out = a.dl + ((long)s * R + row) * Mp + m;
-        if (a.row_leak && a.row_leak[row]) { *out = 0; continue; }
-        if (a.tgt[((long)b * T + t) * N + k] == 0.f) continue;
-        const long ri = (long)s * R + row, ci = (long)s * Mp + m;
-        const float e = __expf((a.diag[(((long)s * a.B + b) * T + t) * N + k] - 1.0f) * inv_tau);
-        const float pv = a.possum_v[ri], pt = a.possum_t[ci];
-        float corr = 0.f;
-        if (!a.col_invalid[m] && pv > 0.f) corr += a.g_v[ri] / pv;
-        if (pt > 0.f) corr += a.g_t[ci] / pt;
-        *out = f2bf(bf2f(*out) - e * corr * inv_tau);
+    if (a.diag) {
+        const int b_lo = m0 / T, b_hi = min(m0 + 127, R - 1) / T;
+        for (int p = b_lo * N + tid; p < (b_hi + 1) * N; p += 256) {
+            const int m = a.colmap ? a.colmap[p] : p;
+            if (m >= 0) { atomicMin(&crange[0], m); atomicMax(&crange[1], m); }
+        }
+    }
+    if (tid < 128) {
+        const long ri = (long)s * R + min(m0 + tid, R - 1);
+        rf[tid] = a.g_v[ri] / a.rowsum[ri] * inv_tau;
+    } else {
+        const int c = tid - 128, col = min(c0 + c, Mp - 1);
+        const long ci = (long)s * Mp + col;
+        cf[c] = a.g_t[ci] / a.colsum[ci] * inv_tau;
+        cv[c] = !a.col_invalid[col];
+    }
+    __syncthreads();
+    const unsigned* E = reinterpret_cast<const unsigned*>(a.ekeep) + (((long)s * npanel + panel) * nct + ct) * 8192;
+#pragma unroll 8
+    for (int q = tid; q < 8192; q += 256) {
+        const unsigned w = E[q];
+        const int gw = q >> 11, rem = q & 2047, ij = rem >> 9, rp = (rem >> 6) & 7, ln = rem & 63;
+        const int r = 2 * rp;
+        const int row = (gw >> 1) * 64 + (ij >> 1) * 32 + acc_row(r, ln), col = (gw & 1) * 64 + (ij & 1) * 32 + (ln & 31);
+        const float e0 = __uint_as_float(w << 16), e1 = __uint_as_float(w & 0xffff0000u);
+        const float c = cf[col];
+        tile[row * LD + col] = f2bf(e0 * ((cv[col] ? rf[row] : 0.f) + c));
+        tile[(row + 1) * LD + col] = f2bf(e1 * ((cv[col] ? rf[row + 1] : 0.f) + c));
+    }
+    __syncthreads();
+    if (a.diag && crange[0] <= c0 + 127 && crange[1] >= c0) {          // (block-uniform) 1-2 of a panel's column tiles
+        const int nrow = min(128, R - m0);
+        for (int i = tid; i < nrow * N; i += 256) {
+            const int lr = i / N, k = i - lr * N, row = m0 + lr;
+            const int b = row / T, t = row - b * T;
+            const int m = a.colmap ? a.colmap[b * N + k] : b * N + k;
+            if (m < c0 || m >= c0 + 128 || m >= Mp) continue;
+            bf16_t* out = tile + lr * LD + (m - c0);
+            if (a.row_leak && a.row_leak[row]) { *out = 0; continue; }
+            if (a.tgt[((long)b * T + t) * N + k] == 0.f) continue;
+            const long ri = (long)s * R + row, ci = (long)s * Mp + m;
+            const float e = __expf((a.diag[(((long)s * a.B + b) * T + t) * N + k] - 1.0f) * inv_tau);
+            const float pv = a.possum_v[ri], pt = a.possum_t[ci];
+            float corr = 0.f;
+            if (!a.col_invalid[m] && pv > 0.f) corr += a.g_v[ri] / pv;
+            if (pt > 0.f) corr += a.g_t[ci] / pt;
+            *out = f2bf(bf2f(*out) - e * corr * inv_tau);
+        }
+        __syncthreads();
+    }
+    const bool vec = (Mp & 7) == 0;
+    for (int q = tid; q < 128 * 16; q += 256) {
+        const int lr = q >> 4, cc = (q & 15) * 8, row = m0 + lr, col = c0 + cc;
+        if (row >= R || col >= Mp) continue;
+        bf16_t* dst = a.dl + ((long)s * R + row) * Mp + col;
+        if (vec) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(tile + lr * LD + cc);
+        else for (int j = 0; j < 8 && col + j < Mp; ++j) dst[j] = tile[lr * LD + cc + j];
     }
 }
 
@@ -725,6 +741,8 @@ extern "C" int tan_simnce_keeps(int C) {
     return v != 0 && res_enabled(a) ? 1 : 0;
 }
 
+extern "C" long tan_simnce_keep_elems(int S, int R, int Mp) { return (long)S * cdiv(R, 128) * cdiv(Mp, 128) * 16384; }
+
 extern "C" int tan_simnce_fwd_keep(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
                                    const unsigned char* row_leak, float* rowsum, float* colsum, float* possum_v, float* possum_t,
                                    float* v_terms, float* t_terms, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks,
@@ -759,7 +777,7 @@ static int simnce_bwd_impl(const void* vn, const void* tn, long t_stage_stride, 
         const bool tail = (phases & TAN_SIM_DIAG) != 0;
         if (tail && !(phases & TAN_SIM_DIAG_KEEP) && (rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;
         a.ekeep = (bf16_t*)ekeep; a.diag = tail ? diag : nullptr; a.colmap = colmap;
-        hipLaunchKernelGGL(simnce_dl_kept_kernel, dim3(cdiv(a.R, 8), S), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(simnce_dl_kept_kernel, dim3(cdiv(a.R, 128) * cdiv(a.Mp, 128), S), dim3(256), 0, st, a, cdiv(a.R, 128), cdiv(a.Mp, 128));
         TAN_LAUNCH_CHECK();
         return 0;
     }

@@ -259,7 +259,9 @@ class _FusedNCEFn(torch.autograd.Function):
         ws = torch.empty(L.tan_simnce_ws_floats(C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N)), device=dev)
         # the sweep can keep its exponentials (bf16 [S,R,Mc]) so that the backward is an element-wise pass instead of a second sweep
         want_bwd = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]           # (not the no-grad sweeps of the EMA target)
-        ekeep = torch.empty(S, R, Mc, dtype=torch.bfloat16, device=dev) if want_bwd and L.tan_simnce_keeps(C.c_int(Cw)) else None
+        ekeep = None
+        if want_bwd and L.tan_simnce_keeps(C.c_int(Cw)):
+            ekeep = torch.empty(L.tan_simnce_keep_elems(C.c_int(S), C.c_int(R), C.c_int(Mc)), dtype=torch.bfloat16, device=dev)
         fwd_args = (_p(vn), _p(tn_run), C.c_long(0 if shared else Mc * Cw), _p(tgt), _p(ci_run), _p(row_leak),
                     _p(rowsum), _p(colsum), _p(possum_v), _p(possum_t), _p(v_terms), _p(t_run), _p(ws),
                     C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N), C.c_int(Cw), _p(tn) if compact else None,
