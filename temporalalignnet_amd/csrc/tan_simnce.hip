@@ -435,17 +435,29 @@ __global__ __launch_bounds__(256) void simnce_dl_kept_kernel(SimArgs a, int npan
         cv[c] = !a.col_invalid[col];
     }
     __syncthreads();
-    const unsigned* E = reinterpret_cast<const unsigned*>(a.ekeep) + (((long)s * npanel + panel) * nct + ct) * 8192;
-#pragma unroll 8
-    for (int q = tid; q < 8192; q += 256) {
-        const unsigned w = E[q];
-        const int gw = q >> 11, rem = q & 2047, ij = rem >> 9, rp = (rem >> 6) & 7, ln = rem & 63;
+    // 16 bytes per load = the dwords of four neighbouring lanes = four columns x two rows; all eight loads in flight at once
+    const uint4* E = reinterpret_cast<const uint4*>(a.ekeep) + (((long)s * npanel + panel) * nct + ct) * 2048;
+    uint4 ev[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) ev[n] = E[tid + 256 * n];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int v = tid + 256 * n;                         // dword index 4v: [wave][i][j][r/2][lane]
+        const int gw = v >> 9, ij = (v >> 7) & 3, rp = (v >> 4) & 7, ln = (v & 15) * 4;
         const int r = 2 * rp;
         const int row = (gw >> 1) * 64 + (ij >> 1) * 32 + acc_row(r, ln), col = (gw & 1) * 64 + (ij & 1) * 32 + (ln & 31);
-        const float e0 = __uint_as_float(w << 16), e1 = __uint_as_float(w & 0xffff0000u);
-        const float c = cf[col];
-        tile[row * LD + col] = f2bf(e0 * ((cv[col] ? rf[row] : 0.f) + c));
-        tile[(row + 1) * LD + col] = f2bf(e1 * ((cv[col] ? rf[row + 1] : 0.f) + c));
+        const unsigned w[4] = {ev[n].x, ev[n].y, ev[n].z, ev[n].w};
+        const float r0 = rf[row], r1 = rf[row + 1];
+        float g0[4], g1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float c = cf[col + j];
+            const bool ok = cv[col + j];
+            g0[j] = __uint_as_float(w[j] << 16) * ((ok ? r0 : 0.f) + c);
+            g1[j] = __uint_as_float(w[j] & 0xffff0000u) * ((ok ? r1 : 0.f) + c);
+        }
+        *reinterpret_cast<uint2*>(tile + row * LD + col) = make_uint2(f2bf2(g0[0], g0[1]), f2bf2(g0[2], g0[3]));
+        *reinterpret_cast<uint2*>(tile + (row + 1) * LD + col) = make_uint2(f2bf2(g1[0], g1[1]), f2bf2(g1[2], g1[3]));
     }
     __syncthreads();
     if (a.diag && crange[0] <= c0 + 127 && crange[1] >= c0) {          // (block-uniform) 1-2 of a panel's column tiles
