@@ -120,3 +120,59 @@ def test_compaction_lifts_the_padded_column_count_over_the_sweep_limit():
         tr.zero_grad()
         losses.append(tr.forward_backward(to_device_batch(b_np))["loss"].item())
     assert abs(losses[0] - losses[1]) < 2e-3 * abs(losses[1]), losses
+
+
+@pytest.mark.parametrize("S,B,T,N,shared,compact,leak", [(2, 3, 70, 5, False, False, False), (3, 4, 64, 9, True, True, True),
+                                                         (1, 5, 40, 16, False, True, False), (2, 6, 64, 30, True, False, True)])
+def test_kept_exponentials_match_the_recomputing_backward(S, B, T, N, shared, compact, leak):
+    """_FusedNCEFn with the exponentials kept by the statistics sweep (tan_simnce_fwd_keep / tan_simnce_bwd_dl_kept: one element-wise
+    pass) against the recomputing backward (tan_simnce_bwd_dl) on the same inputs: ragged R = B*T and column counts that are not
+    multiples of the 128 x 128 tiles, shared and per-stage text features, column compaction, leaked (padded) frames.  Terms are
+    the same sweep's; the feature gradients differ by one extra bf16 rounding of e."""
+    from temporalalignnet_amd import _lib, loss as L
+    if not _lib.lib().tan_simnce_keeps(512):
+        pytest.skip("kept-exponentials path not available")
+    g = torch.Generator(device="cpu").manual_seed(1234 + S + B)
+    R, Mp, Cw = B * T, B * N, 512
+    vn = torch.nn.functional.normalize(torch.randn(S, R, Cw, generator=g), dim=-1).cuda().bfloat16()
+    tn = torch.nn.functional.normalize(torch.randn(1 if shared else S, Mp, Cw, generator=g), dim=-1).cuda().bfloat16()
+    tgt = (torch.rand(B, T, N, generator=g) < 0.15).float().cuda()
+    tpad = torch.zeros(B, N, dtype=torch.bool)
+    for b in range(B):
+        tpad[b, max(1, N - b):] = True                     # video b has N - b real sentences (at least one)
+    col_invalid = tpad.view(-1).to(torch.uint8).cuda()
+    row_leak = None
+    if leak:
+        row_leak = torch.zeros(R, dtype=torch.uint8)
+        row_leak[T - 3:T] = 1; row_leak[R - 2:] = 1
+        row_leak = row_leak.cuda()
+    prep = None
+    if compact:
+        n_valid = int((~tpad).sum())
+        prep = L.compaction_prep(col_invalid, n_valid)
+    outs = []
+    real = _lib.lib
+
+    class NoKeep:
+        def __init__(self, lib): self._lib = lib
+        def __getattr__(self, k): return (lambda *a: 0) if k == "tan_simnce_keeps" else getattr(self._lib, k)
+
+    for keep in (True, False):
+        if not keep:
+            proxy = NoKeep(real())
+            _lib.lib = lambda: proxy
+        try:
+            v = vn.clone().requires_grad_(True); t = tn.clone().requires_grad_(True)
+            v_terms, t_terms = L._FusedNCEFn.apply(v, t, tgt, col_invalid, row_leak, B, T, N, prep)
+            gv = torch.randn(v_terms.shape, generator=g).cuda() if keep else gv
+            gt = torch.randn(t_terms.shape, generator=g).cuda() if keep else gt
+            (v_terms * gv).sum().add((t_terms * gt).sum()).backward()
+            outs.append((v_terms.detach(), t_terms.detach(), v.grad.float(), t.grad.float()))
+        finally:
+            _lib.lib = real
+    (v0, t0, dv0, dt0), (v1, t1, dv1, dt1) = outs
+    # (the same sweep; sums of leaked entries meet in f32 atomics, so the last bit may differ between two runs)
+    assert torch.allclose(v0, v1, rtol=1e-5, atol=1e-5) and torch.allclose(t0, t1, rtol=1e-5, atol=1e-5)
+    for a, c in ((dv0, dv1), (dt0, dt1)):
+        assert torch.isfinite(a).all()
+        assert (a - c).norm().item() <= 6e-3 * c.norm().item() + 1e-6, (a - c).norm().item() / c.norm().item()
