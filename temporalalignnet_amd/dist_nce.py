@@ -44,8 +44,9 @@ class BlockNCE:
     """One rank, one logits family.  vn [S,R,C] bf16 unit video features (local rows), tgt [B,T,N] f32 positives of the local
     videos, row_leak u8 [R] or None.  Text blocks are passed per call: tn_q [1|S, Mp, C] bf16, pad flags u8 [Mp]."""
 
-    def __init__(self, vn, tgt, row_leak, B, T, N, shared_text: bool):
+    def __init__(self, vn, tgt, row_leak, B, T, N, shared_text: bool, keep: bool = False):
         self.vn, self.tgt, self.row_leak = vn, tgt, row_leak
+        self.want_keep = keep          # a backward will follow: the sweeps store their exponentials
         self.S, self.R, self.C = vn.shape
         self.B, self.T, self.N, self.Mp, self.shared = B, T, N, B * N, shared_text
         dev = vn.device
@@ -59,12 +60,14 @@ class BlockNCE:
     def _stride(self):
         return 0 if self.shared else self.Mp * self.C
 
-    def _fwd(self, tn, ci, colsum, v_terms, t_terms, phases):
-        _lib.check(_lib.lib().tan_simnce_fwd(
-            _p(self.vn), _p(tn), C.c_long(self._stride()), _p(self.tgt), _p(ci), _p(self.row_leak), _p(self.rowsum), _p(colsum),
-            _p(self.possum_v), _p(self.possum_t), _p(v_terms), _p(t_terms), _p(self.ws), C.c_int(self.S), C.c_int(self.B),
-            C.c_int(self.T), C.c_int(self.N), C.c_int(self.C), None, C.c_long(0), None, C.c_int(0), C.c_int(phases),
-            ops._stream()), "tan_simnce_fwd")
+    def _fwd(self, tn, ci, colsum, v_terms, t_terms, phases, keep=None):
+        args = (_p(self.vn), _p(tn), C.c_long(self._stride()), _p(self.tgt), _p(ci), _p(self.row_leak), _p(self.rowsum), _p(colsum),
+                _p(self.possum_v), _p(self.possum_t), _p(v_terms), _p(t_terms), _p(self.ws), C.c_int(self.S), C.c_int(self.B),
+                C.c_int(self.T), C.c_int(self.N), C.c_int(self.C), None, C.c_long(0), None, C.c_int(0), C.c_int(phases))
+        if keep is not None:      # the sweep also stores its exponentials (bf16): the backward is an element-wise pass
+            _lib.check(_lib.lib().tan_simnce_fwd_keep(*args, _p(keep), ops._stream()), "tan_simnce_fwd_keep")
+        else:
+            _lib.check(_lib.lib().tan_simnce_fwd(*args, ops._stream()), "tan_simnce_fwd")
 
     # ------------------------------------------------------------------ forward phases
     def sweep(self, tn_blocks, ci_blocks, own: int):
@@ -72,8 +75,15 @@ class BlockNCE:
         the padded-frame quirk).  Positives of the local rows / sentences are computed from the own block."""
         W = len(tn_blocks)
         colparts = torch.empty(W, self.S, self.Mp, device=self.vn.device)
+        L = _lib.lib()
+        self._keep = None
+        if self.want_keep:
+            if L.tan_simnce_keeps(C.c_int(self.C)):
+                n = L.tan_simnce_keep_elems(C.c_int(self.S), C.c_int(self.R), C.c_int(self.Mp))
+                self._keep = [torch.empty(n, dtype=torch.bfloat16, device=self.vn.device) for _ in range(W)]
         for q in range(W):
-            self._fwd(tn_blocks[q], ci_blocks[q], colparts[q], self._dummy_v, self._dummy_t, SWEEP | (ACC_ROWS if q else 0))
+            self._fwd(tn_blocks[q], ci_blocks[q], colparts[q], self._dummy_v, self._dummy_t, SWEEP | (ACC_ROWS if q else 0),
+                      keep=self._keep[q] if self._keep else None)
         self._fwd(tn_blocks[own], ci_blocks[own], colparts[own], self._dummy_v, self._dummy_t, DIAG)
         self._tn, self._ci, self._own = tn_blocks, ci_blocks, own
         return colparts
@@ -97,11 +107,14 @@ class BlockNCE:
         dl = torch.empty(S, R, Mp, dtype=torch.bfloat16, device=dev)
         g_v = g_v.contiguous()
         for q in range(W):
-            _lib.check(_lib.lib().tan_simnce_bwd_dl(
-                _p(self.vn), _p(self._tn[q]), C.c_long(self._stride()), _p(self.tgt), _p(self._ci[q]), _p(self.row_leak),
-                _p(self.rowsum), _p(self.colsum_all[q]), _p(self.possum_v), _p(self.possum_t), _p(g_v), _p(g_t_all[q].contiguous()),
-                _p(dl), _p(self.ws), C.c_int(S), C.c_int(self.B), C.c_int(self.T), C.c_int(self.N), C.c_int(Cw), None, C.c_long(0),
-                None, C.c_int(0), C.c_int(SWEEP | (DIAG if q == self._own else 0)), ops._stream()), "tan_simnce_bwd_dl")
+            args = (_p(self.vn), _p(self._tn[q]), C.c_long(self._stride()), _p(self.tgt), _p(self._ci[q]), _p(self.row_leak),
+                    _p(self.rowsum), _p(self.colsum_all[q]), _p(self.possum_v), _p(self.possum_t), _p(g_v), _p(g_t_all[q].contiguous()),
+                    _p(dl), _p(self.ws), C.c_int(S), C.c_int(self.B), C.c_int(self.T), C.c_int(self.N), C.c_int(Cw), None, C.c_long(0),
+                    None, C.c_int(0), C.c_int(SWEEP | (DIAG if q == self._own else 0)), ops._stream())
+            if self._keep:
+                _lib.check(_lib.lib().tan_simnce_bwd_dl_kept(_p(self._keep[q]), *args), "tan_simnce_bwd_dl_kept")
+            else:
+                _lib.check(_lib.lib().tan_simnce_bwd_dl(*args), "tan_simnce_bwd_dl")
             ops.gemm(dl, self._tn[q], d_vn, M=R, N=Cw, K=Mp, a_kc=True, b_kc=False, lda=Mp, ldb=Cw, batch=S, sA=R * Mp,
                      sB=self._stride(), sC=R * Cw, residual=d_vn if q else None)
             if self.shared:
@@ -154,7 +167,8 @@ class _GlobalNCEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vn, tn, tgt, col_invalid, row_leak, B, T, N):
         W, rank = _world()
-        blk = BlockNCE(vn, tgt, row_leak, B, T, N, shared_text=tn.shape[0] == 1)
+        blk = BlockNCE(vn, tgt, row_leak, B, T, N, shared_text=tn.shape[0] == 1,
+                       keep=bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
         tn_all, ci_all = _all_gather(tn), _all_gather(col_invalid)
         colsum_all = _all_reduce_(blk.sweep(tn_all, ci_all, rank))
         v_terms, t_terms = blk.finish(colsum_all)
