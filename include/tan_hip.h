@@ -382,7 +382,7 @@ int tan_mlp_fwd(const tan_mlp_desc* d, void* stream);
  * rows % 64 == 0, C = 512, FF = 2048, bf16 only.                                                                             */
 typedef struct tan_mlp_bwd_desc {
     long rows; int C, FF;
-    const void* dx;                          /* [rows, C] gradient w.r.t. the block's output (also the residual gradient) */
+    const void* dx;                          /* [rows, C] gradient w.r.t. the block's output (also the residual gradient); see ln1_dxn */
     const void* h_pre;                       /* [rows, FF] pre-activation saved by the forward */
     const void* x_mid;                       /* [rows, C] the branch's input (ln_2 input) */
     const float *mean2, *rstd2, *ln_g;
@@ -390,6 +390,14 @@ typedef struct tan_mlp_bwd_desc {
     void* dh;                                /* out [rows, FF] */
     void* dx2;                               /* out [rows, C] */
     float *g_b_fc, *g_ln_g, *g_ln_b, *g_b_out;   /* accumulated */
+    /* Optional (ln1_dxn != NULL): `dx` is not read but PRODUCED first, as the backward of the NEXT block's ln_1 (tfm_model.py:43):
+     *   dx = ln1_res + LayerNorm-backward(ln1_dxn; ln1_x, ln1_mean, ln1_rstd, ln1_g)      -> dx_out [rows, C] bf16 (and the panel)
+     *   g_ln1_g += colsum(ln1_dxn o xhat), g_ln1_b += colsum(ln1_dxn), g_dx_colsum += colsum(dx)  (= this block's c_proj bias grad)
+     * ln1_res may alias dx2 (a workgroup reads its 64 rows before it writes them).                                              */
+    const void *ln1_dxn, *ln1_x, *ln1_res;
+    const float *ln1_mean, *ln1_rstd, *ln1_g;
+    float *g_ln1_g, *g_ln1_b, *g_dx_colsum;
+    void* dx_out;
 } tan_mlp_bwd_desc;
 int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream);
 

@@ -138,6 +138,9 @@ class MlpBwdDesc(C.Structure):
         ("pwt_proj", C.c_void_p), ("pwt_fc", C.c_void_p),
         ("dh", C.c_void_p), ("dx2", C.c_void_p),
         ("g_b_fc", C.c_void_p), ("g_ln_g", C.c_void_p), ("g_ln_b", C.c_void_p), ("g_b_out", C.c_void_p),
+        ("ln1_dxn", C.c_void_p), ("ln1_x", C.c_void_p), ("ln1_res", C.c_void_p),
+        ("ln1_mean", C.c_void_p), ("ln1_rstd", C.c_void_p), ("ln1_g", C.c_void_p),
+        ("g_ln1_g", C.c_void_p), ("g_ln1_b", C.c_void_p), ("g_dx_colsum", C.c_void_p), ("dx_out", C.c_void_p),
     ]
 
 

@@ -249,6 +249,9 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
     // bias gradients that are column sums of a LayerNorm-backward OUTPUT are accumulated inside that kernel:
     //   g_b_proj[i] <- colsum(dx entering layer i)   = output of layer i+1's LN1 backward (or of the post-LN backward)
     //   g_b_out[i]  <- colsum(dx2)                   = output of layer i's LN2 backward
+    // ln_1 backward of block i+1 handed to block i's row-panel MLP backward as its prologue (TAN_LN1_FUSED=0: its own launch)
+    struct { bool on; int layer; const void *dxn, *x, *res; const float *mean, *rstd, *g; float *gg, *gb, *gcol; } pend{};
+    static const bool ln1_fused = [] { const char* v = getenv("TAN_LN1_FUSED"); return !v || atoi(v) != 0; }();
     for (int i = S - 1; i >= 0; --i) {
         const tan_layer_params& p = e->params[i];
         const tan_layer_bufs& b = e->bufs[i];
@@ -265,7 +268,18 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
             m.pwt_proj = p.wtp_proj; m.pwt_fc = p.wtp_fc;
             m.dh = e->scr_dh; m.dx2 = dx2;
             m.g_b_fc = p.g_b_fc; m.g_ln_g = p.g_ln2_g; m.g_ln_b = p.g_ln2_b; m.g_b_out = p.g_b_out;
+            if (pend.on) {
+                m.ln1_dxn = pend.dxn; m.ln1_x = pend.x; m.ln1_res = pend.res; m.ln1_mean = pend.mean; m.ln1_rstd = pend.rstd;
+                m.ln1_g = pend.g; m.g_ln1_g = pend.gg; m.g_ln1_b = pend.gb; m.g_dx_colsum = pend.gcol; m.dx_out = dx;
+            }
             CK(tan_mlp_bwd(&m, st));
+            if (pend.on) {          // every gradient of block pend.layer is final now
+                pend.on = false;
+                if (e->layer_done && e->layer_done[pend.layer]) {
+                    const hipError_t err = hipEventRecord((hipEvent_t)e->layer_done[pend.layer], (hipStream_t)st);
+                    if (err != hipSuccess) return (int)err;
+                }
+            }
             if (!grouped) CK(linear_bwd_w(dt, e->scr_dh, b.xn2, p.g_w_fc, R, 4 * C, C, e->dw_ws, e->dw_ws_floats, st));
         } else {
             CK(linear_bwd_x(dt, dx, p.w_proj, p.wt_proj, e->scr_dh, R, C, 4 * C, TAN_ACT_QUICKGELU_GRAD, b.h_pre, nullptr, p.g_b_fc, st));
@@ -289,6 +303,14 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         }
         void* dx_in = i == 0 ? e->d_x0 : dx;
         float* next_b_proj = i > 0 ? e->params[i - 1].g_b_proj : nullptr;       // dx_in is layer i-1's x_out gradient
+        if (i > 0 && ln1_fused && grouped && panel_bwd_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0 &&
+            e->params[i - 1].wtp_fc && e->params[i - 1].wtp_proj) {
+            // block i-1's row-panel MLP backward does this LayerNorm backward as its prologue (dx2 and scr_dxn stay untouched until
+            // that launch: it is the next one that writes them)
+            pend.on = true; pend.layer = i; pend.dxn = e->scr_dxn; pend.x = x_in; pend.res = dx2;
+            pend.mean = b.mean1; pend.rstd = b.rstd1; pend.g = p.ln1_g; pend.gg = p.g_ln1_g; pend.gb = p.g_ln1_b; pend.gcol = next_b_proj;
+            continue;
+        }
         CK(tan_layernorm_bwd(e->scr_dxn, x_in, p.ln1_g, b.mean1, b.rstd1, dx2, dx_in, p.g_ln1_g, p.g_ln1_b, next_b_proj, e->ln_ws, R,
                              C, dt, st));
         // every gradient of layer i is final here (g_b_proj[i] was written during iteration i+1 / by the post-LN backward)

@@ -67,6 +67,10 @@ struct MlpBwdArgs {
     bf16_t* h_act;              // dh out [rows][2048] (the "activation" side output of the shared schedule)
     bf16_t* dx2;
     float* g_b_fc; float* g_ln_g; float* g_ln_b; float* g_b_out;
+    // optional prologue: dx = ln1_res + LN-backward(ln1_dxn; ln1_x, ...) of the NEXT block's ln_1 instead of reading dx
+    const bf16_t* ln1_dxn; const bf16_t* ln1_x; const bf16_t* ln1_res;
+    const float* ln1_mean; const float* ln1_rstd; const float* ln1_g;
+    float* g_ln1_g; float* g_ln1_b; float* g_dx_colsum; bf16_t* dx_out;
 };
 
 // Tiles are 16 KiB: c_fc [256 features][32 k], c_proj [512 features][16 k].  A weight fragment is consumed by exactly ONE wave
@@ -492,11 +496,76 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     // the dx panel as it is.
     if constexpr (BWD) {
         constexpr int RPW = PN_ROWS / PN_WAVES;
-        uint4 v[RPW];
+        if (a.ln1_dxn) {
+            // the next block's ln_1 backward, row by row (a wave owns whole rows, a lane 8 features: tan_norm.hip's arithmetic):
+            // the result is this kernel's dx panel, and goes to HBM once for the weight-gradient launch that reads it later
+            const f8 gm = ld8f(a.ln1_g + lane * 8);
+            f8 dg, db, ds;
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) v[r] = *reinterpret_cast<const uint4*>(a.dx + (row0 + wave * RPW + r) * 512 + lane * 8);
+            for (int j = 0; j < 8; ++j) { dg.v[j] = 0.f; db.v[j] = 0.f; ds.v[j] = 0.f; }
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) *reinterpret_cast<uint4*>(pn_panel_slot<1024>(lds + XN_OFF, wave * RPW + r, lane)) = v[r];
+            for (int half = 0; half < RPW / 4; ++half) {
+                f8 xv[4], dv[4], rv[4];
+                float mean[4], rstd[4], s1[4], s2[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const long row = row0 + wave * RPW + half * 4 + q;
+                    xv[q] = ld8(a.ln1_x + row * 512 + lane * 8); dv[q] = ld8(a.ln1_dxn + row * 512 + lane * 8);
+                    rv[q] = ld8(a.ln1_res + row * 512 + lane * 8);
+                    mean[q] = a.ln1_mean[row]; rstd[q] = a.ln1_rstd[row];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    s1[q] = 0.f; s2[q] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        xv[q].v[j] = (xv[q].v[j] - mean[q]) * rstd[q];
+                        const float d = dv[q].v[j];
+                        dv[q].v[j] = d * gm.v[j];
+                        s1[q] += dv[q].v[j]; s2[q] += dv[q].v[j] * xv[q].v[j];
+                        dg.v[j] += d * xv[q].v[j];
+                        db.v[j] += d;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float m1 = wave_sum(s1[q]) * (1.0f / 512), m2 = wave_sum(s2[q]) * (1.0f / 512);
+                    float o[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        o[j] = rstd[q] * (dv[q].v[j] - m1 - xv[q].v[j] * m2) + rv[q].v[j];
+                        ds.v[j] += o[j];
+                    }
+                    const uint4 u = pn_pack8(o);
+                    const int m = wave * RPW + half * 4 + q;
+                    *reinterpret_cast<uint4*>(a.dx_out + (row0 + m) * 512 + lane * 8) = u;
+                    *reinterpret_cast<uint4*>(pn_panel_slot<1024>(lds + XN_OFF, m, lane)) = u;
+                }
+            }
+            // column sums over the panel's 64 rows: the eight waves meet in the (still unused) hidden-activation region
+            float* red = reinterpret_cast<float*>(lds + H_OFF);       // [PN_WAVES][3][512]
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                red[(wave * 3 + 0) * 512 + lane * 8 + j] = dg.v[j];
+                red[(wave * 3 + 1) * 512 + lane * 8 + j] = db.v[j];
+                red[(wave * 3 + 2) * 512 + lane * 8 + j] = ds.v[j];
+            }
+            __syncthreads();
+            for (int idx = tid; idx < 3 * 512; idx += 64 * PN_WAVES) {
+                const int which = idx >> 9, cc = idx & 511;
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < PN_WAVES; ++w) sum += red[(w * 3 + which) * 512 + cc];
+                float* out = which == 0 ? a.g_ln1_g : (which == 1 ? a.g_ln1_b : a.g_dx_colsum);
+                if (out) unsafeAtomicAdd(out + cc, sum);
+            }
+        } else {
+            uint4 v[RPW];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) v[r] = *reinterpret_cast<const uint4*>(a.dx + (row0 + wave * RPW + r) * 512 + lane * 8);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) *reinterpret_cast<uint4*>(pn_panel_slot<1024>(lds + XN_OFF, wave * RPW + r, lane)) = v[r];
+        }
     } else
     {
         constexpr int RPW = PN_ROWS / PN_WAVES;
@@ -880,9 +949,13 @@ extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
 
 extern "C" int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream) {
     TAN_REQUIRE(d && d->rows > 0 && d->rows % PN_ROWS == 0 && d->C == 512 && d->FF == 2048);
-    TAN_REQUIRE(d->dx && d->h_pre && d->x_mid && d->mean2 && d->rstd2 && d->ln_g && d->pwt_proj && d->pwt_fc && d->dh && d->dx2);
+    TAN_REQUIRE((d->dx || d->ln1_dxn) && d->h_pre && d->x_mid && d->mean2 && d->rstd2 && d->ln_g && d->pwt_proj && d->pwt_fc && d->dh && d->dx2);
     TAN_REQUIRE(d->g_b_fc && d->g_ln_g && d->g_ln_b && d->g_b_out);
+    if (d->ln1_dxn) TAN_REQUIRE(d->ln1_x && d->ln1_res && d->ln1_mean && d->ln1_rstd && d->ln1_g && d->dx_out);
     MlpBwdArgs a;
+    a.ln1_dxn = (const bf16_t*)d->ln1_dxn; a.ln1_x = (const bf16_t*)d->ln1_x; a.ln1_res = (const bf16_t*)d->ln1_res;
+    a.ln1_mean = d->ln1_mean; a.ln1_rstd = d->ln1_rstd; a.ln1_g = d->ln1_g;
+    a.g_ln1_g = d->g_ln1_g; a.g_ln1_b = d->g_ln1_b; a.g_dx_colsum = d->g_dx_colsum; a.dx_out = (bf16_t*)d->dx_out;
     a.dx = (const bf16_t*)d->dx; a.h_pre = (const bf16_t*)d->h_pre; a.x_mid = (const bf16_t*)d->x_mid;
     a.mean2 = d->mean2; a.rstd2 = d->rstd2; a.ln_g = d->ln_g;
     a.pw_fc = (const char*)d->pwt_proj; a.pw_proj = (const char*)d->pwt_fc;

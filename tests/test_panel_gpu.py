@@ -167,6 +167,67 @@ def test_mlp_bwd_matches_the_fp32_backward_of_the_branch(R):
     close(g_b_out - 1.0, r_dx2.sum(0), "g_b_out", 2e-3)
 
 
+def test_mlp_bwd_with_the_next_blocks_ln1_backward_as_prologue():
+    """tan_mlp_bwd with ln1_dxn set: dx = ln1_res + LayerNorm-backward(ln1_dxn; ...) is produced in the kernel (and stored to dx_out
+    for the weight-gradient launch) instead of being read -- against tan_layernorm_bwd followed by the plain tan_mlp_bwd.  ln1_res
+    aliases dx2, as in tan_encoder_bwd."""
+    _lib, ops = _lib_ops()
+    R, bf = 256, torch.bfloat16
+    torch.manual_seed(7)
+    x_mid = (torch.randn(R, 512, device="cuda") * 1.5).to(bf)
+    wfc = (torch.randn(2048, 512, device="cuda") * 1024 ** -0.5).to(bf)
+    wpj = (torch.randn(512, 2048, device="cuda") * 0.03).to(bf)
+    g2 = 1 + 0.1 * torch.randn(512, device="cuda")
+    x = x_mid.float()
+    mean2, rstd2 = x.mean(-1), (x.var(-1, unbiased=False) + 1e-5).rsqrt()
+    h_pre = (torch.randn(R, 2048, device="cuda")).to(bf)
+    pwt_proj, pwt_fc = pack([wpj.T.contiguous(), wfc.T.contiguous()])
+    # the next block's ln_1: input x_out (this block's output), upstream gradient dxn, residual-stream gradient res
+    x_out = (torch.randn(R, 512, device="cuda") * 2).to(bf)
+    dxn = (torch.randn(R, 512, device="cuda") * 0.02).to(bf)
+    res = (torch.randn(R, 512, device="cuda") * 0.02).to(bf)
+    g1 = 1 + 0.1 * torch.randn(512, device="cuda")
+    xo = x_out.float()
+    mean1, rstd1 = xo.mean(-1).contiguous(), (xo.var(-1, unbiased=False) + 1e-5).rsqrt().contiguous()
+
+    def run(fused):
+        dh = torch.zeros(R, 2048, device="cuda", dtype=bf)
+        dx2 = res.clone()                                  # the residual gradient arrives in the buffer dx2 leaves in
+        dx = torch.full((R, 512), float("nan"), device="cuda", dtype=bf)
+        acc = {k: torch.full((n,), 0.5, device="cuda") for k, n in (("g_b_fc", 2048), ("g_ln_g", 512), ("g_ln_b", 512),
+                                                                       ("g_b_out", 512), ("g_ln1_g", 512), ("g_ln1_b", 512),
+                                                                       ("g_b_proj", 512))}
+        d = _lib.MlpBwdDesc()
+        d.rows, d.C, d.FF = R, 512, 2048
+        d.h_pre, d.x_mid = h_pre.data_ptr(), x_mid.data_ptr()
+        d.mean2, d.rstd2, d.ln_g = mean2.data_ptr(), rstd2.data_ptr(), g2.data_ptr()
+        d.pwt_proj, d.pwt_fc = pwt_proj.data_ptr(), pwt_fc.data_ptr()
+        d.dh, d.dx2 = dh.data_ptr(), dx2.data_ptr()
+        d.g_b_fc, d.g_ln_g, d.g_ln_b, d.g_b_out = (acc[k].data_ptr() for k in ("g_b_fc", "g_ln_g", "g_ln_b", "g_b_out"))
+        if fused:
+            d.ln1_dxn, d.ln1_x, d.ln1_res = dxn.data_ptr(), x_out.data_ptr(), dx2.data_ptr()
+            d.ln1_mean, d.ln1_rstd, d.ln1_g = mean1.data_ptr(), rstd1.data_ptr(), g1.data_ptr()
+            d.g_ln1_g, d.g_ln1_b, d.g_dx_colsum = acc["g_ln1_g"].data_ptr(), acc["g_ln1_b"].data_ptr(), acc["g_b_proj"].data_ptr()
+            d.dx_out = dx.data_ptr()
+        else:
+            ops.layernorm_bwd(dxn, x_out, g1, mean1, rstd1, dx, acc["g_ln1_g"], acc["g_ln1_b"], dres=dx2, dx_colsum=acc["g_b_proj"])
+            d.dx = dx.data_ptr()
+        _lib.check(_lib.lib().tan_mlp_bwd(C.byref(d), ops._stream()), "tan_mlp_bwd")
+        torch.cuda.synchronize()
+        return dx, dh, dx2, acc
+
+    dx0, dh0, dx20, acc0 = run(False)
+    dx1, dh1, dx21, acc1 = run(True)
+    # the same arithmetic compiled twice (fma contraction may differ by an f32 ulp): equal up to a bf16 rounding step
+    for got, ref, what in ((dx1, dx0, "dx"), (dh1, dh0, "dh"), (dx21, dx20, "dx2")):
+        assert torch.isfinite(got.float()).all(), what
+        err = (got.float() - ref.float()).abs().max().item()
+        assert err <= 2.0 ** -7 * ref.float().abs().max().item(), (what, err)
+        assert (got != ref).float().mean().item() < 0.02, what
+    for k in acc0:          # f32 column sums meet in atomics in a different order
+        assert torch.allclose(acc0[k], acc1[k], rtol=1e-4, atol=1e-5), k
+
+
 def test_mlp_bwd_rejects_what_it_cannot_do():
     _lib, ops = _lib_ops()
     d = _lib.MlpBwdDesc()
