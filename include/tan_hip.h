@@ -393,7 +393,7 @@ typedef struct tan_mlp_bwd_desc {
     /* Optional (ln1_dxn != NULL): `dx` is not read but PRODUCED first, as the backward of the NEXT block's ln_1 (tfm_model.py:43):
      *   dx = ln1_res + LayerNorm-backward(ln1_dxn; ln1_x, ln1_mean, ln1_rstd, ln1_g)      -> dx_out [rows, C] bf16 (and the panel)
      *   g_ln1_g += colsum(ln1_dxn o xhat), g_ln1_b += colsum(ln1_dxn), g_dx_colsum += colsum(dx)  (= this block's c_proj bias grad)
-     * ln1_res may alias dx2 (a workgroup reads its 64 rows before it writes them).                                              */
+     * ln1_res may alias dx2 (a workgroup reads its 64 rows before it writes them) or be NULL (no residual: the stack's post-LayerNorm). */
     const void *ln1_dxn, *ln1_x, *ln1_res;
     const float *ln1_mean, *ln1_rstd, *ln1_g;
     float *g_ln1_g, *g_ln1_b, *g_dx_colsum;

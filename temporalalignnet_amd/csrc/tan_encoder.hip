@@ -237,7 +237,17 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
     void* dx = e->scr_dx;      // gradient w.r.t. the residual stream leaving the current layer
     void* dx2 = e->scr_dx2;
     const void* x_last = e->bufs[S - 1].x_out;
-    if (e->d_stage[S - 1]) {
+    // ln_1 backward of block i+1 handed to block i's row-panel MLP backward as its prologue (TAN_LN1_FUSED=0: its own launch); the
+    // stack's post-LayerNorm backward goes to the last block the same way (no residual gradient next to it)
+    struct { bool on; int layer; const void *dxn, *x, *res; const float *mean, *rstd, *g; float *gg, *gb, *gcol; } pend{};
+    static const bool ln1_fused = [] { const char* v = getenv("TAN_LN1_FUSED"); return !v || atoi(v) != 0; }();
+    const bool panel_all = ln1_fused && grouped_enabled() != 0 && panel_bwd_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0;
+    if (e->d_stage[S - 1] && panel_all && e->params[S - 1].wtp_fc && e->params[S - 1].wtp_proj) {
+        TAN_REQUIRE(e->post_out);
+        pend.on = true; pend.layer = -1; pend.dxn = e->d_stage[S - 1]; pend.x = x_last; pend.res = nullptr;
+        pend.mean = e->post_mean; pend.rstd = e->post_rstd; pend.g = e->post_g; pend.gg = e->g_post_g; pend.gb = e->g_post_b;
+        pend.gcol = e->params[S - 1].g_b_proj;
+    } else if (e->d_stage[S - 1]) {
         TAN_REQUIRE(e->post_out);
         // dx = grad of the last layer's x_out: its column sums are that layer's c_proj bias gradient
         CK(tan_layernorm_bwd(e->d_stage[S - 1], x_last, e->post_g, e->post_mean, e->post_rstd, nullptr, dx, e->g_post_g,
@@ -249,9 +259,6 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
     // bias gradients that are column sums of a LayerNorm-backward OUTPUT are accumulated inside that kernel:
     //   g_b_proj[i] <- colsum(dx entering layer i)   = output of layer i+1's LN1 backward (or of the post-LN backward)
     //   g_b_out[i]  <- colsum(dx2)                   = output of layer i's LN2 backward
-    // ln_1 backward of block i+1 handed to block i's row-panel MLP backward as its prologue (TAN_LN1_FUSED=0: its own launch)
-    struct { bool on; int layer; const void *dxn, *x, *res; const float *mean, *rstd, *g; float *gg, *gb, *gcol; } pend{};
-    static const bool ln1_fused = [] { const char* v = getenv("TAN_LN1_FUSED"); return !v || atoi(v) != 0; }();
     for (int i = S - 1; i >= 0; --i) {
         const tan_layer_params& p = e->params[i];
         const tan_layer_bufs& b = e->bufs[i];
@@ -275,7 +282,7 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
             CK(tan_mlp_bwd(&m, st));
             if (pend.on) {          // every gradient of block pend.layer is final now
                 pend.on = false;
-                if (e->layer_done && e->layer_done[pend.layer]) {
+                if (pend.layer >= 0 && e->layer_done && e->layer_done[pend.layer]) {
                     const hipError_t err = hipEventRecord((hipEvent_t)e->layer_done[pend.layer], (hipStream_t)st);
                     if (err != hipSuccess) return (int)err;
                 }
@@ -303,8 +310,7 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         }
         void* dx_in = i == 0 ? e->d_x0 : dx;
         float* next_b_proj = i > 0 ? e->params[i - 1].g_b_proj : nullptr;       // dx_in is layer i-1's x_out gradient
-        if (i > 0 && ln1_fused && grouped && panel_bwd_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0 &&
-            e->params[i - 1].wtp_fc && e->params[i - 1].wtp_proj) {
+        if (i > 0 && panel_all && e->params[i - 1].wtp_fc && e->params[i - 1].wtp_proj) {
             // block i-1's row-panel MLP backward does this LayerNorm backward as its prologue (dx2 and scr_dxn stay untouched until
             // that launch: it is the next one that writes them)
             pend.on = true; pend.layer = i; pend.dxn = e->scr_dxn; pend.x = x_in; pend.res = dx2;

@@ -500,6 +500,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
             // the next block's ln_1 backward, row by row (a wave owns whole rows, a lane 8 features: tan_norm.hip's arithmetic):
             // the result is this kernel's dx panel, and goes to HBM once for the weight-gradient launch that reads it later
             const f8 gm = ld8f(a.ln1_g + lane * 8);
+            const float rmul = a.ln1_res ? 1.0f : 0.0f;
             f8 dg, db, ds;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { dg.v[j] = 0.f; db.v[j] = 0.f; ds.v[j] = 0.f; }
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                 for (int q = 0; q < 4; ++q) {
                     const long row = row0 + wave * RPW + half * 4 + q;
                     xv[q] = ld8(a.ln1_x + row * 512 + lane * 8); dv[q] = ld8(a.ln1_dxn + row * 512 + lane * 8);
-                    rv[q] = ld8(a.ln1_res + row * 512 + lane * 8);
+                    rv[q] = ld8((a.ln1_res ? a.ln1_res : a.ln1_dxn) + row * 512 + lane * 8);       // (unconditional load; weighted below)
                     mean[q] = a.ln1_mean[row]; rstd[q] = a.ln1_rstd[row];
                 }
 #pragma unroll
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                     float o[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        o[j] = rstd[q] * (dv[q].v[j] - m1 - xv[q].v[j] * m2) + rv[q].v[j];
+                        o[j] = rstd[q] * (dv[q].v[j] - m1 - xv[q].v[j] * m2) + rv[q].v[j] * rmul;
                         ds.v[j] += o[j];
                     }
                     const uint4 u = pn_pack8(o);
@@ -951,7 +952,7 @@ extern "C" int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream) {
     TAN_REQUIRE(d && d->rows > 0 && d->rows % PN_ROWS == 0 && d->C == 512 && d->FF == 2048);
     TAN_REQUIRE((d->dx || d->ln1_dxn) && d->h_pre && d->x_mid && d->mean2 && d->rstd2 && d->ln_g && d->pwt_proj && d->pwt_fc && d->dh && d->dx2);
     TAN_REQUIRE(d->g_b_fc && d->g_ln_g && d->g_ln_b && d->g_b_out);
-    if (d->ln1_dxn) TAN_REQUIRE(d->ln1_x && d->ln1_res && d->ln1_mean && d->ln1_rstd && d->ln1_g && d->dx_out);
+    if (d->ln1_dxn) TAN_REQUIRE(d->ln1_x && d->ln1_mean && d->ln1_rstd && d->ln1_g && d->dx_out);
     MlpBwdArgs a;
     a.ln1_dxn = (const bf16_t*)d->ln1_dxn; a.ln1_x = (const bf16_t*)d->ln1_x; a.ln1_res = (const bf16_t*)d->ln1_res;
     a.ln1_mean = d->ln1_mean; a.ln1_rstd = d->ln1_rstd; a.ln1_g = d->ln1_g;
