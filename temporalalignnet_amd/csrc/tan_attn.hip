@@ -962,17 +962,11 @@ extern "C" int tan_attn_fwd(const void* qkv, const unsigned char* key_padding_ma
     return 0;
 }
 
-// TAN_ATTN_BIAS_FUSED=0: the in_proj bias gradient by tan_colsum_acc over dqkv for every path (A/B measurements)
-static bool bias_fused() {
-    static const int v = [] { const char* e = getenv("TAN_ATTN_BIAS_FUSED"); return e ? atoi(e) : 1; }();
-    return v != 0;
-}
-
 static int attn_bwd_impl(const void* qkv, const unsigned char* key_padding_mask, const void* o, const float* lse,
                          const void* d_o, void* dqkv, float* g_b_qkv, int B, int L, int H, int dtype, void* stream) {
     TAN_REQUIRE(qkv && o && lse && d_o && dqkv && B > 0 && L > 0 && H > 0);
     AttnArgs a{};
-    const bool fuse = g_b_qkv && short_path(dtype, L) && bias_fused();
+    const bool fuse = g_b_qkv && short_path(dtype, L);
     a.gbias = fuse ? g_b_qkv : nullptr;
     a.qkv = qkv; a.keypad = key_padding_mask; a.o = (void*)o; a.lse = (float*)lse; a.d_o = d_o; a.dqkv = dqkv;
     a.B = B; a.L = L; a.H = H; a.Lpad = (L + 63) / 64 * 64;

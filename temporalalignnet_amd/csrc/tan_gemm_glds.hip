@@ -853,8 +853,7 @@ int gemm_dw256_grouped(int nprob, const void* const* dy, const void* const* x, f
     ga.nprob = nprob; ga.K = (int)rows; ga.accumulate = split == 1 ? 1 : 2;       // 1: one slice, plain read-add-write; 2: atomics
     static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_dw256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * D256_STAGE);
     if (attr != hipSuccess) return (int)attr;
-    static const int xmap = [] { const char* e = getenv("TAN_DW256_XCD"); return e ? atoi(e) : 1; }();
-    ga.kchunk = (xmap && 8 % split == 0 && tiles % (8 / split) == 0) ? split : 0;        // slices pinned to XCD groups
+    ga.kchunk = (8 % split == 0 && tiles % (8 / split) == 0) ? split : 0;                 // slices pinned to XCD groups
     if (ga.kchunk) hipLaunchKernelGGL(gemm_dw256_kernel, dim3(tiles * split), dim3(256), 4 * D256_STAGE, st, ga);
     else hipLaunchKernelGGL(gemm_dw256_kernel, dim3(tiles, split), dim3(256), 4 * D256_STAGE, st, ga);
     TAN_LAUNCH_CHECK();

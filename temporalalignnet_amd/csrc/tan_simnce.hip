@@ -490,11 +490,6 @@ __global__ __launch_bounds__(256) void simnce_dl_kept_kernel(SimArgs a, int npan
     }
 }
 
-// TAN_SIM_INLINE_DIAG=0: the dlogits sweep followed by simnce_diag_kernel<true> (A/B measurements)
-static bool inline_diag_enabled() {
-    static const int v = [] { const char* e = getenv("TAN_SIM_INLINE_DIAG"); return e ? atoi(e) : 1; }();
-    return v != 0;
-}
 // TAN_SIM_RES=0: the re-staging kernel for every shape (A/B measurements)
 static bool res_enabled(const SimArgs& a) {
     static const int v = [] { const char* e = getenv("TAN_SIM_RES"); return e ? atoi(e) : 1; }();
@@ -795,7 +790,7 @@ static int simnce_bwd_impl(const void* vn, const void* tn, long t_stage_stride, 
     }
     if (phases & TAN_SIM_SWEEP) {
         const bool res = res_enabled(a);
-        const bool tail = res && inline_diag_enabled() && (phases & TAN_SIM_DIAG);      // corrections as the sweep kernel's tail
+        const bool tail = res && (phases & TAN_SIM_DIAG);      // corrections as the sweep kernel's tail
         if (tail && !(phases & TAN_SIM_DIAG_KEEP) && (rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;
         const int prec = prof_begin(st, TAN_PROF_SIMNCE, 2.0 * S * a.R * (double)a.Mp * C);
         if (res) {
