@@ -67,7 +67,8 @@ _ln_ws = {}
 
 
 def _ws_f32(n, device):
-    key = (device, "ln")
+    # one workspace per (device, stream): two LayerNorm backwards issued on different streams must not share their partial tables
+    key = (device, "ln", torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0)
     buf = _ln_ws.get(key)
     if buf is None or buf.numel() < n:
         buf = torch.empty(n, device=device, dtype=torch.float32)

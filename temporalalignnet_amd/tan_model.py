@@ -987,17 +987,35 @@ class TemporalAligner(nn.Module):
             else:
                 d_lang_t = torch.empty(Mp, Cw, dtype=cd, device=dev)
                 ops.rows_copy(d_xj, d_lang_t, B, N, Cw, L, T, N, 0)
-        # ---- embeddings
+        # ---- embeddings: two chains of ~10 small launches each that share nothing (video / text parameters): the text one on the
+        # side stream (idle now) next to the video one (TAN_TAIL_STREAMS=0: one after the other)
         d_lang = None
+        cur = torch.cuda.current_stream()
+        aux = self._side_stream(dev) if os.environ.get("TAN_TAIL_STREAMS", "1") != "0" else None
+        if aux is not None and aux.cuda_stream == cur.cuda_stream:
+            aux = None
+
+        def text_side():
+            d = None
+            if have_lang_raw:
+                d = self._text_embed_bwd(run["sv_text"], d_lang_raw, need_d_lang)
+            if d_lang_t is not None:
+                d2 = self._text_embed_bwd(run["sv_text_t"], d_lang_t, need_d_lang)
+                d = d2 if d is None else (d + d2 if d2 is not None else d)
+            return d
+
+        if aux is not None:
+            aux.wait_stream(cur)
+            with torch.cuda.stream(aux):
+                d_lang = text_side()
         if any_j and run["sv_video_j"] is not None:
             self._video_embed_bwd_pair(run["sv_video"], d_x0, any_v, run["sv_video_j"], d_x0j)
         elif any_v or any_j:
             self._video_embed_bwd(run["sv_video"], d_x0)
-        if have_lang_raw:
-            d_lang = self._text_embed_bwd(run["sv_text"], d_lang_raw, need_d_lang)
-        if d_lang_t is not None:
-            d2 = self._text_embed_bwd(run["sv_text_t"], d_lang_t, need_d_lang)
-            d_lang = d2 if d_lang is None else (d_lang + d2 if d2 is not None else d_lang)
+        if aux is not None:
+            cur.wait_stream(aux)
+        else:
+            d_lang = text_side()
         self._release_ws(ev)
         self._release_ws(ej)
         return d_lang
