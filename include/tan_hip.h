@@ -326,6 +326,12 @@ typedef struct tan_encoder_desc {
                                                    the stream once every gradient of layer i's parameters is final (layers finish
                                                    last to first) -- lets a data-parallel caller start reducing a layer's slice of
                                                    the flat gradient while the earlier layers' backward still runs */
+    /* forward only */
+    int no_save;                                /* != 0: no backward will follow (torch.no_grad(): the EMA target's forward,
+                                                   tan_model.py:348-351, and every evaluation entry point) -- the tensors that exist
+                                                   only for backward (h_pre, h_act, xn2, mean2 / rstd2, and on the fused attention
+                                                   path qkv, attn_o, lse) are NOT written; bufs[] may then leave them NULL.  The stage
+                                                   outputs (xn1 of layers >= 1, post_out) and x_mid / x_out are written as usual. */
 } tan_encoder_desc;
 int tan_encoder_fwd(const tan_encoder_desc* e, void* stream);
 int tan_encoder_bwd(const tan_encoder_desc* e, void* stream);
@@ -346,7 +352,8 @@ int tan_linear_wgrad_group(int n, const void* const* dy, const void* const* x, f
  * weights are PRE-PACKED (once per optimizer step) into the LDS image of the tiles the kernels consume, in consumption order.
  * tan_pack_weights: entry i packs the row-major bf16 matrix src[src_off ..] of shape [N][K] (the nn.Linear layout, or a W^T
  *   copy) into dst[dst_off ..] as tiles [TN][TK] in (n-block, k-block) order; TN*TK*2 bytes must be 16384, TK in {16,32,64}
- *   (kernels here: TN=256,TK=32 for N > 512, TN=512,TK=16 for N == 512).  `table` is DEVICE memory; max_tiles = the largest
+ *   (kernels here: TN=256,TK=32 for N > 512, TN=512,TK=16 for N == 512; TN=384,TK=32 with N=1536 selects the "qkv16" format of
+ *   tan_attnblk_fwd: 24-KiB tiles of 16 x 32 fragments, see there).  `table` is DEVICE memory; max_tiles = the largest
  *   N/TN * K/TK of the table. */
 typedef struct tan_pack_entry { long src_off, dst_off; int N, K, TN, TK; } tan_pack_entry;
 int tan_panel_waves(void);   /* waves per row-panel workgroup the library was built for (fragment ownership inside a packed tile) */
@@ -354,7 +361,8 @@ int tan_pack_weights(const void* src, void* dst, const tan_pack_entry* table, in
 
 /* tan_mlp_fwd: the MLP half of ResidualAttentionBlock_Step.forward (model/tfm_model.py:23-27,37) for rows % 64 == 0, bf16:
  *   xn2 = LN2(x_mid) ; h = QuickGELU(xn2 W_fc^T + b_fc) ; x_out = x_mid + h W_proj^T + b_proj ; xn_next = LN_next(x_out)
- * xn2 / mean2 / rstd2 / h_pre / h_act are saved for backward (h_pre / h_act may be NULL: not stored); xn_next (optional) is the
+ * xn2 / mean2 / rstd2 / h_pre / h_act are saved for backward (each group may be NULL: not stored -- h_pre and h_act together,
+ * mean2 and rstd2 together, xn2 alone; the no-grad forward passes none of them); xn_next (optional) is the
  * NEXT block's ln_1 output (= this block's deep-supervision feature, tfm_model.py:48-55) or the stack's post-LN.
  * pw_fc = packed c_fc.weight [2048][512] (TN=256,TK=32), pw_proj = packed c_proj.weight [512][2048] (TN=512,TK=16).      */
 typedef struct tan_mlp_desc {
@@ -400,6 +408,30 @@ typedef struct tan_mlp_bwd_desc {
     void* dx_out;
 } tan_mlp_bwd_desc;
 int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream);
+
+/* ---- the attention branch of a block in ONE launch per direction (bf16, C = 512, H = 8, 48 < L <= 80 rows per video) --------
+ * tan_attnblk_fwd: x_mid = x_in + out_proj(MHA(xn1))  with MHA = nn.MultiheadAttention(512, 8) as called at
+ * model/tfm_model.py:30-36 (packed in_proj q|k|v, q scaled by 64^-0.5, key_padding_mask keys = -inf, softmax over keys, dropout 0,
+ * need_weights=False).  One workgroup per video keeps the xn1 panel in LDS; replaces the in_proj GEMM, tan_attn_fwd and the
+ * out_proj GEMM (+bias +residual) of tan_encoder_fwd, and the qkv / attn_o round trips between them.
+ *   pw_qkv = tan_pack_weights image of attn.in_proj_weight [1536][512] with TN = 384, TK = 32 (the "qkv16" format: tile (head
+ *            pair hp, k step) holds, per wave w and feature block fb < 3, the 16 x 32 fragment of in_proj rows
+ *            which*512 + (2hp + j)*64 + fblk*16 .. +15 where p = 3w + fb, which = (p / 4) % 3, j = p / 12, fblk = p % 4)
+ *   pw_out = tan_pack_weights image of attn.out_proj.weight [512][512] with TN = 512, TK = 16
+ * qkv [B*L, 3C], attn_o [B*L, C], lse [B, H, L] are what tan_attn_bwd needs later: all three or none (NULL: the no-grad forward
+ * writes nothing but x_mid).  Fully padded key rows give zeros (lse = -inf), like tan_attn_fwd.                              */
+typedef struct tan_attnblk_desc {
+    int B, L, C, H;
+    const void* xn1;                         /* [B*L, C] bf16: ln_1 output */
+    const void* x_in;                        /* [B*L, C] bf16: the residual stream entering the block */
+    const unsigned char* key_padding_mask;   /* [B, L] bytes, 1 = ignore, or NULL */
+    const void *pw_qkv, *pw_out;
+    const float *b_qkv, *b_out;
+    void *qkv, *attn_o; float* lse;          /* out, saved for backward, or all NULL */
+    void* x_mid;                             /* out [B*L, C] */
+} tan_attnblk_desc;
+int tan_attnblk_supported(int L, int C, int H, int dtype);
+int tan_attnblk_fwd(const tan_attnblk_desc* d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -144,6 +144,15 @@ class MlpBwdDesc(C.Structure):
     ]
 
 
+class AttnBlkDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("L", C.c_int), ("C", C.c_int), ("H", C.c_int),
+        ("xn1", C.c_void_p), ("x_in", C.c_void_p), ("key_padding_mask", C.c_void_p),
+        ("pw_qkv", C.c_void_p), ("pw_out", C.c_void_p), ("b_qkv", C.c_void_p), ("b_out", C.c_void_p),
+        ("qkv", C.c_void_p), ("attn_o", C.c_void_p), ("lse", C.c_void_p), ("x_mid", C.c_void_p),
+    ]
+
+
 class EncoderDesc(C.Structure):
     _fields_ = [
         ("dtype", C.c_int), ("B", C.c_int), ("L", C.c_int), ("C", C.c_int), ("H", C.c_int), ("layers", C.c_int),
@@ -156,4 +165,5 @@ class EncoderDesc(C.Structure):
         ("dw_ws", C.c_void_p), ("dw_ws_floats", C.c_long),
         ("d_stage", C.POINTER(C.c_void_p)), ("d_x0", C.c_void_p),
         ("layer_done", C.POINTER(C.c_void_p)),
+        ("no_save", C.c_int),
     ]

@@ -138,7 +138,8 @@ def make_state(trainer, epoch: int, best_acc: float) -> dict:
     main.py:281, +1 per batch, main.py:140) -- not the optimizer-step count, which differs once backprop_freq > 1 and which the
     AdamW state carries itself (state[*]['step'])."""
     return {"epoch": epoch, "state_dict": {k: v.detach().cpu().clone() for k, v in trainer.model.state_dict().items()},
-            "best_acc": best_acc, "optimizer": optimizer_state_dict(trainer), "iteration": trainer.batches_seen + 1}
+            "best_acc": best_acc, "optimizer": optimizer_state_dict(trainer), "iteration": trainer.batches_seen + 1,
+            "iteration_kind": "batch"}
 
 
 def save_checkpoint(state: dict, is_best=0, gap=1, filename="models/checkpoint.pth.tar", keep_all=False):
@@ -188,7 +189,16 @@ def load_for_resume(trainer, path):
     load_optimizer_state_dict(trainer, ckpt["optimizer"])            # restores the Adam bias-correction step from the state
     # args.iteration = checkpoint['iteration'] (main.py:444) drives the LR schedule; lr_scheduler.step(args.iteration) right
     # after (main.py:499) makes the FIRST batch after a resume run at lambda(iteration) -- one ahead of the uninterrupted run
-    trainer.batches_seen = max(int(ckpt["iteration"]) - 1, 0)
+    # 'iteration_kind' == 'batch' (written by make_state since round 3) or a reference file: the reference's batch counter,
+    # 1 + batches seen.  Files of earlier revisions of this repo stored the optimizer-step count there, without a marker: they are
+    # recognised by 'iteration' being equal to the AdamW step of the saved optimizer state (a reference file has 1 + step * freq).
+    freq = int(getattr(trainer.args, "backprop_freq", 1) or 1)
+    steps = [int(v["step"]) for v in ckpt["optimizer"].get("state", {}).values() if "step" in v]
+    legacy_step_count = "iteration_kind" not in ckpt and bool(steps) and int(ckpt["iteration"]) == steps[0] and steps[0] > 0
+    if legacy_step_count:
+        trainer.batches_seen = int(ckpt["iteration"]) * freq
+    else:
+        trainer.batches_seen = max(int(ckpt["iteration"]) - 1, 0)
     trainer._resume_bump = 1
     return {"start_epoch": ckpt["epoch"] + 1, "best_acc": ckpt["best_acc"], "missing": missing, "unexpected": unexpected}
 

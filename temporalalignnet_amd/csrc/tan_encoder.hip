@@ -177,6 +177,11 @@ static int panel_bwd_enabled() {
     static const int v = [] { const char* e = getenv("TAN_PANEL_BWD"); return e ? atoi(e) : 1; }();
     return v;
 }
+// TAN_ATTN_PANEL=0: the attention branch as in_proj GEMM + attention + out_proj GEMM (what also runs for f32, L <= 48 or L > 80)
+static int attn_panel_enabled() {
+    static const int on = [] { const char* e = getenv("TAN_ATTN_PANEL"); return e ? atoi(e) : 1; }();
+    return on;
+}
 static int panel_enabled() {
     static const int on = [] { const char* e = getenv("TAN_PANEL"); return e ? atoi(e) : 1; }();
     return on;
@@ -188,21 +193,34 @@ extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
     const long R = (long)e->B * e->L;
     const void* x_in = e->x0;
     const bool panel_ok = panel_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0;
+    const bool attn_panel_ok = attn_panel_enabled() && panel_enabled() && tan_attnblk_supported(e->L, C, H, dt);
     bool ln1_done = false;        // the previous block's panel kernel already produced this block's xn1 / mean1 / rstd1
     for (int i = 0; i < e->layers; ++i) {
         const tan_layer_params& p = e->params[i];
         const tan_layer_bufs& b = e->bufs[i];
         if (!ln1_done) CK(tan_layernorm_fwd(x_in, p.ln1_g, p.ln1_b, b.xn1, b.mean1, b.rstd1, nullptr, 0, R, C, 1e-5f, dt, st));
         ln1_done = false;
-        CK(linear_fwd(dt, b.xn1, p.w_qkv, p.b_qkv, b.qkv, R, 3 * C, C, TAN_ACT_NONE, nullptr, nullptr, st));
-        CK(tan_attn_fwd(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->B, e->L, H, dt, st));
-        CK(linear_fwd(dt, b.attn_o, p.w_out, p.b_out, b.x_mid, R, C, C, TAN_ACT_NONE, nullptr, x_in, st));
+        if (attn_panel_ok && p.wp_qkv && p.wp_out) {
+            // one launch: in_proj GEMM, the 8 heads' attention and out_proj + bias + residual, one workgroup per video (tan_attnblk.hip)
+            tan_attnblk_desc ab{};
+            ab.B = e->B; ab.L = e->L; ab.C = C; ab.H = H;
+            ab.xn1 = b.xn1; ab.x_in = x_in; ab.key_padding_mask = e->key_padding_mask;
+            ab.pw_qkv = p.wp_qkv; ab.pw_out = p.wp_out; ab.b_qkv = p.b_qkv; ab.b_out = p.b_out;
+            if (!e->no_save) { ab.qkv = b.qkv; ab.attn_o = b.attn_o; ab.lse = b.lse; }
+            ab.x_mid = b.x_mid;
+            CK(tan_attnblk_fwd(&ab, st));
+        } else {
+            CK(linear_fwd(dt, b.xn1, p.w_qkv, p.b_qkv, b.qkv, R, 3 * C, C, TAN_ACT_NONE, nullptr, nullptr, st));
+            CK(tan_attn_fwd(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->B, e->L, H, dt, st));
+            CK(linear_fwd(dt, b.attn_o, p.w_out, p.b_out, b.x_mid, R, C, C, TAN_ACT_NONE, nullptr, x_in, st));
+        }
         if (panel_ok && p.wp_fc && p.wp_proj) {
             tan_mlp_desc m{};
             m.rows = R; m.C = C; m.FF = 4 * C;
             m.x_mid = b.x_mid; m.ln_g = p.ln2_g; m.ln_b = p.ln2_b;
             m.pw_fc = p.wp_fc; m.pw_proj = p.wp_proj; m.b_fc = p.b_fc; m.b_proj = p.b_proj;
-            m.xn2 = b.xn2; m.mean2 = b.mean2; m.rstd2 = b.rstd2; m.h_pre = b.h_pre; m.h_act = b.h_act; m.x_out = b.x_out;
+            m.x_out = b.x_out;
+            if (!e->no_save) { m.xn2 = b.xn2; m.mean2 = b.mean2; m.rstd2 = b.rstd2; m.h_pre = b.h_pre; m.h_act = b.h_act; }
             m.eps = 1e-5f;
             if (i + 1 < e->layers) {
                 const tan_layer_params& pn = e->params[i + 1];

@@ -31,6 +31,18 @@ __global__ __launch_bounds__(256) void pack_tiles_kernel(const bf16_t* __restric
         const int nb = t / tiles_k, kt = t % tiles_k;
         const bf16_t* s0 = src + e.src_off + (long)nb * e.TN * e.K + (long)kt * e.TK;
         bf16_t* d0 = dst + e.dst_off + (long)t * e.TN * e.TK;
+        if (e.TN == 384) {
+            // "qkv16" format (tan_attnblk.hip, GEMM-a): tile (head pair nb, k step kt of 32) = 24 fragments of 16 features x 32 k,
+            // fragment p = 3 * wave + fb holds in_proj rows which*512 + (2 nb + j)*64 + fblk*16 .. (which = (p/4) % 3: q|k|v,
+            // j = p / 12: head of the pair, fblk = p % 4); lane l: row l & 15, k = 8 (l >> 4) .. + 7 (v_mfma_f32_16x16x32_bf16 A operand)
+            for (int s = threadIdx.x; s < slots; s += blockDim.x) {
+                const int lane = s & 63, p = s >> 6;
+                const int which = (p >> 2) % 3, j = p / 12, fblk = p & 3;
+                const int row = which * 512 + (2 * nb + j) * 64 + fblk * 16 + (lane & 15), k = kt * 32 + 8 * (lane >> 4);
+                *reinterpret_cast<uint4*>(d0 + (long)s * 8) = *reinterpret_cast<const uint4*>(src + e.src_off + (long)row * e.K + k);
+            }
+            continue;
+        }
         for (int s = threadIdx.x; s < slots; s += blockDim.x) {
             const int lane = s & 63, frag = s >> 6;
             const int ks = frag % KS, rb = (frag / KS) % RB, w = frag / (KS * RB);
@@ -591,9 +603,9 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                 for (int j = 0; j < 8; ++j) o[j] = v[r].v[j] * rstd * g.v[j] + b.v[j];
                 const uint4 u = pn_pack8(o);
                 const int m = wave * RPW + half * 8 + r;
-                *reinterpret_cast<uint4*>(a.xn2 + (row0 + m) * 512 + lane * 8) = u;
+                if (a.xn2) *reinterpret_cast<uint4*>(a.xn2 + (row0 + m) * 512 + lane * 8) = u;       // (NULL: no backward will follow)
                 *reinterpret_cast<uint4*>(pn_panel_slot<1024>(lds + XN_OFF, m, lane)) = u;
-                if (lane == 0) { a.mean2[row0 + m] = mean; a.rstd2[row0 + m] = rstd; }
+                if (lane == 0 && a.mean2) { a.mean2[row0 + m] = mean; a.rstd2[row0 + m] = rstd; }
             }
         }
     }
@@ -918,8 +930,10 @@ extern "C" int tan_pack_weights(const void* src, void* dst, const tan_pack_entry
 }
 
 extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
-    TAN_REQUIRE(d && d->x_mid && d->ln_g && d->ln_b && d->pw_fc && d->pw_proj && d->b_fc && d->b_proj && d->xn2 && d->mean2 && d->rstd2 &&
-                d->x_out && d->h_pre && d->h_act);
+    TAN_REQUIRE(d && d->x_mid && d->ln_g && d->ln_b && d->pw_fc && d->pw_proj && d->b_fc && d->b_proj && d->x_out);
+    TAN_REQUIRE((d->h_pre != nullptr) == (d->h_act != nullptr));           // the two side outputs: both or neither
+    TAN_REQUIRE((d->mean2 != nullptr) == (d->rstd2 != nullptr));
+    const bool no_side = !d->h_pre;
     TAN_REQUIRE(d->rows > 0 && d->rows % PN_ROWS == 0 && d->C == 512 && d->FF == 2048);
     TAN_REQUIRE(!d->xn_next || (d->nln_g && d->nln_b && d->nmean && d->nrstd));
     MlpFwdArgs a;
@@ -932,6 +946,11 @@ extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
     const dim3 grid((unsigned)(d->rows / PN_ROWS));
     const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0);
 #define TAN_MLP_LAUNCH(M) hipLaunchKernelGGL((mlp_panel_kernel<M, MlpFwdArgs>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a)
+    // inference / the EMA target's forward: the side outputs of the chunk epilogue (h_pre, h_act: 2 x 4 KiB per row... 67 MB per
+    // 8192 rows) are never read -- the instantiation without their copy-out (everything else identical)
+    if (no_side && d->variant == 0) {
+        TAN_MLP_LAUNCH(16);
+    } else
     switch (d->variant) {
 #ifdef TAN_PANEL_LAB
         case 2: TAN_MLP_LAUNCH(2); break;

@@ -123,6 +123,11 @@ def _ptr8(tensors):
 def l2norm_fwd_multi(xs, y, inv_norm, rows, Cc, grp=None, src_grp_rows=None, src_off=0):
     """all stages of one feature family in one launch: xs = list of per-stage buffers, y [S, rows, C], inv_norm [S * rows] or None"""
     grp = rows if grp is None else grp
+    if len(xs) > 8:          # the C entry point takes up to 8 stage pointers: deeper stacks go in groups of 8
+        for s0 in range(0, len(xs), 8):
+            l2norm_fwd_multi(xs[s0:s0 + 8], y[s0:s0 + 8], None if inv_norm is None else inv_norm[s0 * rows:(s0 + 8) * rows],
+                             rows, Cc, grp, src_grp_rows, src_off)
+        return y
     t = _ptr8(xs)
     _lib.check(_lib.lib().tan_l2norm_fwd_multi(C.byref(t), _ptr(y), _f32(inv_norm), C.c_int(len(xs)), C.c_long(rows), C.c_int(Cc),
                                                 C.c_int(grp), C.c_int(src_grp_rows if src_grp_rows is not None else grp),
@@ -132,6 +137,11 @@ def l2norm_fwd_multi(xs, y, inv_norm, rows, Cc, grp=None, src_grp_rows=None, src
 
 def l2norm_bwd_multi(dy, y, inv_norm, dxs, rows, Cc, grp=None, dst_grp_rows=None, dst_off=0):
     grp = rows if grp is None else grp
+    if len(dxs) > 8:
+        for s0 in range(0, len(dxs), 8):
+            l2norm_bwd_multi(dy[s0:s0 + 8], y[s0:s0 + 8], inv_norm[s0 * rows:(s0 + 8) * rows], dxs[s0:s0 + 8], rows, Cc, grp,
+                             dst_grp_rows, dst_off)
+        return
     t = _ptr8(dxs)
     _lib.check(_lib.lib().tan_l2norm_bwd_multi(_ptr(dy), _ptr(y), _f32(inv_norm), C.byref(t), C.c_int(len(dxs)), C.c_long(rows),
                                                 C.c_int(Cc), C.c_int(grp), C.c_int(dst_grp_rows if dst_grp_rows is not None else grp),

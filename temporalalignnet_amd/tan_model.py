@@ -90,11 +90,15 @@ class _Flat:
 
             def table(transposed):
                 ents, mx = [], 0
-                for n in [n for n in names if ".mlp.c_" in n]:          # only the MLP weights have row-panel consumers
+                for n in names:
                     o, _, (N, K) = self.off[n]
                     if transposed:
+                        if ".mlp.c_" not in n:                          # (no row-panel consumer of the attention weights' transposes yet)
+                            continue
                         N, K = K, N
                     TN, TK = (512, 16) if N == 512 else (256, 32)
+                    if not transposed and n.endswith("attn.in_proj_weight"):
+                        TN, TK = 384, 32                                # the "qkv16" format of tan_attnblk_fwd (include/tan_hip.h)
                     ents.append(_lib.PackEntry(o, o, N, K, TN, TK))
                     mx = max(mx, (N // TN) * (K // TK))
                 arr = (_lib.PackEntry * len(ents))(*ents)
@@ -119,6 +123,12 @@ class _Flat:
     def sync_shadow(self):
         if self.shadow is not None and self.shadow_version != self.flat._version:
             ops.cast(self.flat, self.shadow)
+            self.shadow_rewritten()
+
+    def shadow_rewritten(self):
+        """A kernel (the cast above, tan_adamw_step, tan_ema_update) has just rewritten the bf16 shadow from the f32 masters:
+        the shadow is current, and every image derived from it (W^T copies, packed tiles) is stale."""
+        if self.shadow is not None:
             self.shadow_version = self.flat._version
             self.shadow_epoch += 1
 
@@ -451,8 +461,7 @@ class TemporalAligner(nn.Module):
                 setattr(arr[i], k, f.ptr(wbuf, base + v))
                 setattr(arr[i], "g_" + k, f.ptr(f.grad, base + v))
                 setattr(arr[i], "wt_" + k[2:], f.ptr(wt, base + v) if wt is not None else None)
-                if k in ("w_fc", "w_proj"):
-                    setattr(arr[i], "wp_" + k[2:], f.ptr(wp, base + v) if wp is not None else None)
+                setattr(arr[i], "wp_" + k[2:], f.ptr(wp, base + v) if wp is not None else None)
                 if k in ("w_fc", "w_proj"):
                     setattr(arr[i], "wtp_" + k[2:], f.ptr(wtp, base + v) if wtp is not None else None)
             for k, v in fm.items():
@@ -476,8 +485,9 @@ class TemporalAligner(nn.Module):
         d.post_mean, d.post_rstd = _vp(er.stat["post_mean"]), _vp(er.stat["post_rstd"])
         return d
 
-    def _encoder_fwd(self, er, x0, keypad, post_name):
+    def _encoder_fwd(self, er, x0, keypad, post_name, save=False):
         d = self._enc_desc(er, x0, keypad, post_name)
+        d.no_save = 0 if save else 1         # no backward will follow: the tensors kept only for it are not written
         _lib.check(_lib.lib().tan_encoder_fwd(C.byref(d), ops._stream()), "tan_encoder_fwd")
 
     def _layer_events(self, prefix, layers):
@@ -732,12 +742,12 @@ class TemporalAligner(nn.Module):
             self._ws_pool[key] = scr
         return scr
 
-    def _run_video_stack(self, x0, vmask_u8, B, T):
+    def _run_video_stack(self, x0, vmask_u8, B, T, save=False):
         er = self._take_ws("video_temporal_encoder", self.num_encoder_layers, B, T, x0.dtype, x0.device)
-        self._encoder_fwd(er, x0, vmask_u8, "ln_video_post_enc")
+        self._encoder_fwd(er, x0, vmask_u8, "ln_video_post_enc", save)
         return er
 
-    def _run_joint_stack(self, x0, text_t, vmask_u8, tmask_u8, B, T, N):
+    def _run_joint_stack(self, x0, text_t, vmask_u8, tmask_u8, B, T, N, save=False):
         cd, dev = x0.dtype, x0.device
         L = T + N
         xj = torch.empty(B * L, WIDTH, dtype=cd, device=dev)
@@ -750,7 +760,7 @@ class TemporalAligner(nn.Module):
             tm = tmask_u8 if tmask_u8 is not None else torch.zeros(B, N, dtype=torch.uint8, device=dev)
             keypad = torch.cat([vm, tm], dim=1).contiguous()
         er = self._take_ws("joint_temporal_encoder", self.num_decoder_layers, B, L, cd, dev)
-        self._encoder_fwd(er, xj, keypad, "ln_joint_post_enc")
+        self._encoder_fwd(er, xj, keypad, "ln_joint_post_enc", save)
         er.xj, er.keypad = xj, keypad
         return er
 
@@ -786,15 +796,16 @@ class TemporalAligner(nn.Module):
         tn_d = torch.empty(Mp, Cw, dtype=cd, device=dev)
         tn_j = torch.empty(Sd, Mp, Cw, dtype=cd, device=dev)
         inv = _Blocks(torch.float32, dev, {"vd": Se * R, "vj": Sd * R, "td": Mp, "tj": Sd * Mp})
+        save = bool(opts.get("needs_grad", True))      # False: torch.no_grad() (EMA target, evaluation) -- nothing kept for backward
 
         def video_side():
-            ev_ = self._run_video_stack(x0, vmask_u8, B, T)
+            ev_ = self._run_video_stack(x0, vmask_u8, B, T, save)
             ops.l2norm_fwd_multi([ev_.stage(s) for s in range(Se)], vn_d, inv["vd"], R, Cw)
             ops.l2norm_fwd(lang_raw, tn_d, inv["td"], Mp, Cw)
             return ev_
 
         def joint_side():
-            ej_ = self._run_joint_stack(x0j, lang_t, vmask_u8, tmask_u8, B, T, N)
+            ej_ = self._run_joint_stack(x0j, lang_t, vmask_u8, tmask_u8, B, T, N, save)
             stages = [ej_.stage(s) for s in range(Sd)]
             ops.l2norm_fwd_multi(stages, vn_j, inv["vj"], R, Cw, T, L, 0)
             ops.l2norm_fwd_multi(stages, tn_j, inv["tj"], Mp, Cw, N, L, T)
@@ -1006,8 +1017,15 @@ class TemporalAligner(nn.Module):
 
         if aux is not None:
             aux.wait_stream(cur)
+            # caching-allocator bookkeeping across the two streams: tensors allocated on `cur` and read on `aux` must not be
+            # handed out again on `cur` before aux is done with them, and vice versa for the result
+            d_lang_raw.record_stream(aux)
+            if d_lang_t is not None:
+                d_lang_t.record_stream(aux)
             with torch.cuda.stream(aux):
                 d_lang = text_side()
+            if d_lang is not None:
+                d_lang.record_stream(cur)
         if any_j and run["sv_video_j"] is not None:
             self._video_embed_bwd_pair(run["sv_video"], d_x0, any_v, run["sv_video_j"], d_x0j)
         elif any_v or any_j:
@@ -1288,8 +1306,7 @@ class TwinTemporalAligner(nn.Module):
         fo, ft = self.online._ensure_flat(), self.target._ensure_flat()
         _lib.check(_lib.lib().tan_ema_update(_vp(ft.flat), _vp(fo.flat), C.c_long(fo.total), C.c_float(self.m),
                                              _vp(ft.shadow), ops._stream()), "tan_ema_update")
-        if ft.shadow is not None:
-            ft.shadow_version = ft.flat._version
+        ft.shadow_rewritten()                # also the packed / transposed images built from the shadow
         if self.online.bert is not None:     # language-model parameters live outside the flat buffers
             for po, pt in zip(self.online.bert.parameters(), self.target.bert.parameters()):
                 pt.data.mul_(self.m).add_(po.data, alpha=1.0 - self.m)

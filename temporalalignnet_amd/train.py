@@ -175,8 +175,17 @@ class Trainer:
             dist.broadcast_(m.flat_parameters(), src)
             m.invalidate_shadow()
             if m.bert is not None:
-                for p in m.bert.parameters():
-                    dist.broadcast_(p.data, src)
+                # trainable tensors in ONE broadcast; frozen tables (the ~80 MB word embedding: loaded from the same file on every
+                # rank, never updated) are skipped
+                frozen_table = {id(m.bert.word_embd.weight)} if hasattr(m.bert, "word_embd") else set()
+                ps = [p for p in m.bert.parameters() if id(p) not in frozen_table]
+                if ps:
+                    flat = torch.cat([p.data.reshape(-1) for p in ps])
+                    dist.broadcast_(flat, src)
+                    off = 0
+                    for p in ps:
+                        p.data.copy_(flat[off:off + p.numel()].view_as(p))
+                        off += p.numel()
 
     def _lm_params(self):
         lm = self.online.bert
@@ -265,15 +274,21 @@ class Trainer:
         the per-parameter clip: the clip coefficient is a function of the AVERAGED gradient (utils/train_utils.py:3-13)."""
         if not dist.active():
             return
-        grads = [p.grad for _, p in self._lm_params() if p.grad is not None]
-        if not grads:
+        # the bucket covers EVERY trainable language-model tensor (zeros where this rank has no gradient): its size must not depend
+        # on which ranks happened to get one, or the collective hangs / mixes tensors (ADVICE r2)
+        params = [p for _, p in self._lm_params()]
+        if not params:
             return
-        bucket = torch.cat([g.reshape(-1) for g in grads])
+        bucket = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
         dist.allreduce_sum_(bucket)
         off = 0
-        for g in grads:
-            g.copy_(bucket[off:off + g.numel()].view_as(g))
-            off += g.numel()
+        for p in params:
+            g = bucket[off:off + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += p.numel()
 
     def optimizer_step(self, grad_scale=1.0):
         f, st = self._ensure_state()
@@ -294,7 +309,8 @@ class Trainer:
             _vp(ema.shadow) if ema is not None else None, ops._stream()), "tan_adamw_step")
         f.shadow_epoch += 1                             # the kernel rewrote the bf16 shadow: transposed copies are stale
         if ema is not None:
-            ema.shadow_epoch += 1
+            ema.shadow_epoch += 1                       # (shadow_version is left alone: the flat buffers' version counters did
+            #                                             not move, the kernel writes through raw pointers)
         self._lm_step(grad_scale)
 
     def train_iteration(self, batch, idx):

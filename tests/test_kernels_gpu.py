@@ -99,8 +99,18 @@ def test_l2norm_multi_equals_one_launch_per_stage(dtype):
         ops.l2norm_bwd_multi(dy, y2, i2, d2, rows, C, grp, L, off)
         for a, b in zip(d1, d2):
             assert torch.equal(a, b)
-    with pytest.raises(ValueError):
-        ops.l2norm_fwd_multi([xs[0]] * 9, y2, i2, rows, C, grp, L, off)
+    # more than 8 stages (the C entry point's pointer table): the wrapper goes in groups of 8
+    S9 = 9
+    xs9 = [xs[s % S] for s in range(S9)]
+    y9 = torch.empty(S9, rows, C, device="cuda", dtype=dtype)
+    i9 = torch.empty(S9 * rows, device="cuda")
+    ops.l2norm_fwd_multi(xs9, y9, i9, rows, C, grp, L, off)
+    for s in range(S9):
+        assert torch.equal(y9[s], y1[s % S]) and torch.equal(i9[s * rows:(s + 1) * rows], i1[(s % S) * rows:(s % S + 1) * rows])
+    d9 = [torch.zeros(B * L, C, device="cuda", dtype=dtype) for _ in range(S9)]
+    ops.l2norm_bwd_multi(torch.cat([dy] * 3), y9, i9, d9, rows, C, grp, L, off)
+    for s in range(S9):
+        assert torch.equal(d9[s], d1[s % S])
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -262,3 +262,44 @@ def test_feature_entry_points_match_oracle():
         np.testing.assert_allclose(got.cpu().numpy()[valid], want.numpy()[valid], rtol=1e-4, atol=3e-5, err_msg=name)
     for k in onl:                                         # target == online right after _copy_param
         torch.testing.assert_close(ema[k], onl[k], rtol=0, atol=0, msg=k)
+
+
+@gpu
+def test_momentum_update_refreshes_every_weight_image_of_the_bf16_target():
+    """TwinTemporalAligner._momentum_update() rewrites the target's bf16 shadow in the kernel; the packed / transposed
+    images derived from it (row-panel kernels) must be rebuilt too.  After the update the target must compute exactly what a freshly
+    constructed model loaded with the same parameters computes (model/tan_model.py:339-351)."""
+    from temporalalignnet_amd.tan_model import TemporalAligner, TwinTemporalAligner
+    torch.manual_seed(3)
+    kw = dict(num_encoder_layers=2, num_decoder_layers=2, language_model=None, compute_dtype="bf16", random_pos_start=0)
+    tw = TwinTemporalAligner(0.5, **kw).cuda()
+    b = synth.make_batch(21, B=4, T=64, n_min=4, n_max=16)
+    d = dev_batch(b)
+    args = (d["video"], d["text_embed"], d["padding_mask"], d["text_padding_mask"].bool(), None)
+    with torch.no_grad():
+        tw.forward_from_ema(*args)                     # builds the target's shadow + packed images at the initial weights
+        for p in tw.online.parameters():               # move the online weights far away, then average them in
+            p.add_(torch.randn_like(p) * 0.05)
+        tw.online.invalidate_shadow()
+        tw._momentum_update()
+        got = tw.forward_from_ema(*args)
+        fresh = TemporalAligner(**kw).cuda()
+        fresh.load_state_dict(tw.target.state_dict())
+        want = fresh(*args)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+
+
+@gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_no_grad_forward_skips_the_saved_tensors_and_changes_nothing(dtype):
+    """The no-grad forward (EMA target, evaluation entry points; tan_model.py:348-351) does not write the tensors that only a
+    backward reads (tan_encoder_desc.no_save); every output is bit-identical to the training-mode forward's."""
+    m = make_model(105, 2, 3, True, dtype=dtype, random_pos_start=0)
+    b = synth.make_batch(23, B=4, T=64, n_min=4, n_max=16, video_pad_tail=5)
+    with torch.no_grad():
+        quiet = hip_forward(m, b)
+    loud = hip_forward(m, b)
+    assert any(v.requires_grad for v in loud.values())
+    for k in loud:
+        assert torch.equal(quiet[k], loud[k].detach()), k
