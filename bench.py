@@ -38,9 +38,10 @@ GEMM_KIND_NAMES = {0: "gemm_bf16<A:K-contig,B:K-contig> (Linear fwd, dX through 
                    2: "gemm_bf16<A:K-strided,B:K-contig>", 3: "gemm_bf16<A:K-strided,B:K-strided> (dW)",
                    4: "gemm_f32<kc,kc>", 5: "gemm_f32<kc,ks>", 6: "gemm_f32<ks,kc>", 7: "gemm_f32<ks,ks>",
                    8: "attn_fwd", 9: "attn_bwd", 10: "simnce (logits-free similarity+NCE, fwd stats / bwd dlogits)",
-                   11: "row-panel fused MLP, forward (LN2 + c_fc + QuickGELU + c_proj + residual + next LN) and backward (both dX GEMMs + quickgelu' + LN2 backward)"}
-NKINDS = 12
-FAMILY = list(range(8)) + [10, 11]       # every MFMA GEMM pipeline launch
+                   11: "row-panel fused MLP, forward (LN2 + c_fc + QuickGELU + c_proj + residual + next LN) and backward (both dX GEMMs + quickgelu' + LN2 backward)",
+                   12: "attention branch in one launch per video (in_proj GEMM + 8-head attention + out_proj + residual), forward"}
+NKINDS = 13
+FAMILY = list(range(8)) + [10, 11, 12]   # every MFMA GEMM pipeline launch
 
 
 def parse():
@@ -85,32 +86,64 @@ def cpu_baseline(a, args_ns):
     for _ in range(steps):
         tr.step(b)
     dt = (time.perf_counter() - t0) / steps
-    return {"value": round(a.cpu_batch / dt, 2), "unit": "video-seq/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(a.cpu_batch / dt, 2), "unit": "video-seq/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(),
+            "kind": "port",
             "sample": f"CPU oracle (PyTorch CPU fp32 restatement of the reference) E{E}D{D} T={a.seq_len} N~U[4,16] "
                       f"stage-{a.stage} train step on {a.cpu_batch} videos, {steps} timed steps after 1 warm-up "
                       f"({dt:.2f} s/step)"}
 
 
-def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, timer_every):
+def traffic_profile(stage, batch_size, seq_len):
+    """The committed rocprofv3 PMC passes of this configuration (profiles/README.md), newest round first: `traffic` itself cannot
+    be measured inside this process."""
+    tag = {(1, 128, 64): "", (2, 128, 64): "stage2_b128_", (1, 32, 256): "cfg4_len256_b32_"}.get((stage, batch_size, seq_len))
+    if tag is None:
+        return None
+    for rnd in ("r03", "r02", "r01"):
+        rel = f"profiles/{rnd}_{tag}pmc_traffic.json"
+        path = os.path.join(ROOT, rel)
+        if os.path.exists(path):
+            fam = json.load(open(path)).get("mfma_gemm_family")
+            if fam:
+                return {"file": rel, "hbm_bytes_per_launch": round(fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch"]),
+                        "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run"}
+    return None
+
+
+def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, timer_every, ddp_mode=None, global_negatives=None,
+               with_lm=False):
     """One configuration: W untimed + K timed steps between barriers; returns the result fields (no printing)."""
     from temporalalignnet_amd import _lib, dist, synth
     from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
     args_ns = default_args(model="init" if stage == 1 else "cotrain", num_encoder_layers=a.layers, num_decoder_layers=a.layers,
                            loss_threshold=0.0 if stage == 1 else 0.5, seq_len=seq_len)
     torch.manual_seed(888)
-    model = build_model(args_ns, compute_dtype=a.dtype).to(dev)
+    gneg = a.global_negatives if global_negatives is None else global_negatives
+    model = build_model(args_ns, compute_dtype=a.dtype, language_model="word2vec" if with_lm else None).to(dev)
     if stage == 1:
         model.random_pos_start = 1
     trainer = Trainer(model, args_ns, iter_per_epoch=2890, warmup=1000,   # 370k videos / 128
-                      global_negatives=a.global_negatives)
+                      global_negatives=gneg)
+    if ddp_mode is not None:
+        trainer.ddp_mode = ddp_mode
+    trainer.time_comm = dist.active()
     trainer.batches_seen = 1000                                          # past warm-up: non-zero learning rate
     trainer.iteration = 1000
     if stage == 2:
         model._copy_param()
-    batch = to_device_batch(synth.make_batch(888 + rank, B=batch_size, T=seq_len, n_min=4, n_max=16), device=dev)
+    np_batch = synth.make_batch(888 + rank, B=batch_size, T=seq_len, n_min=4, n_max=16)
+    batch = to_device_batch(np_batch, device=dev)
+    if with_lm:
+        # the reference's step starts from TOKENS: Word2Vec embedder forward + backward inside the step (train/main.py:55-65, row
+        # f1); [n_b, 32] ids per video, the sentence counts of the synthetic batch
+        n_per = [int(n) for n in (1 - np.asarray(np_batch["text_padding_mask"])).sum(1)]
+        ids, _ = synth.w2v_tokens(888 + rank, sum(n_per), 66250)
+        ids = torch.from_numpy(ids).to(dev)
+        batch["token"] = list(torch.split(ids, n_per))
 
     for _ in range(warmup):                                              # (the first step broadcasts rank 0's parameters)
         trainer.step(batch)
+    trainer.comm_events.clear()
     L = _lib.lib()
     use_timer = not a.no_kernel_timer
     if use_timer:
@@ -131,6 +164,20 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
     elapsed = time.perf_counter() - t0
     elapsed = dist.max_over_ranks(elapsed, dev)
     final_loss = float(loss["loss"].item())
+    comm = None
+    if dist.active():
+        import torch.distributed as tdist
+        exposed = [e0.elapsed_time(e1) for e0, e1 in trainer.comm_events]
+        alone = trainer.allreduce_alone_ms()
+        comm = {"world_size_seen_by_backend": tdist.get_world_size(), "backend": tdist.get_backend(),
+                "ddp_mode": "global-negatives (feature all-gather + text-gradient reduce-scatter) + " + trainer.ddp_mode
+                if gneg else trainer.ddp_mode,
+                "gradient_bytes_per_step": alone[2], "collectives_per_step": alone[1],
+                "allreduce_ms_per_step_alone": round(alone[0], 3),
+                "exposed_comm_ms_per_step": round(sum(exposed) / max(len(exposed), 1), 3),
+                "exposed_comm_ms_per_step_max_over_ranks": round(dist.max_over_ranks(sum(exposed) / max(len(exposed), 1), dev), 3),
+                "note": "alone = the step's gradient collectives back to back on an idle GPU; exposed = compute-stream time between the end "
+                        "of backward's enqueue and the last collective's completion (what the overlap did not hide), mean over the timed steps"}
 
     roof = None
     if use_timer:
@@ -171,13 +218,8 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
             ach = twork / (tms * 1e-3) / 1e12
             # `traffic` (HBM bytes per launch) needs rocprofv3 PMC passes, which cannot run inside this process: null here; the
             # committed passes of the same command are referenced separately (profiles/README.md), never passed off as in-run data
-            prof = None
-            pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-            if os.path.exists(pmc) and a.dtype == "bf16" and stage == 1 and batch_size == 128 and seq_len == 64:
-                fam = json.load(open(pmc))["mfma_gemm_family"]
-                prof = {"file": "profiles/r02_pmc_traffic.json", "hbm_bytes_per_launch": round(fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch"]),
-                        "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run"}
-            roof = {"bound": "mfma", "kernel": "tal::gemm_glds_kernel + tal::gemm_dw256_kernel + tal::simnce_res_kernel (direct-to-LDS MFMA pipelines, all operand layouts) + tal::mlp_panel_kernel (row-panel fused MLP, forward and backward)",
+            prof = traffic_profile(stage, batch_size, seq_len) if (a.dtype == "bf16" and not with_lm) else None
+            roof = {"bound": "mfma", "kernel": "tal::gemm_glds_kernel + tal::gemm_dw256_kernel + tal::simnce_res_kernel (direct-to-LDS MFMA pipelines, all operand layouts) + tal::mlp_panel_kernel (row-panel fused MLP, forward and backward) + tal::attnblk_fwd_kernel (attention branch per video)",
                     "achieved": round(ach, 1),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "traffic_profile": prof,
                     "avg_launch_us": round(tms * 1e3 / tcnt, 2), "launches_per_step": round(tcnt / sampled, 1),
@@ -193,9 +235,13 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
                                   f"({'init: multi-positive NCE only' if stage == 1 else 'cotrain: EMA + alignability + NCE'}) "
                                   f"train step (fwd+loss+bwd+AdamW), synthetic HTM-370K-shaped features, N~U[4,16] sentences/video",
                       "global_batch": batch_size * world, "per_gpu_batch": batch_size, "seq_len": seq_len,
-                      "parallelism": f"dp{world}" + ("+global-negatives" if a.global_negatives else ""),
+                      "parallelism": f"dp{world}" + ("+global-negatives" if gneg else ""),
                       "final_loss": round(final_loss, 4)},
            "roofline": roof}
+    if with_lm:
+        res["config"]["workload"] += "; the step starts from token ids: Word2Vec sentence embedder forward + backward + AdamW inside it (train/main.py:55-65)"
+    if comm is not None:
+        res["comm"] = comm
     del trainer, model, batch
     import gc
     gc.collect()
@@ -221,12 +267,27 @@ def main():
     head, args_ns = run_config(a, world, rank, dev, a.stage, a.batch, a.seq_len, a.steps, a.warmup, a.timer_every)
     extra = []
     headline = (a.stage, a.batch, a.seq_len) == (1, 128, 64)
-    if world == 1 and headline and not a.no_extra and a.dtype == "bf16":
+    if world == 1 and not dist.active() and headline and not a.no_extra and a.dtype == "bf16":
         # BASELINE configs[2] (stage-2 co-training, here on one GPU at the per-GPU batch) and configs[3] (len=256) are
-        # driver-timed too, each with its own roofline; shorter runs (the headline keeps the driver's K / W)
-        for st, bs, sl, tag in ((2, 128, 64, "configs[2] on 1 GPU: E6D6 len=64 stage-2 co-training, B=128"),
-                                (1, 32, 256, "configs[3]: len=256 (joint L=272), B=32")):
-            r, _ = run_config(a, world, rank, dev, st, bs, sl, a.extra_steps, 3, 5)
+        # driver-timed too, each with its own roofline; shorter runs (the headline keeps the driver's K / W).  VERDICT r2: the
+        # reference's step also runs the sentence embedder (row f1): a fourth entry starts from token ids.
+        for st, bs, sl, lm, tag in ((2, 128, 64, False, "configs[2] on 1 GPU: E6D6 len=64 stage-2 co-training, B=128"),
+                                    (1, 32, 256, False, "configs[3]: len=256 (joint L=272), B=32"),
+                                    (1, 128, 64, True, "configs[1] with the language model in the step (tokens -> Word2Vec -> aligner)")):
+            r, _ = run_config(a, world, rank, dev, st, bs, sl, a.extra_steps, 3, 5, with_lm=lm)
+            r["name"] = tag
+            extra.append(r)
+    elif dist.active() and headline and not a.no_extra and a.dtype == "bf16" and not a.global_negatives:
+        # Multi-GPU (or TAN_FORCE_DIST=1): the variants the first hardware scaling run has to decide between, in the same run --
+        # the other gradient-reduction mode, global negatives, and BASELINE configs[2] (stage-2 co-training) at B_local 128 / 16
+        # (SURVEY 8(d) config 3).  The headline line keeps the default mode; n_gpus == 1 without TAN_FORCE_DIST prints none of this.
+        other = "flat" if os.environ.get("TAN_DDP_MODE", "buckets") == "buckets" else "buckets"
+        for kw, tag in ((dict(stage=1, bs=128, ddp_mode=other), f"configs[1], gradient reduction mode '{other}' (TAN_DDP_MODE)"),
+                        (dict(stage=1, bs=128, gneg=True), "configs[1] with global negatives (row f3)"),
+                        (dict(stage=2, bs=128), "configs[2]: stage-2 co-training, B_local=128"),
+                        (dict(stage=2, bs=16), "configs[2]: stage-2 co-training, B_local=16 (global 128 at 8 GPUs)")):
+            r, _ = run_config(a, world, rank, dev, kw["stage"], kw["bs"], 64, a.extra_steps, 3, 5, ddp_mode=kw.get("ddp_mode"),
+                              global_negatives=kw.get("gneg", False))
             r["name"] = tag
             extra.append(r)
     if rank == 0:
@@ -234,6 +295,8 @@ def main():
                "unit": head["unit"], "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"], "ms_per_step": head["ms_per_step"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": head["config"], "roofline": head["roofline"]}
+        if "comm" in head:
+            out["comm"] = head["comm"]
         if extra:
             out["extra"] = extra
         if not a.no_cpu_baseline and world == 1:

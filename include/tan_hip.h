@@ -45,8 +45,9 @@ int tan_abi_sizeof(int which);
 #define TAN_PROF_ATTN_FWD 8
 #define TAN_PROF_ATTN_BWD 9
 #define TAN_PROF_SIMNCE 10
-#define TAN_PROF_PANEL 11 /* row-panel fused kernels (tan_mlp_*, tan_attnblock_*) */
-#define TAN_PROF_NKINDS 12
+#define TAN_PROF_PANEL 11   /* row-panel fused MLP kernels (tan_mlp_fwd / tan_mlp_bwd) */
+#define TAN_PROF_ATTNBLK 12 /* the attention branch of a block in one launch (tan_attnblk_*) */
+#define TAN_PROF_NKINDS 13
 int tan_prof_enable(int on, int max_records);
 int tan_prof_collect(double* ms_by_kind, double* work_by_kind, long* count_by_kind, int nkinds);
 

@@ -362,7 +362,7 @@ extern "C" int tan_attnblk_fwd(const tan_attnblk_desc* d, void* stream) {
     a.L = d->L; a.H = d->H;
     const dim3 grid((unsigned)d->B);
     const double rows = (double)d->B * d->L;
-    const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * rows * 512.0 * 2048.0 + 4.0 * rows * d->L * 512.0);
+    const int rec = prof_begin((hipStream_t)stream, TAN_PROF_ATTNBLK, 2.0 * rows * 512.0 * 2048.0 + 4.0 * rows * d->L * 512.0);
     if (d->L <= 64) hipLaunchKernelGGL((attnblk_fwd_kernel<4>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((attnblk_fwd_kernel<5>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
     prof_end((hipStream_t)stream, rec);

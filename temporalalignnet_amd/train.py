@@ -129,6 +129,11 @@ class Trainer:
         # multi-GPU run (no >1-GPU node was available to pick by measurement)
         self.ddp_mode = os.environ.get("TAN_DDP_MODE", "buckets")
         self._params_synced = False
+        # bench.py: with `time_comm` set, every step records two events on the compute stream around the part of the step that
+        # WAITS for gradient collectives (the remainder all-reduce and the joins of the asynchronous buckets): their distance is
+        # the communication time the step could not hide behind backward ("exposed"); comm_events collects the pairs
+        self.time_comm = False
+        self.comm_events = []
 
     # -------------------------------------------------------------- optimizer state
     def _ensure_state(self):
@@ -395,11 +400,45 @@ class Trainer:
         finally:
             self.online._grad_ready_hook = None
         if dist.active():
+            ev = None
+            if self.time_comm:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             for lo, hi in uncovered_ranges(done, flat.numel()):              # whatever the hooks did not cover
                 dist.allreduce_sum_(flat[lo:hi])
             for w in pending:
                 w.wait()
+            if ev is not None:
+                ev[1].record()
+                self.comm_events.append(ev)
         self.optimizer_step(grad_scale=1.0 if self.global_negatives else 1.0 / world)
         self.batches_seen += 1
         self._resume_bump = 0
         return loss_dict
+
+    def allreduce_alone_ms(self, reps=5):
+        """bench.py: the gradient collectives of one step issued back to back on an otherwise idle GPU (the same ranges as `step`
+        reduces: the buckets of both stacks + the remainder, or the whole flat gradient in 'flat' mode) -- the communication time a
+        step has to hide, measured without anything to hide it behind.  The gradient buffer is scaled back afterwards."""
+        if not dist.active():
+            return None
+        flat = self.online.flat_grad()
+        if self.ddp_mode == "flat":
+            ranges = [(0, flat.numel())]
+        else:
+            ranges = []
+            for tag, layers in (("video", self.online.num_encoder_layers), ("joint", self.online.num_decoder_layers)):
+                ranges += [(lo, hi) for lo, hi, _ in self._ddp_buckets(tag, layers)]
+            ranges += uncovered_ranges(sorted(ranges), flat.numel())
+        keep = flat.clone()
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            for lo, hi in ranges:
+                dist.allreduce_sum_(flat[lo:hi])
+        e1.record()
+        torch.cuda.synchronize()
+        flat.copy_(keep)
+        return e0.elapsed_time(e1) / reps, len(ranges), sum(hi - lo for lo, hi in ranges) * 4

@@ -121,6 +121,38 @@ def test_attnblk_fwd_matches_reference_and_unfused_path(B, L, pad, save):
         assert (u_lse - out["lse"]).abs().max().item() < 2e-2
 
 
+def test_attnblk_with_every_key_of_a_video_padded_gives_the_residual_plus_bias():
+    """all keys padded -> attention output 0 (not the reference's NaN; tests/test_kernels_gpu.py pins the stand-alone kernels the
+    same way): x_mid = x_in + b_out for that video, lse = -inf, the other videos unaffected."""
+    _lib, ops = _lib_ops()
+    torch.manual_seed(5)
+    B, L = 3, 64
+    R = B * L
+    xn1 = torch.randn(R, 512, device="cuda").to(bf)
+    x_in = torch.randn(R, 512, device="cuda").to(bf)
+    w_in = (torch.randn(1536, 512, device="cuda") * 512 ** -0.5).to(bf)
+    w_out = (torch.randn(512, 512, device="cuda") * 512 ** -0.5).to(bf)
+    b_in, b_out = torch.randn(1536, device="cuda") * 0.1, torch.randn(512, device="cuda") * 0.1
+    keypad = torch.zeros(B, L, dtype=torch.uint8, device="cuda")
+    keypad[1] = 1
+    pw_qkv, pw_out = pack([(w_in, 384, 32), (w_out, 512, 16)])
+    qkv, o = torch.zeros(R, 1536, device="cuda", dtype=bf), torch.full((R, 512), float("nan"), device="cuda", dtype=bf)
+    lse, x_mid = torch.zeros(B, 8, L, device="cuda"), torch.zeros(R, 512, device="cuda", dtype=bf)
+    d = _lib.AttnBlkDesc()
+    d.B, d.L, d.C, d.H = B, L, 512, 8
+    d.xn1, d.x_in, d.key_padding_mask = xn1.data_ptr(), x_in.data_ptr(), keypad.data_ptr()
+    d.pw_qkv, d.pw_out, d.b_qkv, d.b_out = pw_qkv.data_ptr(), pw_out.data_ptr(), b_in.data_ptr(), b_out.data_ptr()
+    d.qkv, d.attn_o, d.lse, d.x_mid = qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), x_mid.data_ptr()
+    _lib.check(_lib.lib().tan_attnblk_fwd(C.byref(d), ops._stream()), "tan_attnblk_fwd")
+    torch.cuda.synchronize()
+    assert (o.view(B, L, 512)[1] == 0).all() and (lse[1] == float("-inf")).all()
+    want = (x_in.float() + b_out).to(bf).view(B, L, 512)[1]
+    assert torch.equal(x_mid.view(B, L, 512)[1], want)
+    _, _, _, r_xmid = reference(xn1, x_in, w_in, b_in, w_out, b_out, keypad, B, L)
+    keep = torch.tensor([0, 2], device="cuda")
+    assert (x_mid.float().view(B, L, 512)[keep] - r_xmid.view(B, L, 512)[keep]).abs().max().item() <= 2.0 ** -7 * r_xmid.abs().max().item()
+
+
 def test_attnblk_rejects_what_it_cannot_do():
     _lib, ops = _lib_ops()
     d = _lib.AttnBlkDesc()

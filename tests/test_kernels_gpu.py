@@ -230,6 +230,34 @@ def test_attention_fwd_bwd(dtype, B, L, pad):
     close(g - g0, want, 1e-4 * (1.0 + want.abs().max().item()))
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("L", [64, 80, 272])
+def test_attention_with_every_key_padded_gives_zeros_not_nan(dtype, L):
+    """Documented difference: a video whose keys are ALL padded makes nn.MultiheadAttention (tfm_model.py:32)
+    return NaN for every query of that video -- softmax over an all -inf row.  The HIP kernels define that case as zeros:
+    o = 0, lse = -inf, dqkv = 0, and the other videos of the batch are untouched.  (The reference's loaders never produce such a
+    window -- data/loader_htm.py:151 -- so nothing downstream depends on the NaN.)"""
+    from temporalalignnet_amd import ops
+    B, H, C = 3, 8, 512
+    qkv = rnd((B * L, 3 * C), dtype, 40, 1.5)
+    keypad = torch.zeros(B, L, dtype=torch.uint8, device="cuda")
+    keypad[1] = 1                                      # video 1: nothing to attend to
+    o = torch.full((B * L, C), float("nan"), device="cuda", dtype=dtype)
+    lse = torch.full((B, H, L), float("nan"), device="cuda")
+    ops.attn_fwd(qkv, keypad, o, lse, B, L, H)
+    assert torch.isnan(_attn_ref(qkv.double(), keypad, B, L, H).view(B, L, C)[1]).all()          # what torch does
+    ov = o.view(B, L, C)
+    assert (ov[1] == 0).all() and torch.isinf(lse[1]).all() and (lse[1] < 0).all()
+    keep = torch.tensor([0, 2], device="cuda")
+    ref = _attn_ref(qkv.double(), keypad, B, L, H).view(B, L, C)
+    close(ov[keep], ref[keep], 2e-5 if dtype == torch.float32 else 4e-2)
+    d_o = rnd((B * L, C), dtype, 41)
+    dqkv = torch.full_like(qkv, float("nan"))
+    ops.attn_bwd(qkv, keypad, o, lse, d_o, dqkv, B, L, H)
+    dv = dqkv.view(B, L, 3 * C)
+    assert (dv[1] == 0).all() and torch.isfinite(dv).all()
+
+
 def test_transpose_batch():
     """tan_transpose_batch: several bf16 matrices inside one flat buffer -> their transposes at the same offsets."""
     import ctypes as C
