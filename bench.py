@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--timer-every", type=int, default=20, help="HIP-event kernel timer samples one timed step in n (the middle one)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra driver-timed configurations (stage 2, len=256) of the N=1 run")
     ap.add_argument("--extra-steps", type=int, default=10)
+    ap.add_argument("--with-lm", action="store_true", help="the step starts from token ids (Word2Vec embedder inside it, train/main.py:55-65)")
     return ap.parse_args()
 
 
@@ -264,9 +265,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    head, args_ns = run_config(a, world, rank, dev, a.stage, a.batch, a.seq_len, a.steps, a.warmup, a.timer_every)
+    head, args_ns = run_config(a, world, rank, dev, a.stage, a.batch, a.seq_len, a.steps, a.warmup, a.timer_every, with_lm=a.with_lm)
     extra = []
-    headline = (a.stage, a.batch, a.seq_len) == (1, 128, 64)
+    headline = (a.stage, a.batch, a.seq_len) == (1, 128, 64) and not a.with_lm
     if world == 1 and not dist.active() and headline and not a.no_extra and a.dtype == "bf16":
         # BASELINE configs[2] (stage-2 co-training, here on one GPU at the per-GPU batch) and configs[3] (len=256) are
         # driver-timed too, each with its own roofline; shorter runs (the headline keeps the driver's K / W).  VERDICT r2: the

@@ -1,0 +1,107 @@
+"""Activation workspaces of the encoder stacks: the saved tensors of one stack (`_EncRun`, ~1 GB at B=128) and the backward scratch
+come from a per-shape pool -- allocating them afresh every step costs 13 ms of hipMalloc per GB on the host and made the step
+host-bound.  `_WorkspaceMixin` is the pool (an LRU over shapes: real batches vary in N, hence in the joint length T + N)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+WIDTH, HEADS = 512, 8
+
+
+class _Blocks:
+    """Contiguous activation blocks carved out of one allocation."""
+
+    def __init__(self, dtype, device, sizes: dict):
+        self.off, total = {}, 0
+        for k, n in sizes.items():
+            self.off[k] = (total, n)
+            total += (n + 63) // 64 * 64
+        self.buf = torch.empty(total, dtype=dtype, device=device)
+
+    def __getitem__(self, k):
+        o, n = self.off[k]
+        return self.buf[o:o + n]
+
+
+class _EncRun:
+    """Saved activations of one encoder stack + its ctypes descriptor."""
+
+    def __init__(self, model, prefix, layers, B, L, cd, dev):
+        R, Cw = B * L, WIDTH
+        self.prefix, self.layers, self.B, self.L, self.R = prefix, layers, B, L, R
+        per = {"xn1": R * Cw, "qkv": R * 3 * Cw, "attn_o": R * Cw, "x_mid": R * Cw, "xn2": R * Cw, "h_pre": R * 4 * Cw,
+               "h_act": R * 4 * Cw, "x_out": R * Cw}
+        self.act = _Blocks(cd, dev, {f"{i}.{k}": n for i in range(layers) for k, n in per.items()} | {"post": R * Cw})
+        st = {"mean1": R, "rstd1": R, "mean2": R, "rstd2": R, "lse": B * HEADS * L}
+        self.stat = _Blocks(torch.float32, dev, {f"{i}.{k}": n for i in range(layers) for k, n in st.items()}
+                            | {"post_mean": R, "post_rstd": R})
+        self.bufs = (_lib.LayerBufs * layers)()
+        for i in range(layers):
+            for k in per:
+                setattr(self.bufs[i], k, self.act[f"{i}.{k}"].data_ptr())
+            for k in st:
+                setattr(self.bufs[i], k, self.stat[f"{i}.{k}"].data_ptr())
+
+    def stage(self, s):
+        """[R, C] deep-supervision output s (tfm_model.py:48-55)."""
+        if s < self.layers - 1:
+            return self.act[f"{s + 1}.xn1"].view(self.R, WIDTH)
+        return self.act["post"].view(self.R, WIDTH)
+
+
+class _WorkspaceMixin:
+    """Pool state lives on the model: _ws_pool / _ws_lru / _ws_tick / _ws_lock (created in TemporalAligner.__init__)."""
+
+    # Activation workspaces (~1 GB per stack at B=128) are pooled per shape: allocating them afresh every step costs
+    # tens of ms of hipMalloc/hipFree on the host.  A workspace is taken at forward and handed back after backward
+    # (or right after a no-grad forward, whose outputs never alias it).
+    # Workspaces (saved activations of a stack, backward scratch) are pooled per shape: allocating ~1 GB afresh each step costs
+    # 13 ms/GB of host time.  Real batches vary in N (hence in the joint length L = T + N), so the pool is an LRU over shapes
+    # bounded to _WS_POOL_KEYS entries -- at most ~1.3 GB each at B=128.
+    _WS_POOL_KEYS = 10
+
+    def _pool_touch(self, key):
+        with self._ws_lock:
+            self._ws_tick += 1
+            self._ws_lru[key] = self._ws_tick
+            if len(self._ws_lru) > self._WS_POOL_KEYS:
+                for old in sorted(self._ws_lru, key=self._ws_lru.get)[:len(self._ws_lru) - self._WS_POOL_KEYS]:
+                    self._ws_lru.pop(old)
+                    self._ws_pool.pop(old, None)          # tensors return to the caching allocator (stream-ordered reuse)
+
+    def _take_ws(self, prefix, layers, B, L, cd, dev):
+        key = (prefix, layers, B, L, cd, dev)
+        self._pool_touch(key)
+        with self._ws_lock:
+            pool = self._ws_pool.setdefault(key, [])
+            er = pool.pop() if pool else None
+        if er is None:
+            er = _EncRun(self, prefix, layers, B, L, cd, dev)
+        er.pool_key = key
+        return er
+
+    def _release_ws(self, er):
+        if er is not None and getattr(er, "pool_key", None) is not None:
+            with self._ws_lock:
+                if er.pool_key in self._ws_lru:           # its shape may have been evicted meanwhile: then just drop it
+                    pool = self._ws_pool.setdefault(er.pool_key, [])
+                    if len(pool) < 2:
+                        pool.append(er)
+            er.pool_key = None
+
+    def _take_scratch(self, R, cd, dev):
+        key = ("scr", R, cd, dev)
+        self._pool_touch(key)
+        scr = self._ws_pool.get(key)
+        if scr is None:
+            scr = _Blocks(cd, dev, {"dx": R * WIDTH, "dx2": R * WIDTH, "do": R * WIDTH, "dxn": R * WIDTH,
+                                    "dh": R * 4 * WIDTH, "dqkv": R * 3 * WIDTH})
+            n_ws = _lib.lib().tan_layernorm_bwd_ws_floats(C.c_int(WIDTH))
+            scr.ln_ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+            scr.dw_ws = torch.empty(32 * 4 * WIDTH * WIDTH, dtype=torch.float32, device=dev)     # split-K partial tiles
+            self._ws_pool[key] = scr
+        return scr

@@ -150,7 +150,8 @@ def test_attnblk_with_every_key_of_a_video_padded_gives_the_residual_plus_bias()
     assert torch.equal(x_mid.view(B, L, 512)[1], want)
     _, _, _, r_xmid = reference(xn1, x_in, w_in, b_in, w_out, b_out, keypad, B, L)
     keep = torch.tensor([0, 2], device="cuda")
-    assert (x_mid.float().view(B, L, 512)[keep] - r_xmid.view(B, L, 512)[keep]).abs().max().item() <= 2.0 ** -7 * r_xmid.abs().max().item()
+    rk = r_xmid.view(B, L, 512)[keep]                                    # (the torch reference is NaN for video 1)
+    assert (x_mid.float().view(B, L, 512)[keep] - rk).abs().max().item() <= 2.0 ** -7 * rk.abs().max().item()
 
 
 def test_attnblk_rejects_what_it_cannot_do():
