@@ -434,6 +434,27 @@ typedef struct tan_attnblk_desc {
 int tan_attnblk_supported(int L, int C, int H, int dtype);
 int tan_attnblk_fwd(const tan_attnblk_desc* d, void* stream);
 
+/* tan_attnblk_bwd: the first half of the branch's backward in one launch per video -- d_o = dx2 W_out (the out_proj dX GEMM) and
+ * the attention backward of all 8 heads (autograd of nn.MultiheadAttention, model/tfm_model.py:30-32):
+ *   dqkv [B*L, 3C] = d(q | k | v)   (operand of the in_proj dX and dW GEMMs),   g_b_qkv [3C] += column sums of dqkv (optional)
+ * from dx2 (gradient w.r.t. x_mid = the out_proj output), the saved qkv rows and lse of tan_attnblk_fwd / tan_attn_fwd.  d_o never
+ * exists in HBM.  pwt_out = tan_pack_weights image of out_proj.weight^T ([in][out] = the W^T copy) with TN = 512, TK = 16.
+ * Replaces the out_proj dX GEMM and tan_attn_bwd_bias of tan_encoder_bwd; same shapes as tan_attnblk_fwd (bf16, 48 < L <= 80). */
+typedef struct tan_attnblk_bwd_desc {
+    int B, L, C, H;
+    const void* dx2;                         /* [B*L, C] bf16 */
+    const void* qkv;                         /* [B*L, 3C] bf16, saved by the forward */
+    const float* lse;                        /* [B, H, L] */
+    const unsigned char* key_padding_mask;   /* [B, L] or NULL */
+    const void* pwt_out;
+    void* dqkv;                              /* out [B*L, 3C] bf16 */
+    float* g_b_qkv;                          /* [3C] f32, accumulated, or NULL */
+} tan_attnblk_bwd_desc;
+int tan_attnblk_bwd(const tan_attnblk_bwd_desc* d, void* stream);
+/* tools/lab only: device buffer ([8 waves][64] long) that receives workgroup 0's shader clock at the phase boundaries of
+ * tan_attnblk_bwd, or NULL (default): no instrumentation */
+int tan_attnblk_lab_set_dbg(void* device_buffer);
+
 #ifdef __cplusplus
 }
 #endif

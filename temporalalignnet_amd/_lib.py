@@ -153,6 +153,14 @@ class AttnBlkDesc(C.Structure):
     ]
 
 
+class AttnBlkBwdDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("L", C.c_int), ("C", C.c_int), ("H", C.c_int),
+        ("dx2", C.c_void_p), ("qkv", C.c_void_p), ("lse", C.c_void_p), ("key_padding_mask", C.c_void_p),
+        ("pwt_out", C.c_void_p), ("dqkv", C.c_void_p), ("g_b_qkv", C.c_void_p),
+    ]
+
+
 class EncoderDesc(C.Structure):
     _fields_ = [
         ("dtype", C.c_int), ("B", C.c_int), ("L", C.c_int), ("C", C.c_int), ("H", C.c_int), ("layers", C.c_int),

@@ -177,7 +177,10 @@ static int panel_bwd_enabled() {
     static const int v = [] { const char* e = getenv("TAN_PANEL_BWD"); return e ? atoi(e) : 1; }();
     return v;
 }
-// TAN_ATTN_PANEL=0: the attention branch as in_proj GEMM + attention + out_proj GEMM (what also runs for f32, L <= 48 or L > 80)
+// TAN_ATTN_PANEL (bit mask, default 1): 1 = the attention branch's forward as one launch per video (tan_attnblk_fwd), 2 = out_proj dX +
+// attention backward as one launch (tan_attnblk_bwd: correct and tested, but 52 / 82 us per launch at L = 64 / 80 against 36 / 46 us for
+// the two launches it replaces, 5.14 vs 4.96 ms in the step (ABBA x2): off); 0 = in_proj GEMM + attention + out_proj GEMM (what also
+// runs for f32, L <= 48, L > 80)
 static int attn_panel_enabled() {
     static const int on = [] { const char* e = getenv("TAN_ATTN_PANEL"); return e ? atoi(e) : 1; }();
     return on;
@@ -193,7 +196,7 @@ extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
     const long R = (long)e->B * e->L;
     const void* x_in = e->x0;
     const bool panel_ok = panel_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0;
-    const bool attn_panel_ok = attn_panel_enabled() && panel_enabled() && tan_attnblk_supported(e->L, C, H, dt);
+    const bool attn_panel_ok = (attn_panel_enabled() & 1) && panel_enabled() && tan_attnblk_supported(e->L, C, H, dt);
     bool ln1_done = false;        // the previous block's panel kernel already produced this block's xn1 / mean1 / rstd1
     for (int i = 0; i < e->layers; ++i) {
         const tan_layer_params& p = e->params[i];
@@ -315,8 +318,17 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         }
         // ---- attention branch: x_mid = x_in + out_proj(attn(LN1(x_in)))
         if (!grouped) CK(linear_bwd_w(dt, dx2, b.attn_o, p.g_w_out, R, C, C, e->dw_ws, e->dw_ws_floats, st));
-        CK(linear_bwd_x(dt, dx2, p.w_out, p.wt_out, e->scr_do, R, C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
-        CK(tan_attn_bwd_bias(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->scr_do, e->scr_dqkv, p.g_b_qkv, e->B, e->L, H, dt, st));
+        if ((attn_panel_enabled() & 2) && panel_enabled() && tan_attnblk_supported(e->L, C, H, dt) && p.wtp_out) {
+            // one launch: d_o = dx2 W_out and the 8 heads' attention backward incl. the in_proj bias column sums (tan_attnblk.hip)
+            tan_attnblk_bwd_desc ab{};
+            ab.B = e->B; ab.L = e->L; ab.C = C; ab.H = H;
+            ab.dx2 = dx2; ab.qkv = b.qkv; ab.lse = b.lse; ab.key_padding_mask = e->key_padding_mask;
+            ab.pwt_out = p.wtp_out; ab.dqkv = e->scr_dqkv; ab.g_b_qkv = p.g_b_qkv;
+            CK(tan_attnblk_bwd(&ab, st));
+        } else {
+            CK(linear_bwd_x(dt, dx2, p.w_out, p.wt_out, e->scr_do, R, C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
+            CK(tan_attn_bwd_bias(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->scr_do, e->scr_dqkv, p.g_b_qkv, e->B, e->L, H, dt, st));
+        }
         if (!grouped) CK(linear_bwd_w(dt, e->scr_dqkv, b.xn1, p.g_w_qkv, R, 3 * C, C, e->dw_ws, e->dw_ws_floats, st));
         // stage i-1 IS this layer's xn1: its gradient joins here
         const void* dstage = i >= 1 ? e->d_stage[i - 1] : nullptr;

@@ -76,7 +76,7 @@ class _Flat:
                 for n in names:
                     o, _, (N, K) = self.off[n]
                     if transposed:
-                        if ".mlp.c_" not in n:                          # (no row-panel consumer of the attention weights' transposes yet)
+                        if ".mlp.c_" not in n and not n.endswith("attn.out_proj.weight"):     # (in_proj^T has no row-panel consumer)
                             continue
                         N, K = K, N
                     TN, TK = (512, 16) if N == 512 else (256, 32)
