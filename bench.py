@@ -287,7 +287,7 @@ def main():
                         (dict(stage=1, bs=128, gneg=True), "configs[1] with global negatives (row f3)"),
                         (dict(stage=2, bs=128), "configs[2]: stage-2 co-training, B_local=128"),
                         (dict(stage=2, bs=16), "configs[2]: stage-2 co-training, B_local=16 (global 128 at 8 GPUs)")):
-            r, _ = run_config(a, world, rank, dev, kw["stage"], kw["bs"], 64, a.extra_steps, 3, 5, ddp_mode=kw.get("ddp_mode"),
+            r, _ = run_config(a, world, rank, dev, kw["stage"], kw["bs"], 64, a.extra_steps, 5, 5, ddp_mode=kw.get("ddp_mode"),
                               global_negatives=kw.get("gneg", False))
             r["name"] = tag
             extra.append(r)

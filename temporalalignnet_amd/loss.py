@@ -236,7 +236,7 @@ class _FusedNCEFn(torch.autograd.Function):
     `n_valid` (host int, optional) = number of real sentences in the batch.  Padded text columns take part in nothing
     (loss.py:64-70 drops them before the log-sum-exps), so when it is known the sweep runs on the COMPACTED text matrix
     (Mc = n_valid rounded up to 64 columns instead of B*N; ~37 % fewer similarity FLOPs at N ~ U[4,16]); the returned text terms
-    are scattered back to the padded [S, B*N] layout (zeros at pad columns, which every consumer masks)."""
+    stay in the compacted column order [S, Mc] (the callers compact their column masks with the same `prep` index)."""
 
     @staticmethod
     def forward(ctx, vn, tn, tgt, col_invalid, row_leak, B, T, N, prep=None):
@@ -270,10 +270,10 @@ class _FusedNCEFn(torch.autograd.Function):
             _lib.check(L.tan_simnce_fwd_keep(*fwd_args, _p(ekeep), ops._stream()), "tan_simnce_fwd_keep")
         else:
             _lib.check(L.tan_simnce_fwd(*fwd_args, ops._stream()), "tan_simnce_fwd")
-        if compact:
-            t_terms = torch.zeros(S, Mp, device=dev).index_copy_(1, idx, t_run)
-        else:
-            t_terms = t_run
+        # compacted sweeps return the text terms in COMPACTED column order ([S, Mc]; get_loss compacts the column masks of the tail
+        # instead, once and off the critical path): scattering them back to [S, B*N] was a fill + an index_copy per sweep here and
+        # a gather per sweep in the backward, all on the serial chain between the stacks and the backward
+        t_terms = t_run
         ctx.saved = (vn, tn, tn_run, tgt, ci_run, row_leak, rowsum, colsum, possum_v, possum_t, ws, idx, colmap, ekeep)
         ctx.dims = (S, B, T, N, Cw, shared, Mc)
         return v_terms, t_terms
@@ -285,9 +285,7 @@ class _FusedNCEFn(torch.autograd.Function):
         R, Mp, dev = B * T, B * N, vn.device
         compact = idx is not None
         g_v = torch.zeros(S, R, device=dev) if g_v is None else g_v.contiguous()
-        g_t = torch.zeros(S, Mp, device=dev) if g_t is None else g_t.contiguous()
-        if compact:
-            g_t = g_t.index_select(1, idx).contiguous()
+        g_t = torch.zeros(S, Mc, device=dev) if g_t is None else g_t.contiguous()           # [S, Mc]: compacted order, like t_terms
         dl = torch.empty(S, R, Mc, dtype=torch.bfloat16, device=dev)
         bwd_args = (_p(vn), _p(tn_run), C.c_long(0 if shared else Mc * Cw), _p(tgt), _p(ci_run),
                     _p(row_leak), _p(rowsum), _p(colsum), _p(possum_v), _p(possum_t), _p(g_v),
@@ -344,6 +342,8 @@ def prepare_inputs(input_data, video_padding_mask, text_padding_mask, T, N, dev,
         prep["rows_pos"], prep["cols_pos"] = _pos_masks(prep["tgt"], tpad_u8, B, T, N)
     if want_compaction:
         prep["nv"], prep["nv_for"] = compaction_prep(tpad_u8.view(B * N), n_text_valid), n_text_valid
+        if prep["nv"] is not None and "cols_pos" in prep:
+            prep["cols_pos_c"] = prep["cols_pos"].index_select(0, prep["nv"][0])       # the tail's column mask, compacted order
     return prep
 
 
@@ -469,7 +469,13 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
         else:
             v_d, t_d = _FusedNCEFn.apply(fused.vn_d, fused.tn_d, tgt, ci, row_leak, B, T, N, nv)
             v_j, t_j = _FusedNCEFn.apply(fused.vn_j, fused.tn_j, tgt, ci, row_leak, B, T, N, nv)
-    pair = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos, cols_pos, nce_counts)
+    cols_idx = None                 # the sweeps ran on compacted text columns: their text terms are [S, Mc] in that order
+    if fused is not None and not getattr(fused, "global_negatives", False) and nv is not None:
+        cols_idx = nv[0]
+        cols_tail = prep["cols_pos_c"] if (not args.learn_agreement and "cols_pos_c" in prep) else cols_pos.index_select(0, cols_idx)
+    else:
+        cols_tail = cols_pos
+    pair = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos, cols_tail, nce_counts)
     loss_dual, loss_joint = pair[0], pair[1]
     out["loss-dual"], out["loss-joint"] = loss_dual.detach(), loss_joint.detach()
 
@@ -510,7 +516,8 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
             if glob:
                 from .dist_nce import global_counts
                 th_counts = global_counts(rows_pos_th, th_f)
-            pair_th = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos_th, th_f, th_counts)
+            pair_th = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos_th, th_f if cols_idx is None else th_f.index_select(0, cols_idx),
+                                     th_counts)
             loss_dual_th, loss_joint_th = pair_th[0], pair_th[1]
             out["loss-dual"], out["loss-joint"] = loss_dual_th.detach(), loss_joint_th.detach()
         if args.use_alignability_head:
