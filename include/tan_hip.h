@@ -407,6 +407,11 @@ typedef struct tan_mlp_bwd_desc {
     const float *ln1_mean, *ln1_rstd, *ln1_g;
     float *g_ln1_g, *g_ln1_b, *g_dx_colsum;
     void* dx_out;
+    /* Optional tail (pwt_out != NULL): d_o [rows, C] bf16 = dx2 W_out -- the dX GEMM of the block's attention out-projection
+     * (tfm_model.py:21: attn.out_proj), whose input gradient dx2 is sitting in this kernel's LDS panel; pwt_out = tan_pack_weights
+     * image of out_proj.weight^T with TN = 512, TK = 16.  Saves the 8192 x 512 x 512 launch of tan_encoder_bwd. */
+    const void* pwt_out;
+    void* d_o;
 } tan_mlp_bwd_desc;
 int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream);
 

@@ -185,6 +185,10 @@ static int attn_panel_enabled() {
     static const int on = [] { const char* e = getenv("TAN_ATTN_PANEL"); return e ? atoi(e) : 1; }();
     return on;
 }
+static int panel_do_enabled() {
+    static const int on = [] { const char* e = getenv("TAN_PANEL_DO"); return e ? atoi(e) : 1; }();
+    return on;
+}
 static int panel_enabled() {
     static const int on = [] { const char* e = getenv("TAN_PANEL"); return e ? atoi(e) : 1; }();
     return on;
@@ -286,6 +290,7 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         const void* x_in = i == 0 ? e->x0 : e->bufs[i - 1].x_out;
         // ---- MLP branch: x_out = x_mid + c_proj(quickgelu(c_fc(LN2(x_mid))))
         const bool grouped = grouped_enabled() != 0;       // the four dW GEMMs after the dX chain, in one launch
+        bool do_fused = false;                             // d_o = dx2 W_out already produced by the row-panel MLP backward
         if (!grouped) CK(linear_bwd_w(dt, dx, b.h_act, p.g_w_proj, R, C, 4 * C, e->dw_ws, e->dw_ws_floats, st));
         if (panel_bwd_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0 && p.wtp_fc && p.wtp_proj) {
             // one launch: dh = (dx W_proj) o quickgelu'(h_pre), dxn = dh W_fc, LN2 backward + residual -> dx2, four parameter
@@ -300,6 +305,10 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
                 m.ln1_dxn = pend.dxn; m.ln1_x = pend.x; m.ln1_res = pend.res; m.ln1_mean = pend.mean; m.ln1_rstd = pend.rstd;
                 m.ln1_g = pend.g; m.g_ln1_g = pend.gg; m.g_ln1_b = pend.gb; m.g_dx_colsum = pend.gcol; m.dx_out = dx;
             }
+            // the out-projection's dX GEMM as the tail of the same launch (TAN_PANEL_DO=0: its own launch below)
+            do_fused = panel_do_enabled() && p.wtp_out != nullptr &&
+                       !((attn_panel_enabled() & 2) && tan_attnblk_supported(e->L, C, H, dt));      // (tan_attnblk_bwd computes d_o itself)
+            if (do_fused) { m.pwt_out = p.wtp_out; m.d_o = e->scr_do; }
             CK(tan_mlp_bwd(&m, st));
             if (pend.on) {          // every gradient of block pend.layer is final now
                 pend.on = false;
@@ -326,7 +335,7 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
             ab.pwt_out = p.wtp_out; ab.dqkv = e->scr_dqkv; ab.g_b_qkv = p.g_b_qkv;
             CK(tan_attnblk_bwd(&ab, st));
         } else {
-            CK(linear_bwd_x(dt, dx2, p.w_out, p.wt_out, e->scr_do, R, C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
+            if (!do_fused) CK(linear_bwd_x(dt, dx2, p.w_out, p.wt_out, e->scr_do, R, C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
             CK(tan_attn_bwd_bias(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->scr_do, e->scr_dqkv, p.g_b_qkv, e->B, e->L, H, dt, st));
         }
         if (!grouped) CK(linear_bwd_w(dt, e->scr_dqkv, b.xn1, p.g_w_qkv, R, 3 * C, C, e->dw_ws, e->dw_ws_floats, st));

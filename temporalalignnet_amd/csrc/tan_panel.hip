@@ -83,6 +83,9 @@ struct MlpBwdArgs {
     const bf16_t* ln1_dxn; const bf16_t* ln1_x; const bf16_t* ln1_res;
     const float* ln1_mean; const float* ln1_rstd; const float* ln1_g;
     float* g_ln1_g; float* g_ln1_b; float* g_dx_colsum; bf16_t* dx_out;
+    // optional tail: d_o = dx2 W_out (the attention out-projection's dX GEMM) on the resident dx2 panel
+    const char* pwt_out;        // packed W_out^T [512][512]  (tiles [512][16])
+    bf16_t* d_o;
 };
 
 // Tiles are 16 KiB: c_fc [256 features][32 k], c_proj [512 features][16 k].  A weight fragment is consumed by exactly ONE wave
@@ -910,7 +913,51 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
         P.x = a.x_mid; P.mean = a.mean2; P.rstd = a.rstd2; P.gamma = a.ln_g; P.dadd = nullptr;
         P.g_gamma = a.g_ln_g; P.g_beta = a.g_ln_b; P.g_colsum = a.g_b_out;
         pn_ln_bwd_epilogue(acc_o, lds, P, row0, wave, lane);
-        pn_panel_copy_out<1024>(lds + MLP_XN_OFF, a.dx2 + row0 * 512, 512, wave, lane);
+        if (a.pwt_out) {
+            // ---- tail: d_o = dx2 W_out, the out-projection's dX GEMM (a [64 x 512] x [512 x 512] row-local product on the panel that
+            // is sitting in LDS: it was a launch of its own, 8192 x 512 x 512 in 128 x 128 tiles of 8 K-steps -- 17 us of which 9 are
+            // launch, first-tile latency and drain).  "c_proj-like": the wave owns 64 output features, 32 K-steps of 16; W_out^T
+            // streams through the (idle) weight ring, the dx2 rows leave for HBM under it.
+            pn_static_for<0, D>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                mlp_load_w(WQ[J], a.pwt_out + (long)J * TILE, wave, lane);
+            });
+            pn_panel_copy_out<1024>(lds + MLP_XN_OFF, a.dx2 + row0 * 512, 512, wave, lane);
+            f32x16 acc_d[MLP_NBO][2];
+#pragma unroll
+            for (int i = 0; i < MLP_NBO; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc_zero(acc_d[i][j]);
+            pn_static_for<0, 32>([&](auto jc) {
+                constexpr int KT = decltype(jc)::value;
+                MlpWFrags& W = WQ[KT % D];
+                const bf16x8 x0 = pn_pfrag<1024>(lds + MLP_XN_OFF, 0, KT * 16, lane), x1 = pn_pfrag<1024>(lds + MLP_XN_OFF, 1, KT * 16, lane);
+#pragma unroll
+                for (int nb = 0; nb < MLP_NBO; ++nb) {
+                    acc_d[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], x0, acc_d[nb][0], 0, 0, 0);
+                    acc_d[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], x1, acc_d[nb][1], 0, 0, 0);
+                }
+                if constexpr (KT + D < 32) mlp_load_w(W, a.pwt_out + (long)(KT + D) * TILE, wave, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            char* do_panel = lds + MLP_H_OFF;          // (the hidden panels are idle since the last c_proj-like phase)
+#pragma unroll
+            for (int nb = 0; nb < MLP_NBO; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = acc_d[nb][mb][8 * p + e];
+                        const int nu = wave * (32 * MLP_NBO) + nb * 32 + 8 * p;
+                        *reinterpret_cast<uint4*>(pn_panel_slot<1024>(do_panel, mb * 32 + (lane & 31), (nu >> 3) + 2 * hi)) = pn_pack8(v);
+                    }
+            __syncthreads();
+            pn_panel_copy_out<1024>(do_panel, a.d_o + row0 * 512, 512, wave, lane);
+        } else {
+            pn_panel_copy_out<1024>(lds + MLP_XN_OFF, a.dx2 + row0 * 512, 512, wave, lane);
+        }
     }
 }
 
@@ -981,8 +1028,10 @@ extern "C" int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream) {
     a.pw_fc = (const char*)d->pwt_proj; a.pw_proj = (const char*)d->pwt_fc;
     a.h_act = (bf16_t*)d->dh; a.dx2 = (bf16_t*)d->dx2;
     a.g_b_fc = d->g_b_fc; a.g_ln_g = d->g_ln_g; a.g_ln_b = d->g_ln_b; a.g_b_out = d->g_b_out;
+    TAN_REQUIRE((d->pwt_out != nullptr) == (d->d_o != nullptr));
+    a.pwt_out = (const char*)d->pwt_out; a.d_o = (bf16_t*)d->d_o;
     const dim3 grid((unsigned)(d->rows / PN_ROWS));
-    const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0);
+    const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0 + (d->pwt_out ? 2.0 * d->rows * 512.0 * 512.0 : 0.0));
 #ifdef TAN_PANEL_LAB
     if (getenv("TAN_PANEL_LAB_CLOCKS")) hipLaunchKernelGGL((mlp_panel_kernel<64, MlpBwdArgs>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
     else

@@ -165,6 +165,21 @@ def test_mlp_bwd_matches_the_fp32_backward_of_the_branch(R):
     close(g_ln_g - 0.25, (r_dxn * xhat).sum(0), "g_ln_g", 2e-3)
     close(g_ln_b + 0.5, r_dxn.sum(0), "g_ln_b", 2e-3)
     close(g_b_out - 1.0, r_dx2.sum(0), "g_b_out", 2e-3)
+    # optional tail: d_o = dx2 W_out (the attention out-projection's dX GEMM) from the resident dx2 panel; everything else unchanged
+    w_out = (torch.randn(512, 512, device="cuda") * 512 ** -0.5).to(bf)
+    (pwt_out,) = pack([w_out.T.contiguous()])
+    d_o = torch.full((R, 512), float("nan"), device="cuda", dtype=bf)
+    dh2, dx22 = torch.zeros_like(dh), torch.zeros_like(dx2)
+    d.dh, d.dx2, d.pwt_out, d.d_o = dh2.data_ptr(), dx22.data_ptr(), pwt_out.data_ptr(), d_o.data_ptr()
+    _lib.check(_lib.lib().tan_mlp_bwd(C.byref(d), ops._stream()), "tan_mlp_bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(dx22, dx2) and torch.equal(dh2, dh)
+    close(d_o, dx2.float() @ w_out.float(), "d_o", 2.0 ** -7)
+    u_do = torch.empty_like(d_o)                                      # the launch it replaces (K-strided W form)
+    ops.gemm(dx2, w_out, u_do, M=R, N=512, K=512, a_kc=True, b_kc=False, ldb=512)
+    torch.cuda.synchronize()
+    diff = (u_do.float() - d_o.float()).abs()
+    assert diff.max().item() <= 2.0 ** -7 * u_do.float().abs().max().item() and (diff > 0).float().mean().item() < 0.02
 
 
 def test_mlp_bwd_with_the_next_blocks_ln1_backward_as_prologue():

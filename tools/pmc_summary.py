@@ -31,7 +31,7 @@ def main(fetch_csv, write_csv, top=14):
         print(f"{k[:80]:80s} {n:6d} {avg:8.1f} {rd / 1e6:9.2f} {wr / 1e6:9.2f} {(rd + wr) / avg / 1e3:9.0f}")
     if len(sys.argv) > 3:
         import json
-        fam = [r for r in rows if any(t in r[1] for t in ("gemm_glds_kernel", "gemm_glds4_kernel", "gemm_dw256_kernel", "gemm_dw_grouped_kernel", "simnce_kernel", "simnce_res_kernel", "mlp_panel_kernel"))]
+        fam = [r for r in rows if any(t in r[1] for t in ("gemm_glds_kernel", "gemm_glds4_kernel", "gemm_dw256_kernel", "gemm_dw_grouped_kernel", "simnce_kernel", "simnce_res_kernel", "mlp_panel_kernel", "attnblk_fwd_kernel", "attnblk_bwd_kernel"))]
         calls = sum(r[2] for r in fam)
         out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB units, FETCH_SIZE x2 (gfx950 correction)",
                "mfma_gemm_family": {"launches": calls,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates profiles/ on an MI355X box: run as  gpurun -- 'bash tools/refresh_profiles.sh'  (writes under gpurun_out/refresh/);
-# then copy gpurun_out/refresh/* over profiles/r02_*.  Counters are collected in their own passes (--pmc with --kernel-trace only).
+# then copy gpurun_out/refresh/* over profiles/r03_*.  Counters are collected in their own passes (--pmc with --kernel-trace only).
 set -x
 R=$PWD; O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
@@ -27,4 +27,8 @@ python $R/tools/pmc_summary.py $(find /tmp/pmc4_FETCH_SIZE -name "*counter_colle
 # ---- stage 2 (configs[2] on one GPU)
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats2 -- python $R/bench.py --stage 2 --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timer > $O/stage2_bench_under_rocprof.json 2> $O/stage2_under_rocprof.err
 cp $(find /tmp/prof_stats2 -name "*kernel_stats.csv" | head -1) $O/stage2_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc2_$c -- python $R/bench.py --stage 2 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer > /dev/null 2> $O/stage2_pmc_$c.err
+done
+python $R/tools/pmc_summary.py $(find /tmp/pmc2_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/pmc2_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/stage2_b128_pmc_traffic.json > $O/stage2_b128_pmc_traffic.txt
 tail -1 $O/bench.json | cut -c1-400
