@@ -264,10 +264,13 @@ def test_bf16_self_labelling_floors_on_trained_weights():
     pos32, pos16 = a32["max_position_dual"].cpu().numpy(), a16["max_position_dual"].cpu().numpy()
     exact, near = (pos32 == pos16)[valid].mean(), (np.abs(pos32 - pos16) <= 1)[valid].mean()
     same = {k: (a32[k].cpu().numpy() == a16[k].cpu().numpy()).mean() for k in ("agreement_tgt", "dual_self_tgt", "joint_self_tgt")}
-    l32, l16 = res["fp32"][0]["loss"].item(), res["bf16"][0]["loss"].item()
+    # ('loss-total' = the NCE before the loss_threshold re-weighting: the thresholded 'loss' keeps half of the ~30 real sentences, and
+    # one sentence crossing the quantile moves it by several per cent on these saturated logits -- 1.00 .. 1.23 run to run in bf16)
+    l32, l16 = res["fp32"][0]["loss-total"].item(), res["bf16"][0]["loss-total"].item()
     loss_err = abs(l16 - l32) / max(1.0, abs(l32))       # (the trained loss is ~1e-2: absolute below 1)
     msg = (f"trained weights (loss {first:.3f} -> {last:.3f}): argmax exact {exact:.3f} / within-1 {near:.3f}, targets "
-           f"{ {k: round(float(v), 4) for k, v in same.items()} }, cotrain loss fp32 {l32:.4f} / bf16 {l16:.4f}")
+           f"{ {k: round(float(v), 4) for k, v in same.items()} }, NCE (loss-total) fp32 {l32:.4f} / bf16 {l16:.4f}, thresholded loss "
+           f"fp32 {res['fp32'][0]['loss'].item():.3f} / bf16 {res['bf16'][0]['loss'].item():.3f}")
     print(msg)
     assert near >= 0.90 and exact >= 0.75, msg
     assert min(same.values()) >= 0.97, msg
