@@ -252,6 +252,14 @@ int tan_simnce_bwd_dl_kept(const void* e_keep, const void* vn, const void* tn, l
  * for tan_nce_tail_bwd, which turns d loss/d out2 into the gradients of the four term tensors.  One launch each.
  * counts_in (optional, [2]): divide by these (GLOBAL) mask sums instead of the local ones -- global negatives, row f3.     */
 int tan_pos_masks(const float* tgt, const unsigned char* text_pad, float* rows_pos, float* cols_pos, int B, int T, int N, void* stream);
+/* Everything get_loss derives from the batch's masks alone (train/loss.py:58-70: pad masks, the [B,T,N] start/end target) in one launch,
+ * plus the text-column compaction of the logits-free sweeps: text_pad as f32 0/1 (train/main.py:62-65) OR as bytes (exactly one non-NULL),
+ * video_pad bytes [B,T], tgt_raw bytes [B,N,T] (get_mask_from_time) -> tpad_u8 / valid (bytes) / valid_f (f32) [B*N], vpad_u8 [B*T],
+ * tgt f32 [B,T,N]; with idx != NULL also idx [Mc] (int64: real sentences in order, then padded columns in order = a stable sort of the
+ * pad flags), colmap [B*N] (int32 rank among the real sentences, -1 = padded), ci_run [Mc] (pad flags of the compacted columns).      */
+int tan_loss_prep(const float* text_pad_f32, const unsigned char* text_pad_u8, const unsigned char* video_pad_u8,
+                  const unsigned char* tgt_raw, unsigned char* tpad_u8, unsigned char* vpad_u8, unsigned char* valid, float* valid_f,
+                  float* tgt, long* idx, int* colmap, unsigned char* ci_run, int B, int T, int N, int Mc, void* stream);
 int tan_nce_tail_fwd(const float* v_d, const float* t_d, const float* v_j, const float* t_j, const float* rows_mask,
                      const float* cols_mask, int Sd, int Sj, long R, long M, float* out2, float* counts2, const float* counts_in,
                      void* stream);

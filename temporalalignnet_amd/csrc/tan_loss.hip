@@ -512,6 +512,66 @@ extern "C" int tan_masked_quantile(const float* x, const unsigned char* invalid,
     return 0;
 }
 
+// ---- everything get_loss derives from the batch's masks in ONE launch (prepare_inputs of loss.py; train/loss.py:58-70):
+//   tpad_u8 [B*N], vpad_u8 [B*T], valid (bool) and valid_f (f32) [B*N], tgt f32 [B,T,N] = transpose of the [B,N,T] bool start/end mask,
+//   and the text-column compaction of the fused sweeps: idx [Mc] (int64: the real sentences in order, then padded columns in order --
+//   what a stable sort of the pad flags gives), colmap [B*N] (int32: rank among the real sentences, -1 for padded columns),
+//   ci_run [Mc] (pad flags of the compacted columns).  One block; the ranks come from a block-wide prefix sum over <= 1024-column pieces.
+__global__ __launch_bounds__(1024) void loss_prep_kernel(const float* tpad_f, const unsigned char* tpad_b, const unsigned char* vpad_b,
+                                                         const unsigned char* tgt_raw, unsigned char* tpad_u8, unsigned char* vpad_u8,
+                                                         unsigned char* valid, float* valid_f, float* tgt, long long* idx, int* colmap,
+                                                         unsigned char* ci_run, int B, int T, int N, int Mc) {
+    __shared__ int scan[1024];
+    __shared__ int base_valid, base_pad, n_valid_total;
+    const int tid = threadIdx.x, Mp = B * N, R = B * T;
+    for (int i = tid; i < R; i += 1024) vpad_u8[i] = vpad_b[i] ? 1 : 0;
+    for (long i = tid; i < (long)B * T * N; i += 1024) {           // tgt[b][t][n] = tgt_raw[b][n][t]
+        const int n = (int)(i % N), t = (int)((i / N) % T), b = (int)(i / ((long)N * T));
+        tgt[i] = tgt_raw[((long)b * N + n) * T + t] ? 1.0f : 0.0f;
+    }
+    // first pass: total number of real sentences (the padded columns' ranks start behind them)
+    int local = 0;
+    for (int c = tid; c < Mp; c += 1024) {
+        const bool pad = tpad_f ? tpad_f[c] != 0.0f : tpad_b[c] != 0;
+        tpad_u8[c] = pad; valid[c] = !pad; valid_f[c] = pad ? 0.0f : 1.0f;
+        local += !pad;
+    }
+    scan[tid] = local;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (tid < o) scan[tid] += scan[tid + o]; __syncthreads(); }
+    if (tid == 0) { n_valid_total = scan[0]; base_valid = 0; base_pad = 0; }
+    __syncthreads();
+    if (!idx) return;
+    for (int c0 = 0; c0 < Mp; c0 += 1024) {                            // pieces of 1024 columns, in order
+        const int c = c0 + tid;
+        const bool in = c < Mp, pad = in && tpad_u8[c];
+        const int v = in && !pad;
+        scan[tid] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {                           // inclusive Hillis-Steele scan of the valid flags
+            const int add = tid >= o ? scan[tid - o] : 0;
+            __syncthreads();
+            scan[tid] += add;
+            __syncthreads();
+        }
+        const int incl = scan[tid], piece_valid = scan[1023];
+        if (in) {
+            if (!pad) {
+                const int r = base_valid + incl - 1;
+                colmap[c] = r;
+                if (r < Mc) { idx[r] = c; ci_run[r] = 0; }
+            } else {
+                colmap[c] = -1;
+                const int r = n_valid_total + base_pad + (tid + 1 - incl) - 1;     // pads before and including this one, in order
+                if (r < Mc) { idx[r] = c; ci_run[r] = 1; }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { base_valid += piece_valid; base_pad += (Mp - c0 < 1024 ? Mp - c0 : 1024) - piece_valid; }
+        __syncthreads();
+    }
+}
+
 extern "C" int tan_pos_masks(const float* tgt, const unsigned char* text_pad, float* rows_pos, float* cols_pos, int B, int T, int N,
                              void* stream) {
     TAN_REQUIRE(tgt && text_pad && rows_pos && cols_pos && B > 0 && T > 0 && N > 0);
@@ -536,6 +596,19 @@ extern "C" int tan_nce_tail_bwd(const float* g_out2, const float* rows_mask, con
     const long n = R > M ? R : M;
     hipLaunchKernelGGL(nce_tail_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, g_out2, rows_mask, cols_mask,
                        counts2, Sd, Sj, R, M, g_v_d, g_t_d, g_v_j, g_t_j);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_loss_prep(const float* text_pad_f32, const unsigned char* text_pad_u8, const unsigned char* video_pad_u8,
+                             const unsigned char* tgt_raw, unsigned char* tpad_u8, unsigned char* vpad_u8, unsigned char* valid,
+                             float* valid_f, float* tgt, long* idx, int* colmap, unsigned char* ci_run, int B, int T, int N, int Mc,
+                             void* stream) {
+    TAN_REQUIRE((text_pad_f32 != nullptr) != (text_pad_u8 != nullptr));
+    TAN_REQUIRE(video_pad_u8 && tgt_raw && tpad_u8 && vpad_u8 && valid && valid_f && tgt && B > 0 && T > 0 && N > 0);
+    TAN_REQUIRE(!idx || (colmap && ci_run && Mc > 0 && Mc <= B * N));
+    hipLaunchKernelGGL(loss_prep_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, text_pad_f32, text_pad_u8, video_pad_u8, tgt_raw,
+                       tpad_u8, vpad_u8, valid, valid_f, tgt, (long long*)idx, colmap, ci_run, B, T, N, Mc);
     TAN_LAUNCH_CHECK();
     return 0;
 }

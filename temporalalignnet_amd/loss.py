@@ -328,22 +328,43 @@ def prepare_inputs(input_data, video_padding_mask, text_padding_mask, T, N, dev,
     compaction.  ~20 tiny launches that do not depend on the model: the training driver issues them on a side stream next to the
     forward (`Trainer.forward_backward`), get_loss computes them itself otherwise."""
     B = text_padding_mask.shape[0]
-    tpad = text_padding_mask.to(dev).bool()
-    tpad_u8 = tpad.to(torch.uint8).contiguous()
-    vpad_u8 = video_padding_mask.to(dev).bool().to(torch.uint8).contiguous()
-    valid = (~tpad).view(B * N)
-    prep = {"tpad": tpad, "tpad_u8": tpad_u8, "vpad_u8": vpad_u8, "valid": valid, "valid_f": valid.float()}
     tgt_raw = input_data.get("_tgt_raw") if isinstance(input_data, dict) else None
     if tgt_raw is None:
         tgt_raw, _, _ = get_mask_from_time(input_data["start"], input_data["end"], T, N, device=dev)   # [B,N,T] bool
-    prep["tgt_raw"] = tgt_raw
+    tgt_raw = tgt_raw.contiguous()
+    tp = text_padding_mask.to(dev)
+    tp = tp.contiguous() if tp.dtype in (torch.float32, torch.bool, torch.uint8) else tp.float().contiguous()
+    vp = video_padding_mask.to(dev)
+    vp = vp.contiguous() if vp.dtype in (torch.bool, torch.uint8) else vp.bool().contiguous()
+    Mp = B * N
+    Mc = 0
+    if want_compaction and n_text_valid is not None:
+        Mc = min(Mp, (int(n_text_valid) + 63) // 64 * 64)
+        if Mc >= Mp:
+            Mc = 0                                   # nothing would be dropped
+    # ONE launch (tan_loss_prep) instead of ~15 tiny ATen kernels: pad masks in the kernels' formats, the transposed f32 target, and
+    # the column compaction (a stable partition of the pad flags; was sort + cumsum + compare + masked_fill + gathers)
+    tpad_u8 = torch.empty(B, N, dtype=torch.uint8, device=dev)
+    vpad_u8 = torch.empty(vp.shape, dtype=torch.uint8, device=dev)
+    valid = torch.empty(Mp, dtype=torch.bool, device=dev)
+    valid_f = torch.empty(Mp, device=dev)
+    tgt = torch.empty(B, T, N, device=dev)
+    idx = torch.empty(Mc, dtype=torch.int64, device=dev) if Mc else None
+    colmap = torch.empty(Mp, dtype=torch.int32, device=dev) if Mc else None
+    ci_run = torch.empty(Mc, dtype=torch.uint8, device=dev) if Mc else None
+    is_f = tp.dtype == torch.float32
+    _lib.check(_lib.lib().tan_loss_prep(_p(tp) if is_f else None, None if is_f else _p(tp), _p(vp), _p(tgt_raw), _p(tpad_u8), _p(vpad_u8),
+                                        _p(valid), _p(valid_f), _p(tgt), _p(idx), _p(colmap), _p(ci_run), C.c_int(B), C.c_int(T),
+                                        C.c_int(N), C.c_int(Mc), ops._stream()), "tan_loss_prep")
+    prep = {"tpad": tpad_u8.view(torch.bool), "tpad_u8": tpad_u8, "vpad_u8": vpad_u8, "valid": valid, "valid_f": valid_f,
+            "tgt_raw": tgt_raw}
     if not args.learn_agreement:
-        prep["tgt"] = tgt_raw.permute(0, 2, 1).float().contiguous()                                   # [B,T,N]
-        prep["rows_pos"], prep["cols_pos"] = _pos_masks(prep["tgt"], tpad_u8, B, T, N)
+        prep["tgt"] = tgt                                                                             # [B,T,N]
+        prep["rows_pos"], prep["cols_pos"] = _pos_masks(tgt, tpad_u8, B, T, N)
     if want_compaction:
-        prep["nv"], prep["nv_for"] = compaction_prep(tpad_u8.view(B * N), n_text_valid), n_text_valid
+        prep["nv"], prep["nv_for"] = ((idx, colmap, ci_run) if Mc else None), n_text_valid
         if prep["nv"] is not None and "cols_pos" in prep:
-            prep["cols_pos_c"] = prep["cols_pos"].index_select(0, prep["nv"][0])       # the tail's column mask, compacted order
+            prep["cols_pos_c"] = prep["cols_pos"].index_select(0, idx)                 # the tail's column mask, compacted order
     return prep
 
 

@@ -278,3 +278,32 @@ def test_bf16_self_labelling_floors_on_trained_weights():
     # NCE loss of the set is ~1e-3 the cosines sit near +-1 and the 1/0.07 temperature turns bf16's ~3e-3 cosine error into a few
     # per cent of the re-weighted (thresholded + BCE) loss -- the index tensors, which drive the targets, stay within the floors
     assert loss_err < 1e-1, msg
+
+
+@pytest.mark.parametrize("B,T,N,fmt", [(4, 16, 5, "f32"), (128, 64, 16, "f32"), (37, 20, 31, "bool"), (200, 8, 12, "u8")])
+def test_loss_prep_kernel_equals_the_torch_glue_it_replaces(B, T, N, fmt):
+    """tan_loss_prep (one launch) == the ~15 ATen calls prepare_inputs used to make: pad masks, transposed f32 target, and the text-column
+    compaction (`compaction_prep`: a stable sort of the pad flags) -- incl. more than 1024 columns (two scan pieces) and Mc rounded up
+    into the padded columns."""
+    from temporalalignnet_amd import loss as L
+    g = torch.Generator().manual_seed(B * 31 + N)
+    tpad = torch.rand(B, N, generator=g) < 0.35
+    tpad[:, 0] = False
+    vpad = torch.rand(B, T, generator=g) < 0.1
+    tgt_raw = (torch.rand(B, N, T, generator=g) < 0.2).cuda()
+    text_mask = {"f32": tpad.float(), "bool": tpad, "u8": tpad.to(torch.uint8)}[fmt].cuda()
+    n_valid = int((~tpad).sum())
+    args = loss_ref.default_args()
+    prep = L.prepare_inputs({"_tgt_raw": tgt_raw}, vpad.cuda(), text_mask, T, N, torch.device("cuda"), args, n_text_valid=n_valid,
+                            want_compaction=True)
+    assert torch.equal(prep["tpad"].cpu(), tpad) and torch.equal(prep["tpad_u8"].cpu(), tpad.to(torch.uint8))
+    assert torch.equal(prep["vpad_u8"].cpu(), vpad.to(torch.uint8))
+    assert torch.equal(prep["valid"].cpu(), ~tpad.view(-1)) and torch.equal(prep["valid_f"].cpu(), (~tpad).view(-1).float())
+    assert torch.equal(prep["tgt"], tgt_raw.permute(0, 2, 1).float().contiguous())
+    want = L.compaction_prep(tpad.view(-1).to(torch.uint8).cuda(), n_valid)
+    if want is None:
+        assert prep["nv"] is None
+    else:
+        for got, ref in zip(prep["nv"], want):
+            assert torch.equal(got, ref.to(got.dtype))
+        assert torch.equal(prep["cols_pos_c"], prep["cols_pos"].index_select(0, want[0]))
