@@ -122,6 +122,9 @@ int tan_colsum_acc(const void* x, float* out, long rows, int C, int dtype, void*
  * tan_model.py:201 and its backward split) */
 int tan_rows_copy(const void* src, void* dst, int G, int R, int C, long src_grp_rows, long src_off, long dst_grp_rows,
                   long dst_off, int accumulate, int dtype, void* stream);
+/* dst[s][m][:] = map[m] >= 0 ? src[s][map[m]][:] : 0, s < S  (src [S, Msrc, C], dst [S, Mdst, C], map int32 [Mdst]): the compacted
+ * text-feature gradient of the logits-free NCE back in the padded [B*N] row order -- torch.zeros().index_copy_() in one launch */
+int tan_rows_gather(const void* src, void* dst, const int* map, int S, long Msrc, long Mdst, int C, int dtype, void* stream);
 /* out[r][c] = sum_g x[g*R + r][c]  (backward of the broadcast position add) */
 int tan_group_sum(const void* x, void* out, int G, int R, int C, int dtype, void* stream);
 int tan_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);

@@ -444,6 +444,22 @@ __global__ __launch_bounds__(256) void rows_kernel(const T* __restrict__ src, T*
     }
 }
 
+// row gather with a map: dst[s][m][:] = map[m] >= 0 ? src[s][map[m]][:] : 0   (the compacted text-feature gradient back in the padded
+// [B*N] row order: every row is written, so no fill in front of it)
+template <typename T>
+__global__ __launch_bounds__(256) void rows_gather_kernel(const T* __restrict__ src, T* __restrict__ dst, const int* __restrict__ map,
+                                                          int S, long Msrc, long Mdst, int C) {
+    const long n4 = (long)S * Mdst * C / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long e = i * 4;
+        const int c = (int)(e % C);
+        const long sm = e / C, m = sm % Mdst, st = sm / Mdst;
+        const int j = map[m];
+        const float4 v = j >= 0 ? ld4(src + ((st * Msrc + j) * C + c)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        st4(dst + e, v);
+    }
+}
+
 // out[r][c] = sum_g x[(g*R + r)][c]   (broadcast-add backward: position embedding gradient)
 template <typename T>
 __global__ __launch_bounds__(256) void group_sum_kernel(const T* __restrict__ x, T* __restrict__ out, int G, int R, int C) {
@@ -841,6 +857,17 @@ extern "C" int tan_interp_linear_bwd(const float* ddst, float* dsrc, int L_in, i
     TAN_REQUIRE(ddst && dsrc && L_in > 0 && L_out > 0 && C > 0);
     hipLaunchKernelGGL(interp_bwd_kernel, dim3(cdiv((long)L_out * C, 256)), dim3(256), 0, (hipStream_t)stream, ddst, dsrc,
                        L_in, L_out, C);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_rows_gather(const void* src, void* dst, const int* map, int S, long Msrc, long Mdst, int C, int dtype, void* stream) {
+    TAN_REQUIRE(src && dst && map && S > 0 && Msrc > 0 && Mdst > 0 && C > 0 && C % 4 == 0);
+    const long n4 = (long)S * Mdst * C / 4;
+    const unsigned blocks = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    if (dtype == TAN_F32) hipLaunchKernelGGL((rows_gather_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)src, (float*)dst, map, S, Msrc, Mdst, C);
+    else if (dtype == TAN_BF16) hipLaunchKernelGGL((rows_gather_kernel<bf16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, map, S, Msrc, Mdst, C);
+    else return TAN_ERR_BAD_ARG;
     TAN_LAUNCH_CHECK();
     return 0;
 }

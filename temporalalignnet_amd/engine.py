@@ -444,7 +444,7 @@ class _AlignerEngine(_WorkspaceMixin):
         inv = run["inv"]
         dst_v = [None] * Se           # d stage outputs of the video stack
         dst_j = [None] * Sd
-        d_lang_raw = torch.zeros(Mp, Cw, dtype=cd, device=dev)
+        d_lang_raw = torch.empty(Mp, Cw, dtype=cd, device=dev)      # (its first writer overwrites: no fill launch on the backward chain)
         have_lang_raw = False
         # ---- dual similarity: logits_d[s] = vn_d[s] tn_d^T
         d_vn_d = None
@@ -497,7 +497,7 @@ class _AlignerEngine(_WorkspaceMixin):
             w = self._f("binary_head.weight").view(-1)
             gw, gb = self._g("binary_head.weight").view(-1), self._g("binary_head.bias")
             if g_ad is not None:
-                ops.head_bwd(g_ad.contiguous().view(Mp).float(), run["lang_raw"], w, d_lang_raw, gw, gb, Mp, Cw, accumulate_dx=True)
+                ops.head_bwd(g_ad.contiguous().view(Mp).float(), run["lang_raw"], w, d_lang_raw, gw, gb, Mp, Cw, accumulate_dx=have_lang_raw)
                 have_lang_raw = True
             if g_aj is not None:
                 gaj = g_aj.permute(1, 0, 2, 3).contiguous().view(Sd * Mp).float()
@@ -508,7 +508,7 @@ class _AlignerEngine(_WorkspaceMixin):
                         dst_j[s] = torch.zeros(B * L, Cw, dtype=cd, device=dev)
                     ops.rows_copy(d_jt[s], dst_j[s], B, N, Cw, N, 0, L, T, accumulate=True)
         # ---- encoder stacks
-        d_x0 = torch.zeros(R, Cw, dtype=cd, device=dev)
+        d_x0 = torch.empty(R, Cw, dtype=cd, device=dev)             # written in full by the video stack's backward, or by the first rows_copy
         d_x0j = d_x0
         any_v = any(t is not None for t in dst_v)
         any_j = any(t is not None for t in dst_j)

@@ -308,7 +308,12 @@ class _FusedNCEFn(torch.autograd.Function):
             d_run = torch.empty(S, Mc, Cw, dtype=tn.dtype, device=dev)   # S x (Mc/128 x Cw/128) tiles under an R-long contraction
             ops.gemm(dl, vn, d_run, M=Mc, N=Cw, K=R, a_kc=False, b_kc=False, lda=Mc, ldb=Cw, batch=S, sA=R * Mc, sB=R * Cw,
                      sC=Mc * Cw)
-        d_tn = torch.zeros_like(tn).index_copy_(1, idx, d_run) if compact else d_run
+        if compact:                                  # back to the padded row order, zeros at the dropped columns: one launch
+            d_tn = torch.empty_like(tn)
+            _lib.check(_lib.lib().tan_rows_gather(_p(d_run.contiguous()), _p(d_tn), _p(colmap), C.c_int(tn.shape[0]), C.c_long(Mc),
+                                                  C.c_long(Mp), C.c_int(Cw), ops._dt(d_tn), ops._stream()), "tan_rows_gather")
+        else:
+            d_tn = d_run
         return d_vn, d_tn, None, None, None, None, None, None, None
 
 

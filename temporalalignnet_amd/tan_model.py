@@ -226,6 +226,8 @@ class TemporalAligner(_AlignerEngine, nn.Module):
     def _mask_u8(m):
         if m is None:
             return None
+        if m.dtype == torch.bool and m.is_contiguous():
+            return m.view(torch.uint8)          # same bytes (0 / 1): no launch
         return m.to(torch.uint8).contiguous()
 
     def forward(self, video_embed, lang_embed, video_padding_mask, lang_padding_mask, text_timestamp=None,
