@@ -40,6 +40,10 @@ struct SimArgs {
     // simnce_res_kernel<1> with the same-video corrections as its tail (instead of a simnce_diag_kernel<true> launch):
     const float* diag;                 // [S, B, T, N] same-video cosines, or null: no corrections in the sweep kernel
     const int* colmap;                 // padded column b*N+k -> column of the sweep, or -1; null: identity
+    int rot;                           // simnce_res_kernel: panels start their column walk at different tiles
+    int npanel, nfull;                 // simnce_res_kernel: row panels per stage; items (stage, panel) that are not cut in column halves
+    const char* Tp;                    // simnce_res_kernel: fragment-major image of the text features (simnce_pack_text_kernel)
+    long tp_stage_stride;              // bytes, or 0 (text features shared by the stages)
 };
 
 // K-contiguous 128-row operand tile, same image as tan_gemm_glds.hip (slot = chunk ^ ((row >> 1) & 7))
@@ -64,6 +68,7 @@ struct TileCtx {
     const float* colsum; const float* g_t; bf16_t* dl;
     int R, Mp, s, m0, wm, wn, lane;
     float inv_tau;
+    int cinv[2];                  // simnce_res_kernel: pad flags of the wave's two 32-column blocks, requested before the tile's K loop, or -1
 };
 
 // consume one finished 128x128 logit tile (column tile ct) straight from the accumulators.  Positives and the padded-frame
@@ -243,8 +248,11 @@ __device__ __forceinline__ void tile_done_res(const TileCtx& c, f32x16 (&acc)[2]
     for (int j = 0; j < 2; ++j) {
         const int col = c0 + c.wn * 64 + j * 32 + acc_col(lane);
         const bool col_ok = col < Mp;
-        const bool col_valid = col_ok && !c.col_invalid[min(col, Mp - 1)];
+        const bool col_valid = col_ok && !(c.cinv[j] >= 0 ? c.cinv[j] : (int)c.col_invalid[min(col, Mp - 1)]);
         float csum = 0.f, bc = 0.f, e_prev = 0.f;
+        unsigned pk[4] = {0u, 0u, 0u, 0u};
+        const float k1 = 1.4426950408889634f * c.inv_tau, cmask = col_ok ? 1.0f : 0.0f, vmask = col_valid ? 1.0f : 0.0f;
+        const bool rows_full = c.m0 + 128 <= R;
         if (MODE == 1) {
             const long idx = (long)c.s * Mp + min(col, Mp - 1);
             const float gt = c.g_t[idx], cs = c.colsum[idx];
@@ -255,17 +263,21 @@ __device__ __forceinline__ void tile_done_res(const TileCtx& c, f32x16 (&acc)[2]
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = c.m0 + c.wm * 64 + i * 32 + acc_row(r, lane);
-                float e = __expf((acc[i][j][r] - 1.0f) * c.inv_tau);
-                if (!col_ok || row >= R) e = 0.f;
+                // exp((cos - 1) / tau) as one fma + v_exp_f32; columns past Mp by a 0/1 factor, rows past R only in the last panel
+                float e = __builtin_amdgcn_exp2f(fmaf(acc[i][j][r], k1, -k1)) * cmask;
+                if (!rows_full && row >= R) e = 0.f;
                 if (MODE == 0) {
-                    if (col_valid) rowacc[i][r] += e;
+                    rowacc[i][r] = fmaf(e, vmask, rowacc[i][r]);
                     csum += e;
-                    // kept for the backward, in ACCUMULATOR order [i][j][r/2][lane] (two rows per dword): every store instruction
-                    // writes 256 contiguous bytes.  Row-major 2-byte stores (64-byte pieces of lines) cost the sweep +110 us and
+                    // kept for the backward, in ACCUMULATOR order (two rows per dword): every store instruction
+                    // writes contiguous bytes.  Row-major 2-byte stores (64-byte pieces of lines) cost the sweep +110 us and
                     // 200 MB of read-modify-write traffic; simnce_dl_kept_kernel does the transposition, where the LDS is free.
-                    if (c.dl) {
-                        if (r & 1) reinterpret_cast<unsigned*>(c.dl)[((i * 2 + j) * 8 + (r >> 1)) * 64 + lane] = f2bf2(e_prev, e);
+                    if (c.dl) {       // [i][j][r / 8][lane][4 dwords]: 16 bytes per lane, 1 KiB per store instruction (as dword stores --
+                        //                 256 B per instruction -- the 327 KB a workgroup keeps were store-ISSUE bound: a CU retires ~4 B/clk of those)
+                        if (r & 1) pk[(r >> 1) & 3] = f2bf2(e_prev, e);
                         e_prev = e;
+                        if ((r & 7) == 7)
+                            reinterpret_cast<uint4*>(c.dl)[((i * 2 + j) * 2 + (r >> 3)) * 64 + lane] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                     }
                 } else {
                     const float g = e * ((col_valid ? rowacc[i][r] : 0.f) + bc);
@@ -279,25 +291,52 @@ __device__ __forceinline__ void tile_done_res(const TileCtx& c, f32x16 (&acc)[2]
     }
 }
 
+template <int J, int END, typename F>
+__device__ __forceinline__ void pn_static_for_s(F&& f) {
+    if constexpr (J < END) {
+        f(std::integral_constant<int, J>{});
+        pn_static_for_s<J + 1, END>(f);
+    }
+}
+
+// Fragment-major image of the (compacted) unit text features for simnce_res_kernel: piece (column block cb of 32, k step ks of 16) is
+// 1 KiB, lane l's 16 bytes = Tt[cb*32 + (l & 31)][16 ks + 8 (l >> 5) ..] -- the B operand of v_mfma_f32_32x32x16_bf16 as ONE coalesced
+// wave-load.  Columns past Mp repeat the last one (their logits are masked by col_ok).  grid (column blocks, stages), 256 threads.
+__global__ __launch_bounds__(256) void simnce_pack_text_kernel(const bf16_t* __restrict__ Tt, long t_stage_stride, char* __restrict__ Tp,
+                                                               long tp_stage_stride, int Mp) {
+    const int cb = blockIdx.x, st = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bf16_t* src = Tt + (long)st * t_stage_stride + (long)min(cb * 32 + (lane & 31), Mp - 1) * 512 + 8 * (lane >> 5);
+    char* dst = Tp + (long)st * tp_stage_stride + (long)cb * 32 * 1024 + lane * 16;
+    uint4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const uint4*>(src + (w * 8 + i) * 16);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(dst + (long)(w * 8 + i) * 1024) = v[i];
+}
+
 template <int MODE>
 __global__ __launch_bounds__(512) void simnce_res_kernel(SimArgs a) {
-    __shared__ __attribute__((aligned(1024))) char lds[8 * S_TILE + 4 * S_T32];      // [8 frame K tiles][group][2 text tiles]
+    __shared__ __attribute__((aligned(1024))) char lds[8 * S_TILE];      // the frame panel: 8 K tiles of [128 rows][64 channels]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, gw = wave & 3, wm = gw >> 1, wn = gw & 1;
-    const int npanel = gridDim.x;
-    int wg = blockIdx.y * gridDim.x + blockIdx.x;
-    {
-        const int nwg = gridDim.x * gridDim.y, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+    // 1-D grid over (stage, row panel) items, one workgroup per CU.  The items past the last full round of the chip (384 items on 256
+    // CUs: 128) are cut in two column halves each -- two workgroups -- so that the last round keeps every CU busy for half an item
+    // instead of half the CUs for a whole one (a.nfull = items that are not cut; blocks are dispatched in id order).
+    const int npanel = a.npanel;
+    int wg = blockIdx.x, half = -1;
+    if (wg < a.nfull) {
+        const int nwg = a.nfull, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;       // a contiguous run of items per XCD (see simnce_kernel)
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    } else {
+        half = (wg - a.nfull) & 1;
+        wg = a.nfull + ((wg - a.nfull) >> 1);
     }
     const int s = wg / npanel, panel = wg - s * npanel, m0 = panel * 128;
     const int R = a.R, Mp = a.Mp, Cw = a.C, nS = a.S;
     const bf16_t* V = a.V + (long)s * R * Cw;
-    const bf16_t* Tt = a.Tt + (long)s * a.t_stage_stride;
-    const int nct = (Mp + 127) / 128, niter = (nct + 1) / 2;
+    const int nct = (Mp + 127) / 128;
     const float inv_tau = 1.0f / S_TAU;
-    char* tbuf = lds + 8 * S_TILE + grp * 2 * S_T32;
 
     float rowacc[2][16];      // MODE_STATS: running row sums (this group's column tiles); MODE_DL: gv/rowsum/tau
 #pragma unroll
@@ -318,47 +357,75 @@ __global__ __launch_bounds__(512) void simnce_res_kernel(SimArgs a) {
     float* colrow = MODE == 0 ? a.colpart + ((long)(2 * panel + wm) * nS + s) * Mp : nullptr;
 
     f32x16 acc[2][2];
-    // one 32-deep K step of this group's column tile ct_ (wave-uniform `live_`: the odd group idles through a last lone tile)
-#define SIMR_KSTEP(KT, CUR, NXT)                                                                                           \
-    {                                                                                                                      \
-        const int kt_ = (KT);                                                                                              \
-        const int ct2 = kt_ < 15 ? ct_ : ct_ + 2, kt2 = kt_ < 15 ? kt_ + 1 : 0;                                            \
-        if (ct2 < nct) s_stage32(Tt, Cw, ct2 * 128, Mp, kt2 * 32, tbuf + (NXT) * S_T32, gw, lane);                         \
-        if (kt_ == 0) {                                                                                                    \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]); \
-        }                                                                                                                  \
-        if (live_) {                                                                                                       \
-            const char* vt_ = lds + (kt_ >> 1) * S_TILE;                                                                   \
-            _Pragma("unroll") for (int ks = 0; ks < 32; ks += 16) {                                                        \
-                bf16x8 af[2], bfr[2];                                                                                      \
-                _Pragma("unroll") for (int i = 0; i < 2; ++i) af[i] = s_frag(vt_, wm * 64 + i * 32, (kt_ & 1) * 32 + ks, lane); \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j) bfr[j] = s_frag32(tbuf + (CUR) * S_T32, wn * 64 + j * 32, ks, lane); \
-                _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);                \
-            }                                                                                                              \
-            if (kt_ == 15) {                                                                                               \
-                if (MODE == 0 && a.ekeep) c.dl = a.ekeep + ((((long)s * npanel + panel) * nct + ct_) * 4 + gw) * 4096;    \
-                tile_done_res<MODE>(c, acc, rowacc, colrow, ct_);                                                          \
-            }                                                                                                              \
-        }                                                                                                                  \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                   \
-        __syncthreads();                                                                                                   \
+    // The frame panel (8 K tiles of 64) is staged once and stays.  The TEXT operand never touches LDS: every wave streams the B
+    // fragments of its own 64 columns straight into registers from a fragment-major image (simnce_pack_text_kernel: one 1-KiB
+    // wave-load per 32 columns x 16 channels), through a ring RD steps deep that runs across column tiles.  The first version staged
+    // 32-deep text tiles through two 8-KiB LDS buffers per wave group -- all the LDS the panel leaves -- with `s_waitcnt vmcnt(0)` and
+    // a workgroup barrier behind every 8 MFMAs: one K step of prefetch against ~1 us of L2 latency under eight waves' requests, ~2.5k
+    // cycles per step where the matrix pipe needs 0.5k (184 us per sweep).  Now the only barrier is the one behind the panel.
+    constexpr int RD = MODE == 0 ? 8 : 4;          // 8 steps x 2 KiB in flight per wave: a step is only 4 MFMAs (128 cycles), the L2 answers in ~1k
+    //                                               (the recomputing d-logits sweep, MODE 1, has the registers for 4)
+    struct BF { bf16x8 f[2]; };
+    BF ring[RD];
+    const char* Tp = a.Tp + (long)s * a.tp_stage_stride;
+    auto load_b = [&](BF& dst, int ct, int ks) __attribute__((always_inline)) {       // columns ct*128 + wn*64 + j*32 .., k = 16 ks ..
+        const char* pb = Tp + ((long)((ct * 4 + wn * 2) * 32 + ks)) * 1024 + lane * 16;
+        dst.f[0] = *reinterpret_cast<const bf16x8*>(pb);
+        dst.f[1] = *reinterpret_cast<const bf16x8*>(pb + 32 * 1024);
+    };
+    // Every workgroup walks the same text image; in the same order and at the same pace they all ask the same L2 channel for the same
+    // lines at the same time.  Each panel starts its walk at a different column tile (TAN_SIM_ROT=0: all start at tile 0).
+    const int nall = (nct - grp + 1) / 2;                      // column tiles of this wave group: grp, grp + 2, ..
+    const int kbase = half == 1 ? (nall + 1) / 2 : 0;          // .. of which a half item takes the first or the second part
+    const int ngrp = half < 0 ? nall : (half == 0 ? (nall + 1) / 2 : nall / 2);
+    const int rot = ngrp > 0 ? ((a.rot & 1) ? (panel * 7 + s * 3) % ngrp : 0) : 0;
+    if (ngrp > 0) {
+        pn_static_for_s<0, RD>([&](auto jc) { constexpr int J = decltype(jc)::value; load_b(ring[J], 2 * (kbase + rot) + grp, J); });
     }
-
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) s_stage(V, Cw, m0, R, (grp * 4 + kt) * 64, lds + (grp * 4 + kt) * S_TILE, gw, lane);
-    if (grp < nct) s_stage32(Tt, Cw, grp * 128, Mp, 0, tbuf, gw, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int it = 0; it < niter; ++it) {
-        const int ct_ = 2 * it + grp;
-        const bool live_ = ct_ < nct;
-        for (int kt = 0; kt < 16; kt += 2) {
-            SIMR_KSTEP(kt, 0, 1)
-            SIMR_KSTEP(kt + 1, 1, 0)
-        }
+    bf16x8 afA[2], afB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) afA[i] = s_frag(lds, wm * 64 + i * 32, 0, lane);
+    for (int it = 0; it < ngrp; ++it) {
+        const int k_ = it + rot < ngrp ? it + rot : it + rot - ngrp, kn_ = k_ + 1 < ngrp ? k_ + 1 : 0;
+        const int ct_ = 2 * (kbase + k_) + grp, ctn_ = 2 * (kbase + kn_) + grp;
+        const bool more = it + 1 < ngrp;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
+        // the pad flags of this tile's columns: requested here, consumed by the tile epilogue (they were two dependent L2 round trips
+        // at the END of every tile)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c.cinv[j] = a.col_invalid[min(ct_ * 128 + wn * 64 + j * 32 + (lane & 31), Mp - 1)];
+        pn_static_for_s<0, 32>([&](auto jc) {
+            constexpr int KS = decltype(jc)::value;
+            BF& Bf = ring[KS % RD];
+            bf16x8(&af)[2] = (KS & 1) ? afB : afA;          // frame fragments: read from LDS one step ahead
+            bf16x8(&an)[2] = (KS & 1) ? afA : afB;
+            {
+                constexpr int KN = (KS + 1) & 31;
+                const char* vn_ = lds + (KN >> 2) * S_TILE;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) an[i] = s_frag(vn_, wm * 64 + i * 32, (KN & 3) * 16, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], Bf.f[j], acc[i][j], 0, 0, 0);
+            if (!(a.rot & 2)) {          // (lab: bit 1 = no text stream, bit 2 = no tile epilogue -- timing ablations, results undefined)
+                if constexpr (KS + RD < 32) load_b(Bf, ct_, KS + RD);
+                else if (more) load_b(Bf, ctn_, KS + RD - 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (MODE == 0 && a.ekeep) c.dl = a.ekeep + ((((long)s * npanel + panel) * nct + ct_) * 4 + gw) * 4096;
+        if (!(a.rot & 4)) tile_done_res<MODE>(c, acc, rowacc, colrow, ct_);
+        else if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 12345.f) rowacc[0][0] += 1.f;      // keep the MFMAs alive
     }
-#undef SIMR_KSTEP
 
     if (MODE == 0) {
 #pragma unroll
@@ -435,29 +502,25 @@ __global__ __launch_bounds__(256) void simnce_dl_kept_kernel(SimArgs a, int npan
         cv[c] = !a.col_invalid[col];
     }
     __syncthreads();
-    // 16 bytes per load = the dwords of four neighbouring lanes = four columns x two rows; all eight loads in flight at once
+    // 16 bytes per load = one lane's four row pairs of one column (the sweep's store unit); all eight loads in flight at once
     const uint4* E = reinterpret_cast<const uint4*>(a.ekeep) + (((long)s * npanel + panel) * nct + ct) * 2048;
     uint4 ev[8];
 #pragma unroll
     for (int n = 0; n < 8; ++n) ev[n] = E[tid + 256 * n];
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
-        const int v = tid + 256 * n;                         // dword index 4v: [wave][i][j][r/2][lane]
-        const int gw = v >> 9, ij = (v >> 7) & 3, rp = (v >> 4) & 7, ln = (v & 15) * 4;
-        const int r = 2 * rp;
-        const int row = (gw >> 1) * 64 + (ij >> 1) * 32 + acc_row(r, ln), col = (gw & 1) * 64 + (ij & 1) * 32 + (ln & 31);
+        const int v = tid + 256 * n;                         // 16-byte index: [wave][i][j][r / 8][lane] x 4 dwords (row pairs r, r + 1)
+        const int gw = v >> 9, ij = (v >> 7) & 3, q = (v >> 6) & 1, ln = v & 63;
+        const int col = (gw & 1) * 64 + (ij & 1) * 32 + (ln & 31);
         const unsigned w[4] = {ev[n].x, ev[n].y, ev[n].z, ev[n].w};
-        const float r0 = rf[row], r1 = rf[row + 1];
-        float g0[4], g1[4];
+        const float c = cf[col];
+        const bool ok = cv[col];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float c = cf[col + j];
-            const bool ok = cv[col + j];
-            g0[j] = __uint_as_float(w[j] << 16) * ((ok ? r0 : 0.f) + c);
-            g1[j] = __uint_as_float(w[j] & 0xffff0000u) * ((ok ? r1 : 0.f) + c);
+            const int row = (gw >> 1) * 64 + (ij >> 1) * 32 + acc_row(8 * q + 2 * j, ln);
+            tile[row * LD + col] = f2bf(__uint_as_float(w[j] << 16) * ((ok ? rf[row] : 0.f) + c));
+            tile[(row + 1) * LD + col] = f2bf(__uint_as_float(w[j] & 0xffff0000u) * ((ok ? rf[row + 1] : 0.f) + c));
         }
-        *reinterpret_cast<uint2*>(tile + row * LD + col) = make_uint2(f2bf2(g0[0], g0[1]), f2bf2(g0[2], g0[3]));
-        *reinterpret_cast<uint2*>(tile + (row + 1) * LD + col) = make_uint2(f2bf2(g1[0], g1[1]), f2bf2(g1[2], g1[3]));
     }
     __syncthreads();
     if (a.diag && crange[0] <= c0 + 127 && crange[1] >= c0) {          // (block-uniform) 1-2 of a panel's column tiles
@@ -614,7 +677,9 @@ extern "C" int tan_simnce_max_cols(void) { return S_MAXCOLS; }
 
 extern "C" long tan_simnce_ws_floats(int S, int B, int T, int N) {
     const long R = (long)B * T, Mp = (long)B * N;
-    return 2 * (long)cdiv(R, 128) * S * Mp + (long)S * B * T * N;     // column partials (two per row panel) + same-video blocks
+    // column partials (two per row panel) + same-video blocks + the fragment-major text image of the resident sweep (bf16, per stage,
+    // columns rounded up to 128)
+    return 2 * (long)cdiv(R, 128) * S * Mp + (long)S * B * T * N + (long)S * cdiv(Mp, 128) * 128 * 512 / 2 + 4;
 }
 
 static int simnce_common(SimArgs& a, int S, int B, int T, int N, int C) {
@@ -683,6 +748,25 @@ static int simnce_diag_blocks(const SimArgs& a, const bf16_t* tn_blocks, long tb
     return 0;
 }
 
+static int simnce_cus() {
+    static const int n = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
+    return n;
+}
+
+// the resident sweep's text image lives behind the same-video blocks in `ws` (tan_simnce_ws_floats); a.Mp = columns of the sweep
+static int simnce_pack_text(SimArgs& a, float* ws_after_diag, hipStream_t st) {
+    char* base = (char*)(((uintptr_t)ws_after_diag + 15) & ~(uintptr_t)15);
+    const int nblk = cdiv(a.Mp, 128) * 4;
+    const bool shared = a.t_stage_stride == 0;
+    static const int rot = [] { const char* e = getenv("TAN_SIM_ROT"); return e ? atoi(e) : 1; }();
+    a.rot = rot;
+    a.Tp = base;
+    a.tp_stage_stride = shared ? 0 : (long)nblk * 32 * 1024;
+    hipLaunchKernelGGL(simnce_pack_text_kernel, dim3(nblk, shared ? 1 : a.S), dim3(256), 0, st, a.Tt, a.t_stage_stride, base, a.tp_stage_stride, a.Mp);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 // v_terms / t_terms of loss.py:240-253 straight from unit features (no logits); sums are kept for tan_simnce_bwd_dl.
 static int simnce_fwd_impl(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
                            const unsigned char* row_leak, float* rowsum, float* colsum, float* possum_v, float* possum_t,
@@ -714,7 +798,15 @@ static int simnce_fwd_impl(const void* vn, const void* tn, long t_stage_stride, 
         const bool res = res_enabled(a);
         if (ekeep && !res) return TAN_ERR_BAD_ARG;          // tan_simnce_keeps() said no
         a.ekeep = (bf16_t*)ekeep;
-        if (res) hipLaunchKernelGGL((simnce_res_kernel<0>), dim3(npanel, S), dim3(512), 0, st, a);
+        if (res && (rc = simnce_pack_text(a, diag + (long)S * B * T * N, st))) return rc;
+        if (res) {
+            const int items = npanel * S, ncu = simnce_cus(), rem = items % ncu;
+            a.npanel = npanel;
+            // (cutting the items of the last partial round in two column halves -- a.nfull = items - rem, the kernel supports it -- was
+            // measured: 130 vs 125 us per sweep, no gain: off)
+            a.nfull = items; (void)ncu; (void)rem;
+            hipLaunchKernelGGL((simnce_res_kernel<0>), dim3(a.nfull + 2 * (items - a.nfull)), dim3(512), 0, st, a);
+        }
         else hipLaunchKernelGGL((simnce_kernel<0>), dim3(npanel, S), dim3(256), 0, st, a);
         prof_end(st, prec);
         TAN_LAUNCH_CHECK();
@@ -795,7 +887,9 @@ static int simnce_bwd_impl(const void* vn, const void* tn, long t_stage_stride, 
         const int prec = prof_begin(st, TAN_PROF_SIMNCE, 2.0 * S * a.R * (double)a.Mp * C);
         if (res) {
             a.diag = tail ? diag : nullptr; a.colmap = colmap;
-            hipLaunchKernelGGL((simnce_res_kernel<1>), dim3(cdiv(a.R, 128), S), dim3(512), 0, st, a);
+            if ((rc = simnce_pack_text(a, diag + (long)S * B * T * N, st))) return rc;
+            a.npanel = cdiv(a.R, 128); a.nfull = a.npanel * S;
+            hipLaunchKernelGGL((simnce_res_kernel<1>), dim3(a.nfull), dim3(512), 0, st, a);
             if (tail) phases &= ~TAN_SIM_DIAG;
         } else hipLaunchKernelGGL((simnce_kernel<1>), dim3(cdiv(a.R, 128), S), dim3(256), 0, st, a);
         prof_end(st, prec);
