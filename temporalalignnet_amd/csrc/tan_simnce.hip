@@ -303,8 +303,10 @@ __device__ __forceinline__ void pn_static_for_s(F&& f) {
 // 1 KiB, lane l's 16 bytes = Tt[cb*32 + (l & 31)][16 ks + 8 (l >> 5) ..] -- the B operand of v_mfma_f32_32x32x16_bf16 as ONE coalesced
 // wave-load.  Columns past Mp repeat the last one (their logits are masked by col_ok).  grid (column blocks, stages), 256 threads.
 __global__ __launch_bounds__(256) void simnce_pack_text_kernel(const bf16_t* __restrict__ Tt, long t_stage_stride, char* __restrict__ Tp,
-                                                               long tp_stage_stride, int Mp) {
+                                                               long tp_stage_stride, int Mp, float* __restrict__ zero, long nzero) {
     const int cb = blockIdx.x, st = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (zero)      // the sweep's row sums start from zero (they meet in f32 atomics): was a memset launch in front of every sweep
+        for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < nzero; i += (long)gridDim.x * gridDim.y * 256) zero[i] = 0.f;
     const bf16_t* src = Tt + (long)st * t_stage_stride + (long)min(cb * 32 + (lane & 31), Mp - 1) * 512 + 8 * (lane >> 5);
     char* dst = Tp + (long)st * tp_stage_stride + (long)cb * 32 * 1024 + lane * 16;
     uint4 v[8];
@@ -669,6 +671,21 @@ __global__ void simnce_terms(const float* __restrict__ allsum, const float* __re
     terms[i] = den - num;
 }
 
+// v_terms and t_terms in one launch (they were two launches on the loss's serial chain)
+__global__ void simnce_terms2(const float* __restrict__ rowsum, const float* __restrict__ possum_v, float* __restrict__ v_terms, long SR,
+                              float log_cols, const float* __restrict__ colsum, const float* __restrict__ possum_t,
+                              float* __restrict__ t_terms, long SM, float log_rows) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= SR + SM) return;
+    const bool rows = i < SR;
+    const long k = rows ? i : i - SR;
+    const float all = rows ? rowsum[k] : colsum[k], pos = rows ? possum_v[k] : possum_t[k], lc = rows ? log_cols : log_rows;
+    const float shift = 1.0f / S_TAU;
+    const float den = logf(all) + shift;
+    const float num = pos > 0.f ? logf(pos) + shift : -6e4f + lc;
+    (rows ? v_terms : t_terms)[k] = den - num;
+}
+
 }  // namespace tal
 
 using namespace tal;
@@ -754,7 +771,7 @@ static int simnce_cus() {
 }
 
 // the resident sweep's text image lives behind the same-video blocks in `ws` (tan_simnce_ws_floats); a.Mp = columns of the sweep
-static int simnce_pack_text(SimArgs& a, float* ws_after_diag, hipStream_t st) {
+static int simnce_pack_text(SimArgs& a, float* ws_after_diag, hipStream_t st, float* zero = nullptr, long nzero = 0) {
     char* base = (char*)(((uintptr_t)ws_after_diag + 15) & ~(uintptr_t)15);
     const int nblk = cdiv(a.Mp, 128) * 4;
     const bool shared = a.t_stage_stride == 0;
@@ -762,7 +779,7 @@ static int simnce_pack_text(SimArgs& a, float* ws_after_diag, hipStream_t st) {
     a.rot = rot;
     a.Tp = base;
     a.tp_stage_stride = shared ? 0 : (long)nblk * 32 * 1024;
-    hipLaunchKernelGGL(simnce_pack_text_kernel, dim3(nblk, shared ? 1 : a.S), dim3(256), 0, st, a.Tt, a.t_stage_stride, base, a.tp_stage_stride, a.Mp);
+    hipLaunchKernelGGL(simnce_pack_text_kernel, dim3(nblk, shared ? 1 : a.S), dim3(256), 0, st, a.Tt, a.t_stage_stride, base, a.tp_stage_stride, a.Mp, zero, nzero);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -790,15 +807,16 @@ static int simnce_fwd_impl(const void* vn, const void* tn, long t_stage_stride, 
     hipStream_t st = (hipStream_t)stream;
     const long SM = (long)S * a.Mp, SR = (long)S * a.R;
     if (phases & TAN_SIM_SWEEP) {
-        if (!(phases & TAN_SIM_ACC_ROWS)) {
+        const bool res = res_enabled(a);
+        const bool zero_rows = !(phases & TAN_SIM_ACC_ROWS);
+        if (zero_rows && !res) {
             hipError_t e = hipMemsetAsync(rowsum, 0, sizeof(float) * (size_t)S * a.R, st);
             if (e != hipSuccess) return (int)e;
         }
         const int prec = prof_begin(st, TAN_PROF_SIMNCE, 2.0 * S * a.R * (double)a.Mp * C);
-        const bool res = res_enabled(a);
         if (ekeep && !res) return TAN_ERR_BAD_ARG;          // tan_simnce_keeps() said no
         a.ekeep = (bf16_t*)ekeep;
-        if (res && (rc = simnce_pack_text(a, diag + (long)S * B * T * N, st))) return rc;
+        if (res && (rc = simnce_pack_text(a, diag + (long)S * B * T * N, st, zero_rows ? rowsum : nullptr, (long)S * a.R))) return rc;
         if (res) {
             const int items = npanel * S, ncu = simnce_cus(), rem = items % ncu;
             a.npanel = npanel;
@@ -818,8 +836,8 @@ static int simnce_fwd_impl(const void* vn, const void* tn, long t_stage_stride, 
                            possum_v, possum_t, (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, B, T, N, colmap, a.Mp);
     }
     if (phases & TAN_SIM_TERMS) {
-        hipLaunchKernelGGL(simnce_terms, dim3(cdiv(SR, 256)), dim3(256), 0, st, rowsum, possum_v, v_terms, SR, logf((float)a.Mp));
-        hipLaunchKernelGGL(simnce_terms, dim3(cdiv(SM, 256)), dim3(256), 0, st, colsum, possum_t, t_terms, SM, logf((float)a.R));
+        hipLaunchKernelGGL(simnce_terms2, dim3(cdiv(SR + SM, 256)), dim3(256), 0, st, rowsum, possum_v, v_terms, SR, logf((float)a.Mp), colsum,
+                           possum_t, t_terms, SM, logf((float)a.R));
     }
     TAN_LAUNCH_CHECK();
     return 0;

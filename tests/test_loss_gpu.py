@@ -264,20 +264,25 @@ def test_bf16_self_labelling_floors_on_trained_weights():
     pos32, pos16 = a32["max_position_dual"].cpu().numpy(), a16["max_position_dual"].cpu().numpy()
     exact, near = (pos32 == pos16)[valid].mean(), (np.abs(pos32 - pos16) <= 1)[valid].mean()
     same = {k: (a32[k].cpu().numpy() == a16[k].cpu().numpy()).mean() for k in ("agreement_tgt", "dual_self_tgt", "joint_self_tgt")}
-    # ('loss-total' = the NCE before the loss_threshold re-weighting: the thresholded 'loss' keeps half of the ~30 real sentences, and
-    # one sentence crossing the quantile moves it by several per cent on these saturated logits -- 1.00 .. 1.23 run to run in bf16)
-    l32, l16 = res["fp32"][0]["loss-total"].item(), res["bf16"][0]["loss-total"].item()
-    loss_err = abs(l16 - l32) / max(1.0, abs(l32))       # (the trained loss is ~1e-2: absolute below 1)
+    # Loss magnitudes: the self-labelled cotrain losses are NOT compared -- on weights trained until the set's NCE is ~1e-3 the logits
+    # are saturated, and one window that moves by a frame (or one sentence crossing the threshold quantile) changes them by tens of per
+    # cent (bf16 0.60 vs fp32 0.43 for 'loss-total', 1.00 .. 1.29 vs 1.15 for 'loss', run to run).  What is compared is the NCE on the
+    # given (YouTube) targets, model='init': no discrete decisions between the forward and the number.
+    iargs = loss_ref.default_args()
+    nce = {}
+    for tag, m in (("fp32", m32), ("bf16", m16)):
+        with torch.no_grad():
+            lg = _hip_forward(m, d, grad=False)
+            nce[tag] = get_loss(b, d["video"], d["text_embed"], d["padding_mask"], d["text_padding_mask"], lg, iargs, d["abs_text_pos"])["loss"].item()
+    l32, l16 = nce["fp32"], nce["bf16"]
+    loss_err = abs(l16 - l32)
     msg = (f"trained weights (loss {first:.3f} -> {last:.3f}): argmax exact {exact:.3f} / within-1 {near:.3f}, targets "
-           f"{ {k: round(float(v), 4) for k, v in same.items()} }, NCE (loss-total) fp32 {l32:.4f} / bf16 {l16:.4f}, thresholded loss "
-           f"fp32 {res['fp32'][0]['loss'].item():.3f} / bf16 {res['bf16'][0]['loss'].item():.3f}")
+           f"{ {k: round(float(v), 4) for k, v in same.items()} }, NCE on the given targets fp32 {l32:.4f} / bf16 {l16:.4f}; cotrain loss "
+           f"fp32 {res['fp32'][0]['loss'].item():.3f} / bf16 {res['bf16'][0]['loss'].item():.3f} (not compared)")
     print(msg)
     assert near >= 0.90 and exact >= 0.75, msg
     assert min(same.values()) >= 0.97, msg
-    # measured on MI355X: argmax exact 0.967, targets >= 0.997, cotrain loss 1.18 (fp32) vs 1.23 (bf16): on weights trained until the
-    # NCE loss of the set is ~1e-3 the cosines sit near +-1 and the 1/0.07 temperature turns bf16's ~3e-3 cosine error into a few
-    # per cent of the re-weighted (thresholded + BCE) loss -- the index tensors, which drive the targets, stay within the floors
-    assert loss_err < 1e-1, msg
+    assert loss_err < 2e-2, msg          # (measured on MI355X: argmax exact 0.93-0.97, within one frame 1.000, targets >= 0.994)
 
 
 @pytest.mark.parametrize("B,T,N,fmt", [(4, 16, 5, "f32"), (128, 64, 16, "f32"), (37, 20, 31, "bool"), (200, 8, 12, "u8")])
