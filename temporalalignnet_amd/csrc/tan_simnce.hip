@@ -18,7 +18,8 @@ namespace tal {
 
 constexpr float S_TAU = 0.07f;
 constexpr int S_TILE = 128 * 64 * 2;  // 16 KiB operand tile
-constexpr int S_MAXCOLS = 2048;       // B*N limit of the fused path (LDS column accumulators)
+constexpr int S_MAXCOLS = 2048;       // column limit of simnce_kernel (LDS column accumulators)
+constexpr int S_MAXCOLS_RES = 8192;   // column limit of the resident sweep (column partials go to global rows: only the workspace grows)
 
 typedef const void __attribute__((address_space(1)))* sgptr_t;
 typedef void __attribute__((address_space(3)))* slptr_t;
@@ -690,7 +691,11 @@ __global__ void simnce_terms2(const float* __restrict__ rowsum, const float* __r
 
 using namespace tal;
 
-extern "C" int tan_simnce_max_cols(void) { return S_MAXCOLS; }
+extern "C" int tan_simnce_max_cols(void) {
+    SimArgs a{};
+    a.C = 512;
+    return res_enabled(a) ? S_MAXCOLS_RES : S_MAXCOLS;       // (C = 512, what the aligner runs; other channel counts: 2048)
+}
 
 extern "C" long tan_simnce_ws_floats(int S, int B, int T, int N) {
     const long R = (long)B * T, Mp = (long)B * N;
@@ -803,7 +808,7 @@ static int simnce_fwd_impl(const void* vn, const void* tn, long t_stage_stride, 
     float* diag = ws + 2 * (long)npanel * S * a.Mp;      // sized for the padded column count
     if (colmap) a.Mp = Mc;
     else { tn_blocks = tn; tb_stage_stride = t_stage_stride; }
-    if (a.Mp > S_MAXCOLS) return TAN_ERR_BAD_ARG;        // columns of the sweep (compacted or not): one LDS accumulator each
+    if (a.Mp > (res_enabled(a) ? S_MAXCOLS_RES : S_MAXCOLS)) return TAN_ERR_BAD_ARG;        // columns of the sweep (compacted or not)
     hipStream_t st = (hipStream_t)stream;
     const long SM = (long)S * a.Mp, SR = (long)S * a.R;
     if (phases & TAN_SIM_SWEEP) {
@@ -889,7 +894,7 @@ static int simnce_bwd_impl(const void* vn, const void* tn, long t_stage_stride, 
     float* diag = ws + 2 * (long)cdiv(a.R, 128) * S * a.Mp;
     if (colmap) a.Mp = Mc;
     else { tn_blocks = tn; tb_stage_stride = t_stage_stride; }
-    if (a.Mp > S_MAXCOLS) return TAN_ERR_BAD_ARG;        // columns of the sweep (compacted or not): one LDS accumulator each
+    if (a.Mp > (res_enabled(a) ? S_MAXCOLS_RES : S_MAXCOLS)) return TAN_ERR_BAD_ARG;        // columns of the sweep (compacted or not)
     if (ekeep && (phases & TAN_SIM_SWEEP)) {        // the statistics sweep kept its exponentials: one element-wise pass, corrections as its tail
         const bool tail = (phases & TAN_SIM_DIAG) != 0;
         if (tail && !(phases & TAN_SIM_DIAG_KEEP) && (rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;

@@ -91,7 +91,8 @@ def test_more_text_columns_than_the_fused_sweep_accepts_falls_back_to_logits():
     from temporalalignnet_amd import _lib
     from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
     lim = _lib.lib().tan_simnce_max_cols()
-    B, N = 72, 40
+    B = 72
+    N = lim // B + 12                     # (8192 columns for the resident sweep at C = 512: B*N = 9 000)
     b_np = synth.make_batch(3, B=B, T=16, n_min=N - 2, n_max=N)
     assert b_np["text_embed"].shape[1] == N and (b_np["text_padding_mask"] == 0).sum() > lim
     args = default_args(model="init", num_encoder_layers=1, num_decoder_layers=1)
@@ -108,7 +109,7 @@ def test_compaction_lifts_the_padded_column_count_over_the_sweep_limit():
     from temporalalignnet_amd import _lib
     from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
     lim = _lib.lib().tan_simnce_max_cols()
-    b_np = synth.make_batch(5, B=72, T=16, n_min=2, n_max=40)
+    b_np = synth.make_batch(5, B=72, T=16, n_min=2, n_max=lim // 72 + 12)
     B, N = b_np["text_embed"].shape[:2]
     n_text = int((b_np["text_padding_mask"] == 0).sum())
     assert B * N > lim and (n_text + 63) // 64 * 64 <= lim
