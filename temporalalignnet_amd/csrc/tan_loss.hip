@@ -516,7 +516,8 @@ extern "C" int tan_masked_quantile(const float* x, const unsigned char* invalid,
 //   tpad_u8 [B*N], vpad_u8 [B*T], valid (bool) and valid_f (f32) [B*N], tgt f32 [B,T,N] = transpose of the [B,N,T] bool start/end mask,
 //   and the text-column compaction of the fused sweeps: idx [Mc] (int64: the real sentences in order, then padded columns in order --
 //   what a stable sort of the pad flags gives), colmap [B*N] (int32: rank among the real sentences, -1 for padded columns),
-//   ci_run [Mc] (pad flags of the compacted columns).  One block; the ranks come from a block-wide prefix sum over <= 1024-column pieces.
+//   ci_run [Mc] (pad flags of the compacted columns).  Block 0 does the flags and the compaction (ranks from a block-wide prefix sum
+// over <= 1024-column pieces), the other blocks the element-wise outputs.
 __global__ __launch_bounds__(1024) void loss_prep_kernel(const float* tpad_f, const unsigned char* tpad_b, const unsigned char* vpad_b,
                                                          const unsigned char* tgt_raw, unsigned char* tpad_u8, unsigned char* vpad_u8,
                                                          unsigned char* valid, float* valid_f, float* tgt, long long* idx, int* colmap,
@@ -524,11 +525,16 @@ __global__ __launch_bounds__(1024) void loss_prep_kernel(const float* tpad_f, co
     __shared__ int scan[1024];
     __shared__ int base_valid, base_pad, n_valid_total;
     const int tid = threadIdx.x, Mp = B * N, R = B * T;
-    for (int i = tid; i < R; i += 1024) vpad_u8[i] = vpad_b[i] ? 1 : 0;
-    for (long i = tid; i < (long)B * T * N; i += 1024) {           // tgt[b][t][n] = tgt_raw[b][n][t]
-        const int n = (int)(i % N), t = (int)((i / N) % T), b = (int)(i / ((long)N * T));
-        tgt[i] = tgt_raw[((long)b * N + n) * T + t] ? 1.0f : 0.0f;
+    if (blockIdx.x > 0) {          // blocks 1..: the element-wise part (video pad bytes, the transposed f32 target), grid-strided
+        const long nb = gridDim.x - 1, g0 = (long)(blockIdx.x - 1) * 1024 + tid, gs = nb * 1024;
+        for (long i = g0; i < R; i += gs) vpad_u8[i] = vpad_b[i] ? 1 : 0;
+        for (long i = g0; i < (long)B * T * N; i += gs) {           // tgt[b][t][n] = tgt_raw[b][n][t]
+            const int n = (int)(i % N), t = (int)((i / N) % T), b = (int)(i / ((long)N * T));
+            tgt[i] = tgt_raw[((long)b * N + n) * T + t] ? 1.0f : 0.0f;
+        }
+        return;
     }
+    // block 0: the text pad flags and the column compaction (one block: the ranks need a prefix sum over all B*N columns)
     // first pass: total number of real sentences (the padded columns' ranks start behind them)
     int local = 0;
     for (int c = tid; c < Mp; c += 1024) {
@@ -607,7 +613,9 @@ extern "C" int tan_loss_prep(const float* text_pad_f32, const unsigned char* tex
     TAN_REQUIRE((text_pad_f32 != nullptr) != (text_pad_u8 != nullptr));
     TAN_REQUIRE(video_pad_u8 && tgt_raw && tpad_u8 && vpad_u8 && valid && valid_f && tgt && B > 0 && T > 0 && N > 0);
     TAN_REQUIRE(!idx || (colmap && ci_run && Mc > 0 && Mc <= B * N));
-    hipLaunchKernelGGL(loss_prep_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, text_pad_f32, text_pad_u8, video_pad_u8, tgt_raw,
+    const long nel = (long)B * T * N;
+    const unsigned nblk = 1 + (unsigned)((nel + 4095) / 4096 < 64 ? (nel + 4095) / 4096 : 64);
+    hipLaunchKernelGGL(loss_prep_kernel, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, text_pad_f32, text_pad_u8, video_pad_u8, tgt_raw,
                        tpad_u8, vpad_u8, valid, valid_f, tgt, (long long*)idx, colmap, ci_run, B, T, N, Mc);
     TAN_LAUNCH_CHECK();
     return 0;
