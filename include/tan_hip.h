@@ -255,6 +255,19 @@ int tan_simnce_bwd_dl_kept(const void* e_keep, const void* vn, const void* tn, l
  * for tan_nce_tail_bwd, which turns d loss/d out2 into the gradients of the four term tensors.  One launch each.
  * counts_in (optional, [2]): divide by these (GLOBAL) mask sums instead of the local ones -- global negatives, row f3.     */
 int tan_pos_masks(const float* tgt, const unsigned char* text_pad, float* rows_pos, float* cols_pos, int B, int T, int N, void* stream);
+/* Stage-2 glue of get_loss (train/loss.py:280-290,309-328,345) in one launch, B*N <= 8192: from md / mj [B*N] (tan_diag_max of the dual /
+ * joint last-stage same-video logits): metric = -(zscore(md) + zscore(mj)) over the real sentences, th = quantile(metric, q_th),
+ * th_mask (bytes) / th_f = (metric <= th) & real, rows_pos_th [B*T] = rows that own a positive among the kept real sentences of tgt
+ * [B,T,N]; with use_align: lab [B*N] (1 / 0 / 2 = ignore; 0 where the sentence's centre abs_text_pos.mean(-1) is < 0.2 or > 0.8;
+ * NaN on padded sentences), sel = (lab != 2) & real, y = lab * sel; scal8 = {n_sel, n_pos, pos_weight = n_sel / n_pos - 1,
+ * confidence ratio = mean(conf | real) (conf bytes or NULL), n_real, th, median(md), median(mj)}.
+ * tan_bce_sel_fwd: out2 = {sum(BCEWithLogits(x, y, pos_weight) * sel) / n_sel, sum(((x > 0) == y) * sel) / n_sel};
+ * tan_bce_sel_bwd: dx = g[0] * d bce / dx * sel / n_sel.                                                                           */
+int tan_stage2_masks(const float* md, const float* mj, const unsigned char* text_pad, const float* tgt, const float* abs_text_pos,
+                     const unsigned char* conf, float q_th, int use_align, int B, int T, int N, float* metric, unsigned char* th_mask,
+                     float* th_f, float* rows_pos_th, float* lab, float* sel, float* y, float* scal8, void* stream);
+int tan_bce_sel_fwd(const float* x, const float* y, const float* sel, const float* scal8, int n, float* out2, void* stream);
+int tan_bce_sel_bwd(const float* x, const float* y, const float* sel, const float* scal8, const float* g, int n, float* dx, void* stream);
 /* Everything get_loss derives from the batch's masks alone (train/loss.py:58-70: pad masks, the [B,T,N] start/end target) in one launch,
  * plus the text-column compaction of the logits-free sweeps: text_pad as f32 0/1 (train/main.py:62-65) OR as bytes (exactly one non-NULL),
  * video_pad bytes [B,T], tgt_raw bytes [B,N,T] (get_mask_from_time) -> tpad_u8 / valid (bytes) / valid_f (f32) [B*N], vpad_u8 [B*T],

@@ -512,6 +512,135 @@ extern "C" int tan_masked_quantile(const float* x, const unsigned char* invalid,
     return 0;
 }
 
+// ---- stage-2 glue of get_loss in ONE launch (train/loss.py:280-290, 309-328, 345): from the per-sentence maxima md / mj of the last-stage
+// same-video logits (tan_diag_max): z-scores over the real sentences, metric = -(z_d + z_j), th = quantile(metric, q), the kept-sentence
+// mask and the rows that still own a positive; the alignability labels (1: both maxima above their medians, 0: both below, 2: ignore;
+// 0 near the video's ends), their selection / target / counts / pos_weight; and confidence-ratio.  ~70 tiny torch kernels before.
+// One block; `buf` (dynamic LDS) holds npow2 floats for the three bitonic sorts.
+__device__ float s2_quantile(float* v, const float* x, const unsigned char* invalid, int n, int npow2, float q, int* cnt) {
+    if (threadIdx.x == 0) *cnt = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+        float val = INFINITY;
+        if (i < n && !invalid[i]) { val = x[i]; atomicAdd(cnt, 1); }
+        v[i] = val;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool up = ((i & k) == 0);
+                    const float a = v[i], b2 = v[ixj];
+                    if ((a > b2) == up) { v[i] = b2; v[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    const int m = *cnt;
+    float out = NAN;
+    if (m > 0) {
+        const float rank = q * (float)(m - 1);
+        const float lo = floorf(rank);
+        const int il = (int)lo, ih = min(il + 1, m - 1);
+        const float w = rank - lo, a = v[il], b2 = v[ih];
+        out = (w < 0.5f) ? a + w * (b2 - a) : b2 - (b2 - a) * (1.0f - w);  // at::lerp
+    }
+    __syncthreads();
+    return out;
+}
+
+__global__ __launch_bounds__(1024) void stage2_masks_kernel(const float* __restrict__ md, const float* __restrict__ mj,
+                                                            const unsigned char* __restrict__ tpad, const float* __restrict__ tgt,
+                                                            const float* __restrict__ abs_pos, const unsigned char* __restrict__ conf,
+                                                            float q_th, int use_align, int B, int T, int N, int npow2,
+                                                            float* __restrict__ metric, unsigned char* __restrict__ th_mask,
+                                                            float* __restrict__ th_f, float* __restrict__ rows_pos_th,
+                                                            float* __restrict__ lab_out, float* __restrict__ sel, float* __restrict__ y,
+                                                            float* __restrict__ scal) {
+    extern __shared__ float buf[];
+    __shared__ float red[16];
+    __shared__ int cnt;
+    const int tid = threadIdx.x, Mp = B * N;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int i = tid; i < Mp; i += 1024) {
+        const float v = tpad[i] ? 0.f : 1.f;
+        a0 += v; a1 += md[i] * v; a2 += mj[i] * v; a3 += (conf ? (float)conf[i] : 0.f) * v;
+    }
+    const float n_valid = block_sum_1024(a0, red), mean_d = block_sum_1024(a1, red) / n_valid, mean_j = block_sum_1024(a2, red) / n_valid;
+    const float conf_ratio = block_sum_1024(a3, red) / n_valid;
+    a0 = 0.f; a1 = 0.f;
+    for (int i = tid; i < Mp; i += 1024) {
+        const float v = tpad[i] ? 0.f : 1.f, dd = md[i] - mean_d, dj = mj[i] - mean_j;
+        a0 += dd * dd * v; a1 += dj * dj * v;
+    }
+    const float sd = sqrtf(block_sum_1024(a0, red) / (n_valid - 1.0f)), sj = sqrtf(block_sum_1024(a1, red) / (n_valid - 1.0f));
+    for (int i = tid; i < Mp; i += 1024) metric[i] = -((md[i] - mean_d) / sd + (mj[i] - mean_j) / sj);
+    __syncthreads();
+    const float th = s2_quantile(buf, metric, tpad, Mp, npow2, q_th, &cnt);
+    for (int i = tid; i < Mp; i += 1024) {
+        const bool keep = (metric[i] <= th) && !tpad[i];
+        th_mask[i] = keep; th_f[i] = keep ? 1.f : 0.f;
+    }
+    __syncthreads();
+    for (int r = tid; r < B * T; r += 1024) {            // rows that still own a positive among the kept, real sentences (loss.py:288-290)
+        const int b = r / T;
+        float acc = 0.f;
+        for (int k = 0; k < N; ++k) acc += tgt[(long)r * N + k] * (tpad[b * N + k] ? 0.f : 1.f) * th_f[b * N + k];
+        rows_pos_th[r] = acc > 0.f ? 1.f : 0.f;
+    }
+    float med_d = 0.f, med_j = 0.f, n_sel = 0.f, n_pos = 0.f;
+    if (use_align) {
+        med_d = s2_quantile(buf, md, tpad, Mp, npow2, 0.5f, &cnt);
+        med_j = s2_quantile(buf, mj, tpad, Mp, npow2, 0.5f, &cnt);
+        a0 = 0.f; a1 = 0.f;
+        for (int i = tid; i < Mp; i += 1024) {
+            float lab = 2.0f;
+            if (md[i] > med_d && mj[i] > med_j) lab = 1.0f;
+            if (md[i] < med_d && mj[i] < med_j) lab = 0.0f;
+            if (abs_pos) {
+                const float centre = (abs_pos[2 * i] + abs_pos[2 * i + 1]) / 2.0f;
+                if (centre < 0.2f || centre > 0.8f) lab = 0.0f;
+            }
+            const float sl = (lab != 2.0f && !tpad[i]) ? 1.f : 0.f;
+            sel[i] = sl; y[i] = lab * sl;
+            lab_out[i] = tpad[i] ? NAN : lab;
+            a0 += sl; a1 += lab * sl;
+        }
+        n_sel = block_sum_1024(a0, red);
+        n_pos = block_sum_1024(a1, red);
+    }
+    if (tid == 0) {
+        scal[0] = n_sel; scal[1] = n_pos; scal[2] = n_sel / n_pos - 1.0f; scal[3] = conf_ratio; scal[4] = n_valid; scal[5] = th;
+        scal[6] = med_d; scal[7] = med_j;
+    }
+}
+
+// BCE-with-logits of the alignability head on the selected sentences (loss.py:345-350: pos_weight = 1 / mean(label) - 1) and its top-1
+// agreement: out[0] = sum(bce * sel) / n_sel, out[1] = sum(((x > 0) == y) * sel) / n_sel; backward: dx = g * dbce/dx * sel / n_sel.
+__global__ __launch_bounds__(1024) void bce_sel_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ sel,
+                                                           const float* __restrict__ scal, int n, float* __restrict__ out) {
+    __shared__ float red[16];
+    const float pw = scal[2];
+    float a0 = 0.f, a1 = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float xi = x[i], yi = y[i], w = 1.0f + (pw - 1.0f) * yi;
+        const float l = (1.0f - yi) * xi + w * (log1pf(expf(-fabsf(xi))) + fmaxf(-xi, 0.f));
+        a0 += l * sel[i];
+        a1 += (((xi > 0.f) ? 1.f : 0.f) == yi ? 1.f : 0.f) * sel[i];
+    }
+    const float s0 = block_sum_1024(a0, red), s1 = block_sum_1024(a1, red);
+    if (threadIdx.x == 0) { out[0] = s0 / scal[0]; out[1] = s1 / scal[0]; }
+}
+__global__ void bce_sel_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ sel,
+                                   const float* __restrict__ scal, const float* __restrict__ g, int n, float* __restrict__ dx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float xi = x[i], yi = y[i], w = 1.0f + (scal[2] - 1.0f) * yi, sg = 1.0f / (1.0f + expf(-xi));
+    dx[i] = g[0] * ((1.0f - yi) - w * (1.0f - sg)) * sel[i] / scal[0];
+}
+
 // ---- everything get_loss derives from the batch's masks in ONE launch (prepare_inputs of loss.py; train/loss.py:58-70):
 //   tpad_u8 [B*N], vpad_u8 [B*T], valid (bool) and valid_f (f32) [B*N], tgt f32 [B,T,N] = transpose of the [B,N,T] bool start/end mask,
 //   and the text-column compaction of the fused sweeps: idx [Mc] (int64: the real sentences in order, then padded columns in order --
@@ -617,6 +746,36 @@ extern "C" int tan_loss_prep(const float* text_pad_f32, const unsigned char* tex
     const unsigned nblk = 1 + (unsigned)((nel + 4095) / 4096 < 64 ? (nel + 4095) / 4096 : 64);
     hipLaunchKernelGGL(loss_prep_kernel, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, text_pad_f32, text_pad_u8, video_pad_u8, tgt_raw,
                        tpad_u8, vpad_u8, valid, valid_f, tgt, (long long*)idx, colmap, ci_run, B, T, N, Mc);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_stage2_masks(const float* md, const float* mj, const unsigned char* text_pad, const float* tgt, const float* abs_text_pos,
+                                const unsigned char* conf, float q_th, int use_align, int B, int T, int N, float* metric,
+                                unsigned char* th_mask, float* th_f, float* rows_pos_th, float* lab, float* sel, float* y, float* scal8,
+                                void* stream) {
+    TAN_REQUIRE(md && mj && text_pad && tgt && metric && th_mask && th_f && rows_pos_th && scal8 && B > 0 && T > 0 && N > 0);
+    TAN_REQUIRE(!use_align || (lab && sel && y));
+    const int Mp = B * N;
+    TAN_REQUIRE(Mp <= 8192);
+    int p2 = 1;
+    while (p2 < Mp) p2 <<= 1;
+    hipLaunchKernelGGL(stage2_masks_kernel, dim3(1), dim3(1024), (size_t)p2 * 4, (hipStream_t)stream, md, mj, text_pad, tgt, abs_text_pos, conf,
+                       q_th, use_align, B, T, N, p2, metric, th_mask, th_f, rows_pos_th, lab, sel, y, scal8);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_bce_sel_fwd(const float* x, const float* y, const float* sel, const float* scal8, int n, float* out2, void* stream) {
+    TAN_REQUIRE(x && y && sel && scal8 && out2 && n > 0);
+    hipLaunchKernelGGL(bce_sel_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, y, sel, scal8, n, out2);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tan_bce_sel_bwd(const float* x, const float* y, const float* sel, const float* scal8, const float* g, int n, float* dx,
+                               void* stream) {
+    TAN_REQUIRE(x && y && sel && scal8 && g && dx && n > 0);
+    hipLaunchKernelGGL(bce_sel_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, sel, scal8, g, n, dx);
     TAN_LAUNCH_CHECK();
     return 0;
 }

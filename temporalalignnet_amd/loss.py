@@ -327,6 +327,35 @@ def _side_stream(dev):
     return st
 
 
+def _stage2_fused(fused, Mp):
+    """tan_stage2_masks computes rank-local batch statistics of up to 8192 sentences (global negatives: all-rank statistics, torch glue
+    with collectives); TAN_STAGE2_FUSED=0 keeps the torch glue (A/B and the parity test)."""
+    return (not getattr(fused, "global_negatives", False)) and Mp <= 8192 and os.environ.get("TAN_STAGE2_FUSED", "1") != "0"
+
+
+class _BCESelFn(torch.autograd.Function):
+    """BCE-with-logits of the alignability head over the selected sentences with pos_weight = 1/mean(label) - 1, and the head's top-1
+    agreement (train/loss.py:341-350): returns [bce, top1]; one launch each way."""
+
+    @staticmethod
+    def forward(ctx, x, y, sel, scal):
+        x = x.contiguous()
+        out = torch.empty(2, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().tan_bce_sel_fwd(_p(x), _p(y), _p(sel), _p(scal), C.c_int(x.numel()), _p(out), ops._stream()),
+                   "tan_bce_sel_fwd")
+        ctx.save_for_backward(x, y, sel, scal)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, sel, scal = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        g = g.contiguous()
+        _lib.check(_lib.lib().tan_bce_sel_bwd(_p(x), _p(y), _p(sel), _p(scal), _p(g), C.c_int(x.numel()), _p(dx), ops._stream()),
+                   "tan_bce_sel_bwd")
+        return dx, None, None, None
+
+
 def prepare_inputs(input_data, video_padding_mask, text_padding_mask, T, N, dev, args, n_text_valid=None, want_compaction=False):
     """Everything get_loss derives from the BATCH alone (train/loss.py:58-70,236-237): pad masks in the kernels' formats, the
     start/end target, and -- when no self-labelling rewrites the target -- the positive row / column masks and the text-column
@@ -363,7 +392,10 @@ def prepare_inputs(input_data, video_padding_mask, text_padding_mask, T, N, dev,
                                         C.c_int(N), C.c_int(Mc), ops._stream()), "tan_loss_prep")
     prep = {"tpad": tpad_u8.view(torch.bool), "tpad_u8": tpad_u8, "vpad_u8": vpad_u8, "valid": valid, "valid_f": valid_f,
             "tgt_raw": tgt_raw}
-    if not args.learn_agreement:
+    if args.learn_agreement:         # self-labelling inputs that depend on the batch alone (loss.py:113-115), off the critical path
+        prep["dur"] = tgt_raw.sum(-1).float().clamp(min=1.0).masked_fill(prep["tpad"], 0.0).contiguous()
+        prep["yt"] = tgt_raw.view(torch.uint8) if tgt_raw.dtype == torch.bool else tgt_raw.to(torch.uint8).contiguous()
+    else:
         prep["tgt"] = tgt                                                                             # [B,T,N]
         prep["rows_pos"], prep["cols_pos"] = _pos_masks(tgt, tpad_u8, B, T, N)
     if want_compaction:
@@ -437,7 +469,7 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
                 src_j, src_d = blk_j, blk_d
             else:
                 src_j, src_d = blk_j, blk_d
-            dur = tgt_raw.sum(-1).float().clamp(min=1.0).masked_fill(tpad, 0.0).contiguous()         # loss.py:113-115
+            dur = prep["dur"]                                                                         # loss.py:113-115
             J = _selflabel(src_j, vpad_u8, tpad_u8, dur, B, T, N)
             D = _selflabel(src_d, vpad_u8, tpad_u8, dur, B, T, N)
             quant = _quantile_global if getattr(fused, "global_negatives", False) else _quantile
@@ -446,12 +478,15 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
             tgt = torch.empty(B, T, N, device=dev)
             iou = torch.empty(B, N, device=dev)
             conf = torch.empty(B, N, dtype=torch.uint8, device=dev)
-            yt = tgt_raw.to(torch.uint8).contiguous()
+            yt = prep["yt"]
             _lib.check(_lib.lib().tan_agreement(_p(J["tgt"]), _p(D["tgt"]), _p(yt), _p(J["max_logit"]), _p(D["max_logit"]),
                                                 _p(q_j), _p(q_d), C.c_int(_KIND[args.temporal_agreement_type]), _p(tgt),
                                                 _p(iou), _p(conf), C.c_int(B), C.c_int(T), C.c_int(N), ops._stream()),
                        "tan_agreement")
-            out["confidence-ratio"] = (conf.view(Mp).float() * valid_f).sum() / valid_f.sum()
+            conf_done = False        # folded into tan_stage2_masks below when that launch runs anyway
+            if not ((args.loss_threshold > 0 or args.use_alignability_head) and _stage2_fused(fused, Mp)):
+                out["confidence-ratio"] = (conf.view(Mp).float() * valid_f).sum() / valid_f.sum()
+                conf_done = True
             out["iou-threshold"] = torch.full((), 0.5, device=dev)       # (torch.tensor(x, device=...) is a SYNCHRONOUS host-to-device copy)
             if not cotrain:      # reference in-place quirk: the -6e4 fills leak into the online logits (loss.py:96-101)
                 row_leak = vpad_u8.view(R)
@@ -513,26 +548,54 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
             mj = _diag_max(blk_j, row_leak, B, T, N)                                                  # loss.py:283
             glob_stats = nce_counts is not None      # global negatives: batch statistics over the sentences of every rank
             quant = _quantile_global if glob_stats else _quantile
+            s2 = None
+        if _stage2_fused(fused, Mp):
+            # rank-local statistics: z-scores, threshold, kept mask, surviving rows, alignability labels / counts / pos_weight and
+            # confidence-ratio in ONE launch (tan_stage2_masks; ~70 tiny ATen kernels before)
+            with torch.no_grad():
+                want_a = bool(args.use_alignability_head)
+                f32 = dict(device=dev, dtype=torch.float32)
+                s2 = dict(metric=torch.empty(Mp, **f32), th_mask=torch.empty(Mp, dtype=torch.bool, device=dev), th_f=torch.empty(Mp, **f32),
+                          rows=torch.empty(R, **f32), scal=torch.empty(8, **f32))
+                if want_a:
+                    s2.update(lab=torch.empty(Mp, **f32), sel=torch.empty(Mp, **f32), y=torch.empty(Mp, **f32))
+                pos = None
+                if want_a and abs_text_pos is not None:
+                    pos = abs_text_pos.to(dev, torch.float32).contiguous()
+                    if pos.numel() != 2 * Mp:
+                        raise ValueError("abs_text_pos must be [B, N, 2]")
+                cf = conf if (args.learn_agreement and not conf_done) else None
+                _lib.check(_lib.lib().tan_stage2_masks(_p(md), _p(mj), _p(tpad_u8), _p(tgt), _p(pos), _p(cf),
+                                                       C.c_float(float(args.loss_threshold)), C.c_int(int(want_a)), C.c_int(B),
+                                                       C.c_int(T), C.c_int(N), _p(s2["metric"]), _p(s2["th_mask"]), _p(s2["th_f"]),
+                                                       _p(s2["rows"]), _p(s2.get("lab")), _p(s2.get("sel")), _p(s2.get("y")),
+                                                       _p(s2["scal"]), ops._stream()), "tan_stage2_masks")
+                th_mask, th_f, rows_pos_th = s2["th_mask"], s2["th_f"], s2["rows"]
+                if cf is not None:
+                    out["confidence-ratio"] = s2["scal"][3]
+                aux.update(t_th_mask=th_mask, max_logits_dual_per_text=md, max_logits_joint_per_text=mj)
+        else:
+          with torch.no_grad():
 
-            def gsum(x):
-                if glob_stats:
-                    from . import dist as _dist
-                    _dist.allreduce_sum_(x)
-                return x
-            n_valid = gsum(valid_f.sum())
+              def gsum(x):
+                  if glob_stats:
+                      from . import dist as _dist
+                      _dist.allreduce_sum_(x)
+                  return x
+              n_valid = gsum(valid_f.sum())
 
-            def zscore(x):
-                mean = gsum((x * valid_f).sum()) / n_valid
-                var = gsum((((x - mean) ** 2) * valid_f).sum()) / (n_valid - 1)
-                return (x - mean) / var.sqrt()
+              def zscore(x):
+                  mean = gsum((x * valid_f).sum()) / n_valid
+                  var = gsum((((x - mean) ** 2) * valid_f).sum()) / (n_valid - 1)
+                  return (x - mean) / var.sqrt()
 
-            metric = -(zscore(md) + zscore(mj))
-            th = quant(metric, tpad_u8.view(-1), float(args.loss_threshold))                          # loss.py:286
-            th_mask = (metric <= th) & valid
-            th_f = th_mask.float()
-            tgt_valid = tgt * (~tpad)[:, None, :].float()
-            rows_pos_th = ((tgt_valid * th_f.view(B, 1, N)).sum(-1) > 0).view(R).float()              # loss.py:288-290
-            aux.update(t_th_mask=th_mask, max_logits_dual_per_text=md, max_logits_joint_per_text=mj)
+              metric = -(zscore(md) + zscore(mj))
+              th = quant(metric, tpad_u8.view(-1), float(args.loss_threshold))                          # loss.py:286
+              th_mask = (metric <= th) & valid
+              th_f = th_mask.float()
+              tgt_valid = tgt * (~tpad)[:, None, :].float()
+              rows_pos_th = ((tgt_valid * th_f.view(B, 1, N)).sum(-1) > 0).view(R).float()              # loss.py:288-290
+              aux.update(t_th_mask=th_mask, max_logits_dual_per_text=md, max_logits_joint_per_text=mj)
         glob = nce_counts is not None        # global negatives: the rank losses are SUMMED over ranks (gradients too), so every mean
         #                                      below divides its rank-local sum by the ALL-rank count (a rank-local mean
         #                                      would weigh these terms W times too much against the globally normalised NCE)
@@ -546,7 +609,14 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
                                      th_counts)
             loss_dual_th, loss_joint_th = pair_th[0], pair_th[1]
             out["loss-dual"], out["loss-joint"] = loss_dual_th.detach(), loss_joint_th.detach()
-        if args.use_alignability_head:
+        if args.use_alignability_head and s2 is not None:
+            aux["t_align_th_mask"] = s2["lab"]
+            a_joint = logits["joint_logits_alignability"][:, 2, :, 0].reshape(Mp)                     # stage index 2 (loss.py:341)
+            bt = _BCESelFn.apply(a_joint, s2["y"], s2["sel"], s2["scal"])
+            bce_joint = bt[0]
+            out["loss-joint-bce"] = bce_joint.detach()
+            out["alignability_top1"] = bt[1].detach()
+        elif args.use_alignability_head:
             with torch.no_grad():
                 med_d = quant(md, tpad_u8.view(-1), 0.5)                                              # loss.py:315-320
                 med_j = quant(mj, tpad_u8.view(-1), 0.5)

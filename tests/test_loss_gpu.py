@@ -312,3 +312,32 @@ def test_loss_prep_kernel_equals_the_torch_glue_it_replaces(B, T, N, fmt):
         for got, ref in zip(prep["nv"], want):
             assert torch.equal(got, ref.to(got.dtype))
         assert torch.equal(prep["cols_pos_c"], prep["cols_pos"].index_select(0, want[0]))
+
+
+@pytest.mark.parametrize("kw", [dict(loss_threshold=0.5), dict(loss_threshold=0.3, learn_agreement=0), dict(loss_threshold=0.0)])
+def test_stage2_masks_kernel_equals_the_torch_glue_it_replaces(monkeypatch, kw):
+    """tan_stage2_masks + tan_bce_sel_* (one launch each) against the ~70 ATen kernels they replace (TAN_STAGE2_FUSED=0): the kept /
+    label masks bit-exactly, every scalar and the alignability gradient to fp32 rounding, at a batch the goldens do not reach."""
+    b = synth.make_batch(23, B=24, T=40, n_min=3, n_max=17, video_pad_tail=5)
+    base = oracle_logits(P(107, 3, 3, True), b, 3, 3)
+    ema = oracle_logits(P(207, 3, 3, True), b, 3, 3)
+    a = dict(model="cotrain", temporal_agreement_type="keep")
+    a.update(kw)
+    args = loss_ref.default_args(**a)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TAN_STAGE2_FUSED", mode)
+        on = to_dev(base, ("logits_dual", "logits_joint", "joint_logits_alignability"))
+        ld, aux = run_hip(b, {**on, **{f"ema-{k}": v for k, v in to_dev(ema).items()}}, args)
+        ld["loss"].backward()
+        res[mode] = (ld, aux, on)
+    (l0, a0, o0), (l1, a1, o1) = res["0"], res["1"]
+    assert set(l0) == set(l1)
+    valid = ~torch.as_tensor(b["text_padding_mask"]).bool().view(-1)
+    assert torch.equal(a0["t_th_mask"].cpu()[valid], a1["t_th_mask"].cpu()[valid])
+    assert torch.equal(a0["t_align_th_mask"].cpu()[valid], a1["t_align_th_mask"].cpu()[valid])
+    assert torch.isnan(a1["t_align_th_mask"].cpu()[~valid]).all()
+    for k in l0:
+        np.testing.assert_allclose(l1[k].detach().cpu().numpy(), l0[k].detach().cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg=k)
+    for k in ("logits_dual", "logits_joint", "joint_logits_alignability"):
+        np.testing.assert_allclose(o1[k].grad.cpu().numpy(), o0[k].grad.cpu().numpy(), rtol=2e-5, atol=1e-9, err_msg=k)
