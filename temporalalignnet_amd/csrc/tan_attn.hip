@@ -835,6 +835,255 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_long_kernel(AttnArgs a) {
     rows_to_global(Di, k0, lane, out + 2 * C, ld, kt0, L);
 }
 
+// ======================================================================================================
+// Mid-length bf16 path (128 < L <= 288: the len=256 configuration, L = 256 video / 272 joint).  The short kernels' scheme with the
+// whole head resident: one workgroup per (video, head), ceil(L/32) waves (up to nine), q / k / v (/ dO) images staged ONCE
+// (110 / 147 KiB of LDS) -- the streamed kernels below re-staged K and V per 128-query block (and padded L = 272 to 3 x 3
+// blocks of 128: twice the work).  Forward: online softmax over chunks of three key blocks (the running max / sum is a per-lane
+// scalar in the transposed-score layout); backward: delta = rowsum(dO * O) from the O rows in global memory, then the short
+// kernel's two phases, each streaming the other axis one 32-row block at a time (no score panel in registers).
+template <int NKB>
+__global__ __launch_bounds__(64 * NKB) void attn_fwd_mid_kernel(AttnArgs a) {
+    constexpr int LP = 32 * NKB, CH = 3;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* Qi = smem; char* Ki = Qi + LP * 128; char* Vi = Ki + LP * 128;
+    float* bias = (float*)(Vi + LP * 128);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
+    const int C = a.H * DH, L = a.L;
+    const long ld = 3L * C;
+    const bf16_t* base = (const bf16_t*)a.qkv + (long)b * L * ld + h * DH;
+    stage_images<NKB>(smem, 0, 3, base, C, ld, L, wave, lane);
+    const unsigned char* kp = a.keypad ? a.keypad + (long)b * L : nullptr;
+    for (int j = tid; j < LP; j += 64 * NKB) bias[j] = (j >= L || (kp && kp[j])) ? -INFINITY : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int q0 = wave * 32;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = img_frag_kc(Qi, q0 + c, 2 * ks + hh);
+    f32x16 o[2];
+    acc_zero(o[0]); acc_zero(o[1]);
+    float m = -INFINITY, l = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < NKB; kc += CH) {
+        f32x16 s[CH];
+        float bm = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            if (kc + i >= NKB) continue;
+            const int kb = kc + i;
+            acc_zero(s[i]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Ki, 32 * kb + c, 2 * ks + hh), qf[ks], s[i], 0, 0, 0);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 bv = *reinterpret_cast<const float4*>(bias + 32 * kb + 8 * g4 + 4 * hh);
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = s[i][4 * g4 + e] * 0.125f + bb[e];
+                    s[i][4 * g4 + e] = v;
+                    bm = fmaxf(bm, v);
+                }
+            }
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float m_new = fmaxf(m, bm);
+        const bool dead = (m_new == -INFINITY);           // nothing but padded keys so far
+        const float alpha = dead ? 1.f : __expf(m - m_new);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            if (kc + i >= NKB) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = dead ? 0.f : __expf(s[i][r] - m_new);
+                s[i][r] = e;
+                sum += e;
+            }
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        l = l * alpha + sum;
+        m = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            if (kc + i >= NKB) continue;
+            const int kb = kc + i;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 pf = acc_frag(s[i], j);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_tr(Vi, 32 * kb + 16 * j, 32 * db, lane), pf, o[db], 0, 0, 0);
+            }
+        }
+    }
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    if (hh == 0 && q0 + c < L) a.lse[((long)b * a.H + h) * L + q0 + c] = l > 0.f ? m + logf(l) : -INFINITY;
+    tiles_to_rows(Qi, q0, c, hh, o, inv);               // the wave's own (now dead) q rows
+    rows_to_global(Qi, q0, lane, (bf16_t*)a.o + (long)b * L * C + h * DH, C, 0, L);
+}
+
+template <int NKB>
+__global__ __launch_bounds__(64 * NKB) void attn_bwd_mid_kernel(AttnArgs a) {
+    constexpr int LP = 32 * NKB;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* Qi = smem; char* Ki = Qi + LP * 128; char* Vi = Ki + LP * 128; char* Di = Vi + LP * 128;
+    float* bias = (float*)(Di + LP * 128);
+    float* lse_s = bias + LP;
+    float* delta_s = lse_s + LP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
+    const int C = a.H * DH, L = a.L;
+    const long ld = 3L * C;
+    const bf16_t* base = (const bf16_t*)a.qkv + (long)b * L * ld + h * DH;
+    const bf16_t* dOg = (const bf16_t*)a.d_o + (long)b * L * C + h * DH;
+    const bf16_t* Og = (const bf16_t*)a.o + (long)b * L * C + h * DH;
+    stage_images<NKB>(smem, 0, 3, base, C, ld, L, wave, lane);
+    stage_images<NKB>(smem, 3, 1, dOg, 0, C, L, wave, lane);
+    const unsigned char* kp = a.keypad ? a.keypad + (long)b * L : nullptr;
+    for (int j = tid; j < LP; j += 64 * NKB) {
+        bias[j] = (j >= L || (kp && kp[j])) ? -INFINITY : 0.f;
+        float lv = INFINITY;                     // rows past L and fully padded rows: p = exp(. - inf) = 0
+        if (j < L) { lv = a.lse[((long)b * a.H + h) * L + j]; if (lv == -INFINITY) lv = INFINITY; }
+        lse_s[j] = lv;
+    }
+    {   // delta[row] = sum_d dO[row][d] * O[row][d] straight from global memory (two lanes per row; rows past L: 0)
+        const int row = tid >> 1, half = tid & 1;
+        float acc = 0.f;
+        if (row < L) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8 d = *reinterpret_cast<const bf16x8*>(dOg + (long)row * C + (4 * half + j) * 8);
+                const bf16x8 o = *reinterpret_cast<const bf16x8*>(Og + (long)row * C + (4 * half + j) * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += (float)d[e] * (float)o[e];
+            }
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        if (half == 0 && row < LP) delta_s[row] = acc;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bf16_t* out = (bf16_t*)a.dqkv + (long)b * L * ld + h * DH;
+
+    f32x16 dq[2];
+    {   // ---- phase A: this wave's 32 queries against every key block: dq
+        const int q0 = wave * 32;
+        bf16x8 qf[4], dof[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qf[ks] = img_frag_kc(Qi, q0 + c, 2 * ks + hh); dof[ks] = img_frag_kc(Di, q0 + c, 2 * ks + hh); }
+        const float my_lse = lse_s[q0 + c], my_delta = delta_s[q0 + c];
+        acc_zero(dq[0]); acc_zero(dq[1]);
+#pragma unroll 1
+        for (int kb = 0; kb < NKB; ++kb) {
+            f32x16 p, dp;
+            acc_zero(p); acc_zero(dp);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Ki, 32 * kb + c, 2 * ks + hh), qf[ks], p, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Vi, 32 * kb + c, 2 * ks + hh), dof[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 bv = *reinterpret_cast<const float4*>(bias + 32 * kb + 8 * g4 + 4 * hh);
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pv = __expf(p[4 * g4 + e] * 0.125f + bb[e] - my_lse);
+                    p[4 * g4 + e] = pv * (dp[4 * g4 + e] - my_delta);            // dS^T
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 df = acc_frag(p, j);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_tr(Ki, 32 * kb + 16 * j, 32 * db, lane), df, dq[db], 0, 0, 0);
+            }
+        }
+    }
+    {   // ---- phase B: this wave's 32 keys against every query block: dk, dv (reads only the images: no barrier since phase A)
+        const int k0 = wave * 32;
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = img_frag_kc(Ki, k0 + c, 2 * ks + hh); vf[ks] = img_frag_kc(Vi, k0 + c, 2 * ks + hh); }
+        const float my_bias = bias[k0 + c];
+        f32x16 dk[2], dv[2];
+        acc_zero(dk[0]); acc_zero(dk[1]); acc_zero(dv[0]); acc_zero(dv[1]);
+#pragma unroll 1
+        for (int qb = 0; qb < NKB; ++qb) {
+            f32x16 p, dp;
+            acc_zero(p); acc_zero(dp);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Qi, 32 * qb + c, 2 * ks + hh), kf[ks], p, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Di, 32 * qb + c, 2 * ks + hh), vf[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 lv = *reinterpret_cast<const float4*>(lse_s + 32 * qb + 8 * g4 + 4 * hh);
+                const float4 dl = *reinterpret_cast<const float4*>(delta_s + 32 * qb + 8 * g4 + 4 * hh);
+                const float ll[4] = {lv.x, lv.y, lv.z, lv.w}, dd[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pv = __expf(p[4 * g4 + e] * 0.125f + my_bias - ll[e]);
+                    p[4 * g4 + e] = pv;
+                    dp[4 * g4 + e] = pv * (dp[4 * g4 + e] - dd[e]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 pf = acc_frag(p, j), df = acc_frag(dp, j);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_tr(Di, 32 * qb + 16 * j, 32 * db, lane), pf, dv[db], 0, 0, 0);
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_tr(Qi, 32 * qb + 16 * j, 32 * db, lane), df, dk[db], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();            // every wave is done with the images: each parks its three result tiles in its own rows
+        tiles_to_rows(Qi, k0, c, hh, dq, 0.125f);
+        tiles_to_rows(Ki, k0, c, hh, dk, 0.125f);
+        tiles_to_rows(Vi, k0, c, hh, dv, 1.0f);
+        rows_to_global(Qi, k0, lane, out, ld, 0, L);
+        rows_to_global(Ki, k0, lane, out + C, ld, 0, L);
+        rows_to_global(Vi, k0, lane, out + 2 * C, ld, 0, L);
+        if (a.gbias) {               // in_proj bias gradient: column sums of the 32 rows this wave parked (rows past L hold zeros)
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) {
+                const int row = k0 + r, off = row * 128 + (((lane >> 3) ^ img_swz(row)) << 4) + (lane & 7) * 2;
+                s0 += bf2f(*reinterpret_cast<const bf16_t*>(Qi + off));
+                s1 += bf2f(*reinterpret_cast<const bf16_t*>(Ki + off));
+                s2 += bf2f(*reinterpret_cast<const bf16_t*>(Vi + off));
+            }
+            float* g = a.gbias + h * DH + lane;
+            unsafeAtomicAdd(g, s0); unsafeAtomicAdd(g + C, s1); unsafeAtomicAdd(g + 2 * C, s2);
+        }
+    }
+}
+
+template <int NKB> static int launch_fwd_mid(const AttnArgs& a, hipStream_t st) {
+    const size_t sm = 3 * NKB * 32 * 128 + NKB * 32 * 4;
+    int rc = set_smem(attn_fwd_mid_kernel<NKB>, sm);
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_fwd_mid_kernel<NKB>), dim3(a.B * a.H), dim3(64 * NKB), sm, st, a);
+    return 0;
+}
+template <int NKB> static int launch_bwd_mid(const AttnArgs& a, hipStream_t st) {
+    const size_t sm = 4 * NKB * 32 * 128 + 3 * NKB * 32 * 4;
+    int rc = set_smem(attn_bwd_mid_kernel<NKB>, sm);
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_bwd_mid_kernel<NKB>), dim3(a.B * a.H), dim3(64 * NKB), sm, st, a);
+    return 0;
+}
+
 template <int NKB> static int launch_fwd_short(const AttnArgs& a, hipStream_t st) {
     const size_t sm = 3 * NKB * 32 * 128 + NKB * 32 * 4;
     int rc = set_smem(attn_fwd_short_kernel<NKB>, sm);
@@ -858,6 +1107,11 @@ using namespace tal;
 static bool long_path() {
     static const bool off = [] { const char* e = getenv("TAN_ATTN_GENERIC"); return e && e[0] == '1'; }();
     return !off;
+}
+// TAN_ATTN_MID=0 sends 128 < L <= 288 to the streamed kernels (A/B measurements)
+static bool mid_path(int dtype, int L) {
+    static const bool off = [] { const char* e = getenv("TAN_ATTN_MID"); return e && e[0] == '0'; }();
+    return dtype == TAN_BF16 && L > 128 && L <= 288 && !off && long_path();
 }
 static bool short_path(int dtype, int L) {
     static const bool off = [] { const char* e = getenv("TAN_ATTN_GENERIC"); return e && e[0] == '1'; }();
@@ -883,6 +1137,11 @@ extern "C" int tan_attn_fwd(const void* qkv, const unsigned char* key_padding_ma
         rc = nkb == 1 ? launch_fwd_short<1>(a, st) : nkb == 2 ? launch_fwd_short<2>(a, st)
            : nkb == 3 ? launch_fwd_short<3>(a, st) : launch_fwd_short<4>(a, st);
         if (rc) return rc;
+    } else if (mid_path(dtype, L)) {
+        const int nkb = (L + 31) / 32;
+        rc = nkb == 5 ? launch_fwd_mid<5>(a, st) : nkb == 6 ? launch_fwd_mid<6>(a, st) : nkb == 7 ? launch_fwd_mid<7>(a, st)
+           : nkb == 8 ? launch_fwd_mid<8>(a, st) : launch_fwd_mid<9>(a, st);
+        if (rc) return rc;
     } else if (dtype == TAN_BF16 && long_path()) {
         hipLaunchKernelGGL(attn_fwd_long_kernel, dim3(cdiv(L, LBLK), B * H), dim3(256), 0, st, a);
     } else if (dtype == TAN_BF16) {
@@ -899,7 +1158,7 @@ static int attn_bwd_impl(const void* qkv, const unsigned char* key_padding_mask,
                          const void* d_o, void* dqkv, float* g_b_qkv, int B, int L, int H, int dtype, void* stream) {
     TAN_REQUIRE(qkv && o && lse && d_o && dqkv && B > 0 && L > 0 && H > 0);
     AttnArgs a{};
-    const bool fuse = g_b_qkv && short_path(dtype, L);
+    const bool fuse = g_b_qkv && (short_path(dtype, L) || mid_path(dtype, L));
     a.gbias = fuse ? g_b_qkv : nullptr;
     a.qkv = qkv; a.keypad = key_padding_mask; a.o = (void*)o; a.lse = (float*)lse; a.d_o = d_o; a.dqkv = dqkv;
     a.B = B; a.L = L; a.H = H; a.Lpad = (L + 63) / 64 * 64;
@@ -916,6 +1175,11 @@ static int attn_bwd_impl(const void* qkv, const unsigned char* key_padding_mask,
         const int nkb = (L + 31) / 32;
         rc = nkb == 1 ? launch_bwd_short<1>(a, st) : nkb == 2 ? launch_bwd_short<2>(a, st)
            : nkb == 3 ? launch_bwd_short<3>(a, st) : launch_bwd_short<4>(a, st);
+        if (rc) return rc;
+    } else if (mid_path(dtype, L)) {
+        const int nkb = (L + 31) / 32;
+        rc = nkb == 5 ? launch_bwd_mid<5>(a, st) : nkb == 6 ? launch_bwd_mid<6>(a, st) : nkb == 7 ? launch_bwd_mid<7>(a, st)
+           : nkb == 8 ? launch_bwd_mid<8>(a, st) : launch_bwd_mid<9>(a, st);
         if (rc) return rc;
     } else if (dtype == TAN_BF16 && long_path()) {
         hipLaunchKernelGGL(attn_bwd_dq_long_kernel, dim3(cdiv(L, LBLK), B * H), dim3(256), 0, st, a);

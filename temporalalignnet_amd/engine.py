@@ -94,6 +94,7 @@ class _AlignerEngine(_WorkspaceMixin):
 
     def _encoder_fwd(self, er, x0, keypad, post_name, save=False):
         d = self._enc_desc(er, x0, keypad, post_name)
+        self._flat.join_images()
         d.no_save = 0 if save else 1         # no backward will follow: the tensors kept only for it are not written
         _lib.check(_lib.lib().tan_encoder_fwd(C.byref(d), ops._stream()), "tan_encoder_fwd")
 
@@ -114,6 +115,7 @@ class _AlignerEngine(_WorkspaceMixin):
     def _encoder_bwd(self, er, x0, keypad, post_name, d_stage, d_x0):
         cd, dev, R = x0.dtype, x0.device, er.R
         d = self._enc_desc(er, x0, keypad, post_name)
+        self._flat.join_images()
         if self._grad_ready_hook is not None:
             evs = self._layer_events(er.prefix, er.layers)
             ev_arr = (C.c_void_p * er.layers)(*evs)

@@ -103,6 +103,26 @@ class _Flat:
             self.shadow_p_epoch = self.shadow_epoch
         return self.shadow_p
 
+    def refresh_images_async(self, side, backward=True):
+        """After an optimizer step: rebuild every image derived from the bf16 shadow (packed tiles; W^T copies and their packed tiles
+        when a backward will need them) on `side`, next to whatever the caller's stream does before its first encoder kernel (the
+        input embeddings of the next step).  Consumers call `join_images` on the stream they launch on."""
+        if self.shadow is None:
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.sync_shadow_p()
+            if backward and self.shadow_t is not None:
+                self.sync_shadow_t()
+                if self.shadow_tp is not None:
+                    self.sync_shadow_tp()
+            self.images_event = side.record_event()
+
+    def join_images(self):
+        ev = getattr(self, "images_event", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)      # a finished event costs nothing on the GPU
+
     def sync_shadow(self):
         if self.shadow is not None and self.shadow_version != self.flat._version:
             ops.cast(self.flat, self.shadow)

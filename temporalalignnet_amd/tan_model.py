@@ -148,6 +148,13 @@ class TemporalAligner(_AlignerEngine, nn.Module):
             f.sync_shadow_p()
         return f
 
+    def _ensure_flat_nosync(self):
+        """The flat buffers without touching the derived images (the caller refreshes them itself)."""
+        f = self._flat
+        if not f.bound():
+            return self._ensure_flat()
+        return f
+
     def flat_parameters(self):
         return self._ensure_flat().flat
 

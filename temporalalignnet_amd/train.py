@@ -131,6 +131,13 @@ class Trainer:
         self.ddp_bucket_layers = max(1, int(os.environ.get("TAN_DDP_BUCKET_LAYERS", "2") if ddp_bucket_layers is None
                                             else ddp_bucket_layers))
         self._comm_streams = {}
+        self._opt_streams = {}
+        self._zero_ev = None
+        # TAN_STEP_ASYNC=1 (default): `step` fills the gradient buffer and rebuilds the weight images on a side stream, next to the
+        # next forward's input embeddings, instead of in front of them
+        self.step_async = os.environ.get("TAN_STEP_ASYNC", "1") != "0"
+        # TAN_OPT_OVERLAP=1: `step` issues each gradient bucket's AdamW update next to backward (see step)
+        self.opt_overlap = os.environ.get("TAN_OPT_OVERLAP", "0") != "0"
         # TAN_DDP_MODE: "buckets" (default) = per-layer-group all-reduces overlapped with backward; "flat" = ONE all-reduce of the whole
         # flat gradient after backward, what BASELINE.json's north_star literally describes -- an A/B switch for the first
         # multi-GPU run (no >1-GPU node was available to pick by measurement)
@@ -168,6 +175,12 @@ class Trainer:
         return self.args.lr * lr_multiplier(max(b + getattr(self, "_resume_bump", 0), 1), self.iter_per_epoch, self.args.epochs,
                                             self.warmup)
 
+    def _opt_stream(self, device):
+        st = self._opt_streams.get(device)
+        if st is None:
+            st = self._opt_streams[device] = torch.cuda.Stream(device=device)
+        return st
+
     def _comm_order_stream(self, device):
         """The stream the gradient collectives are issued under: it only ever waits for layer events, so a bucket's all-reduce
         is ordered after ITS layers and not after whatever else the compute streams have queued."""
@@ -203,9 +216,16 @@ class Trainer:
         lm = self.online.bert
         return [] if lm is None else [(n, p) for n, p in lm.named_parameters() if p.requires_grad]
 
-    def zero_grad(self):
+    def zero_grad(self, side=None):
+        """side: a stream to fill on -- the fill then runs next to the forward and `forward_backward` joins it before backward."""
         f = self.online._ensure_flat()
-        f.grad.zero_()
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                f.grad.zero_()
+                self._zero_ev = side.record_event()
+        else:
+            f.grad.zero_()
         self.online._bind_grads()
         for _, p in self._lm_params():
             p.grad = None
@@ -278,6 +298,9 @@ class Trainer:
             logits = {**logits, **{f"ema-{k}": v for k, v in ema.items()}}
         loss_dict = get_loss(batch, batch["video"], batch["text_embed"], batch["padding_mask"], batch["text_padding_mask"],
                              logits, a, batch.get("abs_text_pos"))
+        if self._zero_ev is not None:                  # the gradient buffer's fill ran on a side stream next to the forward
+            torch.cuda.current_stream().wait_event(self._zero_ev)
+            self._zero_ev = None
         loss_dict["loss"].backward()
         return loss_dict
 
@@ -302,10 +325,33 @@ class Trainer:
                 p.grad.copy_(g)
             off += p.numel()
 
-    def optimizer_step(self, grad_scale=1.0):
+    def _adamw_range(self, lo, hi, grad_scale, step):
+        """tan_adamw_step over flat[lo:hi) (+ its EMA twin range) on the current stream."""
+        f, st = self._ensure_state()
+        ema = self.model.target._ensure_flat() if self.twin else None
+        _lib.check(_lib.lib().tan_adamw_step(
+            _vp(f.flat[lo:hi]), _vp(f.grad[lo:hi]), _vp(st["m"][lo:hi]), _vp(st["v"][lo:hi]), _vp(st["mode"][lo:hi]), C.c_long(hi - lo),
+            C.c_double(self.current_lr()), C.c_double(self.betas[0]), C.c_double(self.betas[1]), C.c_double(self.eps),
+            C.c_double(self.args.wd), C.c_int(step), C.c_float(grad_scale), _vp(f.shadow[lo:hi]) if f.shadow is not None else None,
+            _vp(ema.flat[lo:hi]) if ema is not None else None, C.c_float(self.model.m if self.twin else 0.0),
+            _vp(ema.shadow[lo:hi]) if (ema is not None and ema.shadow is not None) else None, ops._stream()), "tan_adamw_step")
+
+    def optimizer_step(self, grad_scale=1.0, stepped=None):
+        """`stepped`: sorted [(lo, hi)] flat ranges whose AdamW update `step` already issued next to backward (same step count,
+        learning rate and grad_scale); the rest of the buffer follows here."""
         f, st = self._ensure_state()
         a = self.args
         self._lm_allreduce()
+        if stepped:
+            assert a.clip_grad <= 0
+            self.iteration += 1
+            for lo, hi in uncovered_ranges(stepped, f.total):
+                self._adamw_range(lo, hi, grad_scale, self.iteration)
+            f.shadow_epoch += 1
+            if self.twin:
+                self.model.target._ensure_flat().shadow_epoch += 1
+            self._lm_step(grad_scale)
+            return
         if a.clip_grad > 0:                            # per-parameter L2 clip, utils/train_utils.py:3-13 (language model included)
             for p in list(f.params) + [q for _, q in self._lm_params()]:
                 if p.grad is not None:
@@ -383,24 +429,51 @@ class Trainer:
         post-LNs) follow at the end in one call."""
         if not self._params_synced:
             self.sync_parameters()
-        self.zero_grad()
+        dev0 = self.online._ensure_flat().flat.device
+        aside = None
+        if self.step_async and dev0.type == "cuda":
+            from .loss import _side_stream
+            aside = _side_stream(dev0)
+        self.zero_grad(side=aside)
         world = dist.world_size()
-        pending, done = [], []
+        gscale = 1.0 if self.global_negatives else 1.0 / world
+        pending, done, stepped = [], [], []
+        # AdamW next to backward: a bucket's parameters (+ EMA twin, + bf16 shadows) are updated on a side stream as soon as its
+        # gradient is final (and, with N>1, summed), while earlier layers are still being differentiated -- the update is HBM-bound,
+        # backward is not.  Needs the whole-buffer options off: per-parameter clipping reads finished gradients from torch.
+        early = (self.opt_overlap and self.args.clip_grad <= 0 and not self._accum_open
+                 and not (dist.active() and self.ddp_mode == "flat"))
+        opt = self._opt_stream(self.online._ensure_flat().flat.device) if early else None
         if dist.active() and self.ddp_mode == "flat":
             flat = self.online.flat_grad()
-        elif dist.active():
+        elif dist.active() or early:
             flat = self.online.flat_grad()
-            comm = self._comm_order_stream(flat.device)
+            comm = self._comm_order_stream(flat.device) if dist.active() else None
+            if early:
+                self._ensure_state()
 
             def hook(tag, layer_events):
                 for lo, hi, last in self._ddp_buckets(tag, len(layer_events)):
                     # comm waits (on the GPU) for the event of the bucket's lowest layer; the process group's own stream
                     # then waits for comm, i.e. for exactly the layers this bucket covers
-                    _lib.check(_lib.lib().tan_stream_wait_event(C.c_void_p(comm.cuda_stream), C.c_void_p(layer_events[last])),
-                               "tan_stream_wait_event")
-                    with torch.cuda.stream(comm):
-                        pending.append(dist.allreduce_sum_(flat[lo:hi], async_op=True))
-                    done.append((lo, hi))
+                    work = None
+                    if comm is not None:
+                        _lib.check(_lib.lib().tan_stream_wait_event(C.c_void_p(comm.cuda_stream), C.c_void_p(layer_events[last])),
+                                   "tan_stream_wait_event")
+                        with torch.cuda.stream(comm):
+                            work = dist.allreduce_sum_(flat[lo:hi], async_op=True)
+                        done.append((lo, hi))
+                    if early:
+                        with torch.cuda.stream(opt):
+                            if work is not None:
+                                work.wait()                  # opt waits (on the GPU) for this bucket's all-reduce
+                            else:
+                                _lib.check(_lib.lib().tan_stream_wait_event(C.c_void_p(opt.cuda_stream),
+                                                                            C.c_void_p(layer_events[last])), "tan_stream_wait_event")
+                            self._adamw_range(lo, hi, gscale, self.iteration + 1)
+                        stepped.append((lo, hi))
+                    elif work is not None:
+                        pending.append(work)
             self.online._grad_ready_hook = hook
         try:
             loss_dict = self.forward_backward(batch)
@@ -418,7 +491,13 @@ class Trainer:
             if ev is not None:
                 ev[1].record()
                 self.comm_events.append(ev)
-        self.optimizer_step(grad_scale=1.0 if self.global_negatives else 1.0 / world)
+        if stepped:
+            torch.cuda.current_stream().wait_stream(opt)
+        self.optimizer_step(grad_scale=gscale, stepped=sorted(stepped))
+        if aside is not None:
+            self.online._ensure_flat_nosync().refresh_images_async(aside, backward=True)
+            if self.twin:
+                self.model.target._ensure_flat_nosync().refresh_images_async(aside, backward=False)
         self.batches_seen += 1
         self._resume_bump = 0
         return loss_dict

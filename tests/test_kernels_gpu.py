@@ -199,7 +199,8 @@ def _attn_ref(qkv, keypad, B, L, H):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("B,L,pad", [(2, 64, False), (3, 80, True), (1, 272, True), (2, 17, True), (2, 128, True), (2, 100, False), (2, 200, True), (1, 400, False)])
+@pytest.mark.parametrize("B,L,pad", [(2, 64, False), (3, 80, True), (1, 272, True), (2, 17, True), (2, 128, True), (2, 100, False), (2, 200, True), (1, 400, False),
+                                     (2, 129, True), (1, 160, False), (2, 192, True), (1, 224, True), (2, 256, True), (2, 288, True), (1, 289, True)])
 def test_attention_fwd_bwd(dtype, B, L, pad):
     from temporalalignnet_amd import ops
     H, C = 8, 512
@@ -231,7 +232,7 @@ def test_attention_fwd_bwd(dtype, B, L, pad):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("L", [64, 80, 272])
+@pytest.mark.parametrize("L", [64, 80, 272, 256, 400])
 def test_attention_with_every_key_padded_gives_zeros_not_nan(dtype, L):
     """Documented difference: a video whose keys are ALL padded makes nn.MultiheadAttention (tfm_model.py:32)
     return NaN for every query of that video -- softmax over an all -inf row.  The HIP kernels define that case as zeros:
