@@ -250,7 +250,8 @@ int tan_simnce_bwd_dl_kept(const void* e_keep, const void* vn, const void* tn, l
 
 /* NCE tail (loss.py:236-237,254-275).  tan_pos_masks: rows_pos[b*T+t] = 1 if frame t of video b has a positive among its
  * unpadded sentences, cols_pos[b*N+k] = 1 if sentence k is unpadded and has a positive frame (tgt [B,T,N] f32, text_pad [B,N]).
- * tan_nce_tail_fwd: out2[0] = (mean(v_d | rows_mask) + mean(t_d | cols_mask)) / 2 and out2[1] the same for the joint terms,
+ * tan_nce_tail_fwd: out2[0] = (mean(v_d | rows_mask) + mean(t_d | cols_mask)) / 2, out2[1] the same for the joint terms and
+ * out2[2] = (out2[0] + out2[1]) / 2 (THREE floats; tan_nce_tail_bwd takes d loss / d each of them, any may be NULL = 0),
  * mean(x | m) = sum_{s,k} x[s,k] m[k] / (S sum m)  (NaN for an empty mask, like .mean() of nothing); counts2 = mask sums, kept
  * for tan_nce_tail_bwd, which turns d loss/d out2 into the gradients of the four term tensors.  One launch each.
  * counts_in (optional, [2]): divide by these (GLOBAL) mask sums instead of the local ones -- global negatives, row f3.     */
@@ -279,8 +280,9 @@ int tan_loss_prep(const float* text_pad_f32, const unsigned char* text_pad_u8, c
 int tan_nce_tail_fwd(const float* v_d, const float* t_d, const float* v_j, const float* t_j, const float* rows_mask,
                      const float* cols_mask, int Sd, int Sj, long R, long M, float* out2, float* counts2, const float* counts_in,
                      void* stream);
-int tan_nce_tail_bwd(const float* g_out2, const float* rows_mask, const float* cols_mask, const float* counts2, int Sd, int Sj,
-                     long R, long M, float* g_v_d, float* g_t_d, float* g_v_j, float* g_t_j, void* stream);
+int tan_nce_tail_bwd(const float* g_dual, const float* g_joint, const float* g_mean, const float* rows_mask, const float* cols_mask,
+                     const float* counts2, int Sd, int Sj, long R, long M, float* g_v_d, float* g_t_d, float* g_v_j, float* g_t_j,
+                     void* stream);
 
 /* ---- sentence embedder (model/word2vec_model.py:76-102) ----------------------------------------
  * tan_embed_gather: out[r, 0:D] = table[ids[r], :] cast to `dtype`, out[r, D:Dpad] = 0 (ids NULL = identity: a padded

@@ -398,15 +398,18 @@ __global__ __launch_bounds__(1024) void nce_tail_fwd_kernel(const float* __restr
         const float nr = counts_in ? counts_in[0] : tot[4], nc = counts_in ? counts_in[1] : tot[5];    // global counts (row f3)
         out[0] = 0.5f * (tot[0] / (Sd * nr) + tot[1] / (Sd * nc));
         out[1] = 0.5f * (tot[2] / (Sj * nr) + tot[3] / (Sj * nc));
+        out[2] = (out[0] + out[1]) / 2.0f;                       // loss.py:352 (the default total), one launch less each way
         counts[0] = nr; counts[1] = nc;
     }
 }
 
-__global__ void nce_tail_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ rmask, const float* __restrict__ cmask,
+__global__ void nce_tail_bwd_kernel(const float* __restrict__ g_d, const float* __restrict__ g_j, const float* __restrict__ g_m,
+                                    const float* __restrict__ rmask, const float* __restrict__ cmask,
                                     const float* __restrict__ counts, int Sd, int Sj, long R, long M, float* __restrict__ g_v_d,
                                     float* __restrict__ g_t_d, float* __restrict__ g_v_j, float* __restrict__ g_t_j) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const float gd = 0.5f * g_out[0], gj = 0.5f * g_out[1];
+    const float gm = g_m ? 0.5f * g_m[0] : 0.f;
+    const float gd = 0.5f * ((g_d ? g_d[0] : 0.f) + gm), gj = 0.5f * ((g_j ? g_j[0] : 0.f) + gm);
     if (i < R) {
         const float m = rmask[i] / counts[0];
         for (int s = 0; s < Sd; ++s) g_v_d[(long)s * R + i] = gd * m / Sd;
@@ -725,11 +728,12 @@ extern "C" int tan_nce_tail_fwd(const float* v_d, const float* t_d, const float*
     return 0;
 }
 
-extern "C" int tan_nce_tail_bwd(const float* g_out2, const float* rows_mask, const float* cols_mask, const float* counts2, int Sd,
-                                int Sj, long R, long M, float* g_v_d, float* g_t_d, float* g_v_j, float* g_t_j, void* stream) {
-    TAN_REQUIRE(g_out2 && rows_mask && cols_mask && counts2 && g_v_d && g_t_d && g_v_j && g_t_j && Sd > 0 && Sj > 0 && R > 0 && M > 0);
+extern "C" int tan_nce_tail_bwd(const float* g_dual, const float* g_joint, const float* g_mean, const float* rows_mask,
+                                const float* cols_mask, const float* counts2, int Sd, int Sj, long R, long M, float* g_v_d, float* g_t_d,
+                                float* g_v_j, float* g_t_j, void* stream) {
+    TAN_REQUIRE((g_dual || g_joint || g_mean) && rows_mask && cols_mask && counts2 && g_v_d && g_t_d && g_v_j && g_t_j && Sd > 0 && Sj > 0 && R > 0 && M > 0);
     const long n = R > M ? R : M;
-    hipLaunchKernelGGL(nce_tail_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, g_out2, rows_mask, cols_mask,
+    hipLaunchKernelGGL(nce_tail_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, g_dual, g_joint, g_mean, rows_mask, cols_mask,
                        counts2, Sd, Sj, R, M, g_v_d, g_t_d, g_v_j, g_t_j);
     TAN_LAUNCH_CHECK();
     return 0;

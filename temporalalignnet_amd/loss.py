@@ -203,23 +203,26 @@ class _NCETail(torch.autograd.Function):
         v_d, t_d, v_j, t_j = (x.contiguous() for x in (v_d, t_d, v_j, t_j))
         (Sd, R), (Sj, M) = v_d.shape, t_j.shape
         assert t_d.shape == (Sd, M) and v_j.shape == (Sj, R)
-        out = torch.empty(4, device=v_d.device)               # [loss_dual, loss_joint, n_rows, n_cols]
+        out = torch.empty(5, device=v_d.device)               # [loss_dual, loss_joint, their mean, n_rows, n_cols]
         _lib.check(_lib.lib().tan_nce_tail_fwd(_p(v_d), _p(t_d), _p(v_j), _p(t_j), _p(rows_mask), _p(cols_mask), C.c_int(Sd),
-                                               C.c_int(Sj), C.c_long(R), C.c_long(M), _p(out), _p(out[2:]), _p(counts), ops._stream()),
+                                               C.c_int(Sj), C.c_long(R), C.c_long(M), _p(out), _p(out[3:]), _p(counts), ops._stream()),
                    "tan_nce_tail_fwd")
         ctx.saved = (rows_mask, cols_mask, out, Sd, Sj, R, M)
-        return out[:2]
+        ctx.set_materialize_grads(False)          # an unused output costs nothing (a zero fill per output otherwise)
+        return out[0], out[1], out[2]             # three scalars: no select / add / div nodes between the tail and the loss
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g_d, g_j, g_m):
         rows_mask, cols_mask, out, Sd, Sj, R, M = ctx.saved
         dev = out.device
-        g = g.contiguous()
+        if g_d is None and g_j is None and g_m is None:
+            return (None,) * 7
+        g_d, g_j, g_m = (None if g is None else g.contiguous().float() for g in (g_d, g_j, g_m))
         g_v_d, g_t_d = torch.empty(Sd, R, device=dev), torch.empty(Sd, M, device=dev)
         g_v_j, g_t_j = torch.empty(Sj, R, device=dev), torch.empty(Sj, M, device=dev)
-        _lib.check(_lib.lib().tan_nce_tail_bwd(_p(g), _p(rows_mask), _p(cols_mask), _p(out[2:]), C.c_int(Sd), C.c_int(Sj),
-                                               C.c_long(R), C.c_long(M), _p(g_v_d), _p(g_t_d), _p(g_v_j), _p(g_t_j), ops._stream()),
-                   "tan_nce_tail_bwd")
+        _lib.check(_lib.lib().tan_nce_tail_bwd(_p(g_d), _p(g_j), _p(g_m), _p(rows_mask), _p(cols_mask), _p(out[3:]), C.c_int(Sd),
+                                               C.c_int(Sj), C.c_long(R), C.c_long(M), _p(g_v_d), _p(g_t_d), _p(g_v_j), _p(g_t_j),
+                                               ops._stream()), "tan_nce_tail_bwd")
         return g_v_d, g_t_d, g_v_j, g_t_j, None, None, None
 
 
@@ -536,8 +539,7 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
         cols_tail = prep["cols_pos_c"] if (not args.learn_agreement and "cols_pos_c" in prep) else cols_pos.index_select(0, cols_idx)
     else:
         cols_tail = cols_pos
-    pair = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos, cols_tail, nce_counts)
-    loss_dual, loss_joint = pair[0], pair[1]
+    loss_dual, loss_joint, loss_mean = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos, cols_tail, nce_counts)
     out["loss-dual"], out["loss-joint"] = loss_dual.detach(), loss_joint.detach()
 
     if args.loss_threshold > 0 or args.use_alignability_head:
@@ -605,9 +607,8 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
             if glob:
                 from .dist_nce import global_counts
                 th_counts = global_counts(rows_pos_th, th_f)
-            pair_th = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos_th, th_f if cols_idx is None else th_f.index_select(0, cols_idx),
-                                     th_counts)
-            loss_dual_th, loss_joint_th = pair_th[0], pair_th[1]
+            loss_dual_th, loss_joint_th, loss_mean_th = _NCETail.apply(
+                v_d, t_d, v_j, t_j, rows_pos_th, th_f if cols_idx is None else th_f.index_select(0, cols_idx), th_counts)
             out["loss-dual"], out["loss-joint"] = loss_dual_th.detach(), loss_joint_th.detach()
         if args.use_alignability_head and s2 is not None:
             aux["t_align_th_mask"] = s2["lab"]
@@ -644,10 +645,10 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
 
     nce_w = 0 if args.optim_policy == "bce" else 1
     if args.loss_threshold > 0:
-        out["loss-total"] = ((loss_dual + loss_joint) / 2).detach()
-        loss = (loss_dual_th + loss_joint_th) / 2
+        out["loss-total"] = loss_mean.detach()
+        loss = loss_mean_th
     else:
-        loss = (loss_dual + loss_joint) / 2
+        loss = loss_mean
     if args.use_alignability_head:
         loss = loss * nce_w + bce_joint
     out["loss"] = loss
