@@ -929,6 +929,9 @@ __global__ __launch_bounds__(64 * NKB) void attn_fwd_mid_kernel(AttnArgs a) {
     rows_to_global(Qi, q0, lane, (bf16_t*)a.o + (long)b * L * C + h * DH, C, 0, L);
 }
 
+#ifndef TAN_MID_UNROLL
+#define TAN_MID_UNROLL 1
+#endif
 template <int NKB>
 __global__ __launch_bounds__(64 * NKB) void attn_bwd_mid_kernel(AttnArgs a) {
     constexpr int LP = 32 * NKB;
@@ -980,7 +983,7 @@ __global__ __launch_bounds__(64 * NKB) void attn_bwd_mid_kernel(AttnArgs a) {
         for (int ks = 0; ks < 4; ++ks) { qf[ks] = img_frag_kc(Qi, q0 + c, 2 * ks + hh); dof[ks] = img_frag_kc(Di, q0 + c, 2 * ks + hh); }
         const float my_lse = lse_s[q0 + c], my_delta = delta_s[q0 + c];
         acc_zero(dq[0]); acc_zero(dq[1]);
-#pragma unroll 1
+#pragma unroll TAN_MID_UNROLL
         for (int kb = 0; kb < NKB; ++kb) {
             f32x16 p, dp;
             acc_zero(p); acc_zero(dp);
@@ -1016,7 +1019,7 @@ __global__ __launch_bounds__(64 * NKB) void attn_bwd_mid_kernel(AttnArgs a) {
         const float my_bias = bias[k0 + c];
         f32x16 dk[2], dv[2];
         acc_zero(dk[0]); acc_zero(dk[1]); acc_zero(dv[0]); acc_zero(dv[1]);
-#pragma unroll 1
+#pragma unroll TAN_MID_UNROLL
         for (int qb = 0; qb < NKB; ++qb) {
             f32x16 p, dp;
             acc_zero(p); acc_zero(dp);
