@@ -438,6 +438,14 @@ typedef struct tan_mlp_bwd_desc {
      * image of out_proj.weight^T with TN = 512, TK = 16.  Saves the 8192 x 512 x 512 launch of tan_encoder_bwd. */
     const void* pwt_out;
     void* d_o;
+    /* Optional head (pwt_in != NULL; needs the ln_1 fields above, ln1_dxn = NULL): ln1_dxn is PRODUCED first, in LDS only:
+     *   ln1_dxn = dqkv W_in (+ dstage)  -- the dX GEMM of the NEXT block's attention in-projection (tfm_model.py:21: attn.in_proj) with
+     * dqkv [rows, 3C] bf16 (tan_attn_bwd's output), pwt_in = tan_pack_weights image of in_proj_weight^T [C][3C] (TN = 512, TK = 16),
+     * dstage [rows, C] bf16 or NULL = the deep-supervision gradient that joins at that ln_1 output.  Saves the 8192 x 1536 x 512
+     * launch per block of tan_encoder_bwd and the [rows, C] round trip of its result. */
+    const void* dqkv;
+    const void* pwt_in;
+    const void* dstage;
 } tan_mlp_bwd_desc;
 int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream);
 

@@ -185,6 +185,11 @@ static int attn_panel_enabled() {
     static const int on = [] { const char* e = getenv("TAN_ATTN_PANEL"); return e ? atoi(e) : 1; }();
     return on;
 }
+// TAN_PANEL_IN=0: the in_proj dX GEMM of a block as its own launch instead of the head of the next row-panel MLP backward
+static int panel_in_enabled() {
+    static const int on = [] { const char* e = getenv("TAN_PANEL_IN"); return e ? atoi(e) : 1; }();
+    return on;
+}
 static int panel_do_enabled() {
     static const int on = [] { const char* e = getenv("TAN_PANEL_DO"); return e ? atoi(e) : 1; }();
     return on;
@@ -264,7 +269,8 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
     const void* x_last = e->bufs[S - 1].x_out;
     // ln_1 backward of block i+1 handed to block i's row-panel MLP backward as its prologue (TAN_LN1_FUSED=0: its own launch); the
     // stack's post-LayerNorm backward goes to the last block the same way (no residual gradient next to it)
-    struct { bool on; int layer; const void *dxn, *x, *res; const float *mean, *rstd, *g; float *gg, *gb, *gcol; } pend{};
+    struct { bool on; int layer; const void *dxn, *x, *res; const float *mean, *rstd, *g; float *gg, *gb, *gcol;
+             const void *dqkv, *pwt_in, *dstage; } pend{};
     static const bool ln1_fused = [] { const char* v = getenv("TAN_LN1_FUSED"); return !v || atoi(v) != 0; }();
     const bool panel_all = ln1_fused && grouped_enabled() != 0 && panel_bwd_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0;
     if (e->d_stage[S - 1] && panel_all && e->params[S - 1].wtp_fc && e->params[S - 1].wtp_proj) {
@@ -304,6 +310,7 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
             if (pend.on) {
                 m.ln1_dxn = pend.dxn; m.ln1_x = pend.x; m.ln1_res = pend.res; m.ln1_mean = pend.mean; m.ln1_rstd = pend.rstd;
                 m.ln1_g = pend.g; m.g_ln1_g = pend.gg; m.g_ln1_b = pend.gb; m.g_dx_colsum = pend.gcol; m.dx_out = dx;
+                m.dqkv = pend.dqkv; m.pwt_in = pend.pwt_in; m.dstage = pend.dstage;      // (the in_proj dX GEMM in front of it, or NULLs)
             }
             // the out-projection's dX GEMM as the tail of the same launch (TAN_PANEL_DO=0: its own launch below)
             do_fused = panel_do_enabled() && p.wtp_out != nullptr &&
@@ -341,7 +348,11 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         if (!grouped) CK(linear_bwd_w(dt, e->scr_dqkv, b.xn1, p.g_w_qkv, R, 3 * C, C, e->dw_ws, e->dw_ws_floats, st));
         // stage i-1 IS this layer's xn1: its gradient joins here
         const void* dstage = i >= 1 ? e->d_stage[i - 1] : nullptr;
-        CK(linear_bwd_x(dt, e->scr_dqkv, p.w_qkv, p.wt_qkv, e->scr_dxn, R, 3 * C, C, TAN_ACT_NONE, nullptr, dstage, nullptr, st));
+        // block i-1's row-panel MLP backward takes the ln_1 backward as its prologue -- and (TAN_PANEL_IN) this dX GEMM in front of it
+        const bool ln1_next = i > 0 && panel_all && e->params[i - 1].wtp_fc && e->params[i - 1].wtp_proj;
+        const bool in_fused = ln1_next && panel_in_enabled() && p.wtp_qkv != nullptr;
+        if (!in_fused)
+            CK(linear_bwd_x(dt, e->scr_dqkv, p.w_qkv, p.wt_qkv, e->scr_dxn, R, 3 * C, C, TAN_ACT_NONE, nullptr, dstage, nullptr, st));
         if (grouped) {      // dx, scr_dh, dx2, scr_dqkv are all still intact here (LN1 backward below overwrites dx)
             const DwItem items[4] = {{e->scr_dh, b.xn2, p.g_w_fc, 4 * C, C}, {dx, b.h_act, p.g_w_proj, C, 4 * C},
                                      {e->scr_dqkv, b.xn1, p.g_w_qkv, 3 * C, C}, {dx2, b.attn_o, p.g_w_out, C, C}};
@@ -349,10 +360,11 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         }
         void* dx_in = i == 0 ? e->d_x0 : dx;
         float* next_b_proj = i > 0 ? e->params[i - 1].g_b_proj : nullptr;       // dx_in is layer i-1's x_out gradient
-        if (i > 0 && panel_all && e->params[i - 1].wtp_fc && e->params[i - 1].wtp_proj) {
-            // block i-1's row-panel MLP backward does this LayerNorm backward as its prologue (dx2 and scr_dxn stay untouched until
-            // that launch: it is the next one that writes them)
-            pend.on = true; pend.layer = i; pend.dxn = e->scr_dxn; pend.x = x_in; pend.res = dx2;
+        if (ln1_next) {
+            // block i-1's row-panel MLP backward does this LayerNorm backward as its prologue (dx2 and scr_dxn / scr_dqkv stay
+            // untouched until that launch: it is the next one that writes them)
+            pend.on = true; pend.layer = i; pend.dxn = in_fused ? nullptr : e->scr_dxn; pend.x = x_in; pend.res = dx2;
+            pend.dqkv = in_fused ? e->scr_dqkv : nullptr; pend.pwt_in = in_fused ? p.wtp_qkv : nullptr; pend.dstage = in_fused ? dstage : nullptr;
             pend.mean = b.mean1; pend.rstd = b.rstd1; pend.g = p.ln1_g; pend.gg = p.g_ln1_g; pend.gb = p.g_ln1_b; pend.gcol = next_b_proj;
             continue;
         }

@@ -86,6 +86,11 @@ struct MlpBwdArgs {
     // optional tail: d_o = dx2 W_out (the attention out-projection's dX GEMM) on the resident dx2 panel
     const char* pwt_out;        // packed W_out^T [512][512]  (tiles [512][16])
     bf16_t* d_o;
+    // optional head (MODE & 512, with the ln_1 prologue): ln1_dxn is not read but PRODUCED first, dxn1 = dqkv W_in (+ dstage) -- the
+    // dX GEMM of the NEXT block's attention in-projection, a [64 x 1536] x [1536 x 512] row-local product
+    const bf16_t* dqkv;         // [rows][1536]
+    const char* pwt_in;         // packed W_in^T [512][1536]  (tiles [512][16])
+    const bf16_t* dstage;       // [rows][512] or NULL: the deep-supervision gradient that joins at that ln_1 output
 };
 
 // Tiles are 16 KiB: c_fc [256 features][32 k], c_proj [512 features][16 k].  A weight fragment is consumed by exactly ONE wave
@@ -149,6 +154,14 @@ __device__ __forceinline__ void mlp_load_x_fc(MlpXFrags& F, const MlpXAddr& A) {
         F.f[2 * i + 0] = mlp_lds_frag<0>(A.xn[(cJ & 15) >> 1] + (cJ & ~15) * 16);
         F.f[2 * i + 1] = mlp_lds_frag<32 * 1024>(A.xn[(cJ & 15) >> 1] + (cJ & ~15) * 16);
     }
+}
+// fragments of K step KT (k = 16 KT) of a [64 rows][512] panel with 1-KiB rows at byte offset POFF from the input panel
+template <int KT, int POFF>
+__device__ __forceinline__ void mlp_load_x_k16(bf16x8 (&f)[2], const MlpXAddr& A) {
+    constexpr int cJ = KT * 2;
+    const unsigned a0 = A.xn[(cJ & 15) >> 1] + (cJ & ~15) * 16;
+    f[0] = mlp_lds_frag<POFF>(a0);
+    f[1] = mlp_lds_frag<POFF + 32 * 1024>(a0);
 }
 template <int KT>
 __device__ __forceinline__ void mlp_load_x_proj(MlpXFrags& F, const MlpXAddr& A, int hb) {
@@ -500,18 +513,106 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
             (void)*reinterpret_cast<const volatile uint32_t*>(q);
         }
     }
+    constexpr bool INP = BWD && (MODE & 512) != 0;      // the next block's in_proj dX GEMM runs first (its packed W_in^T leads the ring)
+    const char* pin = pfc;
+    if constexpr (INP) {
+        pin = a.pwt_in;
+        const int L = blockIdx.x * (64 * PN_WAVES) + tid;          // first touch of its 1.5 MiB as well
+        if (L < 12288) (void)*reinterpret_cast<const volatile uint32_t*>(pin + (long)L * 128);
+    }
     // the weight stream does not depend on the activations: start it before anything else (ring slots 0..7 = c_fc(0) tiles 0..7)
     MlpWFrags WQ[D];
     pn_static_for<0, D>([&](auto jc) {
         constexpr int J = decltype(jc)::value;
-        mlp_load_w(WQ[J], pfc + (long)J * TILE, wave, lane);
+        mlp_load_w(WQ[J], pin + (long)J * TILE, wave, lane);
     });
 
     // ---- prologue.  Forward: LN2 of the panel, 64 / PN_WAVES rows per wave (batches of 8), one 16-byte chunk per lane.  Backward:
     // the dx panel as it is.
+    if constexpr (INP) {
+        // ---- head: dxn1 = dqkv W_in (+ dstage), K = 1536 as three [64 x 512] panels of dqkv staged in the (idle) input / hidden
+        // panel space, "c_proj-like" (the wave owns 64 output features, 96 K-steps of 16); the result lands in the hidden panel space
+        // as the [64 x 512] bf16 panel the ln_1 backward below reads instead of HBM rows.  Was a launch of its own per block:
+        // 8192 x 1536 x 512 in 128 x 128 tiles, one workgroup of four waves per CU, 36 us of the whole chip at 14 % of its MFMA peak.
+        constexpr int RPW = PN_ROWS / PN_WAVES;
+        char* pX = lds + XN_OFF;
+        char* pH = lds + H_OFF;
+        // dqkv K panels go HBM -> LDS by LDS-DMA (no staging registers): one wave-instruction per 1-KiB panel row, the panel's chunk
+        // swizzle applied on the global side
+        auto stage_panel = [&](int kp, char* panel) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = wave * RPW + r;
+                const bf16_t* g = a.dqkv + (row0 + row) * 1536 + kp * 512 + ((lane ^ (row & 15)) << 3);
+                __builtin_amdgcn_global_load_lds((pn_gptr_t)g, (pn_lptr_t)(panel + row * 1024), 16, 0, 0);
+            }
+        };
+        stage_panel(0, pX);
+        stage_panel(1, pH);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x16 acc_d[MLP_NBO][2];
+#pragma unroll
+        for (int i = 0; i < MLP_NBO; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc_zero(acc_d[i][j]);
+        MlpXAddr XH;
+        mlp_xaddr_init(XH, lds, lane);
+        auto gemm_panel = [&](auto kpc, auto poffc) __attribute__((always_inline)) {
+            constexpr int KP = decltype(kpc)::value, POFF = decltype(poffc)::value;
+            bf16x8 xf[2][2];                   // the activation fragments of the even / odd steps: read one step ahead of their MFMAs
+            mlp_load_x_k16<0, POFF>(xf[0], XH);
+            pn_static_for<0, 32>([&](auto jc) {
+                constexpr int KT = decltype(jc)::value, T = KP * 32 + KT;
+                MlpWFrags& W = WQ[T % D];
+                if constexpr (KT < 31) mlp_load_x_k16<KT + 1, POFF>(xf[(KT + 1) & 1], XH);
+                const bf16x8 x0 = xf[KT & 1][0], x1 = xf[KT & 1][1];
+#pragma unroll
+                for (int nb = 0; nb < MLP_NBO; ++nb) {
+                    acc_d[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], x0, acc_d[nb][0], 0, 0, 0);
+                    acc_d[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], x1, acc_d[nb][1], 0, 0, 0);
+                }
+                if constexpr (T + D < 96) mlp_load_w(W, pin + (long)(T + D) * TILE, wave, lane);
+                else mlp_load_w(W, pfc + (long)(T + D - 96) * TILE, wave, lane);          // the ring ends on c_fc(0)'s first tiles
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        gemm_panel(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        __syncthreads();                       // every wave is done with K panel 0
+        stage_panel(2, pX);                    // in flight under K panel 1
+        gemm_panel(std::integral_constant<int, 1>{}, std::integral_constant<int, H_OFF - XN_OFF>{});
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * MLP_WFR) : "memory");     // (in-order returns: everything older than the ring's last D steps)
+        __syncthreads();                       // K panel 2 is in place, every wave is done with K panel 1
+        uint4 dsq[MLP_NBO][2][2];
+        const bf16_t* dsp = a.dstage ? a.dstage : a.ln1_x;                 // (unconditional loads; weighted below)
+        const float dmul = a.dstage ? 1.0f : 0.0f;
+#pragma unroll
+        for (int nb = 0; nb < MLP_NBO; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+                    dsq[nb][mb][pp] = *reinterpret_cast<const uint4*>(dsp + (row0 + mb * 32 + (lane & 31)) * 512 + wave * (32 * MLP_NBO) +
+                                                                      nb * 32 + 8 * pp + 16 * hi);
+        gemm_panel(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+#pragma unroll
+        for (int nb = 0; nb < MLP_NBO; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    float v[8], d8[8];
+                    pn_unpack8(dsq[nb][mb][pp], d8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = acc_d[nb][mb][8 * pp + e] + d8[e] * dmul;
+                    const int nu = wave * (32 * MLP_NBO) + nb * 32 + 8 * pp;
+                    *reinterpret_cast<uint4*>(pn_panel_slot<1024>(pH, mb * 32 + (lane & 31), (nu >> 3) + 2 * hi)) = pn_pack8(v);
+                }
+        __syncthreads();
+    }
     if constexpr (BWD) {
         constexpr int RPW = PN_ROWS / PN_WAVES;
-        if (a.ln1_dxn) {
+        if (INP || a.ln1_dxn) {
             // the next block's ln_1 backward, row by row (a wave owns whole rows, a lane 8 features: tan_norm.hip's arithmetic):
             // the result is this kernel's dx panel, and goes to HBM once for the weight-gradient launch that reads it later
             const f8 gm = ld8f(a.ln1_g + lane * 8);
@@ -526,8 +627,10 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const long row = row0 + wave * RPW + half * 4 + q;
-                    xv[q] = ld8(a.ln1_x + row * 512 + lane * 8); dv[q] = ld8(a.ln1_dxn + row * 512 + lane * 8);
-                    rv[q] = ld8((a.ln1_res ? a.ln1_res : a.ln1_dxn) + row * 512 + lane * 8);       // (unconditional load; weighted below)
+                    xv[q] = ld8(a.ln1_x + row * 512 + lane * 8);
+                    if constexpr (INP) dv[q] = ld8(reinterpret_cast<const bf16_t*>(pn_panel_slot<1024>(lds + H_OFF, wave * RPW + half * 4 + q, lane)));
+                    else dv[q] = ld8(a.ln1_dxn + row * 512 + lane * 8);
+                    rv[q] = ld8((a.ln1_res ? a.ln1_res : a.ln1_x) + row * 512 + lane * 8);       // (unconditional load; weighted below)
                     mean[q] = a.ln1_mean[row]; rstd[q] = a.ln1_rstd[row];
                 }
 #pragma unroll
@@ -559,6 +662,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                 }
             }
             // column sums over the panel's 64 rows: the eight waves meet in the (still unused) hidden-activation region
+            if constexpr (INP) __syncthreads();       // (which held the dxn1 panel: every wave has read its rows)
             float* red = reinterpret_cast<float*>(lds + H_OFF);       // [PN_WAVES][3][512]
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -928,10 +1032,13 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
             for (int i = 0; i < MLP_NBO; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc_zero(acc_d[i][j]);
+            bf16x8 xt[2][2];                   // activation fragments read one step ahead of their MFMAs
+            mlp_load_x_k16<0, 0>(xt[0], XA);
             pn_static_for<0, 32>([&](auto jc) {
                 constexpr int KT = decltype(jc)::value;
                 MlpWFrags& W = WQ[KT % D];
-                const bf16x8 x0 = pn_pfrag<1024>(lds + MLP_XN_OFF, 0, KT * 16, lane), x1 = pn_pfrag<1024>(lds + MLP_XN_OFF, 1, KT * 16, lane);
+                if constexpr (KT < 31) mlp_load_x_k16<KT + 1, 0>(xt[(KT + 1) & 1], XA);
+                const bf16x8 x0 = xt[KT & 1][0], x1 = xt[KT & 1][1];
 #pragma unroll
                 for (int nb = 0; nb < MLP_NBO; ++nb) {
                     acc_d[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], x0, acc_d[nb][0], 0, 0, 0);
@@ -1016,9 +1123,10 @@ extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
 
 extern "C" int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream) {
     TAN_REQUIRE(d && d->rows > 0 && d->rows % PN_ROWS == 0 && d->C == 512 && d->FF == 2048);
-    TAN_REQUIRE((d->dx || d->ln1_dxn) && d->h_pre && d->x_mid && d->mean2 && d->rstd2 && d->ln_g && d->pwt_proj && d->pwt_fc && d->dh && d->dx2);
+    TAN_REQUIRE((d->dx || d->ln1_dxn || d->pwt_in) && d->h_pre && d->x_mid && d->mean2 && d->rstd2 && d->ln_g && d->pwt_proj && d->pwt_fc && d->dh && d->dx2);
     TAN_REQUIRE(d->g_b_fc && d->g_ln_g && d->g_ln_b && d->g_b_out);
-    if (d->ln1_dxn) TAN_REQUIRE(d->ln1_x && d->ln1_mean && d->ln1_rstd && d->ln1_g && d->dx_out);
+    if (d->ln1_dxn || d->pwt_in) TAN_REQUIRE(d->ln1_x && d->ln1_mean && d->ln1_rstd && d->ln1_g && d->dx_out);
+    TAN_REQUIRE((d->pwt_in != nullptr) == (d->dqkv != nullptr) && !(d->pwt_in && d->ln1_dxn));
     MlpBwdArgs a;
     a.ln1_dxn = (const bf16_t*)d->ln1_dxn; a.ln1_x = (const bf16_t*)d->ln1_x; a.ln1_res = (const bf16_t*)d->ln1_res;
     a.ln1_mean = d->ln1_mean; a.ln1_rstd = d->ln1_rstd; a.ln1_g = d->ln1_g;
@@ -1030,13 +1138,16 @@ extern "C" int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream) {
     a.g_b_fc = d->g_b_fc; a.g_ln_g = d->g_ln_g; a.g_ln_b = d->g_ln_b; a.g_b_out = d->g_b_out;
     TAN_REQUIRE((d->pwt_out != nullptr) == (d->d_o != nullptr));
     a.pwt_out = (const char*)d->pwt_out; a.d_o = (bf16_t*)d->d_o;
+    a.dqkv = (const bf16_t*)d->dqkv; a.pwt_in = (const char*)d->pwt_in; a.dstage = (const bf16_t*)d->dstage;
     const dim3 grid((unsigned)(d->rows / PN_ROWS));
-    const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0 + (d->pwt_out ? 2.0 * d->rows * 512.0 * 512.0 : 0.0));
+    const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0 + (d->pwt_out ? 2.0 * d->rows * 512.0 * 512.0 : 0.0) +
+                                                                         (d->pwt_in ? 2.0 * d->rows * 1536.0 * 512.0 : 0.0));
 #ifdef TAN_PANEL_LAB
     if (getenv("TAN_PANEL_LAB_CLOCKS")) hipLaunchKernelGGL((mlp_panel_kernel<64, MlpBwdArgs>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
     else
 #endif
-    hipLaunchKernelGGL((mlp_panel_kernel<0, MlpBwdArgs>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
+    if (d->pwt_in) hipLaunchKernelGGL((mlp_panel_kernel<512, MlpBwdArgs>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((mlp_panel_kernel<0, MlpBwdArgs>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
     prof_end((hipStream_t)stream, rec);
     TAN_LAUNCH_CHECK();
     return 0;

@@ -69,8 +69,7 @@ class _AlignerEngine(_WorkspaceMixin):
                 setattr(arr[i], "g_" + k, f.ptr(f.grad, base + v))
                 setattr(arr[i], "wt_" + k[2:], f.ptr(wt, base + v) if wt is not None else None)
                 setattr(arr[i], "wp_" + k[2:], f.ptr(wp, base + v) if wp is not None else None)
-                if k in ("w_fc", "w_proj", "w_out"):
-                    setattr(arr[i], "wtp_" + k[2:], f.ptr(wtp, base + v) if wtp is not None else None)
+                setattr(arr[i], "wtp_" + k[2:], f.ptr(wtp, base + v) if wtp is not None else None)
             for k, v in fm.items():
                 setattr(arr[i], k, f.ptr(f.flat, base + v))
                 setattr(arr[i], "g_" + k, f.ptr(f.grad, base + v))

@@ -76,8 +76,8 @@ class _Flat:
                 for n in names:
                     o, _, (N, K) = self.off[n]
                     if transposed:
-                        if ".mlp.c_" not in n and not n.endswith("attn.out_proj.weight"):     # (in_proj^T has no row-panel consumer)
-                            continue
+                        # (all four have a row-panel consumer in the backward: the MLP's two dX GEMMs, the out_proj dX tail, the
+                        #  in_proj dX head)
                         N, K = K, N
                     TN, TK = (512, 16) if N == 512 else (256, 32)
                     if not transposed and n.endswith("attn.in_proj_weight"):

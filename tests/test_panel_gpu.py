@@ -243,6 +243,77 @@ def test_mlp_bwd_with_the_next_blocks_ln1_backward_as_prologue():
         assert torch.allclose(acc0[k], acc1[k], rtol=1e-4, atol=1e-5), k
 
 
+@pytest.mark.parametrize("with_stage", [False, True])
+def test_mlp_bwd_with_the_next_blocks_in_proj_dx_gemm_as_head(with_stage):
+    """tan_mlp_bwd with pwt_in set: ln1_dxn = dqkv W_in (+ dstage) is computed in the kernel (LDS only) in front of the ln_1 backward
+    prologue -- against the GEMM launch it replaces followed by the ln1_dxn form of the same kernel; and the GEMM itself against fp32."""
+    _lib, ops = _lib_ops()
+    R, bf = 320, torch.bfloat16
+    torch.manual_seed(11)
+    x_mid = (torch.randn(R, 512, device="cuda") * 1.5).to(bf)
+    wfc = (torch.randn(2048, 512, device="cuda") * 1024 ** -0.5).to(bf)
+    wpj = (torch.randn(512, 2048, device="cuda") * 0.03).to(bf)
+    w_in = (torch.randn(1536, 512, device="cuda") * 512 ** -0.5).to(bf)
+    g2 = 1 + 0.1 * torch.randn(512, device="cuda")
+    x = x_mid.float()
+    mean2, rstd2 = x.mean(-1), (x.var(-1, unbiased=False) + 1e-5).rsqrt()
+    h_pre = (torch.randn(R, 2048, device="cuda")).to(bf)
+    pwt_proj, pwt_fc, pwt_in = pack([wpj.T.contiguous(), wfc.T.contiguous(), w_in.T.contiguous()])
+    x_out = (torch.randn(R, 512, device="cuda") * 2).to(bf)
+    dqkv = (torch.randn(R, 1536, device="cuda") * 0.02).to(bf)
+    dstage = (torch.randn(R, 512, device="cuda") * 0.02).to(bf) if with_stage else None
+    res = (torch.randn(R, 512, device="cuda") * 0.02).to(bf)
+    g1 = 1 + 0.1 * torch.randn(512, device="cuda")
+    xo = x_out.float()
+    mean1, rstd1 = xo.mean(-1).contiguous(), (xo.var(-1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    r_dxn = dqkv.float() @ w_in.float() + (dstage.float() if with_stage else 0.0)
+    dxn = r_dxn.to(bf)                                     # what the stand-alone GEMM stores (one rounding of the f32 sum)
+
+    def run(head):
+        dh = torch.zeros(R, 2048, device="cuda", dtype=bf)
+        dx2 = res.clone()
+        dx = torch.full((R, 512), float("nan"), device="cuda", dtype=bf)
+        acc = {k: torch.full((n,), 0.5, device="cuda") for k, n in (("g_b_fc", 2048), ("g_ln_g", 512), ("g_ln_b", 512),
+                                                                       ("g_b_out", 512), ("g_ln1_g", 512), ("g_ln1_b", 512),
+                                                                       ("g_b_proj", 512))}
+        d = _lib.MlpBwdDesc()
+        d.rows, d.C, d.FF = R, 512, 2048
+        d.h_pre, d.x_mid = h_pre.data_ptr(), x_mid.data_ptr()
+        d.mean2, d.rstd2, d.ln_g = mean2.data_ptr(), rstd2.data_ptr(), g2.data_ptr()
+        d.pwt_proj, d.pwt_fc = pwt_proj.data_ptr(), pwt_fc.data_ptr()
+        d.dh, d.dx2 = dh.data_ptr(), dx2.data_ptr()
+        d.g_b_fc, d.g_ln_g, d.g_ln_b, d.g_b_out = (acc[k].data_ptr() for k in ("g_b_fc", "g_ln_g", "g_ln_b", "g_b_out"))
+        d.ln1_x, d.ln1_res = x_out.data_ptr(), dx2.data_ptr()
+        d.ln1_mean, d.ln1_rstd, d.ln1_g = mean1.data_ptr(), rstd1.data_ptr(), g1.data_ptr()
+        d.g_ln1_g, d.g_ln1_b, d.g_dx_colsum = acc["g_ln1_g"].data_ptr(), acc["g_ln1_b"].data_ptr(), acc["g_b_proj"].data_ptr()
+        d.dx_out = dx.data_ptr()
+        if head:
+            d.dqkv, d.pwt_in = dqkv.data_ptr(), pwt_in.data_ptr()
+            d.dstage = dstage.data_ptr() if with_stage else None
+        else:
+            d.ln1_dxn = dxn.data_ptr()
+        _lib.check(_lib.lib().tan_mlp_bwd(C.byref(d), ops._stream()), "tan_mlp_bwd")
+        torch.cuda.synchronize()
+        return dx, dh, dx2, acc
+
+    dx0, dh0, dx20, acc0 = run(False)
+    dx1, dh1, dx21, acc1 = run(True)
+    # the head accumulates K = 1536 in another order than the reference product: dxn1 differs by a bf16 rounding step on a few
+    # elements, and everything downstream by as much
+    for got, ref, what in ((dx1, dx0, "dx"), (dh1, dh0, "dh"), (dx21, dx20, "dx2")):
+        assert torch.isfinite(got.float()).all(), what
+        err = (got.float() - ref.float()).abs().max().item()
+        assert err <= 2.0 ** -6 * ref.float().abs().max().item(), (what, err)
+        assert (got != ref).float().mean().item() < 0.10, what
+    for k in acc0:
+        assert torch.allclose(acc0[k], acc1[k], rtol=2e-3, atol=2e-4), k
+    # both at once is a contradiction; the head without the ln_1 fields too
+    d = _lib.MlpBwdDesc()
+    d.rows, d.C, d.FF = R, 512, 2048
+    d.pwt_in = pwt_in.data_ptr()
+    assert _lib.lib().tan_mlp_bwd(C.byref(d), ops._stream()) == -1
+
+
 def test_mlp_bwd_rejects_what_it_cannot_do():
     _lib, ops = _lib_ops()
     d = _lib.MlpBwdDesc()
