@@ -446,6 +446,9 @@ typedef struct tan_mlp_bwd_desc {
     const void* dqkv;
     const void* pwt_in;
     const void* dstage;
+    /* head_only != 0 (with pwt_in): nothing but dx_out = ln1_res + LayerNorm-backward(dqkv W_in + dstage) and its three column sums --
+     * block 0 of a stack, whose ln_1 backward has no MLP backward below it to ride on; every MLP field may be NULL. */
+    int head_only;
 } tan_mlp_bwd_desc;
 int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream);
 

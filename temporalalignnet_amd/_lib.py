@@ -142,7 +142,7 @@ class MlpBwdDesc(C.Structure):
         ("ln1_mean", C.c_void_p), ("ln1_rstd", C.c_void_p), ("ln1_g", C.c_void_p),
         ("g_ln1_g", C.c_void_p), ("g_ln1_b", C.c_void_p), ("g_dx_colsum", C.c_void_p), ("dx_out", C.c_void_p),
         ("pwt_out", C.c_void_p), ("d_o", C.c_void_p),
-        ("dqkv", C.c_void_p), ("pwt_in", C.c_void_p), ("dstage", C.c_void_p),
+        ("dqkv", C.c_void_p), ("pwt_in", C.c_void_p), ("dstage", C.c_void_p), ("head_only", C.c_int),
     ]
 
 

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     // miss goes to HBM in the middle of the kernel's own 100 MB of side-output writes and the ring (eight steps) cannot cover that
     // latency: 97-104 us per launch against 72-77 us with the weights resident in the Infinity Cache (tools/lab/mlp_lab.py, E2/E3).
     // So the whole set is requested up front, one dword per 128-byte line spread over the first 64 workgroups, while HBM is quiet.
-    if (!(MODE & 256)) {
+    if (!(MODE & (256 | 1024))) {
         const int L = blockIdx.x * (64 * PN_WAVES) + tid;
         if (L < 32768) {
             const char* q = L < 16384 ? pfc + (long)L * 128 : ppj + (long)(L - 16384) * 128;
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                     acc_d[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], x1, acc_d[nb][1], 0, 0, 0);
                 }
                 if constexpr (T + D < 96) mlp_load_w(W, pin + (long)(T + D) * TILE, wave, lane);
-                else mlp_load_w(W, pfc + (long)(T + D - 96) * TILE, wave, lane);          // the ring ends on c_fc(0)'s first tiles
+                else if constexpr (!(MODE & 1024)) mlp_load_w(W, pfc + (long)(T + D - 96) * TILE, wave, lane);   // the ring ends on c_fc(0)'s first tiles
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
@@ -716,6 +716,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
             }
         }
     }
+    if constexpr (BWD && (MODE & 1024) != 0) return;      // head only (block 0: the stack's input gradient is the ln_1 backward's output)
     __syncthreads();
 
     f32x16 acc_o[MLP_NBO][2];      // [feature block of the wave's output features][row block]
@@ -1123,6 +1124,21 @@ extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
 
 extern "C" int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream) {
     TAN_REQUIRE(d && d->rows > 0 && d->rows % PN_ROWS == 0 && d->C == 512 && d->FF == 2048);
+    if (d->head_only) {        // dx_out = ln1_res + LN-backward(dqkv W_in + dstage): the head and the ln_1 prologue, nothing else
+        TAN_REQUIRE(d->pwt_in && d->dqkv && !d->ln1_dxn && d->ln1_x && d->ln1_mean && d->ln1_rstd && d->ln1_g && d->dx_out);
+        MlpBwdArgs a{};
+        a.ln1_x = (const bf16_t*)d->ln1_x; a.ln1_res = (const bf16_t*)d->ln1_res;
+        a.ln1_mean = d->ln1_mean; a.ln1_rstd = d->ln1_rstd; a.ln1_g = d->ln1_g;
+        a.g_ln1_g = d->g_ln1_g; a.g_ln1_b = d->g_ln1_b; a.g_dx_colsum = d->g_dx_colsum; a.dx_out = (bf16_t*)d->dx_out;
+        a.dqkv = (const bf16_t*)d->dqkv; a.pwt_in = (const char*)d->pwt_in; a.dstage = (const bf16_t*)d->dstage;
+        a.pw_fc = a.pwt_in; a.pw_proj = a.pwt_in;
+        const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 1536.0 * 512.0);
+        hipLaunchKernelGGL((mlp_panel_kernel<512 | 1024, MlpBwdArgs>), dim3((unsigned)(d->rows / PN_ROWS)), dim3(64 * PN_WAVES), 0,
+                           (hipStream_t)stream, a);
+        prof_end((hipStream_t)stream, rec);
+        TAN_LAUNCH_CHECK();
+        return 0;
+    }
     TAN_REQUIRE((d->dx || d->ln1_dxn || d->pwt_in) && d->h_pre && d->x_mid && d->mean2 && d->rstd2 && d->ln_g && d->pwt_proj && d->pwt_fc && d->dh && d->dx2);
     TAN_REQUIRE(d->g_b_fc && d->g_ln_g && d->g_ln_b && d->g_b_out);
     if (d->ln1_dxn || d->pwt_in) TAN_REQUIRE(d->ln1_x && d->ln1_mean && d->ln1_rstd && d->ln1_g && d->dx_out);

@@ -307,6 +307,21 @@ def test_mlp_bwd_with_the_next_blocks_in_proj_dx_gemm_as_head(with_stage):
         assert (got != ref).float().mean().item() < 0.10, what
     for k in acc0:
         assert torch.allclose(acc0[k], acc1[k], rtol=2e-3, atol=2e-4), k
+    # head only (block 0 of a stack): dx_out and the ln_1 column sums, nothing else
+    dxh = torch.full((R, 512), float("nan"), device="cuda", dtype=bf)
+    acch = {k: torch.full((512,), 0.5, device="cuda") for k in ("g_ln1_g", "g_ln1_b", "g_b_proj")}
+    d = _lib.MlpBwdDesc()
+    d.rows, d.C, d.FF, d.head_only = R, 512, 2048, 1
+    d.dqkv, d.pwt_in, d.dstage = dqkv.data_ptr(), pwt_in.data_ptr(), (dstage.data_ptr() if with_stage else None)
+    d.ln1_x, d.ln1_res = x_out.data_ptr(), res.data_ptr()
+    d.ln1_mean, d.ln1_rstd, d.ln1_g = mean1.data_ptr(), rstd1.data_ptr(), g1.data_ptr()
+    d.g_ln1_g, d.g_ln1_b, d.g_dx_colsum = (acch[k].data_ptr() for k in ("g_ln1_g", "g_ln1_b", "g_b_proj"))
+    d.dx_out = dxh.data_ptr()
+    _lib.check(_lib.lib().tan_mlp_bwd(C.byref(d), ops._stream()), "tan_mlp_bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(dxh, dx1)
+    for k in acch:
+        assert torch.allclose(acch[k], acc1[k], rtol=1e-4, atol=1e-5), k
     # both at once is a contradiction; the head without the ln_1 fields too
     d = _lib.MlpBwdDesc()
     d.rows, d.C, d.FF = R, 512, 2048
