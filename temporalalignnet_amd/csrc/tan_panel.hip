@@ -115,6 +115,12 @@ constexpr int MLP_KDF = 32, MLP_KDP = 16, MLP_TILE = 16384, MLP_TF = 512 / MLP_K
 #ifndef TAN_MLP_D
 #define TAN_MLP_D 4
 #endif
+#ifndef TAN_MLP_BURST
+#define TAN_MLP_BURST 0          // 1: all waves in the same phase, epilogue arithmetic in bursts between MFMA bursts (measured: no gain); 0: the skewed wave groups
+#endif
+#ifndef TAN_MLP_BURST_SLEEP
+#define TAN_MLP_BURST_SLEEP 8    // s_sleep units (64 clocks) the second wave group starts an epilogue phase late
+#endif
 constexpr int MLP_D = TAN_MLP_D;                 // weight prefetch distance in steps (4: as fast as 8 once the weights are requested up front, 32 registers less)
 constexpr int MLP_XN_OFF = 0, MLP_H_OFF = 65536, MLP_PRE_OFF = 131072, MLP_LDS = 163840;   // input panel | hidden x2 | pre-activation
 static_assert(PN_WAVES == 8, "eight waves: two groups of four, one wave of each per SIMD");
@@ -200,7 +206,7 @@ __device__ __forceinline__ void mlp_mma_proj(const MlpWFrags& W, const MlpXFrags
 // issue: the wave's own MFMAs then execute under its VALU work, and the quarter-rate v_exp_f32 / v_rcp_f32 results are consumed one
 // MFMA later):  P1 scale, 2 x exp2;  P2 1 + e, 2 x rcp;  P3 x * r, two packs, stores.  The bias is NOT added here: the accumulator
 // of a chunk starts from it (mlp_init_h).
-struct MlpEpiState { float ce[2]; uint32_t pre[4], act[4]; };
+struct MlpEpiState { float ce[2]; uint32_t pre[4], act[4]; float cb[4][2]; };      // cb: the burst schedule keeps four half-units in flight
 struct MlpBias32 { float b[32]; };       // b_fc[c * 256 + wave * 32 ..]: wave-uniform, through scalar loads
 __device__ __forceinline__ void mlp_bias32_load(MlpBias32& B, const float* b_fc, int c, int wave) {
     pn_cfptr_t bp = (pn_cfptr_t)(uintptr_t)b_fc + c * 256 + wave * 32;
@@ -240,12 +246,30 @@ __device__ __forceinline__ void mlp_epi_p3(MlpEpiState& E, const f32x16 (&acc_h)
     }
 }
 
+// burst schedule: pieces of FOUR half-units J = 4 r .. 4 r + 3 issued together (all exps, all rcps, then the products / packs / store)
+template <int J>
+__device__ __forceinline__ void mlp_epi_b1(MlpEpiState& E, const f32x16 (&acc_h)[MLP_NBH][2]) {
+    constexpr int mb = J >> 3, r = 2 * (J & 7);
+    E.cb[J & 3][0] = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * acc_h[0][mb][r]);
+    E.cb[J & 3][1] = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * acc_h[0][mb][r + 1]);
+}
+template <int J>
+__device__ __forceinline__ void mlp_epi_b2(MlpEpiState& E) {
+    E.cb[J & 3][0] = __builtin_amdgcn_rcpf(1.0f + E.cb[J & 3][0]);
+    E.cb[J & 3][1] = __builtin_amdgcn_rcpf(1.0f + E.cb[J & 3][1]);
+}
+template <int J>
+__device__ __forceinline__ void mlp_epi_b3(MlpEpiState& E, const f32x16 (&acc_h)[MLP_NBH][2], char* lds, int hb, int wave, int lane) {
+    E.ce[0] = E.cb[J & 3][0]; E.ce[1] = E.cb[J & 3][1];
+    mlp_epi_p3<J>(E, acc_h, lds, hb, wave, lane);
+}
+
 // ---- backward chunk epilogue: dh = acc o quickgelu'(h_pre), step J = row block J & 1, register pair q = J >> 1 (both row blocks of
 // a feature pair in adjacent steps: their sum is the lane's share of the c_fc bias gradient).  The pre-activations come straight
 // from HBM in the accumulator's layout (16 consecutive features of a row = two 16-byte loads per row block), issued under the
 // c_fc-like phase of the same chunk.
 struct MlpHPre { uint4 q[2][2]; };       // [row block][8-feature half]
-struct MlpBwdEpi { float x[2], ce[2], cs[16]; uint32_t w[2][4]; };
+struct MlpBwdEpi { float x[2], ce[2], cs[16]; uint32_t w[2][4]; float xb[4][2], cb[4][2]; };
 template <int MB, int HALF>
 __device__ __forceinline__ void mlp_hpre_load(MlpHPre& H, const bf16_t* h_pre, long row0, int c, int wave, int lane) {
     H.q[MB][HALF] = *reinterpret_cast<const uint4*>(h_pre + (row0 + MB * 32 + (lane & 31)) * 2048 + c * 256 + wave * 32 + 16 * (lane >> 5) + 8 * HALF);
@@ -292,6 +316,22 @@ __device__ __forceinline__ void mlp_bepi_p3(MlpBwdEpi& E, const f32x16 (&acc_h)[
         const int ch = (wave * 32 >> 3) + 2 * (lane >> 5) + (q >> 2), m = mb * 32 + (lane & 31);
         *reinterpret_cast<uint4*>(pn_panel_slot<512>(lds + MLP_H_OFF + hb * 32768, m, ch)) = make_uint4(E.w[mb][0], E.w[mb][1], E.w[mb][2], E.w[mb][3]);
     }
+}
+
+template <int J>
+__device__ __forceinline__ void mlp_bepi_b1(MlpBwdEpi& E, const MlpHPre& H) {
+    mlp_bepi_p1<J>(E, H);
+    E.xb[J & 3][0] = E.x[0]; E.xb[J & 3][1] = E.x[1]; E.cb[J & 3][0] = E.ce[0]; E.cb[J & 3][1] = E.ce[1];
+}
+template <int J>
+__device__ __forceinline__ void mlp_bepi_b2(MlpBwdEpi& E) {
+    E.cb[J & 3][0] = __builtin_amdgcn_rcpf(1.0f + E.cb[J & 3][0]);
+    E.cb[J & 3][1] = __builtin_amdgcn_rcpf(1.0f + E.cb[J & 3][1]);
+}
+template <int J>
+__device__ __forceinline__ void mlp_bepi_b3(MlpBwdEpi& E, const f32x16 (&acc_h)[MLP_NBH][2], char* lds, int hb, int wave, int lane) {
+    E.x[0] = E.xb[J & 3][0]; E.x[1] = E.xb[J & 3][1]; E.ce[0] = E.cb[J & 3][0]; E.ce[1] = E.cb[J & 3][1];
+    mlp_bepi_p3<J>(E, acc_h, lds, hb, wave, lane);
 }
 
 // The side outputs (pre-activation and activation chunk, the operands of backward) leave for HBM ONE row-instruction at a time,
@@ -739,6 +779,8 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     mlp_load_x_fc<0>(FA, XA);
     __builtin_amdgcn_sched_barrier(0);
 
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    constexpr bool BURST = TAN_MLP_BURST != 0 && !(MODE & (256 | 128));
     // the two 16-step phases; the flags are compile-time so that every step is ONE basic block (the scheduler interleaves the
     // epilogue half-unit with the MFMAs only inside a block)
     auto fc_phase = [&](int c, auto has_copy) __attribute__((always_inline)) {            // c_fc(c) (|| side outputs of chunk c-1)
@@ -777,6 +819,63 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
         constexpr bool PROJ = decltype(has_proj)::value, EPI = decltype(has_epi)::value;
         constexpr bool ARITH = EPI && !(MODE & (8 | 32));
         const int hb = c & 1;
+        if constexpr (BURST) {
+            // Burst schedule (all eight waves in the same phase): four rounds of [16 MFMAs of four steps | the arithmetic of four
+            // epilogue half-units].  A wave that waits for the matrix pipe cannot issue its VALU work (in-order issue), so MFMAs and
+            // epilogue pieces alternating one by one ran at the SUM of both waves' MFMA time and the wave's own arithmetic; in bursts,
+            // with the second wave group half a round behind, one wave of a SIMD computes its epilogue pieces while the other has the
+            // matrix pipe to itself.
+            if constexpr (PROJ && ARITH) { if (grp) __builtin_amdgcn_s_sleep(TAN_MLP_BURST_SLEEP); }
+            pn_static_for<0, 4>([&](auto rc) {
+                constexpr int RB = decltype(rc)::value * 4;
+                pn_static_for<0, 4>([&](auto jc) {
+                    constexpr int J = RB + decltype(jc)::value;
+                    MlpXFrags& cur = (J & 1) ? FB : FA;
+                    MlpXFrags& nxt = (J & 1) ? FA : FB;
+                    MlpWFrags& W = WQ[J % D];
+                    if constexpr (PROJ) {
+                        if (!(MODE & 4)) {
+                            if constexpr (J < 15) mlp_load_x_proj<J + 1>(nxt, XA, hb ^ 1);
+                        }
+                        if constexpr (!EPI && !BWD) {
+                            if (!(MODE & (8 | 16))) mlp_copy_step8<J>(CP, lds, a.h_pre, a.h_act, row0, 7);
+                        } else {
+                            if (!(MODE & (8 | 16))) mlp_copy_step4<J, true, (MODE & 128) != 0>(CP, lds, a.h_act, row0, c - 1);
+                        }
+                        if (!(MODE & 1)) {
+                            acc_o[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[0], cur.f[0], acc_o[0][0], 0, 0, 0);
+                            acc_o[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[0], cur.f[1], acc_o[0][1], 0, 0, 0);
+                            acc_o[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[1], cur.f[0], acc_o[1][0], 0, 0, 0);
+                            acc_o[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[1], cur.f[1], acc_o[1][1], 0, 0, 0);
+                        }
+                        if (!(MODE & 2)) {
+                            if constexpr (J + D < 16) mlp_load_w(W, ppj + (long)((c - 1) * 16 + J + D) * TILE, wave, lane);
+                            else if constexpr (EPI)
+                                mlp_load_w(W, c < 7 ? pfc + (long)((c + 1) * 16 + J + D - 16) * TILE : ppj + (long)(7 * 16 + J + D - 16) * TILE,
+                                           wave, lane);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if constexpr (ARITH) {
+                    // the round's MFMAs are issued before its arithmetic starts (and the next round's after it ends): pure nodes, tied
+                    // through the registers they produce
+                    if constexpr (PROJ) asm volatile("" : "+v"(acc_o[0][0]), "+v"(acc_o[0][1]), "+v"(acc_o[1][0]), "+v"(acc_o[1][1]), "+v"(acc_h[0][RB >> 3]));
+                    if constexpr (BWD) {
+                        pn_static_for<0, 4>([&](auto jc) { mlp_bepi_b1<RB + decltype(jc)::value>(BE, HP); });
+                        pn_static_for<0, 4>([&](auto jc) { mlp_bepi_b2<RB + decltype(jc)::value>(BE); });
+                        pn_static_for<0, 4>([&](auto jc) { mlp_bepi_b3<RB + decltype(jc)::value>(BE, acc_h, lds, hb, wave, lane); });
+                        if constexpr (PROJ) asm volatile("" : "+v"(acc_o[0][0]), "+v"(BE.w[0][(RB >> 1) & 3]), "+v"(BE.w[1][(RB >> 1) & 3]), "+v"(BE.cs[RB]), "+v"(BE.cs[RB + 3]));
+                    } else {
+                        pn_static_for<0, 4>([&](auto jc) { mlp_epi_b1<RB + decltype(jc)::value>(ES, acc_h); });
+                        pn_static_for<0, 4>([&](auto jc) { mlp_epi_b2<RB + decltype(jc)::value>(ES); });
+                        pn_static_for<0, 4>([&](auto jc) { mlp_epi_b3<RB + decltype(jc)::value>(ES, acc_h, lds, hb, wave, lane); });
+                        if constexpr (PROJ) asm volatile("" : "+v"(acc_o[0][0]), "+v"(ES.pre[0]), "+v"(ES.act[0]), "+v"(ES.pre[3]), "+v"(ES.act[3]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        } else
         pn_static_for<0, 16>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
             MlpXFrags& cur = (J & 1) ? FB : FA;
@@ -861,7 +960,6 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
     auto start_h = [&]() __attribute__((always_inline)) {       // a chunk's accumulator starts from the bias (forward) / zero
         if constexpr (BWD) {
             acc_zero(acc_h[0][0]);
@@ -879,7 +977,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
         }
     };
     tick();
-    if (grp) slot_barrier();
+    if (!BURST && grp) slot_barrier();
     // body(0) and body(8) are peeled as straight-line code around the loop: as if / else arms INSIDE the loop every extra variant of
     // a phase cost ~300 spilled registers at the joins
     start_h();
@@ -902,11 +1000,11 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
         if (c < 7) mlp_load_x_fc<0>(FA, XA);                        // fragments of the next body's first step
         __builtin_amdgcn_sched_barrier(0);
     }
-    slot_barrier();                                                  // (slot of the empty phase "c_fc(8)")
+    if (!BURST) slot_barrier();                                      // (slot of the empty phase "c_fc(8)")
     mlp_load_x_proj<0>(FA, XA, 1);                                   // c_proj(7) reads hidden panel 7 & 1
     __builtin_amdgcn_sched_barrier(0);
     tick(); proj_phase(8, T_{}, F_{}); tick();
-    if (!grp) slot_barrier();
+    if (!BURST && !grp) slot_barrier();
     tick();
     if (MODE & 1) {          // stream-only experiment: keep the loaded fragments alive
 #pragma unroll
@@ -1109,6 +1207,11 @@ extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
     switch (d->variant) {
 #ifdef TAN_PANEL_LAB
         case 2: TAN_MLP_LAUNCH(2); break;
+        case 8: TAN_MLP_LAUNCH(8); break;
+        case 32: TAN_MLP_LAUNCH(32); break;
+        case 10: TAN_MLP_LAUNCH(10); break;
+        case 72: TAN_MLP_LAUNCH(72); break;
+        case 96: TAN_MLP_LAUNCH(96); break;
         case 16: TAN_MLP_LAUNCH(16); break;
         case 64: TAN_MLP_LAUNCH(64); break;
         case 80: TAN_MLP_LAUNCH(80); break;
