@@ -63,6 +63,7 @@ struct MlpFwdArgs {
     bf16_t* h_pre; bf16_t* h_act; bf16_t* x_out;
     const float* nln_g; const float* nln_b; bf16_t* xn_next; float* nmean; float* nrstd;
     float eps;
+    int rot;
 };
 // Backward of the same branch, same schedule with the roles of the two weights exchanged (tan_mlp_bwd):
 //   dh_c = (dx W_proj[:, c]) o quickgelu'(h_pre_c)      "c_fc-like": K = 512 over the resident dx panel, packed W_proj^T tiles
@@ -91,6 +92,7 @@ struct MlpBwdArgs {
     const bf16_t* dqkv;         // [rows][1536]
     const char* pwt_in;         // packed W_in^T [512][1536]  (tiles [512][16])
     const bf16_t* dstage;       // [rows][512] or NULL: the deep-supervision gradient that joins at that ln_1 output
+    int rot;
 };
 
 // Tiles are 16 KiB: c_fc [256 features][32 k], c_proj [512 features][16 k].  A weight fragment is consumed by exactly ONE wave
@@ -351,30 +353,30 @@ __device__ __forceinline__ void mlp_copy_init(MlpCopy& C, int wave, int lane) {
 // step J of a 16-step phase moving the group's half of ONE panel (ACT: activation panel of chunk cprev, else the pre-activation
 // panel): row-instruction i = J / 4 is read from LDS at J = 4 i and stored at J = 4 i + 1
 template <int J, bool ACT, bool CM = false>
-__device__ __forceinline__ void mlp_copy_step4(MlpCopy& C, const char* lds, bf16_t* dst, long row0, int cprev) {
+__device__ __forceinline__ void mlp_copy_step4(MlpCopy& C, const char* lds, bf16_t* dst, long row0, int cprev, int cdata) {
     constexpr int i = J >> 2;
     if constexpr ((J & 3) == 0) {
         const char* panel = ACT ? lds + MLP_H_OFF + (cprev & 1) * 32768 : lds + MLP_PRE_OFF;
         C.v = *reinterpret_cast<const uint4*>(panel + ((C.lds0 ^ (i << 6)) + i * 2048));      // row & 15 gains 4 i: no carry
     } else if constexpr ((J & 3) == 1) {
         if constexpr (CM) {    // lab experiment: chunk-major side outputs [chunk][row][256] (a panel's chunk = 32 KiB contiguous)
-            bf16_t* base = dst + (long)cprev * gridDim.x * (64 * 256) + row0 * 256;
+            bf16_t* base = dst + (long)cdata * gridDim.x * (64 * 256) + row0 * 256;
             *reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + (C.voff >> 12) * 512 + (C.voff & 511) + i * 2048) = C.v;
         } else {
-            bf16_t* base = dst + row0 * 2048 + cprev * 256;                 // wave-uniform
+            bf16_t* base = dst + row0 * 2048 + cdata * 256;                 // wave-uniform (cdata: the chunk's place in the hidden dimension)
             *reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + C.voff + i * 16384) = C.v;
         }
     }
 }
 // both panels in one 16-step phase (the last one): pair q = J / 2
 template <int J>
-__device__ __forceinline__ void mlp_copy_step8(MlpCopy& C, const char* lds, bf16_t* dst_pre, bf16_t* dst_act, long row0, int cprev) {
+__device__ __forceinline__ void mlp_copy_step8(MlpCopy& C, const char* lds, bf16_t* dst_pre, bf16_t* dst_act, long row0, int cprev, int cdata) {
     constexpr int q = J >> 1, i = q & 3;
     if constexpr ((J & 1) == 0) {
         const char* panel = q < 4 ? lds + MLP_PRE_OFF : lds + MLP_H_OFF + (cprev & 1) * 32768;
         C.v = *reinterpret_cast<const uint4*>(panel + ((C.lds0 ^ (i << 6)) + i * 2048));
     } else {
-        bf16_t* base = (q < 4 ? dst_pre : dst_act) + row0 * 2048 + cprev * 256;
+        bf16_t* base = (q < 4 ? dst_pre : dst_act) + row0 * 2048 + cdata * 256;
         *reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + C.voff + i * 16384) = C.v;
     }
 }
@@ -539,6 +541,10 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
     const long row0 = (long)blockIdx.x * PN_ROWS;
+    // The hidden chunks are independent terms of the branch's sum: workgroup w walks them starting at chunk rot(w), so that the
+    // workgroups of an XCD do not all pull the same weight lines through the same L2 channel at the same time (TAN_MLP_ROT)
+    const int rot = a.rot == 1 ? (blockIdx.x & 7) : a.rot == 2 ? ((blockIdx.x >> 3) & 7) : a.rot == 3 ? ((blockIdx.x + (blockIdx.x >> 3)) & 7) : 0;
+    auto CC = [&](int c) __attribute__((always_inline)) { return (c + rot) & 7; };
     const char* const pfc = a.pw_fc;
     const char* const ppj = a.pw_proj;
 
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     MlpWFrags WQ[D];
     pn_static_for<0, D>([&](auto jc) {
         constexpr int J = decltype(jc)::value;
-        mlp_load_w(WQ[J], pin + (long)J * TILE, wave, lane);
+        mlp_load_w(WQ[J], pin + (long)((INP ? 0 : CC(0) * 16) + J) * TILE, wave, lane);
     });
 
     // ---- prologue.  Forward: LN2 of the panel, 64 / PN_WAVES rows per wave (batches of 8), one 16-byte chunk per lane.  Backward:
@@ -613,7 +619,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                     acc_d[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], x1, acc_d[nb][1], 0, 0, 0);
                 }
                 if constexpr (T + D < 96) mlp_load_w(W, pin + (long)(T + D) * TILE, wave, lane);
-                else if constexpr (!(MODE & 1024)) mlp_load_w(W, pfc + (long)(T + D - 96) * TILE, wave, lane);   // the ring ends on c_fc(0)'s first tiles
+                else if constexpr (!(MODE & 1024)) mlp_load_w(W, pfc + (long)(CC(0) * 16 + T + D - 96) * TILE, wave, lane);   // the ring ends on c_fc(0)'s first tiles
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
@@ -770,7 +776,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     MlpBias32 B32;           // bias of the next chunk: loaded before a slot barrier, consumed right after it (mlp_init_h)
     MlpHPre HP;              // backward: pre-activations of the chunk in the accumulator layout
     MlpBwdEpi BE;
-    if constexpr (!BWD) mlp_bias32_load(B32, a.b_fc, 0, wave);
+    if constexpr (!BWD) mlp_bias32_load(B32, a.b_fc, CC(0), wave);
     static_assert(MLP_NBO == 2 && MLP_WFR == 2, "eight waves");
     MlpXAddr XA;
     mlp_xaddr_init(XA, lds, lane);
@@ -798,18 +804,18 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                 // all four together: each is a cold HBM read in the in-order vmcnt queue in front of the weight ring, and the
                 // ring stalls once per batch of them, not once per load
                 if constexpr (J == TAN_HPRE_STEP) {
-                    mlp_hpre_load<0, 0>(HP, a.h_pre, row0, c, wave, lane);
-                    mlp_hpre_load<1, 0>(HP, a.h_pre, row0, c, wave, lane);
-                    mlp_hpre_load<0, 1>(HP, a.h_pre, row0, c, wave, lane);
-                    mlp_hpre_load<1, 1>(HP, a.h_pre, row0, c, wave, lane);
+                    mlp_hpre_load<0, 0>(HP, a.h_pre, row0, CC(c), wave, lane);
+                    mlp_hpre_load<1, 0>(HP, a.h_pre, row0, CC(c), wave, lane);
+                    mlp_hpre_load<0, 1>(HP, a.h_pre, row0, CC(c), wave, lane);
+                    mlp_hpre_load<1, 1>(HP, a.h_pre, row0, CC(c), wave, lane);
                 }
             } else if constexpr (COPY) {
-                if (!(MODE & (8 | 16))) mlp_copy_step4<J, false, (MODE & 128) != 0>(CP, lds, a.h_pre, row0, c - 1);
+                if (!(MODE & (8 | 16))) mlp_copy_step4<J, false, (MODE & 128) != 0>(CP, lds, a.h_pre, row0, c - 1, CC(c - 1));
             }
             if (!(MODE & 2)) {      // the tile eight steps on: c_fc(c) J+8, else the first half of the next phase that streams
-                const char* src = J + D < 16 ? pfc + (long)(c * 16 + J + D) * TILE
-                                             : (c == 0 ? pfc + (long)(16 + J + D - 16) * TILE      // body(0) has no c_proj phase
-                                                       : ppj + (long)((c - 1) * 16 + J + D - 16) * TILE);
+                const char* src = J + D < 16 ? pfc + (long)(CC(c) * 16 + J + D) * TILE
+                                             : (c == 0 ? pfc + (long)(CC(1) * 16 + J + D - 16) * TILE      // body(0) has no c_proj phase
+                                                       : ppj + (long)(CC(c - 1) * 16 + J + D - 16) * TILE);
                 mlp_load_w(WQ[J % D], src, wave, lane);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -838,9 +844,9 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                             if constexpr (J < 15) mlp_load_x_proj<J + 1>(nxt, XA, hb ^ 1);
                         }
                         if constexpr (!EPI && !BWD) {
-                            if (!(MODE & (8 | 16))) mlp_copy_step8<J>(CP, lds, a.h_pre, a.h_act, row0, 7);
+                            if (!(MODE & (8 | 16))) mlp_copy_step8<J>(CP, lds, a.h_pre, a.h_act, row0, 7, CC(7));
                         } else {
-                            if (!(MODE & (8 | 16))) mlp_copy_step4<J, true, (MODE & 128) != 0>(CP, lds, a.h_act, row0, c - 1);
+                            if (!(MODE & (8 | 16))) mlp_copy_step4<J, true, (MODE & 128) != 0>(CP, lds, a.h_act, row0, c - 1, CC(c - 1));
                         }
                         if (!(MODE & 1)) {
                             acc_o[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[0], cur.f[0], acc_o[0][0], 0, 0, 0);
@@ -849,9 +855,9 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                             acc_o[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[1], cur.f[1], acc_o[1][1], 0, 0, 0);
                         }
                         if (!(MODE & 2)) {
-                            if constexpr (J + D < 16) mlp_load_w(W, ppj + (long)((c - 1) * 16 + J + D) * TILE, wave, lane);
+                            if constexpr (J + D < 16) mlp_load_w(W, ppj + (long)(CC(c - 1) * 16 + J + D) * TILE, wave, lane);
                             else if constexpr (EPI)
-                                mlp_load_w(W, c < 7 ? pfc + (long)((c + 1) * 16 + J + D - 16) * TILE : ppj + (long)(7 * 16 + J + D - 16) * TILE,
+                                mlp_load_w(W, c < 7 ? pfc + (long)(CC(c + 1) * 16 + J + D - 16) * TILE : ppj + (long)(CC(7) * 16 + J + D - 16) * TILE,
                                            wave, lane);
                         }
                     }
@@ -886,9 +892,9 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                     if constexpr (J < 15) mlp_load_x_proj<J + 1>(nxt, XA, hb ^ 1);
                 }
                 if constexpr (!EPI && !BWD) {       // body(8): the side outputs of chunk 7 under c_proj(7)
-                    if (!(MODE & (8 | 16))) mlp_copy_step8<J>(CP, lds, a.h_pre, a.h_act, row0, 7);
+                    if (!(MODE & (8 | 16))) mlp_copy_step8<J>(CP, lds, a.h_pre, a.h_act, row0, 7, CC(7));
                 } else {                    // the activation panel of chunk c-1 (c_proj(c-1) reads it too; rewritten in body c+1)
-                    if (!(MODE & (8 | 16))) mlp_copy_step4<J, true, (MODE & 128) != 0>(CP, lds, a.h_act, row0, c - 1);
+                    if (!(MODE & (8 | 16))) mlp_copy_step4<J, true, (MODE & 128) != 0>(CP, lds, a.h_act, row0, c - 1, CC(c - 1));
                 }
             }
             // c_proj: W.f[nb] = output features wave*64 + nb*32 .., one k step; the epilogue pieces sit between the MFMAs.  Neither
@@ -923,9 +929,9 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
             if constexpr (PROJ) {
                 if (!(MODE & 1)) acc_o[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[1], cur.f[1], acc_o[1][1], 0, 0, 0);
                 if (!(MODE & 2)) {  // c_proj(c-1) J+8, else the first half of the next body's first phase
-                    if constexpr (J + D < 16) mlp_load_w(W, ppj + (long)((c - 1) * 16 + J + D) * TILE, wave, lane);
+                    if constexpr (J + D < 16) mlp_load_w(W, ppj + (long)(CC(c - 1) * 16 + J + D) * TILE, wave, lane);
                     else if constexpr (EPI)     // c <= 7: body(c+1) starts with c_fc(c+1), body(8) with c_proj(7)
-                        mlp_load_w(W, c < 7 ? pfc + (long)((c + 1) * 16 + J + D - 16) * TILE : ppj + (long)(7 * 16 + J + D - 16) * TILE,
+                        mlp_load_w(W, c < 7 ? pfc + (long)(CC(c + 1) * 16 + J + D - 16) * TILE : ppj + (long)(CC(7) * 16 + J + D - 16) * TILE,
                                    wave, lane);
                 }
             }
@@ -971,9 +977,9 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     auto after_epi = [&](int c) __attribute__((always_inline)) {   // after the epilogue of chunk c, before the slot barrier
         if constexpr (BWD) {       // c_fc bias gradient: column sums of the wave's 32 features over the panel's 64 rows
             const float tot = pn_colsum16(BE.cs, lane);
-            if (!(lane & 2)) unsafeAtomicAdd(a.g_b_fc + c * 256 + wave * 32 + 16 * hi + pn_colsum16_index(lane), tot);
+            if (!(lane & 2)) unsafeAtomicAdd(a.g_b_fc + CC(c) * 256 + wave * 32 + 16 * hi + pn_colsum16_index(lane), tot);
         } else {
-            mlp_bias32_load(B32, a.b_fc, min(c + 1, 7), wave);
+            mlp_bias32_load(B32, a.b_fc, CC(min(c + 1, 7)), wave);
         }
     };
     tick();
@@ -1174,6 +1180,12 @@ using namespace tal;
 
 extern "C" int tan_panel_waves(void) { return PN_WAVES; }
 
+// TAN_MLP_ROT: 0 = every workgroup walks the hidden chunks 0..7; 1 / 2 / 3 = start at chunk (w & 7) / ((w >> 3) & 7) / ((w + (w >> 3)) & 7)
+static int mlp_rot() {
+    static const int v = [] { const char* e = getenv("TAN_MLP_ROT"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 extern "C" int tan_pack_weights(const void* src, void* dst, const tan_pack_entry* table, int n, int max_tiles, void* stream) {
     TAN_REQUIRE(src && dst && table && n > 0 && max_tiles > 0);
     hipLaunchKernelGGL(pack_tiles_kernel, dim3(max_tiles < 64 ? max_tiles : 64, n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
@@ -1196,6 +1208,7 @@ extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
     a.h_pre = (bf16_t*)d->h_pre; a.h_act = (bf16_t*)d->h_act; a.x_out = (bf16_t*)d->x_out;
     a.nln_g = d->nln_g; a.nln_b = d->nln_b; a.xn_next = (bf16_t*)d->xn_next; a.nmean = d->nmean; a.nrstd = d->nrstd;
     a.eps = d->eps;
+    a.rot = mlp_rot();
     const dim3 grid((unsigned)(d->rows / PN_ROWS));
     const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0);
 #define TAN_MLP_LAUNCH(M) hipLaunchKernelGGL((mlp_panel_kernel<M, MlpFwdArgs>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a)
@@ -1258,6 +1271,7 @@ extern "C" int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream) {
     TAN_REQUIRE((d->pwt_out != nullptr) == (d->d_o != nullptr));
     a.pwt_out = (const char*)d->pwt_out; a.d_o = (bf16_t*)d->d_o;
     a.dqkv = (const bf16_t*)d->dqkv; a.pwt_in = (const char*)d->pwt_in; a.dstage = (const bf16_t*)d->dstage;
+    a.rot = mlp_rot();
     const dim3 grid((unsigned)(d->rows / PN_ROWS));
     const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0 + (d->pwt_out ? 2.0 * d->rows * 512.0 * 512.0 : 0.0) +
                                                                          (d->pwt_in ? 2.0 * d->rows * 1536.0 * 512.0 : 0.0));
