@@ -177,3 +177,24 @@ class EncoderDesc(C.Structure):
         ("layer_done", C.POINTER(C.c_void_p)),
         ("no_save", C.c_int),
     ]
+
+
+# ---- HIP streams by ROLE, one per device for the whole process.  Streams map onto a few hardware queues in creation order: when
+# every model / trainer created its own, two roles that must overlap (the joint stack's stream and the main stream) could land on one
+# queue depending on how many objects had been built before -- the same configuration ran 6.7 or 8.4 ms per step depending on what
+# the process had run earlier (tools/lab/seq_cfg.py).
+_ROLE_STREAMS = {}
+
+
+def role_stream(dev, role):
+    import torch
+    dev = torch.device(dev)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), role)
+    st = _ROLE_STREAMS.get(key)
+    if st is None:
+        for r in ("stack", "loss", "comm", "opt"):             # fixed creation order, whatever is asked for first
+            k = (key[0], key[1], r)
+            if k not in _ROLE_STREAMS:
+                _ROLE_STREAMS[k] = torch.cuda.Stream(device=torch.device(key[0], key[1]))
+        st = _ROLE_STREAMS.setdefault(key, _ROLE_STREAMS.get(key) or torch.cuda.Stream(device=torch.device(key[0], key[1])))
+    return st

@@ -282,7 +282,7 @@ class _AlignerEngine(_WorkspaceMixin):
         if not self.overlap_stacks:
             return None
         if self._side is None or self._side.device != dev:
-            self._side = torch.cuda.Stream(device=dev)
+            self._side = _lib.role_stream(dev, "stack")          # one per device and process (see _lib.role_stream)
         return self._side
 
     def _on_side(self, side, fn):

@@ -326,7 +326,7 @@ _SIDE = {}
 def _side_stream(dev):
     st = _SIDE.get(dev)
     if st is None:
-        st = _SIDE[dev] = torch.cuda.Stream(device=dev)
+        st = _SIDE[dev] = _lib.role_stream(dev, "loss")
     return st
 
 

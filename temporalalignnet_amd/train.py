@@ -178,7 +178,7 @@ class Trainer:
     def _opt_stream(self, device):
         st = self._opt_streams.get(device)
         if st is None:
-            st = self._opt_streams[device] = torch.cuda.Stream(device=device)
+            st = self._opt_streams[device] = _lib.role_stream(device, "opt")
         return st
 
     def _comm_order_stream(self, device):
@@ -186,7 +186,7 @@ class Trainer:
         is ordered after ITS layers and not after whatever else the compute streams have queued."""
         st = self._comm_streams.get(device)
         if st is None:
-            st = self._comm_streams[device] = torch.cuda.Stream(device=device)
+            st = self._comm_streams[device] = _lib.role_stream(device, "comm")
         return st
 
     def sync_parameters(self, src=0):
