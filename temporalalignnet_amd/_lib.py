@@ -192,7 +192,8 @@ def role_stream(dev, role):
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), role)
     st = _ROLE_STREAMS.get(key)
     if st is None:
-        for r in ("stack", "loss", "comm", "opt"):             # fixed creation order, whatever is asked for first
+        order = os.environ.get("TAN_STREAM_ORDER", "stack,loss,comm,opt").split(",")         # (lab: which roles share a queue)
+        for r in order:                                        # fixed creation order, whatever is asked for first
             k = (key[0], key[1], r)
             if k not in _ROLE_STREAMS:
                 _ROLE_STREAMS[k] = torch.cuda.Stream(device=torch.device(key[0], key[1]))
