@@ -359,6 +359,12 @@ typedef struct tan_encoder_desc {
                                                    only for backward (h_pre, h_act, xn2, mean2 / rstd2, and on the fused attention
                                                    path qkv, attn_o, lse) are NOT written; bufs[] may then leave them NULL.  The stage
                                                    outputs (xn1 of layers >= 1, post_out) and x_mid / x_out are written as usual. */
+    /* backward only, optional: a second stream for the blocks' weight-gradient launches (they only feed the optimizer; in-stream they
+     * sit on the dX chain) with the second set of the four scratch buffers they read -- blocks alternate between the sets.  Ignored
+     * with layer_done (data-parallel callers), outside the row-panel path, or when any pointer is NULL.  On return `stream` has been
+     * made to wait for all of them. */
+    void* dw_stream;
+    void *scr2_dx, *scr2_dx2, *scr2_dh, *scr2_dqkv;
 } tan_encoder_desc;
 int tan_encoder_fwd(const tan_encoder_desc* e, void* stream);
 int tan_encoder_bwd(const tan_encoder_desc* e, void* stream);

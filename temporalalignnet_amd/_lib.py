@@ -176,6 +176,7 @@ class EncoderDesc(C.Structure):
         ("d_stage", C.POINTER(C.c_void_p)), ("d_x0", C.c_void_p),
         ("layer_done", C.POINTER(C.c_void_p)),
         ("no_save", C.c_int),
+        ("dw_stream", C.c_void_p), ("scr2_dx", C.c_void_p), ("scr2_dx2", C.c_void_p), ("scr2_dh", C.c_void_p), ("scr2_dqkv", C.c_void_p),
     ]
 
 
@@ -192,7 +193,7 @@ def role_stream(dev, role):
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), role)
     st = _ROLE_STREAMS.get(key)
     if st is None:
-        order = os.environ.get("TAN_STREAM_ORDER", "stack,loss,comm,opt").split(",")         # (lab: which roles share a queue)
+        order = os.environ.get("TAN_STREAM_ORDER", "stack,loss,comm,opt,dwj,dwv").split(",")         # (lab: which roles share a queue)
         for r in order:                                        # fixed creation order, whatever is asked for first
             k = (key[0], key[1], r)
             if k not in _ROLE_STREAMS:

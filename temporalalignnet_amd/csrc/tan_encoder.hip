@@ -265,8 +265,6 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
     const int dt = e->dtype, C = e->C, H = e->H, S = e->layers;
     const long R = (long)e->B * e->L;
     const size_t esz = dt == TAN_F32 ? 4 : 2;
-    void* dx = e->scr_dx;      // gradient w.r.t. the residual stream leaving the current layer
-    void* dx2 = e->scr_dx2;
     const void* x_last = e->bufs[S - 1].x_out;
     // ln_1 backward of block i+1 handed to block i's row-panel MLP backward as its prologue (TAN_LN1_FUSED=0: its own launch); the
     // stack's post-LayerNorm backward goes to the last block the same way (no residual gradient next to it)
@@ -274,6 +272,26 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
              const void *dqkv, *pwt_in, *dstage; } pend{};
     static const bool ln1_fused = [] { const char* v = getenv("TAN_LN1_FUSED"); return !v || atoi(v) != 0; }();
     const bool panel_all = ln1_fused && grouped_enabled() != 0 && panel_bwd_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0;
+    // Weight gradients OFF the stack's chain (dw_stream != NULL): block i's grouped dW launch only feeds the optimizer, but in-stream it
+    // sits between block i's and block i-1's dX kernels (120 of ~300 us per block on the longer -- joint -- chain).  It reads dh, dx,
+    // dqkv, dx2 of block i, which block i-1 overwrites: those four scratch buffers exist twice, blocks alternate between the sets,
+    // and the chain waits for dW(i) before block i-2 reuses block i's set.
+    bool dw_async = e->dw_stream && e->scr2_dx && e->scr2_dx2 && e->scr2_dh && e->scr2_dqkv && !e->layer_done && panel_all && S <= 16;
+    for (int i = 0; i < S && dw_async; ++i) dw_async = e->params[i].wtp_fc && e->params[i].wtp_proj;
+    void* const dxs[2] = {e->scr_dx, dw_async ? e->scr2_dx : e->scr_dx};
+    void* const dx2s[2] = {e->scr_dx2, dw_async ? e->scr2_dx2 : e->scr_dx2};
+    void* const dhs[2] = {e->scr_dh, dw_async ? e->scr2_dh : e->scr_dh};
+    void* const dqkvs[2] = {e->scr_dqkv, dw_async ? e->scr2_dqkv : e->scr_dqkv};
+    static thread_local hipEvent_t ev_in[16], ev_done[16];
+    static thread_local bool ev_made = false;
+    if (dw_async && !ev_made) {
+        for (int i = 0; i < 16; ++i) {
+            if (hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming) != hipSuccess) return -3;
+            if (hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming) != hipSuccess) return -3;
+        }
+        ev_made = true;
+    }
+    void* dx = dxs[(S - 1) & 1];      // gradient w.r.t. the residual stream leaving the current layer
     if (e->d_stage[S - 1] && panel_all && e->params[S - 1].wtp_fc && e->params[S - 1].wtp_proj) {
         TAN_REQUIRE(e->post_out);
         pend.on = true; pend.layer = -1; pend.dxn = e->d_stage[S - 1]; pend.x = x_last; pend.res = nullptr;
@@ -295,6 +313,13 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         const tan_layer_params& p = e->params[i];
         const tan_layer_bufs& b = e->bufs[i];
         const void* x_in = i == 0 ? e->x0 : e->bufs[i - 1].x_out;
+        const int P = i & 1;
+        dx = dxs[P];
+        void* const dx2 = dx2s[P];
+        void* const scr_dh = dhs[P];
+        void* const scr_dqkv = dqkvs[P];
+        if (dw_async && i + 2 < S)         // block i + 2 used this set: its weight gradients must have read it
+            if (hipStreamWaitEvent((hipStream_t)st, ev_done[i + 2], 0) != hipSuccess) return -3;
         // ---- MLP branch: x_out = x_mid + c_proj(quickgelu(c_fc(LN2(x_mid))))
         const bool grouped = grouped_enabled() != 0;       // the four dW GEMMs after the dX chain, in one launch
         bool do_fused = false;                             // d_o = dx2 W_out already produced by the row-panel MLP backward
@@ -306,7 +331,7 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
             m.rows = R; m.C = C; m.FF = 4 * C;
             m.dx = dx; m.h_pre = b.h_pre; m.x_mid = b.x_mid; m.mean2 = b.mean2; m.rstd2 = b.rstd2; m.ln_g = p.ln2_g;
             m.pwt_proj = p.wtp_proj; m.pwt_fc = p.wtp_fc;
-            m.dh = e->scr_dh; m.dx2 = dx2;
+            m.dh = scr_dh; m.dx2 = dx2;
             m.g_b_fc = p.g_b_fc; m.g_ln_g = p.g_ln2_g; m.g_ln_b = p.g_ln2_b; m.g_b_out = p.g_b_out;
             if (pend.on) {
                 m.ln1_dxn = pend.dxn; m.ln1_x = pend.x; m.ln1_res = pend.res; m.ln1_mean = pend.mean; m.ln1_rstd = pend.rstd;
@@ -325,11 +350,11 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
                     if (err != hipSuccess) return (int)err;
                 }
             }
-            if (!grouped) CK(linear_bwd_w(dt, e->scr_dh, b.xn2, p.g_w_fc, R, 4 * C, C, e->dw_ws, e->dw_ws_floats, st));
+            if (!grouped) CK(linear_bwd_w(dt, scr_dh, b.xn2, p.g_w_fc, R, 4 * C, C, e->dw_ws, e->dw_ws_floats, st));
         } else {
-            CK(linear_bwd_x(dt, dx, p.w_proj, p.wt_proj, e->scr_dh, R, C, 4 * C, TAN_ACT_QUICKGELU_GRAD, b.h_pre, nullptr, p.g_b_fc, st));
-            if (!grouped) CK(linear_bwd_w(dt, e->scr_dh, b.xn2, p.g_w_fc, R, 4 * C, C, e->dw_ws, e->dw_ws_floats, st));
-            CK(linear_bwd_x(dt, e->scr_dh, p.w_fc, p.wt_fc, e->scr_dxn, R, 4 * C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
+            CK(linear_bwd_x(dt, dx, p.w_proj, p.wt_proj, scr_dh, R, C, 4 * C, TAN_ACT_QUICKGELU_GRAD, b.h_pre, nullptr, p.g_b_fc, st));
+            if (!grouped) CK(linear_bwd_w(dt, scr_dh, b.xn2, p.g_w_fc, R, 4 * C, C, e->dw_ws, e->dw_ws_floats, st));
+            CK(linear_bwd_x(dt, scr_dh, p.w_fc, p.wt_fc, e->scr_dxn, R, 4 * C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
             CK(tan_layernorm_bwd(e->scr_dxn, b.x_mid, p.ln2_g, b.mean2, b.rstd2, dx, dx2, p.g_ln2_g, p.g_ln2_b, p.g_b_out, e->ln_ws, R, C,
                                  dt, st));
         }
@@ -340,13 +365,13 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
             tan_attnblk_bwd_desc ab{};
             ab.B = e->B; ab.L = e->L; ab.C = C; ab.H = H;
             ab.dx2 = dx2; ab.qkv = b.qkv; ab.lse = b.lse; ab.key_padding_mask = e->key_padding_mask;
-            ab.pwt_out = p.wtp_out; ab.dqkv = e->scr_dqkv; ab.g_b_qkv = p.g_b_qkv;
+            ab.pwt_out = p.wtp_out; ab.dqkv = scr_dqkv; ab.g_b_qkv = p.g_b_qkv;
             CK(tan_attnblk_bwd(&ab, st));
         } else {
             if (!do_fused) CK(linear_bwd_x(dt, dx2, p.w_out, p.wt_out, e->scr_do, R, C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
-            CK(tan_attn_bwd_bias(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->scr_do, e->scr_dqkv, p.g_b_qkv, e->B, e->L, H, dt, st));
+            CK(tan_attn_bwd_bias(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->scr_do, scr_dqkv, p.g_b_qkv, e->B, e->L, H, dt, st));
         }
-        if (!grouped) CK(linear_bwd_w(dt, e->scr_dqkv, b.xn1, p.g_w_qkv, R, 3 * C, C, e->dw_ws, e->dw_ws_floats, st));
+        if (!grouped) CK(linear_bwd_w(dt, scr_dqkv, b.xn1, p.g_w_qkv, R, 3 * C, C, e->dw_ws, e->dw_ws_floats, st));
         // stage i-1 IS this layer's xn1: its gradient joins here
         const void* dstage = i >= 1 ? e->d_stage[i - 1] : nullptr;
         // block i-1's row-panel MLP backward takes the ln_1 backward as its prologue -- and (TAN_PANEL_IN) this dX GEMM in front of it
@@ -355,26 +380,32 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         // block 0: the same head + ln_1 backward as a launch of its own (64-row panels) instead of the tiled GEMM + LayerNorm backward
         const bool head_only = i == 0 && panel_all && (panel_in_enabled() & 2) && p.wtp_qkv != nullptr;
         if (!in_fused && !head_only)
-            CK(linear_bwd_x(dt, e->scr_dqkv, p.w_qkv, p.wt_qkv, e->scr_dxn, R, 3 * C, C, TAN_ACT_NONE, nullptr, dstage, nullptr, st));
+            CK(linear_bwd_x(dt, scr_dqkv, p.w_qkv, p.wt_qkv, e->scr_dxn, R, 3 * C, C, TAN_ACT_NONE, nullptr, dstage, nullptr, st));
         if (grouped) {      // dx, scr_dh, dx2, scr_dqkv are all still intact here (LN1 backward below overwrites dx)
-            const DwItem items[4] = {{e->scr_dh, b.xn2, p.g_w_fc, 4 * C, C}, {dx, b.h_act, p.g_w_proj, C, 4 * C},
-                                     {e->scr_dqkv, b.xn1, p.g_w_qkv, 3 * C, C}, {dx2, b.attn_o, p.g_w_out, C, C}};
+            const DwItem items[4] = {{scr_dh, b.xn2, p.g_w_fc, 4 * C, C}, {dx, b.h_act, p.g_w_proj, C, 4 * C},
+                                     {scr_dqkv, b.xn1, p.g_w_qkv, 3 * C, C}, {dx2, b.attn_o, p.g_w_out, C, C}};
+            if (dw_async) {
+                if (hipEventRecord(ev_in[i], (hipStream_t)st) != hipSuccess) return -3;
+                if (hipStreamWaitEvent((hipStream_t)e->dw_stream, ev_in[i], 0) != hipSuccess) return -3;
+                CK(linear_bwd_w_group(dt, items, 4, R, e->dw_ws, e->dw_ws_floats, e->dw_stream));
+                if (hipEventRecord(ev_done[i], (hipStream_t)e->dw_stream) != hipSuccess) return -3;
+            } else
             CK(linear_bwd_w_group(dt, items, 4, R, e->dw_ws, e->dw_ws_floats, st));
         }
-        void* dx_in = i == 0 ? e->d_x0 : dx;
+        void* dx_in = i == 0 ? e->d_x0 : dxs[(i - 1) & 1];
         float* next_b_proj = i > 0 ? e->params[i - 1].g_b_proj : nullptr;       // dx_in is layer i-1's x_out gradient
         if (ln1_next) {
             // block i-1's row-panel MLP backward does this LayerNorm backward as its prologue (dx2 and scr_dxn / scr_dqkv stay
             // untouched until that launch: it is the next one that writes them)
             pend.on = true; pend.layer = i; pend.dxn = in_fused ? nullptr : e->scr_dxn; pend.x = x_in; pend.res = dx2;
-            pend.dqkv = in_fused ? e->scr_dqkv : nullptr; pend.pwt_in = in_fused ? p.wtp_qkv : nullptr; pend.dstage = in_fused ? dstage : nullptr;
+            pend.dqkv = in_fused ? scr_dqkv : nullptr; pend.pwt_in = in_fused ? p.wtp_qkv : nullptr; pend.dstage = in_fused ? dstage : nullptr;
             pend.mean = b.mean1; pend.rstd = b.rstd1; pend.g = p.ln1_g; pend.gg = p.g_ln1_g; pend.gb = p.g_ln1_b; pend.gcol = next_b_proj;
             continue;
         }
         if (head_only) {
             tan_mlp_bwd_desc m{};
             m.rows = R; m.C = C; m.FF = 4 * C; m.head_only = 1;
-            m.dqkv = e->scr_dqkv; m.pwt_in = p.wtp_qkv; m.dstage = dstage;
+            m.dqkv = scr_dqkv; m.pwt_in = p.wtp_qkv; m.dstage = dstage;
             m.ln1_x = x_in; m.ln1_res = dx2; m.ln1_mean = b.mean1; m.ln1_rstd = b.rstd1; m.ln1_g = p.ln1_g;
             m.g_ln1_g = p.g_ln1_g; m.g_ln1_b = p.g_ln1_b; m.g_dx_colsum = next_b_proj; m.dx_out = dx_in;
             CK(tan_mlp_bwd(&m, st));
@@ -387,5 +418,8 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
             if (err != hipSuccess) return (int)err;
         }
     }
+    if (dw_async)        // the caller sees every gradient on `st` (the last two blocks' launches may still be running)
+        for (int i = 0; i < S && i < 2; ++i)
+            if (hipStreamWaitEvent((hipStream_t)st, ev_done[i], 0) != hipSuccess) return -3;
     return 0;
 }

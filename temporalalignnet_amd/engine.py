@@ -124,6 +124,12 @@ class _AlignerEngine(_WorkspaceMixin):
         d.scr_dh, d.scr_dqkv = _vp(scr["dh"]), _vp(scr["dqkv"])
         d.ln_ws = _vp(scr.ln_ws)
         d.dw_ws, d.dw_ws_floats = _vp(scr.dw_ws), scr.dw_ws.numel()
+        # TAN_DW_STREAM: 1 = the joint stack's weight-gradient launches on their own stream (it is the longer chain), 2 = both stacks'
+        mode = int(os.environ.get("TAN_DW_STREAM", "0"))
+        if self._grad_ready_hook is None and dev.type == "cuda" and (mode >= 2 or (mode == 1 and er.prefix.startswith("joint"))):
+            aux = _lib.role_stream(dev, "dwj" if er.prefix.startswith("joint") else "dwv")
+            d.dw_stream = C.c_void_p(aux.cuda_stream)
+            d.scr2_dx, d.scr2_dx2, d.scr2_dh, d.scr2_dqkv = (_vp(scr[k]) for k in ("dx_b", "dx2_b", "dh_b", "dqkv_b"))
         arr = (C.c_void_p * er.layers)(*[(t.data_ptr() if t is not None else None) for t in d_stage])
         d.d_stage = arr
         d.d_x0 = _vp(d_x0)

@@ -83,13 +83,15 @@ def test_gradient_accumulation_follows_the_reference_loop():
 @pytest.mark.parametrize("model_kind", ["init", "cotrain"])
 def test_step_boundary_options_do_not_change_the_arithmetic(monkeypatch, model_kind):
     """`Trainer.step` with the gradient fill / weight-image rebuilds on a side stream (TAN_STEP_ASYNC, default) and with AdamW issued
-    per gradient bucket next to backward (TAN_OPT_OVERLAP) runs the SAME kernels on the same values as the plain sequence: after three
+    per gradient bucket next to backward (TAN_OPT_OVERLAP), or the weight-gradient launches on their own stream with alternating scratch
+    sets (TAN_DW_STREAM), runs the SAME kernels on the same values as the plain sequence: after three
     steps in bf16 (where the packed weight images matter) the parameters agree up to the order of the f32 gradient atomics."""
     kw = dict(model=model_kind, **({"loss_threshold": 0.5} if model_kind == "cotrain" else {}))
     batches = [_batch(40 + i, B=8, T=64) for i in range(3)]
     flats = {}
     for tag, env in (("plain", {"TAN_STEP_ASYNC": "0", "TAN_OPT_OVERLAP": "0"}), ("async", {"TAN_STEP_ASYNC": "1", "TAN_OPT_OVERLAP": "0"}),
-                     ("overlap", {"TAN_STEP_ASYNC": "1", "TAN_OPT_OVERLAP": "1"})):
+                     ("overlap", {"TAN_STEP_ASYNC": "1", "TAN_OPT_OVERLAP": "1"}),
+                     ("dwstream", {"TAN_STEP_ASYNC": "1", "TAN_OPT_OVERLAP": "0", "TAN_DW_STREAM": "2"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         tr, _ = _trainer(seed=3, dtype="bf16", **kw)
@@ -102,7 +104,7 @@ def test_step_boundary_options_do_not_change_the_arithmetic(monkeypatch, model_k
         flats[tag] = (tr.online.flat_parameters().clone(), tr.model.target.flat_parameters().clone() if model_kind == "cotrain" else None)
     ref = flats["plain"]
     assert torch.isfinite(ref[0]).all()
-    for tag in ("async", "overlap"):
+    for tag in ("async", "overlap", "dwstream"):
         d = (flats[tag][0] - ref[0]).abs()
         # Adam turns atomics-order noise on ~zero gradients into lr-sized (1e-3) updates of a few elements: bounded by the three steps' total
         assert d.max().item() <= 3.5e-3 and d.mean().item() <= 5e-6, (tag, d.max().item(), d.mean().item())
