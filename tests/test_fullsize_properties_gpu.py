@@ -194,3 +194,44 @@ def test_len256_full_size_bf16_tracks_fp32():
         assert abs(res["bf16"][0][k] - ref) < 1e-2 * abs(ref), (k, res["bf16"][0][k], ref)
     g32, g16 = res["fp32"][1], res["bf16"][1]
     assert float((g32 * g16).sum() / (g32.norm() * g16.norm())) > 0.99
+
+
+@pytest.mark.parametrize("L", [256, 272])
+def test_len256_full_size_attention_core_matches_sdpa(L):
+    """BASELINE configs[3] size (B = 32, 8 heads, L = 256 video / 272 joint rows): the mid-length attention kernels (whole head resident
+    in LDS) against torch's scaled-dot-product attention in fp32 on the same bf16 inputs -- forward output, log-sum-exp, and all three
+    input gradients, with the last rows of every video padded as keys."""
+    from temporalalignnet_amd import ops
+    B, H, C = 32, 8, 512
+    g = torch.Generator(device="cuda").manual_seed(77 + L)
+    qkv = (torch.randn(B * L, 3 * C, device="cuda", generator=g) * 1.2).bfloat16()
+    d_o = torch.randn(B * L, C, device="cuda", generator=g).bfloat16()
+    keypad = torch.zeros(B, L, dtype=torch.uint8, device="cuda")
+    keypad[:, L - 9:] = 1
+    o = torch.empty(B * L, C, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(B, H, L, device="cuda")
+    ops.attn_fwd(qkv, keypad, o, lse, B, L, H)
+    dqkv = torch.full_like(qkv, float("nan"))
+    ops.attn_bwd(qkv, keypad, o, lse, d_o, dqkv, B, L, H)
+    x = qkv.float().requires_grad_(True)
+    q, k, v = x.view(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    mask = keypad.bool()[:, None, None, :]
+    s = (q * 0.125) @ k.transpose(-1, -2)
+    s = s.masked_fill(mask, float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * L, C)
+    ref.backward(d_o.float())
+    assert torch.isfinite(dqkv.float()).all()
+    err_o = (o.float() - ref).abs().max().item()
+    assert err_o <= 2.0 ** -7 * ref.abs().max().item() + 1e-3, err_o
+    err_l = (lse - torch.logsumexp(s, -1)).abs().max().item()
+    assert err_l <= 5e-3, err_l
+    gr = x.grad
+    err_g = (dqkv.float() - gr).abs().max().item()
+    assert err_g <= 2.0 ** -6 * gr.abs().max().item(), (err_g, gr.abs().max().item())
+    # and a checksum that does not depend on the kernel's tiling: sum over everything of dq . q + dk . k is 0 for softmax attention
+    # (scores are invariant under q -> a q, k -> k / a), up to the bf16 rounding of dqkv
+    dq, dk = dqkv.float().view(B, L, 3, H, 64)[:, :, 0], dqkv.float().view(B, L, 3, H, 64)[:, :, 1]
+    qq, kk = qkv.float().view(B, L, 3, H, 64)[:, :, 0], qkv.float().view(B, L, 3, H, 64)[:, :, 1]
+    inv = ((dq * qq).sum() - (dk * kk).sum()).abs().item()
+    scale = (dq * qq).abs().sum().item()
+    assert inv <= 2e-3 * scale, (inv, scale)
