@@ -411,6 +411,11 @@ typedef struct tan_mlp_desc {
     void* xn_next; float *nmean, *nrstd;
     float eps;
     int variant;                             /* 0; (1: stream only, 2: no streaming -- timing experiments, results undefined) */
+    /* Optional head (pw_out != NULL): x_mid is not read but WRITTEN first, x_mid = x_in + attn_o W_out^T + b_out -- the attention
+     * out-projection + bias + residual of the block (tfm_model.py:30-36: what follows the attention core) for shapes the one-launch
+     * attention branch (tan_attnblk_fwd) does not take (L > 80): attn_o [rows, C] bf16 = tan_attn_fwd's output, pw_out =
+     * tan_pack_weights image of out_proj.weight [C][C] (TN = 512, TK = 16), b_out f32 [C], x_in [rows, C] bf16 the block's input. */
+    const void* attn_o; const void* pw_out; const float* b_out; const void* x_in;
 } tan_mlp_desc;
 int tan_mlp_fwd(const tan_mlp_desc* d, void* stream);
 

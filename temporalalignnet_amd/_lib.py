@@ -127,6 +127,7 @@ class MlpDesc(C.Structure):
         ("h_pre", C.c_void_p), ("h_act", C.c_void_p), ("x_out", C.c_void_p),
         ("nln_g", C.c_void_p), ("nln_b", C.c_void_p), ("xn_next", C.c_void_p), ("nmean", C.c_void_p), ("nrstd", C.c_void_p),
         ("eps", C.c_float), ("variant", C.c_int),
+        ("attn_o", C.c_void_p), ("pw_out", C.c_void_p), ("b_out", C.c_void_p), ("x_in", C.c_void_p),
     ]
 
 

@@ -191,6 +191,11 @@ static int panel_in_enabled() {
     static const int on = [] { const char* e = getenv("TAN_PANEL_IN"); return e ? atoi(e) : 1; }();
     return on;
 }
+// TAN_PANEL_OUT=0: out_proj + bias + residual as its own launch where the one-launch attention branch does not run
+static int panel_out_enabled() {
+    static const int on = [] { const char* e = getenv("TAN_PANEL_OUT"); return e ? atoi(e) : 1; }();
+    return on;
+}
 static int panel_do_enabled() {
     static const int on = [] { const char* e = getenv("TAN_PANEL_DO"); return e ? atoi(e) : 1; }();
     return on;
@@ -213,6 +218,7 @@ extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
         const tan_layer_bufs& b = e->bufs[i];
         if (!ln1_done) CK(tan_layernorm_fwd(x_in, p.ln1_g, p.ln1_b, b.xn1, b.mean1, b.rstd1, nullptr, 0, R, C, 1e-5f, dt, st));
         ln1_done = false;
+        bool out_head = false;
         if (attn_panel_ok && p.wp_qkv && p.wp_out) {
             // one launch: in_proj GEMM, the 8 heads' attention and out_proj + bias + residual, one workgroup per video (tan_attnblk.hip)
             tan_attnblk_desc ab{};
@@ -225,11 +231,14 @@ extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
         } else {
             CK(linear_fwd(dt, b.xn1, p.w_qkv, p.b_qkv, b.qkv, R, 3 * C, C, TAN_ACT_NONE, nullptr, nullptr, st));
             CK(tan_attn_fwd(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->B, e->L, H, dt, st));
-            CK(linear_fwd(dt, b.attn_o, p.w_out, p.b_out, b.x_mid, R, C, C, TAN_ACT_NONE, nullptr, x_in, st));
+            // out_proj + bias + residual: the head of the row-panel MLP forward below (TAN_PANEL_OUT=0: its own launch)
+            out_head = panel_ok && p.wp_fc && p.wp_proj && p.wp_out && panel_out_enabled();
+            if (!out_head) CK(linear_fwd(dt, b.attn_o, p.w_out, p.b_out, b.x_mid, R, C, C, TAN_ACT_NONE, nullptr, x_in, st));
         }
         if (panel_ok && p.wp_fc && p.wp_proj) {
             tan_mlp_desc m{};
             m.rows = R; m.C = C; m.FF = 4 * C;
+            if (out_head) { m.attn_o = b.attn_o; m.pw_out = p.wp_out; m.b_out = p.b_out; m.x_in = x_in; }
             m.x_mid = b.x_mid; m.ln_g = p.ln2_g; m.ln_b = p.ln2_b;
             m.pw_fc = p.wp_fc; m.pw_proj = p.wp_proj; m.b_fc = p.b_fc; m.b_proj = p.b_proj;
             m.x_out = b.x_out;

@@ -64,6 +64,9 @@ struct MlpFwdArgs {
     const float* nln_g; const float* nln_b; bf16_t* xn_next; float* nmean; float* nrstd;
     float eps;
     int rot;
+    // optional head (MODE & 2048): x_mid is not read but PRODUCED first, x_mid = x_in + attn_o W_out^T + b_out -- the attention
+    // out-projection + bias + residual of the block (tfm_model.py:30-36) where the fused attention launch does not run (L > 80)
+    const bf16_t* attn_o; const char* pw_out; const float* b_out; const bf16_t* x_in; bf16_t* x_mid_w;
 };
 // Backward of the same branch, same schedule with the roles of the two weights exchanged (tan_mlp_bwd):
 //   dh_c = (dx W_proj[:, c]) o quickgelu'(h_pre_c)      "c_fc-like": K = 512 over the resident dx panel, packed W_proj^T tiles
@@ -560,7 +563,9 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
         }
     }
     constexpr bool INP = BWD && (MODE & 512) != 0;      // the next block's in_proj dX GEMM runs first (its packed W_in^T leads the ring)
+    constexpr bool OUTP = !BWD && (MODE & 2048) != 0;   // forward: the block's out_proj + bias + residual runs first (packed W_out leads)
     const char* pin = pfc;
+    if constexpr (OUTP) pin = a.pw_out;
     if constexpr (INP) {
         pin = a.pwt_in;
         const int L = blockIdx.x * (64 * PN_WAVES) + tid;          // first touch of its 1.5 MiB as well
@@ -570,11 +575,78 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     MlpWFrags WQ[D];
     pn_static_for<0, D>([&](auto jc) {
         constexpr int J = decltype(jc)::value;
-        mlp_load_w(WQ[J], pin + (long)((INP ? 0 : CC(0) * 16) + J) * TILE, wave, lane);
+        mlp_load_w(WQ[J], pin + (long)(((INP || OUTP) ? 0 : CC(0) * 16) + J) * TILE, wave, lane);
     });
 
     // ---- prologue.  Forward: LN2 of the panel, 64 / PN_WAVES rows per wave (batches of 8), one 16-byte chunk per lane.  Backward:
     // the dx panel as it is.
+    if constexpr (OUTP) {
+        // ---- head (forward): x_mid = x_in + attn_o W_out^T + b_out.  The attn_o panel goes HBM -> LDS by LDS-DMA into the hidden panel
+        // space, 32 K-steps of 16 through the weight ring (which then runs into c_fc(0)'s tiles), the bf16 result lands in the input
+        // panel space -- where LN2 below normalises it in place -- and leaves for HBM as whole rows (the backward and this kernel's
+        // own residual read it from there).
+        constexpr int RPW = PN_ROWS / PN_WAVES;
+        char* pX = lds + XN_OFF;
+        char* pH = lds + H_OFF;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int row = wave * RPW + r;
+            const bf16_t* g = a.attn_o + (row0 + row) * 512 + ((lane ^ (row & 15)) << 3);
+            __builtin_amdgcn_global_load_lds((pn_gptr_t)g, (pn_lptr_t)(pH + row * 1024), 16, 0, 0);
+        }
+        uint4 rq[MLP_NBO][2][2];          // residual rows in the accumulator layout
+#pragma unroll
+        for (int nb = 0; nb < MLP_NBO; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+                    rq[nb][mb][pp] = *reinterpret_cast<const uint4*>(a.x_in + (row0 + mb * 32 + (lane & 31)) * 512 + wave * (32 * MLP_NBO) +
+                                                                     nb * 32 + 8 * pp + 16 * hi);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        MlpXAddr XH;
+        mlp_xaddr_init(XH, lds, lane);
+        f32x16 acc_d[MLP_NBO][2];
+#pragma unroll
+        for (int i = 0; i < MLP_NBO; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc_zero(acc_d[i][j]);
+        bf16x8 xf[2][2];
+        mlp_load_x_k16<0, H_OFF - XN_OFF>(xf[0], XH);
+        pn_static_for<0, 32>([&](auto jc) {
+            constexpr int KT = decltype(jc)::value;
+            MlpWFrags& W = WQ[KT % D];
+            if constexpr (KT < 31) mlp_load_x_k16<KT + 1, H_OFF - XN_OFF>(xf[(KT + 1) & 1], XH);
+            const bf16x8 x0 = xf[KT & 1][0], x1 = xf[KT & 1][1];
+#pragma unroll
+            for (int nb = 0; nb < MLP_NBO; ++nb) {
+                acc_d[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], x0, acc_d[nb][0], 0, 0, 0);
+                acc_d[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], x1, acc_d[nb][1], 0, 0, 0);
+            }
+            if constexpr (KT + D < 32) mlp_load_w(W, pin + (long)(KT + D) * TILE, wave, lane);
+            else mlp_load_w(W, pfc + (long)(CC(0) * 16 + KT + D - 32) * TILE, wave, lane);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int nb = 0; nb < MLP_NBO; ++nb) {
+            const int nbase = wave * (32 * MLP_NBO) + nb * 32;
+            pn_cfptr_t bp = (pn_cfptr_t)(uintptr_t)(a.b_out) + nbase;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    float bias[8], res[8], v[8];
+                    pn_uniform8(bp + 8 * pp, bp + 16 + 8 * pp, hi, bias);
+                    pn_unpack8(rq[nb][mb][pp], res);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = acc_d[nb][mb][8 * pp + e] + bias[e] + res[e];
+                    *reinterpret_cast<uint4*>(pn_panel_slot<1024>(pX, mb * 32 + (lane & 31), ((nbase + 8 * pp) >> 3) + 2 * hi)) = pn_pack8(v);
+                }
+        }
+        __syncthreads();
+        pn_panel_copy_out<1024>(pX, a.x_mid_w + row0 * 512, 512, wave, lane);
+    }
     if constexpr (INP) {
         // ---- head: dxn1 = dqkv W_in (+ dstage), K = 1536 as three [64 x 512] panels of dqkv staged in the (idle) input / hidden
         // panel space, "c_proj-like" (the wave owns 64 output features, 96 K-steps of 16); the result lands in the hidden panel space
@@ -740,7 +812,10 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
         for (int half = 0; half < RPW / 8; ++half) {
             f8 v[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = ld8(a.x_mid + (row0 + wave * RPW + half * 8 + r) * 512 + lane * 8);
+            for (int r = 0; r < 8; ++r) {
+                if constexpr (OUTP) v[r] = ld8(reinterpret_cast<const bf16_t*>(pn_panel_slot<1024>(lds + XN_OFF, wave * RPW + half * 8 + r, lane)));
+                else v[r] = ld8(a.x_mid + (row0 + wave * RPW + half * 8 + r) * 512 + lane * 8);
+            }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 float s = 0.f;
@@ -1209,12 +1284,19 @@ extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
     a.nln_g = d->nln_g; a.nln_b = d->nln_b; a.xn_next = (bf16_t*)d->xn_next; a.nmean = d->nmean; a.nrstd = d->nrstd;
     a.eps = d->eps;
     a.rot = mlp_rot();
+    a.attn_o = (const bf16_t*)d->attn_o; a.pw_out = (const char*)d->pw_out; a.b_out = d->b_out; a.x_in = (const bf16_t*)d->x_in;
+    a.x_mid_w = (bf16_t*)d->x_mid;
+    const bool outp = d->pw_out != nullptr;
+    if (outp) TAN_REQUIRE(d->attn_o && d->b_out && d->x_in && d->variant == 0);
     const dim3 grid((unsigned)(d->rows / PN_ROWS));
-    const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0);
+    const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0 + (outp ? 2.0 * d->rows * 512.0 * 512.0 : 0.0));
 #define TAN_MLP_LAUNCH(M) hipLaunchKernelGGL((mlp_panel_kernel<M, MlpFwdArgs>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a)
     // inference / the EMA target's forward: the side outputs of the chunk epilogue (h_pre, h_act: 2 x 4 KiB per row... 67 MB per
     // 8192 rows) are never read -- the instantiation without their copy-out (everything else identical)
-    if (no_side && d->variant == 0) {
+    if (outp) {
+        if (no_side) TAN_MLP_LAUNCH(2048 | 16);
+        else TAN_MLP_LAUNCH(2048);
+    } else if (no_side && d->variant == 0) {
         TAN_MLP_LAUNCH(16);
     } else
     switch (d->variant) {

@@ -108,6 +108,59 @@ def test_mlp_fwd_matches_reference_and_unfused_path(R, next_ln):
         assert (diff > 0).float().mean().item() < 0.02, k        # different summation order flips a rounding now and then
 
 
+@pytest.mark.parametrize("save", [True, False])
+def test_mlp_fwd_with_the_out_projection_as_head(save):
+    """tan_mlp_fwd with pw_out set: x_mid = x_in + attn_o W_out^T + b_out is computed in the kernel (and written) in front of LN2 --
+    against the GEMM launch it replaces followed by the plain kernel; x_mid itself against fp32."""
+    _lib, ops = _lib_ops()
+    R, bf = 448, torch.bfloat16
+    torch.manual_seed(5)
+    x_in = (torch.randn(R, 512, device="cuda") * 1.5).to(bf)
+    attn_o = torch.randn(R, 512, device="cuda").to(bf)
+    w_out = (torch.randn(512, 512, device="cuda") * 512 ** -0.5).to(bf)
+    b_out = torch.randn(512, device="cuda") * 0.1
+    wfc = (torch.randn(2048, 512, device="cuda") * 1024 ** -0.5).to(bf)
+    wpj = (torch.randn(512, 2048, device="cuda") * 0.03).to(bf)
+    bfc, bpj = torch.randn(2048, device="cuda") * 0.1, torch.randn(512, device="cuda") * 0.1
+    g2, b2 = 1 + 0.1 * torch.randn(512, device="cuda"), 0.1 * torch.randn(512, device="cuda")
+    g1, b1 = 1 + 0.1 * torch.randn(512, device="cuda"), 0.1 * torch.randn(512, device="cuda")
+    pw_fc, pw_pj, pw_out = pack([wfc, wpj, w_out])
+
+    def run(head):
+        out = {k: torch.zeros(R, 512, device="cuda", dtype=bf) for k in ("xn2", "xout", "xn1", "xmid")}
+        out |= {k: torch.zeros(R, 2048, device="cuda", dtype=bf) for k in ("hpre", "hact")}
+        out |= {k: torch.zeros(R, device="cuda") for k in ("mean2", "rstd2", "mean1", "rstd1")}
+        d = _lib.MlpDesc()
+        d.rows, d.C, d.FF = R, 512, 2048
+        d.x_mid, d.ln_g, d.ln_b = out["xmid"].data_ptr(), g2.data_ptr(), b2.data_ptr()
+        d.pw_fc, d.pw_proj, d.b_fc, d.b_proj = pw_fc.data_ptr(), pw_pj.data_ptr(), bfc.data_ptr(), bpj.data_ptr()
+        d.x_out = out["xout"].data_ptr()
+        if save:
+            d.xn2, d.mean2, d.rstd2 = out["xn2"].data_ptr(), out["mean2"].data_ptr(), out["rstd2"].data_ptr()
+            d.h_pre, d.h_act = out["hpre"].data_ptr(), out["hact"].data_ptr()
+        d.nln_g, d.nln_b, d.xn_next = g1.data_ptr(), b1.data_ptr(), out["xn1"].data_ptr()
+        d.nmean, d.nrstd = out["mean1"].data_ptr(), out["rstd1"].data_ptr()
+        d.eps, d.variant = 1e-5, 0
+        if head:
+            d.attn_o, d.pw_out, d.b_out, d.x_in = attn_o.data_ptr(), pw_out.data_ptr(), b_out.data_ptr(), x_in.data_ptr()
+        else:
+            ops.gemm(attn_o, w_out, out["xmid"], M=R, N=512, K=512, bias=b_out, residual=x_in)
+        _lib.check(_lib.lib().tan_mlp_fwd(C.byref(d), ops._stream()), "tan_mlp_fwd")
+        torch.cuda.synchronize()
+        return out
+
+    o0, o1 = run(False), run(True)
+    ref = x_in.float() + attn_o.float() @ w_out.float().T + b_out
+    assert (o1["xmid"].float() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    for k in o0:
+        a, b = o0[k].float(), o1[k].float()
+        assert torch.isfinite(b).all(), k
+        tol = 2.0 ** -6 * a.abs().max().item() if o0[k].dtype == bf else 2e-3
+        assert (a - b).abs().max().item() <= tol + 1e-6, (k, (a - b).abs().max().item())
+        if o0[k].dtype == bf:
+            assert (a != b).float().mean().item() < 0.10, k
+
+
 def test_mlp_fwd_rejects_what_it_cannot_do():
     _lib, ops = _lib_ops()
     d = _lib.MlpDesc()
