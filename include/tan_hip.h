@@ -321,6 +321,7 @@ typedef struct tan_layer_params {
     const void *wt_qkv, *wt_out, *wt_fc, *wt_proj; /* optional (bf16): W^T copies, [in, out] row-major, for the dX GEMMs; NULL = read W K-strided */
     const void *wp_qkv, *wp_out, *wp_fc, *wp_proj; /* optional (bf16): tan_pack_weights images of w_* for the row-panel kernels; NULL = unfused path */
     const void *wtp_qkv, *wtp_out, *wtp_fc, *wtp_proj; /* optional (bf16): tan_pack_weights images of wt_* (backward row-panel kernels) */
+    const void* wp_qkv_k16;                        /* optional (bf16): in_proj packed with TN = 512, TK = 16 (the MLP forward's in_proj tail, L > 80) */
 } tan_layer_params;
 
 /* per-layer saved activations, rows R = B*L */
@@ -416,6 +417,10 @@ typedef struct tan_mlp_desc {
      * attention branch (tan_attnblk_fwd) does not take (L > 80): attn_o [rows, C] bf16 = tan_attn_fwd's output, pw_out =
      * tan_pack_weights image of out_proj.weight [C][C] (TN = 512, TK = 16), b_out f32 [C], x_in [rows, C] bf16 the block's input. */
     const void* attn_o; const void* pw_out; const float* b_out; const void* x_in;
+    /* Optional tail (pw_in != NULL; needs the head above and xn_next): qkv_out [rows, 3C] bf16 = xn_next W_in^T + b_qkv -- the NEXT
+     * block's attention in-projection (tfm_model.py:21, 30-36) from the xn_next panel that is sitting in LDS; pw_in =
+     * tan_pack_weights image of that block's in_proj_weight [3C][C] with TN = 512, TK = 16; b_qkv f32 [3C]. */
+    const void* pw_in; const float* b_qkv; void* qkv_out;
 } tan_mlp_desc;
 int tan_mlp_fwd(const tan_mlp_desc* d, void* stream);
 

@@ -102,7 +102,7 @@ class LayerParams(C.Structure):
         "w_qkv", "w_out", "w_fc", "w_proj", "b_qkv", "b_out", "b_fc", "b_proj", "ln1_g", "ln1_b", "ln2_g", "ln2_b",
         "g_w_qkv", "g_w_out", "g_w_fc", "g_w_proj", "g_b_qkv", "g_b_out", "g_b_fc", "g_b_proj",
         "g_ln1_g", "g_ln1_b", "g_ln2_g", "g_ln2_b", "wt_qkv", "wt_out", "wt_fc", "wt_proj",
-        "wp_qkv", "wp_out", "wp_fc", "wp_proj", "wtp_qkv", "wtp_out", "wtp_fc", "wtp_proj")]
+        "wp_qkv", "wp_out", "wp_fc", "wp_proj", "wtp_qkv", "wtp_out", "wtp_fc", "wtp_proj", "wp_qkv_k16")]
 
 
 class LayerBufs(C.Structure):
@@ -128,6 +128,7 @@ class MlpDesc(C.Structure):
         ("nln_g", C.c_void_p), ("nln_b", C.c_void_p), ("xn_next", C.c_void_p), ("nmean", C.c_void_p), ("nrstd", C.c_void_p),
         ("eps", C.c_float), ("variant", C.c_int),
         ("attn_o", C.c_void_p), ("pw_out", C.c_void_p), ("b_out", C.c_void_p), ("x_in", C.c_void_p),
+        ("pw_in", C.c_void_p), ("b_qkv", C.c_void_p), ("qkv_out", C.c_void_p),
     ]
 
 

@@ -191,7 +191,8 @@ static int panel_in_enabled() {
     static const int on = [] { const char* e = getenv("TAN_PANEL_IN"); return e ? atoi(e) : 1; }();
     return on;
 }
-// TAN_PANEL_OUT=0: out_proj + bias + residual as its own launch where the one-launch attention branch does not run
+// TAN_PANEL_OUT (bit mask, default 1; bit 2 measured neutral at len=256: 4.544 vs 4.544 ms), where the one-launch attention branch does not run: 1 = out_proj + bias + residual as the head of
+// the row-panel MLP forward, 2 = the next block's in_proj as its tail; 0 = their own launches
 static int panel_out_enabled() {
     static const int on = [] { const char* e = getenv("TAN_PANEL_OUT"); return e ? atoi(e) : 1; }();
     return on;
@@ -213,11 +214,14 @@ extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
     const bool panel_ok = panel_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0;
     const bool attn_panel_ok = (attn_panel_enabled() & 1) && panel_enabled() && tan_attnblk_supported(e->L, C, H, dt);
     bool ln1_done = false;        // the previous block's panel kernel already produced this block's xn1 / mean1 / rstd1
+    bool qkv_done = false;        // ... and this block's qkv (the in_proj tail of its forward)
     for (int i = 0; i < e->layers; ++i) {
         const tan_layer_params& p = e->params[i];
         const tan_layer_bufs& b = e->bufs[i];
         if (!ln1_done) CK(tan_layernorm_fwd(x_in, p.ln1_g, p.ln1_b, b.xn1, b.mean1, b.rstd1, nullptr, 0, R, C, 1e-5f, dt, st));
         ln1_done = false;
+        const bool qkv_ready = qkv_done;
+        qkv_done = false;
         bool out_head = false;
         if (attn_panel_ok && p.wp_qkv && p.wp_out) {
             // one launch: in_proj GEMM, the 8 heads' attention and out_proj + bias + residual, one workgroup per video (tan_attnblk.hip)
@@ -229,7 +233,7 @@ extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
             ab.x_mid = b.x_mid;
             CK(tan_attnblk_fwd(&ab, st));
         } else {
-            CK(linear_fwd(dt, b.xn1, p.w_qkv, p.b_qkv, b.qkv, R, 3 * C, C, TAN_ACT_NONE, nullptr, nullptr, st));
+            if (!qkv_ready) CK(linear_fwd(dt, b.xn1, p.w_qkv, p.b_qkv, b.qkv, R, 3 * C, C, TAN_ACT_NONE, nullptr, nullptr, st));
             CK(tan_attn_fwd(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->B, e->L, H, dt, st));
             // out_proj + bias + residual: the head of the row-panel MLP forward below (TAN_PANEL_OUT=0: its own launch)
             out_head = panel_ok && p.wp_fc && p.wp_proj && p.wp_out && panel_out_enabled();
@@ -249,6 +253,11 @@ extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
                 const tan_layer_bufs& bn = e->bufs[i + 1];
                 m.nln_g = pn.ln1_g; m.nln_b = pn.ln1_b; m.xn_next = bn.xn1; m.nmean = bn.mean1; m.nrstd = bn.rstd1;
                 ln1_done = true;
+                // the next block's in-projection as this launch's tail (the next block takes the same unfused attention path)
+                if (out_head && (panel_out_enabled() & 2) && pn.wp_qkv_k16 && bn.qkv) {
+                    m.pw_in = pn.wp_qkv_k16; m.b_qkv = pn.b_qkv; m.qkv_out = bn.qkv;
+                    qkv_done = true;
+                }
             } else if (e->post_out) {
                 m.nln_g = e->post_g; m.nln_b = e->post_b; m.xn_next = e->post_out; m.nmean = e->post_mean; m.nrstd = e->post_rstd;
                 ln1_done = true;      // = the post-LN is done

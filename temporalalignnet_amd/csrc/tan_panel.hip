@@ -67,6 +67,8 @@ struct MlpFwdArgs {
     // optional head (MODE & 2048): x_mid is not read but PRODUCED first, x_mid = x_in + attn_o W_out^T + b_out -- the attention
     // out-projection + bias + residual of the block (tfm_model.py:30-36) where the fused attention launch does not run (L > 80)
     const bf16_t* attn_o; const char* pw_out; const float* b_out; const bf16_t* x_in; bf16_t* x_mid_w;
+    // optional tail (MODE & 4096): qkv = xn_next W_in^T + b_qkv, the NEXT block's attention in-projection, from the xn_next panel
+    const char* pw_in; const float* b_qkv; bf16_t* qkv_out;
 };
 // Backward of the same branch, same schedule with the roles of the two weights exchanged (tan_mlp_bwd):
 //   dh_c = (dx W_proj[:, c]) o quickgelu'(h_pre_c)      "c_fc-like": K = 512 over the resident dx panel, packed W_proj^T tiles
@@ -1189,6 +1191,57 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                 }
             }
         __syncthreads();
+        if constexpr ((MODE & 4096) != 0) {
+            // ---- tail: qkv = xn_next W_in^T + b_qkv for the next block (a [64 x 512] x [512 x 1536] row-local product on the panel
+            // that is sitting in LDS), three groups of 512 output features (q | k | v), 32 K-steps of 16 each, packed W_in through the
+            // idle weight ring; every group leaves through the (idle) input panel space as whole 1-KiB rows of the [rows][1536] tensor
+            pn_static_for<0, D>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                mlp_load_w(WQ[J], a.pw_in + (long)J * TILE, wave, lane);
+            });
+            pn_panel_copy_out<1024>(xn_panel, a.xn_next + row0 * 512, 512, wave, lane);
+            pn_static_for<0, 3>([&](auto gc) {
+                constexpr int G = decltype(gc)::value;
+                f32x16 acc_q[MLP_NBO][2];
+#pragma unroll
+                for (int i = 0; i < MLP_NBO; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc_zero(acc_q[i][j]);
+                bf16x8 xq[2][2];
+                mlp_load_x_k16<0, MLP_H_OFF - MLP_XN_OFF>(xq[0], XA);
+                pn_static_for<0, 32>([&](auto jc) {
+                    constexpr int KT = decltype(jc)::value, T = G * 32 + KT;
+                    MlpWFrags& W = WQ[T % D];
+                    if constexpr (KT < 31) mlp_load_x_k16<KT + 1, MLP_H_OFF - MLP_XN_OFF>(xq[(KT + 1) & 1], XA);
+                    const bf16x8 x0 = xq[KT & 1][0], x1 = xq[KT & 1][1];
+#pragma unroll
+                    for (int nb = 0; nb < MLP_NBO; ++nb) {
+                        acc_q[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], x0, acc_q[nb][0], 0, 0, 0);
+                        acc_q[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], x1, acc_q[nb][1], 0, 0, 0);
+                    }
+                    if constexpr (T + D < 96) mlp_load_w(W, a.pw_in + (long)(T + D) * TILE, wave, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if constexpr (G > 0) __syncthreads();          // every wave has copied the previous group's rows out of the panel
+#pragma unroll
+                for (int nb = 0; nb < MLP_NBO; ++nb) {
+                    const int nbase = wave * (32 * MLP_NBO) + nb * 32;
+                    pn_cfptr_t bq = (pn_cfptr_t)(uintptr_t)(a.b_qkv) + G * 512 + nbase;
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp) {
+                            float bias[8], v[8];
+                            pn_uniform8(bq + 8 * pp, bq + 16 + 8 * pp, hi, bias);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = acc_q[nb][mb][8 * pp + e] + bias[e];
+                            *reinterpret_cast<uint4*>(pn_panel_slot<1024>(xo_panel, mb * 32 + (lane & 31), ((nbase + 8 * pp) >> 3) + 2 * hi)) = pn_pack8(v);
+                        }
+                }
+                __syncthreads();
+                pn_panel_copy_out<1024>(xo_panel, a.qkv_out + row0 * 1536 + G * 512, 1536, wave, lane);
+            });
+        } else
         pn_panel_copy_out<1024>(xn_panel, a.xn_next + row0 * 512, 512, wave, lane);
     }
 
@@ -1286,14 +1339,19 @@ extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
     a.rot = mlp_rot();
     a.attn_o = (const bf16_t*)d->attn_o; a.pw_out = (const char*)d->pw_out; a.b_out = d->b_out; a.x_in = (const bf16_t*)d->x_in;
     a.x_mid_w = (bf16_t*)d->x_mid;
-    const bool outp = d->pw_out != nullptr;
+    const bool outp = d->pw_out != nullptr, intail = d->pw_in != nullptr;
     if (outp) TAN_REQUIRE(d->attn_o && d->b_out && d->x_in && d->variant == 0);
+    if (intail) TAN_REQUIRE(outp && d->xn_next && d->b_qkv && d->qkv_out);
+    a.pw_in = (const char*)d->pw_in; a.b_qkv = d->b_qkv; a.qkv_out = (bf16_t*)d->qkv_out;
     const dim3 grid((unsigned)(d->rows / PN_ROWS));
-    const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0 + (outp ? 2.0 * d->rows * 512.0 * 512.0 : 0.0));
+    const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0 + (outp ? 2.0 * d->rows * 512.0 * 512.0 : 0.0) + (intail ? 2.0 * d->rows * 512.0 * 1536.0 : 0.0));
 #define TAN_MLP_LAUNCH(M) hipLaunchKernelGGL((mlp_panel_kernel<M, MlpFwdArgs>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a)
     // inference / the EMA target's forward: the side outputs of the chunk epilogue (h_pre, h_act: 2 x 4 KiB per row... 67 MB per
     // 8192 rows) are never read -- the instantiation without their copy-out (everything else identical)
-    if (outp) {
+    if (outp && intail) {
+        if (no_side) TAN_MLP_LAUNCH(4096 | 2048 | 16);
+        else TAN_MLP_LAUNCH(4096 | 2048);
+    } else if (outp) {
         if (no_side) TAN_MLP_LAUNCH(2048 | 16);
         else TAN_MLP_LAUNCH(2048);
     } else if (no_side && d->variant == 0) {

@@ -51,8 +51,9 @@ class _AlignerEngine(_WorkspaceMixin):
         wt = f.shadow_t if (self.compute_dtype == torch.bfloat16 and self.transposed_dx) else None
         wp = f.shadow_p if (self.compute_dtype == torch.bfloat16 and self.panel_kernels) else None
         wtp = f.shadow_tp if (wt is not None and wp is not None) else None
+        wpk = getattr(f, "shadow_pk", None) if wp is not None else None
         sig = (f.flat.data_ptr(), f.grad.data_ptr(), wbuf.data_ptr(), wt.data_ptr() if wt is not None else 0,
-               wp.data_ptr() if wp is not None else 0, wtp.data_ptr() if wtp is not None else 0)
+               wp.data_ptr() if wp is not None else 0, wtp.data_ptr() if wtp is not None else 0, wpk.data_ptr() if wpk is not None else 0)
         hit = self._lp_cache.get((prefix, layers))
         if hit is not None and hit[0] == sig:
             return hit[1]
@@ -70,6 +71,7 @@ class _AlignerEngine(_WorkspaceMixin):
                 setattr(arr[i], "wt_" + k[2:], f.ptr(wt, base + v) if wt is not None else None)
                 setattr(arr[i], "wp_" + k[2:], f.ptr(wp, base + v) if wp is not None else None)
                 setattr(arr[i], "wtp_" + k[2:], f.ptr(wtp, base + v) if wtp is not None else None)
+            arr[i].wp_qkv_k16 = f.ptr(wpk, base + m["w_qkv"]) if wpk is not None else None
             for k, v in fm.items():
                 setattr(arr[i], k, f.ptr(f.flat, base + v))
                 setattr(arr[i], "g_" + k, f.ptr(f.grad, base + v))
@@ -80,6 +82,9 @@ class _AlignerEngine(_WorkspaceMixin):
         d = _lib.EncoderDesc()
         d.dtype = ops._dt(x0)
         d.B, d.L, d.C, d.H, d.layers = er.B, er.L, WIDTH, HEADS, er.layers
+        if (self.panel_kernels and self.compute_dtype == torch.bfloat16 and not 48 < er.L <= 80
+                and int(os.environ.get("TAN_PANEL_OUT", "1")) & 2):
+            self._flat.sync_shadow_pk()       # in_proj in the tile format of the MLP forward's tail (first use builds it)
         d.key_padding_mask = _vp(keypad)
         d.x0 = _vp(x0)
         er.params = self._layer_params(er.prefix, er.layers)

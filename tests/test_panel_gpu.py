@@ -16,12 +16,19 @@ def _lib_ops():
 
 def pack(mats):
     _lib, ops = _lib_ops()
+    mats = list(mats)
+    ents, off, mx = [], 0, 0
+    fmts = []
+    for i, m in enumerate(mats):
+        if isinstance(m, tuple):                       # (matrix, TN, TK): an explicit tile format
+            mats[i], tn, tk = m
+            fmts.append((tn, tk))
+        else:
+            fmts.append((512, 16) if m.shape[0] == 512 else (256, 32))
     src = torch.cat([m.reshape(-1) for m in mats])
     dst = torch.empty_like(src)
-    ents, off, mx = [], 0, 0
-    for m in mats:
+    for m, (TN, TK) in zip(mats, fmts):
         N, K = m.shape
-        TN, TK = (512, 16) if N == 512 else (256, 32)
         ents.append(_lib.PackEntry(off, off, N, K, TN, TK))
         mx = max(mx, (N // TN) * (K // TK))
         off += N * K
@@ -124,7 +131,9 @@ def test_mlp_fwd_with_the_out_projection_as_head(save):
     bfc, bpj = torch.randn(2048, device="cuda") * 0.1, torch.randn(512, device="cuda") * 0.1
     g2, b2 = 1 + 0.1 * torch.randn(512, device="cuda"), 0.1 * torch.randn(512, device="cuda")
     g1, b1 = 1 + 0.1 * torch.randn(512, device="cuda"), 0.1 * torch.randn(512, device="cuda")
-    pw_fc, pw_pj, pw_out = pack([wfc, wpj, w_out])
+    w_in = (torch.randn(1536, 512, device="cuda") * 512 ** -0.5).to(bf)          # the NEXT block's in_proj (the optional tail)
+    b_in = torch.randn(1536, device="cuda") * 0.1
+    pw_fc, pw_pj, pw_out, pw_in = pack([wfc, wpj, w_out, (w_in, 512, 16)])
 
     def run(head):
         out = {k: torch.zeros(R, 512, device="cuda", dtype=bf) for k in ("xn2", "xout", "xn1", "xmid")}
@@ -141,17 +150,23 @@ def test_mlp_fwd_with_the_out_projection_as_head(save):
         d.nln_g, d.nln_b, d.xn_next = g1.data_ptr(), b1.data_ptr(), out["xn1"].data_ptr()
         d.nmean, d.nrstd = out["mean1"].data_ptr(), out["rstd1"].data_ptr()
         d.eps, d.variant = 1e-5, 0
+        out["qkv"] = torch.full((R, 1536), float("nan"), device="cuda", dtype=bf)
         if head:
             d.attn_o, d.pw_out, d.b_out, d.x_in = attn_o.data_ptr(), pw_out.data_ptr(), b_out.data_ptr(), x_in.data_ptr()
+            d.pw_in, d.b_qkv, d.qkv_out = pw_in.data_ptr(), b_in.data_ptr(), out["qkv"].data_ptr()
         else:
             ops.gemm(attn_o, w_out, out["xmid"], M=R, N=512, K=512, bias=b_out, residual=x_in)
         _lib.check(_lib.lib().tan_mlp_fwd(C.byref(d), ops._stream()), "tan_mlp_fwd")
+        if not head:                                   # the launch the tail replaces
+            ops.gemm(out["xn1"], w_in, out["qkv"], M=R, N=1536, K=512, bias=b_in)
         torch.cuda.synchronize()
         return out
 
     o0, o1 = run(False), run(True)
     ref = x_in.float() + attn_o.float() @ w_out.float().T + b_out
     assert (o1["xmid"].float() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    ref_q = o1["xn1"].float() @ w_in.float().T + b_in
+    assert (o1["qkv"].float() - ref_q).abs().max().item() <= 2.0 ** -7 * ref_q.abs().max().item()
     for k in o0:
         a, b = o0[k].float(), o1[k].float()
         assert torch.isfinite(b).all(), k
