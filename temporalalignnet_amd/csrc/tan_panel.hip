@@ -125,6 +125,12 @@ constexpr int MLP_KDF = 32, MLP_KDP = 16, MLP_TILE = 16384, MLP_TF = 512 / MLP_K
 #ifndef TAN_MLP_BURST
 #define TAN_MLP_BURST 0          // 1: all waves in the same phase, epilogue arithmetic in bursts between MFMA bursts (measured: no gain); 0: the skewed wave groups
 #endif
+#ifndef TAN_MLP_PRIO
+#define TAN_MLP_PRIO 0           // s_setprio of a wave while it is in a c_proj || epilogue phase (0: leave the hardware's oldest-first order)
+#endif
+#ifndef TAN_MLP_PRIO_FC
+#define TAN_MLP_PRIO_FC 0        // the same for the pure-MFMA c_fc phases (both measured: 2 is 3-6 % slower either way)
+#endif
 #ifndef TAN_MLP_BURST_SLEEP
 #define TAN_MLP_BURST_SLEEP 8    // s_sleep units (64 clocks) the second wave group starts an epilogue phase late
 #endif
@@ -869,6 +875,8 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     auto fc_phase = [&](int c, auto has_copy) __attribute__((always_inline)) {            // c_fc(c) (|| side outputs of chunk c-1)
         constexpr bool COPY = decltype(has_copy)::value;
         const int hb = c & 1;
+        if constexpr (TAN_MLP_PRIO_FC != 0) __builtin_amdgcn_s_setprio(TAN_MLP_PRIO_FC);
+        struct PrioResetF { __device__ ~PrioResetF() { if (TAN_MLP_PRIO_FC != 0) __builtin_amdgcn_s_setprio(0); } } prio_reset_f;
         pn_static_for<0, 16>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
             MlpXFrags& cur = (J & 1) ? FB : FA;
@@ -902,6 +910,10 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
         constexpr bool PROJ = decltype(has_proj)::value, EPI = decltype(has_epi)::value;
         constexpr bool ARITH = EPI && !(MODE & (8 | 32));
         const int hb = c & 1;
+        // the wave in this phase carries the chunk epilogue next to its MFMAs and is the slot's long pole: let its instructions go
+        // first (the other wave of the SIMD is in a pure-MFMA phase and fills the gaps)
+        if constexpr (TAN_MLP_PRIO != 0 && EPI && PROJ) __builtin_amdgcn_s_setprio(TAN_MLP_PRIO);
+        struct PrioReset { __device__ ~PrioReset() { if (TAN_MLP_PRIO != 0) __builtin_amdgcn_s_setprio(0); } } prio_reset;
         if constexpr (BURST) {
             // Burst schedule (all eight waves in the same phase): four rounds of [16 MFMAs of four steps | the arithmetic of four
             // epilogue half-units].  A wave that waits for the matrix pipe cannot issue its VALU work (in-order issue), so MFMAs and
