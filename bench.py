@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--timer-every", type=int, default=20, help="HIP-event kernel timer samples one timed step in n (the middle one)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra driver-timed configurations (stage 2, len=256) of the N=1 run")
     ap.add_argument("--extra-steps", type=int, default=10)
+    ap.add_argument("--settle-s", type=float, default=2.0, help="bound [s] of the extra untimed warm-up that runs until the step time is "
+                    "steady (two consecutive steps and two consecutive 4-step blocks within 1 %%); 0 = only --warmup")
     ap.add_argument("--with-lm", action="store_true", help="the step starts from token ids (Word2Vec embedder inside it, train/main.py:55-65)")
     return ap.parse_args()
 
@@ -92,6 +94,36 @@ def cpu_baseline(a, args_ns):
             "sample": f"CPU oracle (PyTorch CPU fp32 restatement of the reference) E{E}D{D} T={a.seq_len} N~U[4,16] "
                       f"stage-{a.stage} train step on {a.cpu_batch} videos, {steps} timed steps after 1 warm-up "
                       f"({dt:.2f} s/step)"}
+
+
+def settle_steps(trainer, batch, dev, max_s=None, tol=0.01, block=4):
+    """Extra UNTIMED warm-up after the --warmup steps: blocks of `block` steps, each step bracketed by events, until the last two
+    steps of a block agree within `tol` AND the block's mean agrees with the previous block's, bounded at --settle-s seconds
+    (default 2).  A fresh process on a fresh lease pays allocator growth, lazy code-object loads and the clock ramp in its first
+    ~10 steps (profiles/r04_fresh_lease.txt: 150-210 ms, 5.9, 5.1, 4.9, 4.8 ... 4.7 ms); 5 warm-up steps = 25 ms of GPU work end before
+    that is over.  With N > 1 ranks every rank must run the same number of steps (they contain collectives): the stop decision is
+    the max over ranks of 'not settled yet'."""
+    from temporalalignnet_amd import dist
+    max_s = SETTLE_S if max_s is None else max_s
+    t0, n, prev = time.perf_counter(), 0, None
+    while True:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(block + 1)]
+        for i in range(block):
+            ev[i].record()
+            trainer.step(batch)
+        ev[block].record()
+        torch.cuda.synchronize()
+        ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(block)]
+        n += block
+        mean = sum(ms) / block
+        ok = abs(ms[-1] - ms[-2]) <= tol * ms[-1] and prev is not None and abs(mean - prev) <= tol * mean
+        prev = mean
+        more = 0.0 if (ok or time.perf_counter() - t0 > max_s) else 1.0
+        if dist.max_over_ranks(more, dev) == 0.0:
+            return n
+
+
+SETTLE_S = 2.0
 
 
 def traffic_profile(stage, batch_size, seq_len):
@@ -144,6 +176,7 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
 
     for _ in range(warmup):                                              # (the first step broadcasts rank 0's parameters)
         trainer.step(batch)
+    settle = settle_steps(trainer, batch, dev) if a.settle_s > 0 else 0
     trainer.comm_events.clear()
     L = _lib.lib()
     use_timer = not a.no_kernel_timer
@@ -153,17 +186,22 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     sampled = 0
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]     # step boundaries on the main stream (no host sync)
     for i in range(steps):
+        marks[i].record()
         if use_timer:                                  # ~200 timing events cost 1-1.7 ms in the step they bracket: one step in
             every = min(timer_every, steps)            # `timer_every` is sampled, the middle one (the host is ahead of the GPU there)
             on = (i % every == every // 2)
             L.tan_prof_enable(2 if on else 0, 0)
             sampled += on
         loss = trainer.step(batch)
+    marks[steps].record()
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = dist.max_over_ranks(elapsed, dev)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    srt = sorted(step_ms)
     final_loss = float(loss["loss"].item())
     comm = None
     if dist.active():
@@ -232,6 +270,10 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
                     "by_kernel": [{**x, "ms_per_step": round(x["ms_per_step"], 3), "tflops": round(x["tflops"], 1)} for x in kinds]}
     res = {"value": round(batch_size * world * steps / elapsed, 1), "unit": "video-seq/s", "steps": steps, "warmup": warmup,
            "ms_per_step": round(elapsed / steps * 1e3, 3), "dtype": a.dtype,
+           # GPU time between consecutive step boundaries (events on the main stream; the step that carries the ~200 kernel-timer events
+           # is the max), and the extra untimed warm-up the steady-state rule below asked for
+           "step_ms_min": round(srt[0], 3), "step_ms_p50": round(srt[len(srt) // 2], 3), "step_ms_max": round(srt[-1], 3),
+           "first_timed_step_ms": round(step_ms[0], 3), "settle_steps": settle,
            "config": {"workload": f"E{a.layers}D{a.layers} len={seq_len} {a.dtype} stage-{stage} "
                                   f"({'init: multi-positive NCE only' if stage == 1 else 'cotrain: EMA + alignability + NCE'}) "
                                   f"train step (fwd+loss+bwd+AdamW), synthetic HTM-370K-shaped features, N~U[4,16] sentences/video",
@@ -265,6 +307,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    global SETTLE_S
+    SETTLE_S = a.settle_s
     head, args_ns = run_config(a, world, rank, dev, a.stage, a.batch, a.seq_len, a.steps, a.warmup, a.timer_every, with_lm=a.with_lm)
     extra = []
     headline = (a.stage, a.batch, a.seq_len) == (1, 128, 64) and not a.with_lm
@@ -282,7 +326,7 @@ def main():
         # Multi-GPU (or TAN_FORCE_DIST=1): the variants the first hardware scaling run has to decide between, in the same run --
         # the other gradient-reduction mode, global negatives, and BASELINE configs[2] (stage-2 co-training) at B_local 128 / 16
         # (SURVEY 8(d) config 3).  The headline line keeps the default mode; n_gpus == 1 without TAN_FORCE_DIST prints none of this.
-        other = "flat" if os.environ.get("TAN_DDP_MODE", "buckets") == "buckets" else "buckets"
+        other = "buckets" if os.environ.get("TAN_DDP_MODE", "flat") == "flat" else "flat"
         for kw, tag in ((dict(stage=1, bs=128, ddp_mode=other), f"configs[1], gradient reduction mode '{other}' (TAN_DDP_MODE)"),
                         (dict(stage=1, bs=128, gneg=True), "configs[1] with global negatives (row f3)"),
                         (dict(stage=2, bs=128), "configs[2]: stage-2 co-training, B_local=128"),
@@ -294,6 +338,8 @@ def main():
     if rank == 0:
         out = {"metric": "video-seq/sec (len=64, E6D6) at 1/2/4/8 MI355X; HTM-Align ROC-AUC parity", "value": head["value"],
                "unit": head["unit"], "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"], "ms_per_step": head["ms_per_step"],
+               "step_ms_min": head["step_ms_min"], "step_ms_p50": head["step_ms_p50"], "step_ms_max": head["step_ms_max"],
+               "first_timed_step_ms": head["first_timed_step_ms"], "settle_steps": head["settle_steps"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": head["config"], "roofline": head["roofline"]}
         if "comm" in head:

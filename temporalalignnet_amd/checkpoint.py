@@ -194,8 +194,12 @@ def load_for_resume(trainer, path):
     # recognised by 'iteration' being equal to the AdamW step of the saved optimizer state (a reference file has 1 + step * freq).
     freq = int(getattr(trainer.args, "backprop_freq", 1) or 1)
     steps = [int(v["step"]) for v in ckpt["optimizer"].get("state", {}).values() if "step" in v]
-    legacy_step_count = "iteration_kind" not in ckpt and bool(steps) and int(ckpt["iteration"]) == steps[0] and steps[0] > 0
+    legacy_step_count = "iteration_kind" not in ckpt and bool(steps) and int(ckpt["iteration"]) == max(steps) and max(steps) > 0
     if legacy_step_count:
+        import warnings
+        warnings.warn(f"{path}: no 'iteration_kind' marker and 'iteration' == the AdamW step count ({max(steps)}): read as a legacy "
+                      f"file that stored optimizer steps; batches seen = steps x backprop_freq ({freq}, the CURRENT setting -- "
+                      "resume with the backprop_freq the file was written with, or the LR schedule position is off)")
         trainer.batches_seen = int(ckpt["iteration"]) * freq
     else:
         trainer.batches_seen = max(int(ckpt["iteration"]) - 1, 0)

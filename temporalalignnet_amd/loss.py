@@ -536,7 +536,10 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
     cols_idx = None                 # the sweeps ran on compacted text columns: their text terms are [S, Mc] in that order
     if fused is not None and not getattr(fused, "global_negatives", False) and nv is not None:
         cols_idx = nv[0]
-        cols_tail = prep["cols_pos_c"] if (not args.learn_agreement and "cols_pos_c" in prep) else cols_pos.index_select(0, cols_idx)
+        # prep's compacted column mask belongs to prep's OWN index: when the compaction was redone above (another n_text_valid), the
+        # mask is compacted with the index the sweeps actually used
+        own = nv is prep.get("nv")
+        cols_tail = prep["cols_pos_c"] if (own and not args.learn_agreement and "cols_pos_c" in prep) else cols_pos.index_select(0, cols_idx)
     else:
         cols_tail = cols_pos
     loss_dual, loss_joint, loss_mean = _NCETail.apply(v_d, t_d, v_j, t_j, rows_pos, cols_tail, nce_counts)

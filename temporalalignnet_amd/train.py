@@ -138,10 +138,10 @@ class Trainer:
         self.step_async = os.environ.get("TAN_STEP_ASYNC", "1") != "0"
         # TAN_OPT_OVERLAP=1: `step` issues each gradient bucket's AdamW update next to backward (see step)
         self.opt_overlap = os.environ.get("TAN_OPT_OVERLAP", "0") != "0"
-        # TAN_DDP_MODE: "buckets" (default) = per-layer-group all-reduces overlapped with backward; "flat" = ONE all-reduce of the whole
-        # flat gradient after backward, what BASELINE.json's north_star literally describes -- an A/B switch for the first
-        # multi-GPU run (no >1-GPU node was available to pick by measurement)
-        self.ddp_mode = os.environ.get("TAN_DDP_MODE", "buckets")
+        # TAN_DDP_MODE: "flat" (default) = ONE all-reduce of the whole flat gradient after backward, what BASELINE.json's north_star
+        # states; "buckets" = per-layer-group all-reduces overlapped with backward.  No >1-GPU node was available to pick by
+        # measurement, so the default is the north star's; bench.py reports the other mode as an `extra` entry of a multi-GPU run.
+        self.ddp_mode = os.environ.get("TAN_DDP_MODE", "flat")
         self._params_synced = False
         # bench.py: with `time_comm` set, every step records two events on the compute stream around the part of the step that
         # WAITS for gradient collectives (the remainder all-reduce and the joins of the asynchronous buckets): their distance is
@@ -200,9 +200,15 @@ class Trainer:
             dist.broadcast_(m.flat_parameters(), src)
             m.invalidate_shadow()
             if m.bert is not None:
-                # trainable tensors in ONE broadcast; frozen tables (the ~80 MB word embedding: loaded from the same file on every
-                # rank, never updated) are skipped
+                # every language-model tensor, like DistributedDataParallel's constructor: the trainable ones in ONE broadcast, the
+                # frozen word table (~80 MB, random-initialised by nn.Embedding unless the caller loaded it on every rank) in place,
+                # once -- this function runs on the first step only
                 frozen_table = {id(m.bert.word_embd.weight)} if hasattr(m.bert, "word_embd") else set()
+                for p in m.bert.parameters():
+                    if id(p) in frozen_table:
+                        dist.broadcast_(p.data, src)
+                for b in m.bert.buffers():
+                    dist.broadcast_(b.data, src)
                 ps = [p for p in m.bert.parameters() if id(p) not in frozen_table]
                 if ps:
                     flat = torch.cat([p.data.reshape(-1) for p in ps])
@@ -314,13 +320,19 @@ class Trainer:
         params = [p for _, p in self._lm_params()]
         if not params:
             return
-        bucket = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+        # ... followed by one has-gradient flag per tensor: a tensor NO rank produced a gradient for (batches with precomputed
+        # text_embed) must stay `grad is None`, so that AdamW skips it like the single-GPU run and the reference do
+        flags = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], device=params[0].device)
+        bucket = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params] + [flags])
         dist.allreduce_sum_(bucket)
+        # a rank that has the gradient itself knows the sum is >= 1 without looking; only a rank WITHOUT one reads the flags back
+        seen = bucket[-len(params):].tolist() if any(p.grad is None for p in params) else None
         off = 0
-        for p in params:
+        for i, p in enumerate(params):
             g = bucket[off:off + p.numel()].view_as(p)
             if p.grad is None:
-                p.grad = g.clone()
+                if seen[i] > 0:
+                    p.grad = g.clone()
             else:
                 p.grad.copy_(g)
             off += p.numel()
