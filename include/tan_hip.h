@@ -305,6 +305,23 @@ int tan_wordpool_bwd(const void* d_pooled, const void* pooled, const int* argmax
 int tan_adamw_step(float* p, const float* g, float* m, float* v, const unsigned char* mode, long n, double lr,
                    double beta1, double beta2, double eps, double weight_decay, int step, float grad_scale, void* p_bf16,
                    float* ema, float ema_m, void* ema_bf16, void* stream);
+/* tan_adamw_step plus every weight IMAGE the bf16 kernels read, in the same pass: for each [N][K] matrix of `table` (DEVICE memory;
+ * off = element offset in the flat buffers, shared by all images) the updated values are also written as the row-major W^T (p_t), the
+ * tan_pack_weights image of W in tiles [tn_w][tk_w] (p_packed; tn_w = 384 selects "qkv16", 0 = none) and of W^T in tiles [tn_t][tk_t]
+ * (p_tpacked), and the EMA twin's packed W (ema_packed); any image pointer may be NULL.  unit_prefix (DEVICE, [n_entries + 1]) =
+ * running sum of N/64 * K/64 over the table, n_units its last element; N % 64 == 0, K % 64 == 0.  mode (required) as in
+ * tan_adamw_step; rest_idx (DEVICE, int32 [n_rest], ascending) lists every element of the flat buffer OUTSIDE the table's matrices:
+ * those are updated by the plain kernel in a second launch.  Replaces tan_adamw_step + tan_transpose_batch + 2 x tan_pack_weights of a training step (train/main.py:112-122). */
+typedef struct tan_image_entry { long off; int N, K, tn_w, tk_w, tn_t, tk_t; } tan_image_entry;
+typedef struct tan_adamw_images_desc {
+    float* p; const float* g; float *m, *v; const unsigned char* mode; long n;
+    double lr, beta1, beta2, eps, weight_decay; int step; float grad_scale;
+    void* p_bf16; float* ema; float ema_m; void* ema_bf16;
+    const tan_image_entry* table; const long* unit_prefix; int n_entries; long n_units;
+    void *p_packed, *p_t, *p_tpacked, *ema_packed;
+    const int* rest_idx; long n_rest;
+} tan_adamw_images_desc;
+int tan_adamw_step_images(const tan_adamw_images_desc* d, void* stream);
 /* target = m*target + (1-m)*online  (TwinTemporalAligner._momentum_update, tan_model.py:339-344) */
 int tan_ema_update(float* target, const float* online, long n, float m, void* target_bf16, void* stream);
 
@@ -366,6 +383,8 @@ typedef struct tan_encoder_desc {
      * made to wait for all of them. */
     void* dw_stream;
     void *scr2_dx, *scr2_dx2, *scr2_dh, *scr2_dqkv;
+    /* forward only: != 0: bufs[0].xn1 / mean1 / rstd1 already hold the first block's ln_1(x0) (tan_embed_fwd wrote them) */
+    int xn1_ready;
 } tan_encoder_desc;
 int tan_encoder_fwd(const tan_encoder_desc* e, void* stream);
 int tan_encoder_bwd(const tan_encoder_desc* e, void* stream);
@@ -467,6 +486,27 @@ typedef struct tan_mlp_bwd_desc {
     int head_only;
 } tan_mlp_bwd_desc;
 int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream);
+
+/* ---- input embeddings in ONE launch (bf16 throughput mode, C = 512) ------------------------------------------------------------
+ * tan_embed_fwd: per problem (modality), rows r = (video v, position t) with t = r % T:
+ *   proj = a W^T;  y = LayerNorm(proj; ln_g, ln_b);  out[d][(v*out_grp_rows[d] + out_off[d] + t)] = y + pos[d][t]   (d = 0, 1)
+ *   xn1[d] = LayerNorm(out[d]; ln1_g[d], ln1_b[d])  with mean1 / rstd1 at the same row index        (optional)
+ * replaces model/tan_model.py:155-167 + 187-203 (video_pre_proj, ln_video_init, ln_position_init(pos[p0:p0+T]) for the dual and the
+ * joint offset, the torch.cat into the joint stack's input) resp. 231-234 / 212-228 (text) and the first block's ln_1 of the stack
+ * that consumes out[d] (model/tfm_model.py:35).  a: [rows, K] f32 or bf16 (a_dtype); pw: tan_pack_weights image of W [512][K] with
+ * TN = 512, TK = 16; pos[d]: f32 [T, 512] rows ALREADY normalised by ln_position_init (or NULL); a_bf16 (optional, when a is f32):
+ * the bf16 copy of a the weight-gradient GEMM of the backward reads; proj / mean / rstd: saved for the LayerNorm backward.
+ * pad_dst (optional): pad_dst[v*pad_grp_rows + pad_off + t] = pad_src[r] (or 0): the rows' key-padding flags in the joint [B, L] mask.
+ * Up to two problems (video, text) share one launch. */
+typedef struct tan_embed_desc {
+    const void* a; int a_dtype; long rows; int K, T, C;
+    const void* pw; const float *ln_g, *ln_b;
+    void* a_bf16; void* proj; float *mean, *rstd;
+    void* out[2]; long out_grp_rows[2], out_off[2]; const float* pos[2];
+    const float *ln1_g[2], *ln1_b[2]; void* xn1[2]; float *mean1[2], *rstd1[2];
+    const unsigned char* pad_src; unsigned char* pad_dst; long pad_grp_rows, pad_off;
+} tan_embed_desc;
+int tan_embed_fwd(const tan_embed_desc* d, int nprob, void* stream);
 
 /* ---- the attention branch of a block in ONE launch per direction (bf16, C = 512, H = 8, 48 < L <= 80 rows per video) --------
  * tan_attnblk_fwd: x_mid = x_in + out_proj(MHA(xn1))  with MHA = nn.MultiheadAttention(512, 8) as called at

@@ -114,6 +114,22 @@ class PackEntry(C.Structure):
     _fields_ = [("src_off", C.c_long), ("dst_off", C.c_long), ("N", C.c_int), ("K", C.c_int), ("TN", C.c_int), ("TK", C.c_int)]
 
 
+class ImageEntry(C.Structure):
+    _fields_ = [("off", C.c_long), ("N", C.c_int), ("K", C.c_int), ("tn_w", C.c_int), ("tk_w", C.c_int), ("tn_t", C.c_int), ("tk_t", C.c_int)]
+
+
+class AdamwImagesDesc(C.Structure):
+    _fields_ = [
+        ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("mode", C.c_void_p), ("n", C.c_long),
+        ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double),
+        ("step", C.c_int), ("grad_scale", C.c_float),
+        ("p_bf16", C.c_void_p), ("ema", C.c_void_p), ("ema_m", C.c_float), ("ema_bf16", C.c_void_p),
+        ("table", C.c_void_p), ("unit_prefix", C.c_void_p), ("n_entries", C.c_int), ("n_units", C.c_long),
+        ("p_packed", C.c_void_p), ("p_t", C.c_void_p), ("p_tpacked", C.c_void_p), ("ema_packed", C.c_void_p),
+        ("rest_idx", C.c_void_p), ("n_rest", C.c_long),
+    ]
+
+
 class Ptr8(C.Structure):
     _fields_ = [("p", C.c_void_p * 8)]
 
@@ -148,6 +164,17 @@ class MlpBwdDesc(C.Structure):
     ]
 
 
+class EmbedDesc(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p), ("a_dtype", C.c_int), ("rows", C.c_long), ("K", C.c_int), ("T", C.c_int), ("C", C.c_int),
+        ("pw", C.c_void_p), ("ln_g", C.c_void_p), ("ln_b", C.c_void_p),
+        ("a_bf16", C.c_void_p), ("proj", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+        ("out", C.c_void_p * 2), ("out_grp_rows", C.c_long * 2), ("out_off", C.c_long * 2), ("pos", C.c_void_p * 2),
+        ("ln1_g", C.c_void_p * 2), ("ln1_b", C.c_void_p * 2), ("xn1", C.c_void_p * 2), ("mean1", C.c_void_p * 2), ("rstd1", C.c_void_p * 2),
+        ("pad_src", C.c_void_p), ("pad_dst", C.c_void_p), ("pad_grp_rows", C.c_long), ("pad_off", C.c_long),
+    ]
+
+
 class AttnBlkDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int), ("L", C.c_int), ("C", C.c_int), ("H", C.c_int),
@@ -179,6 +206,7 @@ class EncoderDesc(C.Structure):
         ("layer_done", C.POINTER(C.c_void_p)),
         ("no_save", C.c_int),
         ("dw_stream", C.c_void_p), ("scr2_dx", C.c_void_p), ("scr2_dx2", C.c_void_p), ("scr2_dh", C.c_void_p), ("scr2_dqkv", C.c_void_p),
+        ("xn1_ready", C.c_int),
     ]
 
 

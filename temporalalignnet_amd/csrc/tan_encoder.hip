@@ -213,7 +213,7 @@ extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
     const void* x_in = e->x0;
     const bool panel_ok = panel_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0;
     const bool attn_panel_ok = (attn_panel_enabled() & 1) && panel_enabled() && tan_attnblk_supported(e->L, C, H, dt);
-    bool ln1_done = false;        // the previous block's panel kernel already produced this block's xn1 / mean1 / rstd1
+    bool ln1_done = e->xn1_ready != 0;      // the previous block's panel kernel (block 0: tan_embed_fwd) already produced this block's xn1 / mean1 / rstd1
     bool qkv_done = false;        // ... and this block's qkv (the in_proj tail of its forward)
     for (int i = 0; i < e->layers; ++i) {
         const tan_layer_params& p = e->params[i];

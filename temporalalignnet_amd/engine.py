@@ -96,10 +96,11 @@ class _AlignerEngine(_WorkspaceMixin):
         d.post_mean, d.post_rstd = _vp(er.stat["post_mean"]), _vp(er.stat["post_rstd"])
         return d
 
-    def _encoder_fwd(self, er, x0, keypad, post_name, save=False):
+    def _encoder_fwd(self, er, x0, keypad, post_name, save=False, xn1_ready=False):
         d = self._enc_desc(er, x0, keypad, post_name)
         self._flat.join_images()
         d.no_save = 0 if save else 1         # no backward will follow: the tensors kept only for it are not written
+        d.xn1_ready = 1 if xn1_ready else 0  # tan_embed_fwd already wrote the first block's ln_1 output
         _lib.check(_lib.lib().tan_encoder_fwd(C.byref(d), ops._stream()), "tan_encoder_fwd")
 
     def _layer_events(self, prefix, layers):
@@ -311,14 +312,23 @@ class _AlignerEngine(_WorkspaceMixin):
                 return fn()
         return self._issuer.submit(run)
 
-    def _run_video_stack(self, x0, vmask_u8, B, T, save=False):
-        er = self._take_ws("video_temporal_encoder", self.num_encoder_layers, B, T, x0.dtype, x0.device)
-        self._encoder_fwd(er, x0, vmask_u8, "ln_video_post_enc", save)
+    def _run_video_stack(self, x0, vmask_u8, B, T, save=False, er=None):
+        """`er`: a workspace whose first block's ln_1 output tan_embed_fwd has already written (the fused front-end)."""
+        ready = er is not None
+        if er is None:
+            er = self._take_ws("video_temporal_encoder", self.num_encoder_layers, B, T, x0.dtype, x0.device)
+        self._encoder_fwd(er, x0, vmask_u8, "ln_video_post_enc", save, xn1_ready=ready)
         return er
 
-    def _run_joint_stack(self, x0, text_t, vmask_u8, tmask_u8, B, T, N, save=False):
-        cd, dev = x0.dtype, x0.device
+    def _run_joint_stack(self, x0, text_t, vmask_u8, tmask_u8, B, T, N, save=False, pre=None):
+        """`pre` = (er, xj, keypad) from the fused front-end: the joint input, its key-padding mask and the first ln_1 are done."""
+        cd, dev = (x0 if pre is None else pre[1]).dtype, (x0 if pre is None else pre[1]).device
         L = T + N
+        if pre is not None:
+            er, xj, keypad = pre
+            self._encoder_fwd(er, xj, keypad, "ln_joint_post_enc", save, xn1_ready=True)
+            er.xj, er.keypad = xj, keypad
+            return er
         xj = torch.empty(B * L, WIDTH, dtype=cd, device=dev)
         ops.rows_copy(x0, xj, B, T, WIDTH, T, 0, L, 0)
         ops.rows_copy(text_t, xj, B, N, WIDTH, N, 0, L, T)
@@ -333,6 +343,112 @@ class _AlignerEngine(_WorkspaceMixin):
         er.xj, er.keypad = xj, keypad
         return er
 
+    # ------------------------------------------------------------------ the fused front-end (bf16): ONE launch
+    def _pos_ln_full(self, which):
+        """ln_position_init over the WHOLE position table, (rows [P, C] f32, mean [P], rstd [P]): depends on the parameters only, so it
+        is rebuilt once per optimizer step next to the other weight images (side stream, `_Flat.refresh_images_async`) and a step's
+        random offset is a row offset into it (tan_model.py:162-167)."""
+        f = self._flat
+        cache = self.__dict__.setdefault("_pos_ln_cache", {})
+        ent = cache.get(which)
+        if ent is None or ent["flat"] != f.flat.data_ptr():
+            table = self._pos_table(which)
+            P, dev = table.shape[0], f.flat.device
+            ent = cache[which] = {"flat": f.flat.data_ptr(), "epoch": -1, "out": torch.empty(P, WIDTH, device=dev),
+                                  "mean": torch.empty(P, device=dev), "rstd": torch.empty(P, device=dev)}
+            if self._pos_ln_refresh not in f.image_hooks:
+                f.image_hooks.append(self._pos_ln_refresh)
+        if ent["epoch"] != f.shadow_epoch:
+            ops.layernorm_fwd(self._pos_table(which).contiguous(), self._f("ln_position_init.weight"), self._f("ln_position_init.bias"),
+                              ent["out"], ent["mean"], ent["rstd"])
+            ent["epoch"] = f.shadow_epoch
+        return ent
+
+    def _pos_ln_refresh(self):
+        for which in list(self.__dict__.get("_pos_ln_cache", {})):
+            self._pos_ln_full(which)
+
+    def _embed_fused_ok(self, video, lang, itp):
+        return (self.compute_dtype == torch.bfloat16 and self.panel_kernels and not itp and video.shape[-1] % 128 == 0
+                and lang.shape[-1] % 128 == 0 and video.shape[-1] <= 2048 and os.environ.get("TAN_EMBED_FUSED", "1") != "0")
+
+    @staticmethod
+    def _feature_operand(x):
+        """a caller's feature tensor as tan_embed_fwd reads it: f32 or bf16, contiguous, no copy when it already is"""
+        x = x.detach()
+        if not x.is_cuda:
+            raise _lib.TanHipError("TemporalAligner needs device tensors: the HIP path has no CPU fallback")
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        return x.contiguous()
+
+    def _embed_fused(self, video, lang, vmask_u8, tmask_u8, p_v, p_t, p_j, save):
+        """Both modalities' input embeddings, the joint stack's input / key-padding mask and the first ln_1 of both stacks in ONE launch
+        (tan_embed_fwd).  Returns what `_run_forward` needs: workspaces, inputs and the saved records of the (unfused) backward."""
+        f = self._flat
+        B, T, Dv = video.shape
+        N, Dt = lang.shape[1], lang.shape[2]
+        L, R, Mp = T + N, B * T, B * N
+        cd, dev = self.compute_dtype, video.device
+        video, lang = self._feature_operand(video), self._feature_operand(lang)
+        ev = self._take_ws("video_temporal_encoder", self.num_encoder_layers, B, T, cd, dev)
+        ej = self._take_ws("joint_temporal_encoder", self.num_decoder_layers, B, L, cd, dev)
+        em = self._take_emb(B, T, N, Dv, Dt, cd, dev)
+        pv = self._pos_ln_full("temporal_pos_embed")
+        pt = self._pos_ln_full("text_temporal_pos_embed") if self.use_text_pos_enc else None
+        f.join_images()
+        wp = f.shadow_p
+        keypad = em.keypad if (vmask_u8 is not None or tmask_u8 is not None) else None
+        D = (_lib.EmbedDesc * 2)()
+
+        def fill(d, a, a16, rows, K, Tn, wname, ln, proj, mean, rstd):
+            d.a, d.a_dtype, d.rows, d.K, d.T, d.C = a.data_ptr(), (_lib.TAN_F32 if a.dtype == torch.float32 else _lib.TAN_BF16), rows, K, Tn, WIDTH
+            d.pw = f.ptr(wp, wname)
+            d.ln_g, d.ln_b = self._f(ln + ".weight").data_ptr(), self._f(ln + ".bias").data_ptr()
+            d.a_bf16 = a16.data_ptr() if (save and a.dtype == torch.float32) else None
+            d.proj, d.mean, d.rstd = (proj.data_ptr(), mean.data_ptr(), rstd.data_ptr()) if save else (None, None, None)
+
+        def ln1(d, k, er, prefix):
+            base = f"{prefix}.resblocks.0."
+            d.ln1_g[k], d.ln1_b[k] = self._f(base + "ln_1.weight").data_ptr(), self._f(base + "ln_1.bias").data_ptr()
+            d.xn1[k], d.mean1[k], d.rstd1[k] = er.bufs[0].xn1, er.bufs[0].mean1, er.bufs[0].rstd1
+
+        dv, dt_ = D[0], D[1]
+        fill(dv, video, em["video_c"], R, Dv, T, "video_pre_proj.weight", "ln_video_init", em["proj_v"], em["mean_v"], em["rstd_v"])
+        dv.out[0], dv.out_grp_rows[0], dv.out_off[0] = em["x0"].data_ptr(), T, 0
+        dv.pos[0] = pv["out"].data_ptr() + 4 * WIDTH * p_v
+        ln1(dv, 0, ev, "video_temporal_encoder")
+        dv.out[1], dv.out_grp_rows[1], dv.out_off[1] = em["xj"].data_ptr(), L, 0
+        dv.pos[1] = pv["out"].data_ptr() + 4 * WIDTH * p_j
+        ln1(dv, 1, ej, "joint_temporal_encoder")
+        fill(dt_, lang, em["lang_c"], Mp, Dt, N, "text_pre_proj.weight", "ln_text_init", em["proj_t"], em["mean_t"], em["rstd_t"])
+        dt_.out[0], dt_.out_grp_rows[0], dt_.out_off[0] = em["lang_raw"].data_ptr(), N, 0       # the dual path's text features
+        dt_.out[1], dt_.out_grp_rows[1], dt_.out_off[1] = em["xj"].data_ptr(), L, T             # the joint stack's text rows
+        if pt is not None:
+            dt_.pos[1] = pt["out"].data_ptr() + 4 * WIDTH * p_t
+        ln1(dt_, 1, ej, "joint_temporal_encoder")
+        if keypad is not None:
+            dv.pad_src = vmask_u8.data_ptr() if vmask_u8 is not None else None
+            dv.pad_dst, dv.pad_grp_rows, dv.pad_off = keypad.data_ptr(), L, 0
+            dt_.pad_src = tmask_u8.data_ptr() if tmask_u8 is not None else None
+            dt_.pad_dst, dt_.pad_grp_rows, dt_.pad_off = keypad.data_ptr(), L, T
+        _lib.check(_lib.lib().tan_embed_fwd(D, 2, ops._stream()), "tan_embed_fwd")
+
+        def pos_saved(which, ent, n, start):
+            return {"which": which, "n": n, "start": start, "interp": None, "pos": self._pos_table(which)[start:start + n],
+                    "mean": ent["mean"][start:start + n], "rstd": ent["rstd"][start:start + n]}
+        sv_video = {"proj": em["proj_v"], "mean": em["mean_v"], "rstd": em["rstd_v"], "pos": pos_saved("temporal_pos_embed", pv, T, p_v),
+                    "video_c": (em["video_c"] if video.dtype == torch.float32 else video).view(B, T, Dv)}
+        sv_video_j = {"pos": pos_saved("temporal_pos_embed", pv, T, p_j), "repos_of": sv_video} if p_j != p_v else None
+        lang_c = (em["lang_c"] if lang.dtype == torch.float32 else lang).view(B, N, Dt)
+        sv_text = {"proj": em["proj_t"], "mean": em["mean_t"], "rstd": em["rstd_t"], "pos": None, "lang_c": lang_c}
+        sv_text_t = None
+        if pt is not None:      # the joint stack's text rows carry the position term: their gradient is the text embedding's second use
+            sv_text_t = {"proj": em["proj_t"], "mean": em["mean_t"], "rstd": em["rstd_t"], "lang_c": lang_c,
+                         "pos": pos_saved("text_temporal_pos_embed", pt, N, p_t)}
+        return {"ev": ev, "ej": ej, "em": em, "x0": em["x0"], "xj": em["xj"], "keypad": keypad, "lang_raw": em["lang_raw"],
+                "sv_video": sv_video, "sv_video_j": sv_video_j, "sv_text": sv_text, "sv_text_t": sv_text_t}
+
     def _run_forward(self, video, lang, vmask_u8, tmask_u8, opts, keep=True):  # noqa: C901
         """HIP forward of TemporalAligner.forward (tan_model.py:100-149).  Returns the run record used by backward."""
         self._ensure_flat()
@@ -341,22 +457,31 @@ class _AlignerEngine(_WorkspaceMixin):
         cd, dev = self.compute_dtype, video.device
         Se, Sd, Cw = self.num_encoder_layers, self.num_decoder_layers, WIDTH
         itp = opts.get("interpolate_from")
-        video_c, lang_c = self._prep_inputs(video, lang)
+        save = bool(opts.get("needs_grad", True))      # False: torch.no_grad() (EMA target, evaluation) -- nothing kept for backward
         # reference RNG order: visual, [text-with-time], joint
         p_v = self._draw(T, itp)
         p_t = self._draw(N, itp) if self.use_text_pos_enc else 0
         p_j = self._draw(T, itp)
-        x0, sv_video = self._video_embed(video_c, p_v, itp, keep)
-        if p_j != p_v:      # random_pos_start=1 draws independent offsets for the dual and joint paths: same projection and
-            #                 LayerNorm input, another slice of the position table (one GEMM, not two; see _video_embed_bwd_pair)
-            x0j, sv_video_j = self._video_embed_repos(sv_video, p_j, itp, keep)
+        fe = None
+        if self._embed_fused_ok(video, lang, itp):
+            # ONE launch: cast + both pre-projections + their LayerNorms + the position terms of both offsets + the joint stack's
+            # input and key-padding mask + the first ln_1 of both stacks (tan_embed.hip)
+            fe = self._embed_fused(video, lang, vmask_u8, tmask_u8, p_v, p_t, p_j, save)
+            x0, x0j, lang_raw, lang_t = fe["x0"], None, fe["lang_raw"], None
+            sv_video, sv_video_j, sv_text, sv_text_t = fe["sv_video"], fe["sv_video_j"], fe["sv_text"], fe["sv_text_t"]
         else:
-            x0j, sv_video_j = x0, None
-        lang_raw, sv_text = self._text_embed(lang_c, False, 0, None, keep)
-        if self.use_text_pos_enc:
-            lang_t, sv_text_t = self._text_embed(lang_c, True, p_t, itp, keep)
-        else:
-            lang_t, sv_text_t = lang_raw, None
+            video_c, lang_c = self._prep_inputs(video, lang)
+            x0, sv_video = self._video_embed(video_c, p_v, itp, keep)
+            if p_j != p_v:  # random_pos_start=1 draws independent offsets for the dual and joint paths: same projection and
+                #             LayerNorm input, another slice of the position table (one GEMM, not two; see _video_embed_bwd_pair)
+                x0j, sv_video_j = self._video_embed_repos(sv_video, p_j, itp, keep)
+            else:
+                x0j, sv_video_j = x0, None
+            lang_raw, sv_text = self._text_embed(lang_c, False, 0, None, keep)
+            if self.use_text_pos_enc:
+                lang_t, sv_text_t = self._text_embed(lang_c, True, p_t, itp, keep)
+            else:
+                lang_t, sv_text_t = lang_raw, None
         R, Mp, L = B * T, B * N, T + N
         # L2-normalised features (tan_model.py:116-117,136-137): all stages of a family in one launch, each family right behind the
         # stack that feeds it and on that stack's stream -- 19 per-stage launches after the join sat on the critical path before
@@ -365,16 +490,16 @@ class _AlignerEngine(_WorkspaceMixin):
         tn_d = torch.empty(Mp, Cw, dtype=cd, device=dev)
         tn_j = torch.empty(Sd, Mp, Cw, dtype=cd, device=dev)
         inv = _Blocks(torch.float32, dev, {"vd": Se * R, "vj": Sd * R, "td": Mp, "tj": Sd * Mp})
-        save = bool(opts.get("needs_grad", True))      # False: torch.no_grad() (EMA target, evaluation) -- nothing kept for backward
 
         def video_side():
-            ev_ = self._run_video_stack(x0, vmask_u8, B, T, save)
+            ev_ = self._run_video_stack(x0, vmask_u8, B, T, save, er=fe["ev"] if fe else None)
             ops.l2norm_fwd_multi([ev_.stage(s) for s in range(Se)], vn_d, inv["vd"], R, Cw)
             ops.l2norm_fwd(lang_raw, tn_d, inv["td"], Mp, Cw)
             return ev_
 
         def joint_side():
-            ej_ = self._run_joint_stack(x0j, lang_t, vmask_u8, tmask_u8, B, T, N, save)
+            ej_ = self._run_joint_stack(x0j, lang_t, vmask_u8, tmask_u8, B, T, N, save,
+                                        pre=(fe["ej"], fe["xj"], fe["keypad"]) if fe else None)
             stages = [ej_.stage(s) for s in range(Sd)]
             ops.l2norm_fwd_multi(stages, vn_j, inv["vj"], R, Cw, T, L, 0)
             ops.l2norm_fwd_multi(stages, tn_j, inv["tj"], Mp, Cw, N, L, T)
@@ -412,7 +537,8 @@ class _AlignerEngine(_WorkspaceMixin):
             names = ["lg_d", "lg_j", "vn_d", "tn_d"]
         run = {"B": B, "T": T, "N": N, "ev": ev, "ej": ej, "x0": x0, "x0j": x0j, "sv_video": sv_video,
                "sv_video_j": sv_video_j, "sv_text": sv_text, "sv_text_t": sv_text_t, "lang_raw": lang_raw, "lang_t": lang_t,
-               "vn_d": vn_d, "vn_j": vn_j, "tn_d": tn_d, "tn_j": tn_j, "inv": inv, "vmask": vmask_u8, "tmask": tmask_u8}
+               "vn_d": vn_d, "vn_j": vn_j, "tn_d": tn_d, "tn_j": tn_j, "inv": inv, "vmask": vmask_u8, "tmask": tmask_u8,
+               "em": fe["em"] if fe else None}
         if self.use_alignability_head:
             w, b = self._f("binary_head.weight").view(-1), self._f("binary_head.bias")
             a_d = torch.empty(Mp, device=dev)
@@ -429,6 +555,7 @@ class _AlignerEngine(_WorkspaceMixin):
         if not opts.get("needs_grad", True):       # nothing will call backward: the stacks' workspaces are free again
             self._release_ws(ev)
             self._release_ws(ej)
+            self._release_ws(run.pop("em"))
         return run
 
     # ------------------------------------------------------------------ the HIP backward
@@ -605,4 +732,5 @@ class _AlignerEngine(_WorkspaceMixin):
             d_lang = text_side()
         self._release_ws(ev)
         self._release_ws(ej)
+        self._release_ws(run.get("em"))
         return d_lang

@@ -39,6 +39,9 @@ class _Flat:
         self.shadow_p, self.shadow_tp, self.pack_table, self.shadow_p_epoch, self.shadow_tp_epoch = None, None, None, -1, -1
         self.shadow_pk, self.pk_table, self.shadow_pk_epoch = None, None, -1
         self.device = None
+        # more per-step images owned by the model (callables, run inside refresh_images_async on the side stream): the LayerNorm'ed
+        # position tables of the fused input embeddings
+        self.image_hooks = []
 
     def bound(self):
         p0, pl = self.params[0], self.params[-1]
@@ -67,15 +70,17 @@ class _Flat:
         self.shadow_t, self.shadow_t_table, self.shadow_t_epoch = None, None, -1
         self.shadow_p, self.shadow_tp, self.pack_table, self.shadow_p_epoch, self.shadow_tp_epoch = None, None, None, -1, -1
         self.shadow_pk, self.pk_table, self.shadow_pk_epoch = None, None, -1
+        self._image_table = None
 
     def _pack_tables(self):
         """device tables of tan_pack_entry for the MLP weights of every block ([out, in]) and for their transposes ([in, out])"""
         if self.pack_table is None:
             names = [n for n in self.names if ".resblocks." in n and len(self.off[n][2]) == 2]
+            pre = [n for n in ("video_pre_proj.weight", "text_pre_proj.weight") if n in self.off]     # tan_embed_fwd's operands
 
             def table(transposed):
                 ents, mx = [], 0
-                for n in names:
+                for n in names + ([] if transposed else pre):
                     o, _, (N, K) = self.off[n]
                     if transposed:
                         # (all four have a row-panel consumer in the backward: the MLP's two dX GEMMs, the out_proj dX tail, the
@@ -91,6 +96,40 @@ class _Flat:
                 return dev_t, len(ents), mx
             self.pack_table = (table(False), table(True))
         return self.pack_table
+
+    def image_table(self):
+        """For tan_adamw_step_images: (device table of tan_image_entry, device unit prefix, n entries, n units, [(lo, hi)] flat ranges
+        of the matrices) over every matrix that has a packed image -- the optimizer launch then writes the shadow, the W^T copies and
+        both packed images itself.  Allocates / builds the images once (the kernels that rebuild them lazily stay the fallback)."""
+        if getattr(self, "_image_table", None) is None:
+            self.sync_shadow_p(); self.sync_shadow_t(); self.sync_shadow_tp()
+            import numpy as np
+            ents, prefix, ranges = [], [0], []
+            mats = [n for n in self.names if ".resblocks." in n and len(self.off[n][2]) == 2]
+            pre = [n for n in ("video_pre_proj.weight", "text_pre_proj.weight") if n in self.off]
+            for n in mats + pre:
+                o, k, (N, K) = self.off[n]
+                assert N % 64 == 0 and K % 64 == 0, (n, N, K)
+                tn_w, tk_w = (384, 32) if n.endswith("attn.in_proj_weight") else ((512, 16) if N == 512 else (256, 32))
+                tn_t, tk_t = (0, 0) if n in pre else ((512, 16) if K == 512 else (256, 32))      # W^T is [K][N]: its "N" is K
+                ents.append(_lib.ImageEntry(o, N, K, tn_w, tk_w, tn_t, tk_t))
+                prefix.append(prefix[-1] + (N // 64) * (K // 64))
+                ranges.append((o, o + k))
+            arr = (_lib.ImageEntry * len(ents))(*ents)
+            dev = self.shadow.device
+            tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            pre_t = torch.from_numpy(np.asarray(prefix, dtype=np.int64)).to(dev)
+            self._image_table = (tab, pre_t, len(ents), prefix[-1], ranges)
+        return self._image_table
+
+    def images_rewritten(self, transposes=True):
+        """tan_adamw_step_images has just rewritten the shadow AND the images built from it."""
+        self.shadow_version = self.flat._version
+        self.shadow_epoch += 1
+        self.shadow_p_epoch = self.shadow_epoch
+        if transposes:
+            self.shadow_t_epoch = self.shadow_epoch
+            self.shadow_tp_epoch = self.shadow_epoch
 
     def sync_shadow_p(self):
         """(Re)build the packed images of every 2-D `...resblocks.*` weight from the bf16 shadow: one launch."""
@@ -120,6 +159,8 @@ class _Flat:
                 self.sync_shadow_t()
                 if self.shadow_tp is not None:
                     self.sync_shadow_tp()
+            for hook in self.image_hooks:
+                hook()
             self.images_event = side.record_event()
 
     def join_images(self):

@@ -371,6 +371,10 @@ class Trainer:
                     p.grad.mul_(torch.clamp(coef, max=1.0))
         ema = self.model.target._ensure_flat() if self.twin else None
         self.iteration += 1
+        if self._images_in_optimizer(f, ema):
+            self._adamw_images(f, st, ema, grad_scale)
+            self._lm_step(grad_scale)
+            return
         _lib.check(_lib.lib().tan_adamw_step(
             _vp(f.flat), _vp(f.grad), _vp(st["m"]), _vp(st["v"]), _vp(st["mode"]), C.c_long(f.total),
             C.c_double(self.current_lr()), C.c_double(self.betas[0]), C.c_double(self.betas[1]), C.c_double(self.eps),
@@ -382,6 +386,38 @@ class Trainer:
             ema.shadow_epoch += 1                       # (shadow_version is left alone: the flat buffers' version counters did
             #                                             not move, the kernel writes through raw pointers)
         self._lm_step(grad_scale)
+
+    def _images_in_optimizer(self, f, ema):
+        """The optimizer launch writes the weight images itself (tan_adamw_step_images) when the model computes from them: bf16
+        with the row-panel kernels and the W^T copies (TAN_OPT_IMAGES=0: AdamW, then transpose + 2 x pack on the side stream)."""
+        on = self.online
+        return (f.shadow is not None and on.panel_kernels and on.transposed_dx and os.environ.get("TAN_OPT_IMAGES", "1") != "0"
+                and (ema is None or (ema.shadow is not None and self.model.target.panel_kernels)))
+
+    def _adamw_images(self, f, st, ema, grad_scale):
+        tab, prefix, n_ent, n_units, ranges = f.image_table()
+        if "rest_idx" not in st:                 # every element outside the matrices: the plain kernel's work list
+            own = torch.zeros(f.total, dtype=torch.bool, device=f.flat.device)
+            for lo, hi in ranges:
+                own[lo:hi] = True
+            st["rest_idx"] = (~own).nonzero().flatten().to(torch.int32)
+        if ema is not None:
+            ema.sync_shadow_p()                  # (allocates the twin's packed image on first use)
+        d = _lib.AdamwImagesDesc()
+        d.p, d.g, d.m, d.v, d.mode = (t.data_ptr() for t in (f.flat, f.grad, st["m"], st["v"], st["mode"]))
+        d.n = f.total
+        d.lr, d.beta1, d.beta2, d.eps, d.weight_decay = self.current_lr(), self.betas[0], self.betas[1], self.eps, self.args.wd
+        d.step, d.grad_scale = self.iteration, grad_scale
+        d.p_bf16 = f.shadow.data_ptr()
+        d.table, d.unit_prefix, d.n_entries, d.n_units = tab.data_ptr(), prefix.data_ptr(), n_ent, n_units
+        d.p_packed, d.p_t, d.p_tpacked = f.shadow_p.data_ptr(), f.shadow_t.data_ptr(), f.shadow_tp.data_ptr()
+        d.rest_idx, d.n_rest = st["rest_idx"].data_ptr(), st["rest_idx"].numel()
+        if ema is not None:
+            d.ema, d.ema_m, d.ema_bf16, d.ema_packed = ema.flat.data_ptr(), self.model.m, ema.shadow.data_ptr(), ema.shadow_p.data_ptr()
+        _lib.check(_lib.lib().tan_adamw_step_images(C.byref(d), ops._stream()), "tan_adamw_step_images")
+        f.images_rewritten()
+        if ema is not None:
+            ema.images_rewritten(transposes=False)
 
     def train_iteration(self, batch, idx):
         """One iteration of the reference loop INCLUDING its gradient accumulation (train/main.py:112-139): backward every

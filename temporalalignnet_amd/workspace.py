@@ -53,6 +53,23 @@ class _EncRun:
         return self.act["post"].view(self.R, WIDTH)
 
 
+class _EmbRun:
+    """Buffers of the fused input-embedding launch (tan_embed_fwd) for one (B, T, N): what the stacks read and what the embeddings'
+    backward needs, pooled like the stacks' workspaces (no per-step allocation)."""
+
+    def __init__(self, B, T, N, Dv, Dt, cd, dev):
+        R, Mp, L = B * T, B * N, T + N
+        self.act = _Blocks(cd, dev, {"video_c": R * Dv, "lang_c": Mp * Dt, "proj_v": R * WIDTH, "proj_t": Mp * WIDTH,
+                                     "x0": R * WIDTH, "xj": B * L * WIDTH, "lang_raw": Mp * WIDTH})
+        self.stat = _Blocks(torch.float32, dev, {"mean_v": R, "rstd_v": R, "mean_t": Mp, "rstd_t": Mp})
+        self.keypad = torch.zeros(B, L, dtype=torch.uint8, device=dev)
+        self._shape = {"video_c": (R, Dv), "lang_c": (Mp, Dt), "proj_v": (R, WIDTH), "proj_t": (Mp, WIDTH), "x0": (R, WIDTH),
+                       "xj": (B * L, WIDTH), "lang_raw": (Mp, WIDTH)}
+
+    def __getitem__(self, k):
+        return self.act[k].view(self._shape[k]) if k in self._shape else self.stat[k]
+
+
 class _WorkspaceMixin:
     """Pool state lives on the model: _ws_pool / _ws_lru / _ws_tick / _ws_lock (created in TemporalAligner.__init__)."""
 
@@ -83,6 +100,17 @@ class _WorkspaceMixin:
             er = _EncRun(self, prefix, layers, B, L, cd, dev)
         er.pool_key = key
         return er
+
+    def _take_emb(self, B, T, N, Dv, Dt, cd, dev):
+        key = ("emb", B, T, N, Dv, Dt, cd, dev)
+        self._pool_touch(key)
+        with self._ws_lock:
+            pool = self._ws_pool.setdefault(key, [])
+            em = pool.pop() if pool else None
+        if em is None:
+            em = _EmbRun(B, T, N, Dv, Dt, cd, dev)
+        em.pool_key = key
+        return em
 
     def _release_ws(self, er):
         if er is not None and getattr(er, "pool_key", None) is not None:

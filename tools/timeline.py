@@ -5,7 +5,7 @@ import csv, sys
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"].split("(")[0][-50:]) for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort()
 # steps are delimited by adamw_kernel launches
-idx = [i for i, r in enumerate(rows) if "adamw_kernel" in r[3]]
+idx = [i for i, r in enumerate(rows) if "adamw_kernel" in r[3] or "adamw_rest_kernel" in r[3]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 lo, hi = idx[-k - 1] + 1, idx[-k] + 1
 step = rows[lo:hi]
