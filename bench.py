@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--global-negatives", action="store_true", help="row f3: NCE negatives from every rank (W similarity sweeps)")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--timer-every", type=int, default=20, help="HIP-event kernel timer samples one timed step in n (the middle one)")
+    ap.add_argument("--timer-stride", type=int, default=4, help="the kernel timer brackets every n-th launch of the MFMA family in the sampled step")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra driver-timed configurations (stage 2, len=256) of the N=1 run")
     ap.add_argument("--extra-steps", type=int, default=10)
     ap.add_argument("--settle-s", type=float, default=2.0, help="bound [s] of the extra untimed warm-up that runs until the step time is "
@@ -182,6 +183,7 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
     use_timer = not a.no_kernel_timer
     if use_timer:
         _lib.check(L.tan_prof_enable(1, 1200 * max(steps, 1)), "tan_prof_enable")
+        L.tan_prof_stride(a.timer_stride)        # inside the timed steps: every n-th launch of the family (an event pair costs 8-14 us)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -223,6 +225,8 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
         nk = NKINDS
         ms, work, cnt = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_long * nk)()
         L.tan_prof_collect(ms, work, cnt, nk)
+        work_all, cnt_all = (C.c_double * nk)(), (C.c_long * nk)()
+        L.tan_prof_collect_all(work_all, cnt_all, nk)          # every launch of the sampled step(s), timed or not
         # The timed steps run the video and joint stacks on two concurrent HIP streams, so the per-launch durations above
         # include contention between co-running kernels.  Three extra (untimed) steps with the overlap switched off give the
         # same kernels' stand-alone durations as a second reading.
@@ -234,6 +238,7 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
                 model.target.overlap_stacks = False
             trainer.step(batch)
             torch.cuda.synchronize()
+            L.tan_prof_stride(1)                   # the untimed extra steps bracket every launch
             _lib.check(L.tan_prof_enable(1, 1200 * 3), "tan_prof_enable")
             for _ in range(3):
                 trainer.step(batch)
@@ -248,6 +253,12 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
             if stage == 2:
                 model.target.overlap_stacks = True
         L.tan_prof_enable(0, 0)
+        stride = max(1, a.timer_stride)
+        # every stride-th launch was bracketed: a kind's time per step = its sampled time scaled by (all its work / its sampled work)
+        for k in range(nk):
+            if cnt[k] > 0 and work[k] > 0:
+                ms[k] *= work_all[k] / work[k]
+                work[k], cnt[k] = work_all[k], cnt_all[k]
         kinds = [{"kernel": GEMM_KIND_NAMES[k], "ms_per_step": ms[k] / sampled, "launches_per_step": round(cnt[k] / sampled, 1),
                   "tflops": (work[k] / (ms[k] * 1e-3) / 1e12) if ms[k] > 0 else 0.0} for k in range(nk) if cnt[k] > 0]
         gemm = [k for k in FAMILY if cnt[k] > 0]      # every launch of the MFMA GEMM pipeline
@@ -264,7 +275,8 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
                     "avg_launch_us": round(tms * 1e3 / tcnt, 2), "launches_per_step": round(tcnt / sampled, 1),
                     "gemm_ms_per_step": round(tms / sampled, 3), "algorithmic_gflop_per_step": round(twork / sampled / 1e9, 1),
                     "step_frac": round(twork / sampled / (elapsed / steps) / 1e12 / peak, 4),
-                    "timer": f"HIP events on each launch's own stream, {sampled} of the {steps} timed steps (one in {min(timer_every, steps)})",
+                    "timer": f"HIP events on each launch's own stream, {sampled} of the {steps} timed steps (one in {min(timer_every, steps)}), "
+                             f"every {stride}-th launch in it (a kind's time = its sampled time x all its work / its sampled work; `isolated` brackets every launch)",
                     "concurrency": "2 HIP streams (video || joint stack): durations include co-running kernels",
                     "isolated": iso,
                     "by_kernel": [{**x, "ms_per_step": round(x["ms_per_step"], 3), "tflops": round(x["tflops"], 1)} for x in kinds]}

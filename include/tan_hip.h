@@ -49,6 +49,10 @@ int tan_abi_sizeof(int which);
 #define TAN_PROF_ATTNBLK 12 /* the attention branch of a block in one launch (tan_attnblk_*) */
 #define TAN_PROF_NKINDS 13
 int tan_prof_enable(int on, int max_records);
+/* time only every stride-th eligible launch from now on (1 = all): a sample of the launches instead of each of them */
+int tan_prof_stride(int stride);
+/* work [flop] and launch count of EVERY eligible launch since tan_prof_enable(1, ..) / the last call (timed or not); resets them */
+int tan_prof_collect_all(double* work_by_kind, long* count_by_kind, int nkinds);
 int tan_prof_collect(double* ms_by_kind, double* work_by_kind, long* count_by_kind, int nkinds);
 
 /* Stream-ordering events (no timing) for tan_encoder_desc.layer_done: the reference's DDP (end2end/main_nce.py:142-158) hooks
@@ -507,6 +511,26 @@ typedef struct tan_embed_desc {
     const unsigned char* pad_src; unsigned char* pad_dst; long pad_grp_rows, pad_off;
 } tan_embed_desc;
 int tan_embed_fwd(const tan_embed_desc* d, int nprob, void* stream);
+
+/* tan_embed_bwd: backward of tan_embed_fwd's LayerNorm + position add for up to two problems in one launch (autograd of
+ * model/tan_model.py:155-167, 187-199, 212-234): dy = d_out[0] + d_out[1] (either may be NULL; rows addressed like tan_embed_fwd's out[]),
+ *   d_proj [rows, C] bf16 = LayerNorm-backward(dy; proj, mean, rstd, ln_g)   (operand of the pre-projection's weight gradient)
+ *   g_ln_g += colsum(dy o xhat), g_ln_b += colsum(dy);  d_pos[d] [ceil(videos / tan_embed_bwd_group())][T, C] f32 = per video GROUP,
+ *   the sum over its videos of d_out[d] (plain stores, every plane written in full; NULL = not wanted; tan_pos_ln_bwd adds the planes)
+ * tan_pos_ln_bwd: ln_position_init's backward for up to three used table slices in one launch: g_table rows += LayerNorm-backward(sum of
+ *   the nparts planes d_pos [nparts][n][C];
+ *   x = the raw table rows, mean, rstd, gamma) (g_table NULL: a fixed sine table), g_gamma += colsum(d_pos o xhat), g_beta += colsum(d_pos);
+ *   f32 atomics (the slices of the dual and the joint offset overlap). */
+typedef struct tan_embed_bwd_desc {
+    long rows; int T, C;
+    const void* d_out[2]; long d_out_grp_rows[2], d_out_off[2];
+    const void* proj; const float *mean, *rstd, *ln_g;
+    void* d_proj; float *g_ln_g, *g_ln_b; float* d_pos[2];
+} tan_embed_bwd_desc;
+int tan_embed_bwd(const tan_embed_bwd_desc* d, int nprob, void* stream);
+typedef struct tan_pos_ln_bwd_use { const float *d_pos, *x, *mean, *rstd; float* g_table; int n, nparts; } tan_pos_ln_bwd_use;
+int tan_embed_bwd_group(void);   /* videos per partial plane of tan_embed_bwd's d_pos */
+int tan_pos_ln_bwd(const tan_pos_ln_bwd_use* u, int nuse, const float* gamma, float* g_gamma, float* g_beta, int C, void* stream);
 
 /* ---- the attention branch of a block in ONE launch per direction (bf16, C = 512, H = 8, 48 < L <= 80 rows per video) --------
  * tan_attnblk_fwd: x_mid = x_in + out_proj(MHA(xn1))  with MHA = nn.MultiheadAttention(512, 8) as called at

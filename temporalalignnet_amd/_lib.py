@@ -175,6 +175,19 @@ class EmbedDesc(C.Structure):
     ]
 
 
+class EmbedBwdDesc(C.Structure):
+    _fields_ = [
+        ("rows", C.c_long), ("T", C.c_int), ("C", C.c_int),
+        ("d_out", C.c_void_p * 2), ("d_out_grp_rows", C.c_long * 2), ("d_out_off", C.c_long * 2),
+        ("proj", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("ln_g", C.c_void_p),
+        ("d_proj", C.c_void_p), ("g_ln_g", C.c_void_p), ("g_ln_b", C.c_void_p), ("d_pos", C.c_void_p * 2),
+    ]
+
+
+class PosLnBwdUse(C.Structure):
+    _fields_ = [("d_pos", C.c_void_p), ("x", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("g_table", C.c_void_p), ("n", C.c_int), ("nparts", C.c_int)]
+
+
 class AttnBlkDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int), ("L", C.c_int), ("C", C.c_int), ("H", C.c_int),

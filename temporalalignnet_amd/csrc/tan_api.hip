@@ -10,6 +10,9 @@ struct ProfState {
     bool on = false;
     int cap = 0;
     std::atomic<int> n{0};           // launches are issued from two host threads (main + side-stream helper)
+    std::atomic<int> seen{0};        // every eligible launch, timed or not
+    int stride = 1;                  // time every stride-th eligible launch (the ~8-14 us an event pair costs add up over ~60 launches)
+    std::atomic<long long> all_mflop[TAN_PROF_NKINDS], all_cnt[TAN_PROF_NKINDS];      // work / launches of EVERY eligible launch
     std::vector<hipEvent_t> ev;      // 2 per record
     std::vector<int> kind;
     std::vector<double> work;
@@ -19,6 +22,8 @@ static ProfState g_prof;
 int prof_begin(hipStream_t st, int kind, double work) {
     ProfState& p = g_prof;
     if (!p.on || p.n.load(std::memory_order_relaxed) >= p.cap) return -1;
+    if (kind >= 0 && kind < TAN_PROF_NKINDS) { p.all_mflop[kind].fetch_add((long long)(work * 1e-6)); p.all_cnt[kind].fetch_add(1); }
+    if (p.stride > 1 && p.seen.fetch_add(1) % p.stride != 0) return -1;
     const int i = p.n.fetch_add(1);
     if (i >= p.cap) return -1;
     p.kind[i] = kind;
@@ -50,6 +55,20 @@ extern "C" int tan_abi_sizeof(int which) {
 // Profiling hook (the library's only process-global state; off by default).  While enabled, every tan_gemm /
 // tan_attn_* launch is bracketed by hipEvents on ITS OWN stream; tan_prof_collect synchronises those events and
 // returns, per kernel kind, the summed duration [ms], the summed algorithmic work [flop] and the launch count.
+extern "C" int tan_prof_collect_all(double* work_by_kind, long* count_by_kind, int nkinds) {
+    for (int k = 0; k < nkinds; ++k) {
+        work_by_kind[k] = k < TAN_PROF_NKINDS ? (double)g_prof.all_mflop[k].exchange(0) * 1e6 : 0.0;
+        count_by_kind[k] = k < TAN_PROF_NKINDS ? (long)g_prof.all_cnt[k].exchange(0) : 0;
+    }
+    return 0;
+}
+
+extern "C" int tan_prof_stride(int stride) {
+    g_prof.stride = stride < 1 ? 1 : stride;
+    g_prof.seen = 0;
+    return 0;
+}
+
 extern "C" int tan_prof_enable(int on, int max_records) {
     ProfState& p = g_prof;
     if (on == 2) { p.on = p.cap > 0; return 0; }      // resume after a pause (on == 0): records kept
@@ -66,6 +85,7 @@ extern "C" int tan_prof_enable(int on, int max_records) {
         p.work.assign(max_records, 0.0);
         p.cap = max_records;
         p.n = 0;
+        for (int k = 0; k < TAN_PROF_NKINDS; ++k) { p.all_mflop[k] = 0; p.all_cnt[k] = 0; }
     }
     p.on = on != 0;
     return 0;

@@ -215,3 +215,185 @@ extern "C" int tan_embed_fwd(const tan_embed_desc* d, int nprob, void* stream) {
     TAN_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward of the same front-end in two launches (+ the two weight-gradient GEMMs the caller issues):
+//   embed_bwd_kernel   dy = d_out[0] + d_out[1] (the two uses of the embedding: dual and joint path, read where the stacks'
+//                      backward left them -- no row copies), d_proj = LayerNorm-backward(dy; proj, mean, rstd, ln_g) -> bf16 (operand
+//                      of the pre-projection's weight gradient), g_ln_g / g_ln_b += column sums, d_pos[d][t] += sum over videos of
+//                      d_out[d] (the broadcast position add's backward), f32 atomics
+//   pos_ln_bwd_kernel  ln_position_init's backward on the (up to three) used slices of the position tables: table gradient rows and
+//                      the LayerNorm's own g / b gradients, f32 atomics (the dual and the joint offset overlap in the table)
+// replaces ~25 small launches at the very end of backward (rows_copy x2-3, group_sum x2, cast x2, ln_bwd + finalize x2, rows_copy
+// accumulate x3, ln_bwd x2), 130 us in front of the optimizer.  Autograd of tan_model.py:155-167, 187-199, 212-234.
+namespace tal {
+
+struct EmbBwdProb {
+    long rows; int T, nvid;
+    const bf16_t* dout[2]; long grp[2], off[2];
+    const bf16_t* proj; const float *mean, *rstd, *g;
+    bf16_t* dproj; float *g_g, *g_b; float* dpos[2];
+    int blk0, tblocks;
+};
+struct EmbBwdArgs { EmbBwdProb p0, p1; int nprob; };
+constexpr int EB_VG = 8;        // videos per workgroup: a wave owns one position t and its rows of EB_VG videos, all loads issued up front
+
+__global__ __launch_bounds__(512) void embed_bwd_kernel(const EmbBwdArgs A) {
+    __shared__ float red[2][8][512];
+    const EmbBwdProb P = (A.nprob > 1 && (int)blockIdx.x >= A.p1.blk0) ? A.p1 : A.p0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c8 = lane * 8;
+    const int bl = (int)blockIdx.x - P.blk0, tb = bl % P.tblocks, vg = bl / P.tblocks;
+    const int t = tb * 8 + wave;
+    float gg[8], gb[8], dp0[8], dp1[8], gm[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gg[e] = gb[e] = dp0[e] = dp1[e] = 0.f; gm[e] = P.g[c8 + e]; }
+    if (t < P.T) {
+        constexpr float invC = 1.0f / 512.0f;
+        uint4 r0[EB_VG], r1[EB_VG], rx[EB_VG];
+        float mu[EB_VG], rs[EB_VG];
+#pragma unroll
+        for (int i = 0; i < EB_VG; ++i) {              // one memory round trip for the whole group (rows past the batch: zeros)
+            const int v = vg * EB_VG + i;
+            const bool ok = v < P.nvid;
+            const long row = (long)(ok ? v : 0) * P.T + t;
+            r0[i] = r1[i] = make_uint4(0, 0, 0, 0);
+            if (ok && P.dout[0]) r0[i] = *reinterpret_cast<const uint4*>(P.dout[0] + ((long)v * P.grp[0] + P.off[0] + t) * 512 + c8);
+            if (ok && P.dout[1]) r1[i] = *reinterpret_cast<const uint4*>(P.dout[1] + ((long)v * P.grp[1] + P.off[1] + t) * 512 + c8);
+            rx[i] = *reinterpret_cast<const uint4*>(P.proj + row * 512 + c8);
+            mu[i] = P.mean[row]; rs[i] = P.rstd[row];
+        }
+#pragma unroll
+        for (int i = 0; i < EB_VG; ++i) {
+            const int v = vg * EB_VG + i;
+            if (v >= P.nvid) break;
+            const long row = (long)v * P.T + t;
+            float d0[8], d1[8], x[8];
+            pn_unpack8(r0[i], d0); pn_unpack8(r1[i], d1); pn_unpack8(rx[i], x);
+            float dy[8], xh[8], g[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                dy[e] = d0[e] + d1[e];
+                xh[e] = (x[e] - mu[i]) * rs[i];
+                g[e] = dy[e] * gm[e];
+                s1 += g[e]; s2 += g[e] * xh[e];
+                dp0[e] += d0[e]; dp1[e] += d1[e];
+                gg[e] += dy[e] * xh[e]; gb[e] += dy[e];
+            }
+            const float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rs[i] * (g[e] - m1 - xh[e] * m2);
+            *reinterpret_cast<uint4*>(P.dproj + row * 512 + c8) = pn_pack8(o);
+        }
+        // position-row sums of this video group: plain stores into the group's partial plane (tan_pos_ln_bwd adds the planes)
+        if (P.dpos[0]) { float* d = P.dpos[0] + ((long)vg * P.T + t) * 512 + c8; st4(d, make_float4(dp0[0], dp0[1], dp0[2], dp0[3])); st4(d + 4, make_float4(dp0[4], dp0[5], dp0[6], dp0[7])); }
+        if (P.dpos[1]) { float* d = P.dpos[1] + ((long)vg * P.T + t) * 512 + c8; st4(d, make_float4(dp1[0], dp1[1], dp1[2], dp1[3])); st4(d + 4, make_float4(dp1[4], dp1[5], dp1[6], dp1[7])); }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][wave][c8 + e] = gg[e]; red[1][wave][c8 + e] = gb[e]; }
+    __syncthreads();
+    {
+        const int c = threadIdx.x;
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { a += red[0][w][c]; b += red[1][w][c]; }
+        atomicAdd(P.g_g + c, a);
+        atomicAdd(P.g_b + c, b);
+    }
+}
+
+struct PosBwdUse { const float *dpos, *x, *mean, *rstd; float* g_table; int n, nparts; };
+struct PosBwdArgs { PosBwdUse u[3]; int nuse; const float* gamma; float *g_g, *g_b; };
+constexpr int PB_ROWS = 4;      // rows per workgroup (one per wave): one atomic per column and workgroup for the LayerNorm's own gradients
+
+__global__ __launch_bounds__(256) void pos_ln_bwd_kernel(const PosBwdArgs A) {
+    __shared__ float red[2][4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c8 = lane * 8;
+    const f8 gm = ld8f(A.gamma + c8);
+    float gg[8], gb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gg[e] = gb[e] = 0.f;
+    constexpr float invC = 1.0f / 512.0f;
+    for (int i = 0; i < PB_ROWS / 4; ++i) {
+        int r = (int)blockIdx.x * PB_ROWS + i * 4 + wave;
+        PosBwdUse U = A.u[0];
+        if (r >= U.n && A.nuse > 1) { r -= U.n; U = A.u[1]; if (r >= U.n && A.nuse > 2) { r -= U.n; U = A.u[2]; } }
+        if (r >= U.n) continue;
+        float dy[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dy[e] = 0.f;
+        for (int p0 = 0; p0 < U.nparts; p0 += 8) {     // the video groups' partial planes [nparts][n][512], eight loads in flight
+            f8 q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[j] = ld8f(U.dpos + ((long)min(p0 + j, U.nparts - 1) * U.n + r) * 512 + c8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float w = p0 + j < U.nparts ? 1.0f : 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dy[e] += w * q[j].v[e];
+            }
+        }
+        const f8 x = ld8f(U.x + (long)r * 512 + c8);
+        const float mean = U.mean[r], rstd = U.rstd[r];
+        float xh[8], g[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xh[e] = (x.v[e] - mean) * rstd; g[e] = dy[e] * gm.v[e]; s1 += g[e]; s2 += g[e] * xh[e]; gg[e] += dy[e] * xh[e]; gb[e] += dy[e]; }
+        const float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
+        if (U.g_table) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(U.g_table + (long)r * 512 + c8 + e, rstd * (g[e] - m1 - xh[e] * m2));
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][wave][c8 + e] = gg[e]; red[1][wave][c8 + e] = gb[e]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        atomicAdd(A.g_g + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(A.g_b + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+}
+
+}  // namespace tal
+
+extern "C" int tan_embed_bwd_group(void) { return EB_VG; }
+
+extern "C" int tan_embed_bwd(const tan_embed_bwd_desc* d, int nprob, void* stream) {
+    TAN_REQUIRE(d && nprob >= 1 && nprob <= 2);
+    EmbBwdArgs A{};
+    A.nprob = nprob;
+    int blk = 0;
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < nprob; ++i) {
+        const tan_embed_bwd_desc& s = d[i];
+        TAN_REQUIRE(s.rows > 0 && s.T > 0 && s.rows % s.T == 0 && s.C == 512 && s.proj && s.mean && s.rstd && s.ln_g && s.d_proj && s.g_ln_g && s.g_ln_b);
+        TAN_REQUIRE(s.d_out[0] || s.d_out[1]);
+        EmbBwdProb& p = i ? A.p1 : A.p0;
+        p.rows = s.rows; p.T = s.T; p.nvid = (int)(s.rows / s.T);
+        for (int k = 0; k < 2; ++k) {
+            p.dout[k] = (const bf16_t*)s.d_out[k]; p.grp[k] = s.d_out_grp_rows[k]; p.off[k] = s.d_out_off[k]; p.dpos[k] = s.d_out[k] ? s.d_pos[k] : nullptr;
+        }
+        p.proj = (const bf16_t*)s.proj; p.mean = s.mean; p.rstd = s.rstd; p.g = s.ln_g;
+        p.dproj = (bf16_t*)s.d_proj; p.g_g = s.g_ln_g; p.g_b = s.g_ln_b;
+        p.blk0 = blk; p.tblocks = (s.T + 7) / 8;
+        blk += p.tblocks * ((p.nvid + EB_VG - 1) / EB_VG);
+    }
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(blk), dim3(512), 0, st, A);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_pos_ln_bwd(const tan_pos_ln_bwd_use* u, int nuse, const float* gamma, float* g_gamma, float* g_beta, int C, void* stream) {
+    TAN_REQUIRE(u && nuse >= 1 && nuse <= 3 && gamma && g_gamma && g_beta && C == 512);
+    PosBwdArgs A{};
+    A.nuse = nuse; A.gamma = gamma; A.g_g = g_gamma; A.g_b = g_beta;
+    int rows = 0;
+    for (int i = 0; i < nuse; ++i) {
+        TAN_REQUIRE(u[i].d_pos && u[i].x && u[i].mean && u[i].rstd && u[i].n > 0);
+        TAN_REQUIRE(u[i].nparts >= 1);
+        A.u[i] = PosBwdUse{u[i].d_pos, u[i].x, u[i].mean, u[i].rstd, u[i].g_table, u[i].n, u[i].nparts};
+        rows += u[i].n;
+    }
+    hipLaunchKernelGGL(pos_ln_bwd_kernel, dim3(cdiv(rows, PB_ROWS)), dim3(256), 0, (hipStream_t)stream, A);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}

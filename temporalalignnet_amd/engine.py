@@ -290,6 +290,95 @@ class _AlignerEngine(_WorkspaceMixin):
             return d_lang.float().view(B, N, Dt)
         return None
 
+    def _embed_bwd_fused(self, run, d_x0, d_xj, d_lang_dual, need_d_lang):
+        """Backward of the fused front-end: tan_embed_bwd (both modalities: LayerNorm backward on the sum of the dual- and joint-path
+        gradients read in place, position-row sums, LayerNorm parameter gradients), tan_pos_ln_bwd (all used table slices), and the
+        two pre-projection weight-gradient GEMMs (video on this stream, text -- and d lang when the language model trains -- on the
+        side stream)."""
+        em, B, T, N = run["em"], run["B"], run["T"], run["N"]
+        L, R, Mp = T + N, B * T, B * N
+        cd, dev = self.compute_dtype, em["x0"].device
+        sv_v, sv_vj, sv_t, sv_tt = run["sv_video"], run["sv_video_j"], run["sv_text"], run["sv_text_t"]
+        D = (_lib.EmbedBwdDesc * 2)()
+        dpos = em.dpos
+        d = D[0]
+        d.rows, d.T, d.C = R, T, WIDTH
+        if d_x0 is not None:
+            d.d_out[0], d.d_out_grp_rows[0], d.d_out_off[0], d.d_pos[0] = d_x0.data_ptr(), T, 0, dpos[0].data_ptr()
+        if d_xj is not None:
+            d.d_out[1], d.d_out_grp_rows[1], d.d_out_off[1], d.d_pos[1] = d_xj.data_ptr(), L, 0, dpos[1].data_ptr()
+        d.proj, d.mean, d.rstd = sv_v["proj"].data_ptr(), sv_v["mean"].data_ptr(), sv_v["rstd"].data_ptr()
+        d.ln_g, d.d_proj = self._f("ln_video_init.weight").data_ptr(), em["dproj_v"].data_ptr()
+        d.g_ln_g, d.g_ln_b = self._g("ln_video_init.weight").data_ptr(), self._g("ln_video_init.bias").data_ptr()
+        nprob = 1
+        if d_lang_dual is not None or d_xj is not None:
+            d = D[1]
+            nprob = 2
+            d.rows, d.T, d.C = Mp, N, WIDTH
+            if d_lang_dual is not None:
+                d.d_out[0], d.d_out_grp_rows[0], d.d_out_off[0] = d_lang_dual.data_ptr(), N, 0
+            if d_xj is not None:
+                d.d_out[1], d.d_out_grp_rows[1], d.d_out_off[1] = d_xj.data_ptr(), L, T
+                if sv_tt is not None:
+                    d.d_pos[1] = dpos[2].data_ptr()
+            d.proj, d.mean, d.rstd = sv_t["proj"].data_ptr(), sv_t["mean"].data_ptr(), sv_t["rstd"].data_ptr()
+            d.ln_g, d.d_proj = self._f("ln_text_init.weight").data_ptr(), em["dproj_t"].data_ptr()
+            d.g_ln_g, d.g_ln_b = self._g("ln_text_init.weight").data_ptr(), self._g("ln_text_init.bias").data_ptr()
+        _lib.check(_lib.lib().tan_embed_bwd(D, nprob, ops._stream()), "tan_embed_bwd")
+        # ---- ln_position_init backward on the used slices (the dual offset's slice only if the video stack had a gradient)
+        uses = []
+
+        def use(saved, buf):
+            which = saved["which"]
+            learned = not (which == "temporal_pos_embed" and self.pos_enc != "learned")
+            g_tab = self._g(which)[saved["start"]:saved["start"] + saved["n"]] if learned else None
+            uses.append(_lib.PosLnBwdUse(buf.data_ptr(), saved["pos"].data_ptr(), saved["mean"].data_ptr(), saved["rstd"].data_ptr(),
+                                         g_tab.data_ptr() if g_tab is not None else None, saved["n"], em.nparts))
+        if d_x0 is not None:
+            use(sv_v["pos"], dpos[0])
+        if d_xj is not None:
+            use((sv_vj or sv_v)["pos"], dpos[1])
+            if sv_tt is not None:
+                use(sv_tt["pos"], dpos[2])
+        if uses:
+            U = (_lib.PosLnBwdUse * len(uses))(*uses)
+            _lib.check(_lib.lib().tan_pos_ln_bwd(U, len(uses), self._f("ln_position_init.weight").data_ptr(),
+                                                 self._g("ln_position_init.weight").data_ptr(), self._g("ln_position_init.bias").data_ptr(),
+                                                 WIDTH, ops._stream()), "tan_pos_ln_bwd")
+        # ---- weight gradients of the two pre-projections (train/main.py: autograd of tan_model.py:48-49)
+        cur = torch.cuda.current_stream()
+        aux = self._side_stream(dev) if os.environ.get("TAN_TAIL_STREAMS", "1") != "0" else None
+        if aux is not None and aux.cuda_stream == cur.cuda_stream:
+            aux = None
+        d_lang = None
+
+        def text_side():
+            lang_c = sv_t["lang_c"]
+            Dt = lang_c.shape[-1]
+            ops.gemm(em["dproj_t"], lang_c, self._g("text_pre_proj.weight"), M=WIDTH, N=Dt, K=Mp, a_kc=False, b_kc=False,
+                     lda=WIDTH, ldb=Dt, accumulate=True, split_k=max(1, min(16, Mp // 256)))
+            if need_d_lang:
+                dl = torch.empty(Mp, Dt, dtype=cd, device=dev)
+                ops.gemm(em["dproj_t"], self._w("text_pre_proj.weight"), dl, M=Mp, N=Dt, K=WIDTH, a_kc=True, b_kc=False, ldb=Dt)
+                return dl.float().view(B, N, Dt)
+            return None
+        if nprob == 2 and aux is not None:
+            aux.wait_stream(cur)
+            with torch.cuda.stream(aux):
+                d_lang = text_side()
+            if d_lang is not None:
+                d_lang.record_stream(cur)
+        video_c = sv_v["video_c"]
+        Dv = video_c.shape[-1]
+        ops.gemm(em["dproj_v"], video_c, self._g("video_pre_proj.weight"), M=WIDTH, N=Dv, K=R, a_kc=False, b_kc=False,
+                 lda=WIDTH, ldb=Dv, accumulate=True, split_k=max(1, min(32, R // 1024)))
+        if nprob == 2:
+            if aux is not None:
+                cur.wait_stream(aux)
+            else:
+                d_lang = text_side()
+        return d_lang
+
     def _side_stream(self, dev):
         if not self.overlap_stacks:
             return None
@@ -682,6 +771,12 @@ class _AlignerEngine(_WorkspaceMixin):
                 self._encoder_bwd(ev, run["x0"], run["vmask"], "ln_video_post_enc", dst_v, d_x0)
                 if self._grad_ready_hook is not None:
                     self._grad_ready_hook("video", self._layer_events(ev.prefix, ev.layers))
+        if run.get("em") is not None and os.environ.get("TAN_EMBED_BWD_FUSED", "1") != "0":
+            d_lang = self._embed_bwd_fused(run, d_x0 if any_v else None, d_xj, d_lang_raw if have_lang_raw else None, need_d_lang)
+            self._release_ws(ev)
+            self._release_ws(ej)
+            self._release_ws(run.get("em"))
+            return d_lang
         if any_j:
             if run["sv_video_j"] is not None:
                 d_x0j = torch.empty(R, Cw, dtype=cd, device=dev)

@@ -60,6 +60,8 @@ def to_device_batch(batch: dict, device="cuda") -> dict:
         if k in batch and batch[k] is not None:
             out[k] = torch.as_tensor(batch[k]).to(device, non_blocking=True)
     out["padding_mask"] = torch.as_tensor(batch["padding_mask"]).bool().to(device, non_blocking=True)
+    if "text_padding_mask" in out and torch.is_tensor(out["text_padding_mask"]):
+        out["_text_pad_bool"] = out["text_padding_mask"].bool()          # main.py:86 passes .bool() every step: converted once here
     T, N = out["video"].shape[1], out["text_embed"].shape[1]
     out["_tgt_raw"], _, _ = get_mask_from_time(batch["start"], batch["end"], T, N, device=device)
     if "text_padding_mask" in batch and not torch.is_tensor(batch["text_padding_mask"]):
@@ -266,6 +268,7 @@ class Trainer:
         if "token" in batch and self.online.bert is not None:      # sentence embeddings from the language model (main.py:55-65)
             batch = dict(batch)
             batch["text_embed"], batch["text_padding_mask"] = embed_sentences(m, batch["token"])
+            batch["_text_pad_bool"] = None
             batch["n_text"] = int(sum(t.shape[0] for t in batch["token"]))
         fused = self.fused_loss
         if fused:       # the logits-free sweep keeps one LDS accumulator per text column: beyond its limit use materialised logits
@@ -286,8 +289,9 @@ class Trainer:
             batch["_loss_prep"] = prepare_inputs_async(batch, batch["padding_mask"], batch["text_padding_mask"], Tn, Nn,
                                                        batch["video"].device, a, batch.get("n_text"),
                                                        want_compaction=bool(fused) and not self.global_negatives)
+        tp_bool = batch["_text_pad_bool"] if batch.get("_text_pad_bool") is not None else batch["text_padding_mask"].bool()
         logits = m(batch["video"], batch["text_embed"], video_padding_mask=batch["padding_mask"],
-                   lang_padding_mask=batch["text_padding_mask"].bool(), text_timestamp=batch.get("_tgt_raw"),
+                   lang_padding_mask=tp_bool, text_timestamp=batch.get("_tgt_raw"),
                    abs_text_pos=batch.get("abs_text_pos"),
                    fused="defer" if (fused and not a.learn_agreement and not self.global_negatives) else fused)
         if "_fused" in logits and batch.get("n_text") is not None:
@@ -298,7 +302,7 @@ class Trainer:
             logits["_fused"].global_negatives = True
         if a.model == "cotrain":
             ema = m.forward_from_ema(batch["video"], batch["text_embed"], video_padding_mask=batch["padding_mask"],
-                                     lang_padding_mask=batch["text_padding_mask"].bool(),
+                                     lang_padding_mask=tp_bool,
                                      text_timestamp=batch.get("_tgt_raw"), abs_text_pos=batch.get("abs_text_pos"),
                                      fused=fused)
             logits = {**logits, **{f"ema-{k}": v for k, v in ema.items()}}

@@ -60,11 +60,15 @@ class _EmbRun:
     def __init__(self, B, T, N, Dv, Dt, cd, dev):
         R, Mp, L = B * T, B * N, T + N
         self.act = _Blocks(cd, dev, {"video_c": R * Dv, "lang_c": Mp * Dt, "proj_v": R * WIDTH, "proj_t": Mp * WIDTH,
-                                     "x0": R * WIDTH, "xj": B * L * WIDTH, "lang_raw": Mp * WIDTH})
+                                     "x0": R * WIDTH, "xj": B * L * WIDTH, "lang_raw": Mp * WIDTH,
+                                     "dproj_v": R * WIDTH, "dproj_t": Mp * WIDTH})       # (backward: LayerNorm-backward outputs)
+        # backward: position-row gradient sums (dual, joint, text), one partial plane per group of videos
+        self.nparts = -(-B // _lib.lib().tan_embed_bwd_group())
+        self.dpos = torch.empty(3, self.nparts * max(T, N), WIDTH, device=dev)
         self.stat = _Blocks(torch.float32, dev, {"mean_v": R, "rstd_v": R, "mean_t": Mp, "rstd_t": Mp})
         self.keypad = torch.zeros(B, L, dtype=torch.uint8, device=dev)
         self._shape = {"video_c": (R, Dv), "lang_c": (Mp, Dt), "proj_v": (R, WIDTH), "proj_t": (Mp, WIDTH), "x0": (R, WIDTH),
-                       "xj": (B * L, WIDTH), "lang_raw": (Mp, WIDTH)}
+                       "xj": (B * L, WIDTH), "lang_raw": (Mp, WIDTH), "dproj_v": (R, WIDTH), "dproj_t": (Mp, WIDTH)}
 
     def __getitem__(self, k):
         return self.act[k].view(self._shape[k]) if k in self._shape else self.stat[k]

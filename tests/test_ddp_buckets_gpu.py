@@ -84,6 +84,7 @@ def test_overlapped_bucketed_allreduce_with_a_simulated_identical_peer(one_rank_
     monkeypatch.setattr(dist, "allreduce_sum_", fake_allreduce)
     monkeypatch.setattr(dist, "world_size", lambda: 2)
     tr2 = Trainer(model, args, ddp_bucket_layers=bucket_layers)
+    tr2.ddp_mode = "buckets"                     # (the default is 'flat': one all-reduce after backward, tested below)
     ld1 = tr2.step(batch)
     g1 = tr2.online.flat_grad().clone()
     p1 = tr2.online._flat.flat.clone()
@@ -107,3 +108,23 @@ def test_overlapped_bucketed_allreduce_with_a_simulated_identical_peer(one_rank_
     dp = (p1 - p0).abs()
     assert dp.max() <= 2.1 * lr + 1e-7
     assert (dp > 0.1 * lr).float().mean() < 0.01
+
+
+def test_flat_mode_is_one_allreduce_of_the_whole_gradient(one_rank_rccl, monkeypatch):
+    """The default data-parallel mode (BASELINE north_star: a single RCCL all-reduce of the gradients per step)."""
+    from temporalalignnet_amd import dist
+    Trainer, model, args, batch = _setup(2)
+    calls = []
+    real = dist.allreduce_sum_
+
+    def counting(t, async_op=False):
+        calls.append((t.numel(), async_op))
+        return real(t, async_op=async_op)
+    monkeypatch.setattr(dist, "_FORCE", True)
+    monkeypatch.setattr(dist, "allreduce_sum_", counting)
+    tr = Trainer(model, args)
+    assert tr.ddp_mode == "flat"
+    ld = tr.step(batch)
+    torch.cuda.synchronize()
+    assert calls == [(tr.online.flat_grad().numel(), False)]
+    assert ld["loss"].item() == ld["loss"].item()
