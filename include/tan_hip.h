@@ -342,7 +342,6 @@ typedef struct tan_layer_params {
     const void *wt_qkv, *wt_out, *wt_fc, *wt_proj; /* optional (bf16): W^T copies, [in, out] row-major, for the dX GEMMs; NULL = read W K-strided */
     const void *wp_qkv, *wp_out, *wp_fc, *wp_proj; /* optional (bf16): tan_pack_weights images of w_* for the row-panel kernels; NULL = unfused path */
     const void *wtp_qkv, *wtp_out, *wtp_fc, *wtp_proj; /* optional (bf16): tan_pack_weights images of wt_* (backward row-panel kernels) */
-    const void* wp_qkv_k16;                        /* optional (bf16): in_proj packed with TN = 512, TK = 16 (the MLP forward's in_proj tail, L > 80) */
 } tan_layer_params;
 
 /* per-layer saved activations, rows R = B*L */
@@ -381,12 +380,6 @@ typedef struct tan_encoder_desc {
                                                    only for backward (h_pre, h_act, xn2, mean2 / rstd2, and on the fused attention
                                                    path qkv, attn_o, lse) are NOT written; bufs[] may then leave them NULL.  The stage
                                                    outputs (xn1 of layers >= 1, post_out) and x_mid / x_out are written as usual. */
-    /* backward only, optional: a second stream for the blocks' weight-gradient launches (they only feed the optimizer; in-stream they
-     * sit on the dX chain) with the second set of the four scratch buffers they read -- blocks alternate between the sets.  Ignored
-     * with layer_done (data-parallel callers), outside the row-panel path, or when any pointer is NULL.  On return `stream` has been
-     * made to wait for all of them. */
-    void* dw_stream;
-    void *scr2_dx, *scr2_dx2, *scr2_dh, *scr2_dqkv;
     /* forward only: != 0: bufs[0].xn1 / mean1 / rstd1 already hold the first block's ln_1(x0) (tan_embed_fwd wrote them) */
     int xn1_ready;
 } tan_encoder_desc;
@@ -440,10 +433,6 @@ typedef struct tan_mlp_desc {
      * attention branch (tan_attnblk_fwd) does not take (L > 80): attn_o [rows, C] bf16 = tan_attn_fwd's output, pw_out =
      * tan_pack_weights image of out_proj.weight [C][C] (TN = 512, TK = 16), b_out f32 [C], x_in [rows, C] bf16 the block's input. */
     const void* attn_o; const void* pw_out; const float* b_out; const void* x_in;
-    /* Optional tail (pw_in != NULL; needs the head above and xn_next): qkv_out [rows, 3C] bf16 = xn_next W_in^T + b_qkv -- the NEXT
-     * block's attention in-projection (tfm_model.py:21, 30-36) from the xn_next panel that is sitting in LDS; pw_in =
-     * tan_pack_weights image of that block's in_proj_weight [3C][C] with TN = 512, TK = 16; b_qkv f32 [3C]. */
-    const void* pw_in; const float* b_qkv; void* qkv_out;
 } tan_mlp_desc;
 int tan_mlp_fwd(const tan_mlp_desc* d, void* stream);
 
@@ -485,9 +474,6 @@ typedef struct tan_mlp_bwd_desc {
     const void* dqkv;
     const void* pwt_in;
     const void* dstage;
-    /* head_only != 0 (with pwt_in): nothing but dx_out = ln1_res + LayerNorm-backward(dqkv W_in + dstage) and its three column sums --
-     * block 0 of a stack, whose ln_1 backward has no MLP backward below it to ride on; every MLP field may be NULL. */
-    int head_only;
 } tan_mlp_bwd_desc;
 int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream);
 
@@ -556,25 +542,8 @@ typedef struct tan_attnblk_desc {
 int tan_attnblk_supported(int L, int C, int H, int dtype);
 int tan_attnblk_fwd(const tan_attnblk_desc* d, void* stream);
 
-/* tan_attnblk_bwd: the first half of the branch's backward in one launch per video -- d_o = dx2 W_out (the out_proj dX GEMM) and
- * the attention backward of all 8 heads (autograd of nn.MultiheadAttention, model/tfm_model.py:30-32):
- *   dqkv [B*L, 3C] = d(q | k | v)   (operand of the in_proj dX and dW GEMMs),   g_b_qkv [3C] += column sums of dqkv (optional)
- * from dx2 (gradient w.r.t. x_mid = the out_proj output), the saved qkv rows and lse of tan_attnblk_fwd / tan_attn_fwd.  d_o never
- * exists in HBM.  pwt_out = tan_pack_weights image of out_proj.weight^T ([in][out] = the W^T copy) with TN = 512, TK = 16.
- * Replaces the out_proj dX GEMM and tan_attn_bwd_bias of tan_encoder_bwd; same shapes as tan_attnblk_fwd (bf16, 48 < L <= 80). */
-typedef struct tan_attnblk_bwd_desc {
-    int B, L, C, H;
-    const void* dx2;                         /* [B*L, C] bf16 */
-    const void* qkv;                         /* [B*L, 3C] bf16, saved by the forward */
-    const float* lse;                        /* [B, H, L] */
-    const unsigned char* key_padding_mask;   /* [B, L] or NULL */
-    const void* pwt_out;
-    void* dqkv;                              /* out [B*L, 3C] bf16 */
-    float* g_b_qkv;                          /* [3C] f32, accumulated, or NULL */
-} tan_attnblk_bwd_desc;
-int tan_attnblk_bwd(const tan_attnblk_bwd_desc* d, void* stream);
 /* tools/lab only: device buffer ([8 waves][64] long) that receives workgroup 0's shader clock at the phase boundaries of
- * tan_attnblk_bwd, or NULL (default): no instrumentation */
+ * tan_attnblk_fwd, or NULL (default): no instrumentation */
 int tan_attnblk_lab_set_dbg(void* device_buffer);
 
 #ifdef __cplusplus

@@ -102,7 +102,7 @@ class LayerParams(C.Structure):
         "w_qkv", "w_out", "w_fc", "w_proj", "b_qkv", "b_out", "b_fc", "b_proj", "ln1_g", "ln1_b", "ln2_g", "ln2_b",
         "g_w_qkv", "g_w_out", "g_w_fc", "g_w_proj", "g_b_qkv", "g_b_out", "g_b_fc", "g_b_proj",
         "g_ln1_g", "g_ln1_b", "g_ln2_g", "g_ln2_b", "wt_qkv", "wt_out", "wt_fc", "wt_proj",
-        "wp_qkv", "wp_out", "wp_fc", "wp_proj", "wtp_qkv", "wtp_out", "wtp_fc", "wtp_proj", "wp_qkv_k16")]
+        "wp_qkv", "wp_out", "wp_fc", "wp_proj", "wtp_qkv", "wtp_out", "wtp_fc", "wtp_proj")]
 
 
 class LayerBufs(C.Structure):
@@ -144,7 +144,6 @@ class MlpDesc(C.Structure):
         ("nln_g", C.c_void_p), ("nln_b", C.c_void_p), ("xn_next", C.c_void_p), ("nmean", C.c_void_p), ("nrstd", C.c_void_p),
         ("eps", C.c_float), ("variant", C.c_int),
         ("attn_o", C.c_void_p), ("pw_out", C.c_void_p), ("b_out", C.c_void_p), ("x_in", C.c_void_p),
-        ("pw_in", C.c_void_p), ("b_qkv", C.c_void_p), ("qkv_out", C.c_void_p),
     ]
 
 
@@ -160,7 +159,7 @@ class MlpBwdDesc(C.Structure):
         ("ln1_mean", C.c_void_p), ("ln1_rstd", C.c_void_p), ("ln1_g", C.c_void_p),
         ("g_ln1_g", C.c_void_p), ("g_ln1_b", C.c_void_p), ("g_dx_colsum", C.c_void_p), ("dx_out", C.c_void_p),
         ("pwt_out", C.c_void_p), ("d_o", C.c_void_p),
-        ("dqkv", C.c_void_p), ("pwt_in", C.c_void_p), ("dstage", C.c_void_p), ("head_only", C.c_int),
+        ("dqkv", C.c_void_p), ("pwt_in", C.c_void_p), ("dstage", C.c_void_p),
     ]
 
 
@@ -197,14 +196,6 @@ class AttnBlkDesc(C.Structure):
     ]
 
 
-class AttnBlkBwdDesc(C.Structure):
-    _fields_ = [
-        ("B", C.c_int), ("L", C.c_int), ("C", C.c_int), ("H", C.c_int),
-        ("dx2", C.c_void_p), ("qkv", C.c_void_p), ("lse", C.c_void_p), ("key_padding_mask", C.c_void_p),
-        ("pwt_out", C.c_void_p), ("dqkv", C.c_void_p), ("g_b_qkv", C.c_void_p),
-    ]
-
-
 class EncoderDesc(C.Structure):
     _fields_ = [
         ("dtype", C.c_int), ("B", C.c_int), ("L", C.c_int), ("C", C.c_int), ("H", C.c_int), ("layers", C.c_int),
@@ -217,9 +208,7 @@ class EncoderDesc(C.Structure):
         ("dw_ws", C.c_void_p), ("dw_ws_floats", C.c_long),
         ("d_stage", C.POINTER(C.c_void_p)), ("d_x0", C.c_void_p),
         ("layer_done", C.POINTER(C.c_void_p)),
-        ("no_save", C.c_int),
-        ("dw_stream", C.c_void_p), ("scr2_dx", C.c_void_p), ("scr2_dx2", C.c_void_p), ("scr2_dh", C.c_void_p), ("scr2_dqkv", C.c_void_p),
-        ("xn1_ready", C.c_int),
+        ("no_save", C.c_int), ("xn1_ready", C.c_int),
     ]
 
 
@@ -236,8 +225,7 @@ def role_stream(dev, role):
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), role)
     st = _ROLE_STREAMS.get(key)
     if st is None:
-        order = os.environ.get("TAN_STREAM_ORDER", "stack,loss,comm,opt,dwj,dwv").split(",")         # (lab: which roles share a queue)
-        for r in order:                                        # fixed creation order, whatever is asked for first
+        for r in ("stack", "loss", "comm", "opt"):                                        # fixed creation order, whatever is asked for first
             k = (key[0], key[1], r)
             if k not in _ROLE_STREAMS:
                 _ROLE_STREAMS[k] = torch.cuda.Stream(device=torch.device(key[0], key[1]))

@@ -1106,20 +1106,11 @@ template <int NKB> static int launch_bwd_short(const AttnArgs& a, hipStream_t st
 
 using namespace tal;
 
-// TAN_ATTN_GENERIC=1 forces the tiled any-length kernels for bf16 too (A/B measurements)
-static bool long_path() {
-    static const bool off = [] { const char* e = getenv("TAN_ATTN_GENERIC"); return e && e[0] == '1'; }();
-    return !off;
-}
-// TAN_ATTN_MID=0 sends 128 < L <= 288 to the streamed kernels (A/B measurements)
-static bool mid_path(int dtype, int L) {
-    static const bool off = [] { const char* e = getenv("TAN_ATTN_MID"); return e && e[0] == '0'; }();
-    return dtype == TAN_BF16 && L > 128 && L <= 288 && !off && long_path();
-}
-static bool short_path(int dtype, int L) {
-    static const bool off = [] { const char* e = getenv("TAN_ATTN_GENERIC"); return e && e[0] == '1'; }();
-    return dtype == TAN_BF16 && L <= 128 && !off;
-}
+// bf16 dispatch by length: L <= 128 the whole head in registers / LDS ("short"), 128 < L <= 288 the whole head resident in LDS
+// ("mid"), longer: streamed ("long"); f32 runs the tiled kernels
+static bool long_path() { return true; }
+static bool mid_path(int dtype, int L) { return dtype == TAN_BF16 && L > 128 && L <= 288; }
+static bool short_path(int dtype, int L) { return dtype == TAN_BF16 && L <= 128; }
 
 extern "C" int tan_attn_fwd(const void* qkv, const unsigned char* key_padding_mask, void* o, float* lse, int B, int L, int H,
                             int dtype, void* stream) {

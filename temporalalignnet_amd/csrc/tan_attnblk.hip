@@ -349,282 +349,6 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void attnblk_fwd_kerne
 }
 
 
-// ====================================================================================================================
-// Backward, first half: d_o = dx2 W_out (the out_proj dX GEMM) and the 8 heads' attention backward in ONE launch per video.
-//   GEMM-a   d_o[L, 512] = dx2[L, 512] W_out          wave w owns head w's 64 features; packed W_out^T (TN = 512, TK = 16), K = 512
-//            -> eight [XROWS][64] d_o head images, written IN PLACE over the dx2 panel (through the accumulators, after a barrier)
-//   per head pair: q | k | v images from the saved qkv rows, then tan_attn.hip's short backward per (head, 32-row block) unit:
-//            phase A (unit owns queries) delta and dq, phase B (unit owns keys) dk, dv; results parked in the unit's own image rows,
-//            in_proj bias gradient = their column sums; the rows leave for HBM (dqkv: operand of the in_proj dX / dW GEMMs) while
-//            the next pair's q | k | v -- requested a phase earlier into registers -- take their place, chunk for chunk.
-// The in_proj dX GEMM (K = 1536) stays a tiled launch: its [512 x L] f32 accumulator next to the attention backward's ~200 registers
-// does not fit two waves per SIMD, and one wave per SIMD hides nothing.
-struct AbBwdArgs {
-    const bf16_t* dx2; const bf16_t* qkv; const float* lse; const unsigned char* keypad;
-    const char* pwt_out;        // packed W_out^T [512][512], TN = 512, TK = 16
-    bf16_t* dqkv; float* gbias;
-    int L, H;
-    long long* dbg;             // tools/lab only: shader clock of workgroup 0 at the phase boundaries (tan_attnblk_lab_set_dbg), or NULL
-};
-
-template <int NRB16>
-__global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void attnblk_bwd_kernel(AbBwdArgs a) {
-    constexpr int NKB = (NRB16 + 1) / 2, LP = 32 * NKB, XROWS = 16 * NRB16, D = AB_D;
-    constexpr int R0_OFF = 0, DI_B = XROWS * 128, R1_OFF = XROWS * 1024, IMG_B = LP * 128;
-    constexpr int BIAS_OFF = R1_OFF + 6 * IMG_B, LSE_OFF = BIAS_OFF + LP * 4, DEL_OFF = LSE_OFF + 8 * LP * 4, LDS_B = DEL_OFF + 2 * LP * 4;
-    static_assert(LDS_B <= 163840, "LDS budget");
-    __shared__ __attribute__((aligned(1024))) char lds[LDS_B];
-    constexpr int NPRE = 6 * LP * 8 / (64 * PN_WAVES);        // 16-byte chunks of a head pair's q | k | v per thread (6 | 9)
-
-    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int L = a.L, C = 512;
-    const long row0 = (long)blockIdx.x * L;
-
-    int tick_i = 0;
-    auto tick = [&]() __attribute__((always_inline)) {
-        if (a.dbg) {
-            const long long t = __builtin_readcyclecounter();
-            if (blockIdx.x == 0 && lane == 0) a.dbg[wave * 64 + tick_i] = t;
-            ++tick_i;
-        }
-    };
-    tick();
-    AbWFrags WQ[D];
-    pn_static_for<0, D>([&](auto jc) {
-        constexpr int J = decltype(jc)::value;
-        ab_load_wb(WQ[J], a.pwt_out, J, wave, lane);
-    });
-
-    // chunk g = tid + 512 i of a head pair's six images: image g / (8 LP), row (g / 8) % LP, 16-byte chunk g % 8
-    uint4 pre[NPRE];
-    auto pre_load = [&](int hp) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NPRE; ++i) {
-            const int g = tid + 64 * PN_WAVES * i, im = g / (8 * LP), row = (g >> 3) % LP, chunk = g & 7;
-            const int which = im % 3, h = 2 * hp + im / 3;
-            pre[i] = *reinterpret_cast<const uint4*>(a.qkv + (row0 + min(row, L - 1)) * (3 * C) + which * C + h * 64 + chunk * 8);
-        }
-    };
-    auto pre_slot = [&](int i) __attribute__((always_inline)) -> char* {
-        const int g = tid + 64 * PN_WAVES * i, im = g / (8 * LP), row = (g >> 3) % LP, chunk = g & 7;
-        return lds + R1_OFF + im * IMG_B + row * 128 + ((chunk ^ img_swz(row)) << 4);
-    };
-    pre_load(0);
-
-    // ---- prologue: dx2 panel, key bias, the saved log-sum-exps of all 8 heads (+inf: rows past L and fully padded rows -> p = 0)
-    {
-        constexpr int RPW = XROWS / PN_WAVES;
-        uint4 v[RPW];
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) v[r] = *reinterpret_cast<const uint4*>(a.dx2 + (row0 + min(wave * RPW + r, L - 1)) * C + lane * 8);
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) *reinterpret_cast<uint4*>(pn_panel_slot<1024>(lds + R0_OFF, wave * RPW + r, lane)) = v[r];
-        float* bias = reinterpret_cast<float*>(lds + BIAS_OFF);
-        float* lse_s = reinterpret_cast<float*>(lds + LSE_OFF);
-        const unsigned char* kp = a.keypad ? a.keypad + (long)blockIdx.x * L : nullptr;
-        for (int j = tid; j < LP; j += 64 * PN_WAVES) bias[j] = (j >= L || (kp && kp[j])) ? -INFINITY : 0.f;
-        for (int idx = tid; idx < 8 * LP; idx += 64 * PN_WAVES) {
-            const int h = idx / LP, r = idx % LP;
-            float l = INFINITY;
-            if (r < L) { l = a.lse[((long)blockIdx.x * a.H + h) * L + r]; if (l == -INFINITY) l = INFINITY; }
-            lse_s[idx] = l;
-        }
-    }
-    __syncthreads();
-    tick();      // 1: prologue done
-
-    // ---- GEMM-a: d_o of head `wave` (2 feature blocks of 32) x NKB row blocks, K = 512 in 32 steps of 16
-    {
-        f32x16 acc[2][NKB];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NKB; ++j) acc_zero(acc[i][j]);
-        pn_static_for<0, 32>([&](auto jc) {
-            constexpr int KT = decltype(jc)::value;
-            AbWFrags& W = WQ[KT % D];
-            bf16x8 xf[NKB];
-#pragma unroll
-            for (int mb = 0; mb < NKB; ++mb) xf[mb] = pn_pfrag<1024>(lds + R0_OFF, mb, KT * 16, lane);
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int mb = 0; mb < NKB; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], xf[mb], acc[nb][mb], 0, 0, 0);
-            if constexpr (KT + D < 32) ab_load_wb(W, a.pwt_out, KT + D, wave, lane);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        tick();  // 2: GEMM-a main loop done
-        __syncthreads();        // every wave is done with the dx2 panel: the d_o images take its place
-        char* Dimg = lds + R0_OFF + wave * DI_B;
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int mb = 0; mb < NKB; ++mb) {
-                const int m = mb * 32 + (lane & 31);
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = acc[nb][mb][8 * p + e];
-                    const int chunk = nb * 4 + 2 * hi + p;
-                    if (m < XROWS) *reinterpret_cast<uint4*>(Dimg + m * 128 + ((chunk ^ img_swz(m)) << 4)) = pn_pack8(v);
-                }
-            }
-    }
-    // the first head pair's q | k | v
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) *reinterpret_cast<uint4*>(pre_slot(i)) = pre[i];
-    __syncthreads();
-    tick();      // 3: d_o images + first q|k|v images in place
-
-    const float* bias = reinterpret_cast<const float*>(lds + BIAS_OFF);
-    float* delta_all = reinterpret_cast<float*>(lds + DEL_OFF);
-#pragma unroll 1
-    for (int hp = 0; hp < 4; ++hp) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));          // (keeps the fragment address arithmetic inside the loop: see attnblk_fwd_kernel)
-        const int c = ln & 31, hh = ln >> 5;
-        const bool unit = wave < 2 * NKB;
-        const int j = unit ? wave / NKB : 0, blk = unit ? wave % NKB : 0, h = 2 * hp + j;
-        char* Qi = lds + R1_OFF + (j * 3) * IMG_B;
-        char* Ki = Qi + IMG_B;
-        char* Vi = Ki + IMG_B;
-        const char* Di = lds + R0_OFF + h * DI_B;
-        const float* lse_s = reinterpret_cast<const float*>(lds + LSE_OFF) + h * LP;
-        float* delta_s = delta_all + j * LP;
-        f32x16 dq[2];
-        if (unit) {   // ---- phase A: this unit's 32 queries against every key: delta and dq
-            const int q0 = blk * 32;
-            bf16x8 qf[4], dof[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { qf[ks] = img_frag_kc(Qi, q0 + c, 2 * ks + hh); dof[ks] = img_frag_kc(Di, q0 + c, 2 * ks + hh); }
-            const float my_lse = lse_s[q0 + c];
-            f32x16 p[NKB], dp[NKB];
-            float delta = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < NKB; ++kb) {
-                acc_zero(p[kb]); acc_zero(dp[kb]);
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    p[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Ki, 32 * kb + c, 2 * ks + hh), qf[ks], p[kb], 0, 0, 0);
-                    dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Vi, 32 * kb + c, 2 * ks + hh), dof[ks], dp[kb], 0, 0, 0);
-                }
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const float4 bv = *reinterpret_cast<const float4*>(bias + 32 * kb + 8 * g4 + 4 * hh);
-                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float pv = __expf(p[kb][4 * g4 + e] * 0.125f + bb[e] - my_lse);
-                        p[kb][4 * g4 + e] = pv;
-                        delta += pv * dp[kb][4 * g4 + e];
-                    }
-                }
-            }
-            delta += __shfl_xor(delta, 32, 64);
-            if (hh == 0) delta_s[q0 + c] = delta;
-            acc_zero(dq[0]); acc_zero(dq[1]);
-#pragma unroll
-            for (int kb = 0; kb < NKB; ++kb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) p[kb][r] *= (dp[kb][r] - delta);     // dS^T
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const bf16x8 df = acc_frag(p[kb], jj);
-#pragma unroll
-                    for (int db = 0; db < 2; ++db)
-                        dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_tr(Ki, 32 * kb + 16 * jj, 32 * db, ln), df, dq[db], 0, 0, 0);
-                }
-            }
-        }
-        tick();  // 4 + 5 hp: phase A done
-        if (hp < 3) pre_load(hp + 1);          // the next head pair's q | k | v: in flight under phase B
-        __syncthreads();
-        tick();  // 5 + 5 hp
-        f32x16 dk[2], dv[2];
-        if (unit) {   // ---- phase B: this unit's 32 keys against every query: dk, dv
-            const int k0 = blk * 32;
-            bf16x8 kf[4], vf[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { kf[ks] = img_frag_kc(Ki, k0 + c, 2 * ks + hh); vf[ks] = img_frag_kc(Vi, k0 + c, 2 * ks + hh); }
-            const float my_bias = bias[k0 + c];
-            acc_zero(dk[0]); acc_zero(dk[1]); acc_zero(dv[0]); acc_zero(dv[1]);
-#pragma unroll
-            for (int qb = 0; qb < NKB; ++qb) {
-                f32x16 p, dp;
-                acc_zero(p); acc_zero(dp);
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Qi, 32 * qb + c, 2 * ks + hh), kf[ks], p, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_kc(Di, 32 * qb + c, 2 * ks + hh), vf[ks], dp, 0, 0, 0);
-                }
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const float4 lv = *reinterpret_cast<const float4*>(lse_s + 32 * qb + 8 * g4 + 4 * hh);
-                    const float4 dl = *reinterpret_cast<const float4*>(delta_s + 32 * qb + 8 * g4 + 4 * hh);
-                    const float ll[4] = {lv.x, lv.y, lv.z, lv.w}, dd[4] = {dl.x, dl.y, dl.z, dl.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float pv = __expf(p[4 * g4 + e] * 0.125f + my_bias - ll[e]);
-                        p[4 * g4 + e] = pv;
-                        dp[4 * g4 + e] = pv * (dp[4 * g4 + e] - dd[e]);
-                    }
-                }
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const bf16x8 pf = acc_frag(p, jj), df = acc_frag(dp, jj);
-#pragma unroll
-                    for (int db = 0; db < 2; ++db) {
-                        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_tr(Di, 32 * qb + 16 * jj, 32 * db, ln), pf, dv[db], 0, 0, 0);
-                        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag_tr(Qi, 32 * qb + 16 * jj, 32 * db, ln), df, dk[db], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        tick();  // 6 + 5 hp: phase B done
-        __syncthreads();            // every unit is done with the images: each parks its three result tiles in its own rows
-        if (unit) {
-            const int k0 = blk * 32;
-            tiles_to_rows(Qi, k0, c, hh, dq, 0.125f);
-            tiles_to_rows(Ki, k0, c, hh, dk, 0.125f);
-            tiles_to_rows(Vi, k0, c, hh, dv, 1.0f);
-            if (a.gbias) {
-                // in_proj bias gradient: column sums of the 32 rows this unit parked (the bf16 values dqkv holds; rows past L are
-                // exact zeros), one lane per head feature
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll 8
-                for (int r = 0; r < 32; ++r) {
-                    const int row = k0 + r, off = row * 128 + (((ln >> 3) ^ img_swz(row)) << 4) + (ln & 7) * 2;
-                    s0 += bf2f(*reinterpret_cast<const bf16_t*>(Qi + off));
-                    s1 += bf2f(*reinterpret_cast<const bf16_t*>(Ki + off));
-                    s2 += bf2f(*reinterpret_cast<const bf16_t*>(Vi + off));
-                }
-                float* g = a.gbias + h * 64 + ln;
-                unsafeAtomicAdd(g, s0); unsafeAtomicAdd(g + C, s1); unsafeAtomicAdd(g + 2 * C, s2);
-            }
-        }
-        tick();  // 7 + 5 hp: parked, column sums done
-        __syncthreads();
-        // dq | dk | dv rows leave for HBM; the next pair's q | k | v take their place chunk for chunk (same thread: no barrier between)
-#pragma unroll
-        for (int i = 0; i < NPRE; ++i) {
-            const int g = tid + 64 * PN_WAVES * i, im = g / (8 * LP), row = (g >> 3) % LP, chunk = g & 7;
-            const int which = im % 3, hh2 = 2 * hp + im / 3;
-            char* slot = pre_slot(i);
-            const uint4 v = *reinterpret_cast<const uint4*>(slot);
-            if (row < L) *reinterpret_cast<uint4*>(a.dqkv + (row0 + row) * (3 * C) + which * C + hh2 * 64 + chunk * 8) = v;
-            if (hp < 3) *reinterpret_cast<uint4*>(slot) = pre[i];
-        }
-        tick();  // 8 + 5 hp: copy-out / refill issued
-        __syncthreads();
-    }
-    tick();
-}
-
 }  // namespace tal
 
 using namespace tal;
@@ -651,23 +375,6 @@ extern "C" int tan_attnblk_fwd(const tan_attnblk_desc* d, void* stream) {
     const int rec = prof_begin((hipStream_t)stream, TAN_PROF_ATTNBLK, 2.0 * rows * 512.0 * 2048.0 + 4.0 * rows * d->L * 512.0);
     if (d->L <= 64) hipLaunchKernelGGL((attnblk_fwd_kernel<4>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((attnblk_fwd_kernel<5>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
-    prof_end((hipStream_t)stream, rec);
-    TAN_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int tan_attnblk_bwd(const tan_attnblk_bwd_desc* d, void* stream) {
-    TAN_REQUIRE(d && d->dx2 && d->qkv && d->lse && d->pwt_out && d->dqkv && d->B > 0);
-    TAN_REQUIRE(tan_attnblk_supported(d->L, d->C, d->H, TAN_BF16));
-    AbBwdArgs a;
-    a.dx2 = (const bf16_t*)d->dx2; a.qkv = (const bf16_t*)d->qkv; a.lse = d->lse; a.keypad = d->key_padding_mask;
-    a.pwt_out = (const char*)d->pwt_out; a.dqkv = (bf16_t*)d->dqkv; a.gbias = d->g_b_qkv;
-    a.L = d->L; a.H = d->H; a.dbg = g_ab_dbg;
-    const dim3 grid((unsigned)d->B);
-    const double rows = (double)d->B * d->L;
-    const int rec = prof_begin((hipStream_t)stream, TAN_PROF_ATTNBLK, 2.0 * rows * 512.0 * 512.0 + 10.0 * rows * d->L * 512.0);
-    if (d->L <= 64) hipLaunchKernelGGL((attnblk_bwd_kernel<4>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((attnblk_bwd_kernel<5>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
     prof_end((hipStream_t)stream, rec);
     TAN_LAUNCH_CHECK();
     return 0;

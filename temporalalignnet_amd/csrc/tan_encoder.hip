@@ -90,27 +90,16 @@ int linear_bwd_w(int dt, const void* dy, const void* x, float* gw, long M, int N
 
 #define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 
-// The four weight gradients of one block in ONE grouped launch (see gemm_dw_grouped_kernel), issued after the block's dX chain.
-// TAN_DW_GROUPED = K slices per problem: 1 (default) = 192 workgroups, each contracting ALL rows and adding straight into the f32
-// gradient -- no partial planes, no fold kernels; n > 1 = n x 192 workgroups writing partial planes + four folds; 0 = the four
-// GEMMs one by one (each split-K'ed to ~256 workgroups + a fold).  Measured inside the step (three interleaved rounds):
-// 0: 6.95 ms, 2: 6.85 ms, 1: 6.72 ms.  Falls back to the one-by-one path when the group is not eligible (f32, ragged rows).
+// The four weight gradients of one block in ONE grouped launch, issued after the block's dX chain: the 256 x 256-tile kernel
+// (gemm_dw256_kernel, DW256_SPLIT K slices adding into the f32 gradient with atomics: 2 beat 3, 4 and 5 inside the step), else the
+// 128 x 128 grouped kernel (192 workgroups, each contracting ALL rows straight into the gradient), else -- f32, ragged rows -- the
+// four GEMMs one by one.
 struct DwItem { const void* dy; const void* x; float* gw; int N, K; };
 
-int grouped_enabled() {
-    static const int on = [] { const char* e = getenv("TAN_DW_GROUPED"); return e ? atoi(e) : 1; }();
-    return on;
-}
-
-// TAN_DW256 = K slices of the 256 x 256-tile kernel (gemm_dw256_kernel; default 2, 0 = the 128 x 128 kernel below): slices > 1
-// add into the gradient with f32 atomics (no partial planes, no fold launches on the backward chain)
-int dw256_split() {
-    static const int v = [] { const char* e = getenv("TAN_DW256"); return e ? atoi(e) : 2; }();
-    return v < 0 ? 0 : v;
-}
+constexpr int DW256_SPLIT = 2;
 
 int linear_bwd_w_group(int dt, const DwItem* it, int n, long M, float* ws, long ws_floats, void* st) {
-    if (const int s256 = dt == TAN_BF16 ? dw256_split() : 0) {
+    if (const int s256 = dt == TAN_BF16 ? DW256_SPLIT : 0) {
         bool ok = M % 128 == 0 && M / 128 >= s256;
         for (int i = 0; i < n; ++i) ok = ok && it[i].N % 256 == 0 && it[i].K % 256 == 0;
         if (ok) {
@@ -126,27 +115,16 @@ int linear_bwd_w_group(int dt, const DwItem* it, int n, long M, float* ws, long 
             if (rc != -2) return rc;
         }
     }
-    int split = grouped_enabled();
-    while (split > 1 && (M % split != 0 || (M / split) % 64 != 0)) --split;
-    long need = 0;
-    for (int i = 0; i < n; ++i) need += (long)split * it[i].N * it[i].K;
-    if (dt == TAN_BF16 && M % 64 == 0 && (split == 1 || (ws && need <= ws_floats))) {
+    if (dt == TAN_BF16 && M % 64 == 0) {
         const void* dy[4]; const void* x[4]; float* parts[4]; int Ms[4], Ns[4];
-        long off = 0;
         double work = 0;
         for (int i = 0; i < n; ++i) {
-            dy[i] = it[i].dy; x[i] = it[i].x; parts[i] = split == 1 ? it[i].gw : ws + off; Ms[i] = it[i].N; Ns[i] = it[i].K;
-            off += (long)split * it[i].N * it[i].K;
+            dy[i] = it[i].dy; x[i] = it[i].x; parts[i] = it[i].gw; Ms[i] = it[i].N; Ns[i] = it[i].K;
             work += 2.0 * M * it[i].N * (double)it[i].K;
         }
         const int rec = prof_begin((hipStream_t)st, TAN_PROF_GEMM_BF16 + 3, work);
-        const int rc = gemm_dw_grouped(n, dy, x, parts, Ms, Ns, M, split, split == 1, (hipStream_t)st);
+        const int rc = gemm_dw_grouped(n, dy, x, parts, Ms, Ns, M, 1, 1, (hipStream_t)st);
         prof_end((hipStream_t)st, rec);
-        if (rc == 0) {
-            if (split > 1)
-                for (int i = 0; i < n; ++i) CK(tan_reduce_add(parts[i], it[i].gw, split, (long)it[i].N * it[i].K, st));
-            return 0;
-        }
         if (rc != -2) return rc;
     }
     for (int i = 0; i < n; ++i) CK(linear_bwd_w(dt, it[i].dy, it[i].x, it[i].gw, M, it[i].N, it[i].K, ws, ws_floats, st));
@@ -170,37 +148,13 @@ extern "C" int tan_linear_wgrad(const void* dy, const void* x, float* gw, long M
 }
 
 // Row-panel path (tan_panel.hip): the MLP half of a block -- LN2, c_fc + QuickGELU, c_proj + residual AND the LayerNorm that
-// consumes the block's output (the next block's ln_1, or the stack's post-LN) -- is ONE launch (TAN_PANEL=0: the four launches
-// it replaces).  Stand-alone 74 vs 77 us at 8192 rows and 69 vs 87 us at 10240; the two stacks side by side 122 vs 147 us; inside the
-// training step 6.24 / 6.31 vs 6.31 / 6.42 ms (two interleaved rounds on one box).  DESIGN.md section 3.5 has the ablations.
-static int panel_bwd_enabled() {
-    static const int v = [] { const char* e = getenv("TAN_PANEL_BWD"); return e ? atoi(e) : 1; }();
-    return v;
-}
-// TAN_ATTN_PANEL (bit mask, default 1): 1 = the attention branch's forward as one launch per video (tan_attnblk_fwd), 2 = out_proj dX +
-// attention backward as one launch (tan_attnblk_bwd: correct and tested, but 52 / 82 us per launch at L = 64 / 80 against 36 / 46 us for
-// the two launches it replaces, 5.14 vs 4.96 ms in the step (ABBA x2): off); 0 = in_proj GEMM + attention + out_proj GEMM (what also
-// runs for f32, L <= 48, L > 80)
-static int attn_panel_enabled() {
-    static const int on = [] { const char* e = getenv("TAN_ATTN_PANEL"); return e ? atoi(e) : 1; }();
-    return on;
-}
-// TAN_PANEL_IN (bit mask, default 1; bit 2 measured neutral: 4.80 vs 4.79 ms): 1 = the in_proj dX GEMM of a block as the head of the next row-panel MLP backward; 2 = block
-// 0's in_proj dX GEMM + ln_1 backward as a head-only launch of the same kernel; 0 = the tiled GEMM (+ LayerNorm backward) launches
-static int panel_in_enabled() {
-    static const int on = [] { const char* e = getenv("TAN_PANEL_IN"); return e ? atoi(e) : 1; }();
-    return on;
-}
-// TAN_PANEL_OUT (bit mask, default 1; bit 2 measured neutral at len=256: 4.544 vs 4.544 ms), where the one-launch attention branch does not run: 1 = out_proj + bias + residual as the head of
-// the row-panel MLP forward, 2 = the next block's in_proj as its tail; 0 = their own launches
-static int panel_out_enabled() {
-    static const int on = [] { const char* e = getenv("TAN_PANEL_OUT"); return e ? atoi(e) : 1; }();
-    return on;
-}
-static int panel_do_enabled() {
-    static const int on = [] { const char* e = getenv("TAN_PANEL_DO"); return e ? atoi(e) : 1; }();
-    return on;
-}
+// consumes the block's output (the next block's ln_1, or the stack's post-LN) -- is ONE launch, and so is the attention half where
+// tan_attnblk_fwd takes the shape (48 < L <= 80); elsewhere the out-projection rides as the head of the MLP launch.  Backward: the
+// MLP launch carries the ln_1 backward of the block above as its prologue, that block's in_proj dX GEMM as its head and the own
+// block's out_proj dX GEMM as its tail.  TAN_PANEL=0 (the only switch left here): the unfused launches -- LayerNorm + tiled GEMMs --
+// which are also what runs for f32, C != 512 or rows % 64 != 0.  Every alternative that was measured slower or neutral in rounds 2-3
+// (the one-launch attention backward, the head-only block-0 launch, the in_proj tail, a separate weight-gradient stream, chunk
+// rotation, burst schedules: DESIGN_APPENDIX.md A.9) is gone from the library.
 static int panel_enabled() {
     static const int on = [] { const char* e = getenv("TAN_PANEL"); return e ? atoi(e) : 1; }();
     return on;
@@ -212,16 +166,13 @@ extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
     const long R = (long)e->B * e->L;
     const void* x_in = e->x0;
     const bool panel_ok = panel_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0;
-    const bool attn_panel_ok = (attn_panel_enabled() & 1) && panel_enabled() && tan_attnblk_supported(e->L, C, H, dt);
+    const bool attn_panel_ok = panel_enabled() && tan_attnblk_supported(e->L, C, H, dt);
     bool ln1_done = e->xn1_ready != 0;      // the previous block's panel kernel (block 0: tan_embed_fwd) already produced this block's xn1 / mean1 / rstd1
-    bool qkv_done = false;        // ... and this block's qkv (the in_proj tail of its forward)
     for (int i = 0; i < e->layers; ++i) {
         const tan_layer_params& p = e->params[i];
         const tan_layer_bufs& b = e->bufs[i];
         if (!ln1_done) CK(tan_layernorm_fwd(x_in, p.ln1_g, p.ln1_b, b.xn1, b.mean1, b.rstd1, nullptr, 0, R, C, 1e-5f, dt, st));
         ln1_done = false;
-        const bool qkv_ready = qkv_done;
-        qkv_done = false;
         bool out_head = false;
         if (attn_panel_ok && p.wp_qkv && p.wp_out) {
             // one launch: in_proj GEMM, the 8 heads' attention and out_proj + bias + residual, one workgroup per video (tan_attnblk.hip)
@@ -233,10 +184,10 @@ extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
             ab.x_mid = b.x_mid;
             CK(tan_attnblk_fwd(&ab, st));
         } else {
-            if (!qkv_ready) CK(linear_fwd(dt, b.xn1, p.w_qkv, p.b_qkv, b.qkv, R, 3 * C, C, TAN_ACT_NONE, nullptr, nullptr, st));
+            CK(linear_fwd(dt, b.xn1, p.w_qkv, p.b_qkv, b.qkv, R, 3 * C, C, TAN_ACT_NONE, nullptr, nullptr, st));
             CK(tan_attn_fwd(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->B, e->L, H, dt, st));
-            // out_proj + bias + residual: the head of the row-panel MLP forward below (TAN_PANEL_OUT=0: its own launch)
-            out_head = panel_ok && p.wp_fc && p.wp_proj && p.wp_out && panel_out_enabled();
+            // out_proj + bias + residual: the head of the row-panel MLP forward below
+            out_head = panel_ok && p.wp_fc && p.wp_proj && p.wp_out;
             if (!out_head) CK(linear_fwd(dt, b.attn_o, p.w_out, p.b_out, b.x_mid, R, C, C, TAN_ACT_NONE, nullptr, x_in, st));
         }
         if (panel_ok && p.wp_fc && p.wp_proj) {
@@ -253,11 +204,6 @@ extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
                 const tan_layer_bufs& bn = e->bufs[i + 1];
                 m.nln_g = pn.ln1_g; m.nln_b = pn.ln1_b; m.xn_next = bn.xn1; m.nmean = bn.mean1; m.nrstd = bn.rstd1;
                 ln1_done = true;
-                // the next block's in-projection as this launch's tail (the next block takes the same unfused attention path)
-                if (out_head && (panel_out_enabled() & 2) && pn.wp_qkv_k16 && bn.qkv) {
-                    m.pw_in = pn.wp_qkv_k16; m.b_qkv = pn.b_qkv; m.qkv_out = bn.qkv;
-                    qkv_done = true;
-                }
             } else if (e->post_out) {
                 m.nln_g = e->post_g; m.nln_b = e->post_b; m.xn_next = e->post_out; m.nmean = e->post_mean; m.nrstd = e->post_rstd;
                 ln1_done = true;      // = the post-LN is done
@@ -284,32 +230,12 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
     const long R = (long)e->B * e->L;
     const size_t esz = dt == TAN_F32 ? 4 : 2;
     const void* x_last = e->bufs[S - 1].x_out;
-    // ln_1 backward of block i+1 handed to block i's row-panel MLP backward as its prologue (TAN_LN1_FUSED=0: its own launch); the
-    // stack's post-LayerNorm backward goes to the last block the same way (no residual gradient next to it)
+    // ln_1 backward of block i+1 handed to block i's row-panel MLP backward as its prologue; the stack's post-LayerNorm backward goes
+    // to the last block the same way (no residual gradient next to it)
     struct { bool on; int layer; const void *dxn, *x, *res; const float *mean, *rstd, *g; float *gg, *gb, *gcol;
              const void *dqkv, *pwt_in, *dstage; } pend{};
-    static const bool ln1_fused = [] { const char* v = getenv("TAN_LN1_FUSED"); return !v || atoi(v) != 0; }();
-    const bool panel_all = ln1_fused && grouped_enabled() != 0 && panel_bwd_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0;
-    // Weight gradients OFF the stack's chain (dw_stream != NULL): block i's grouped dW launch only feeds the optimizer, but in-stream it
-    // sits between block i's and block i-1's dX kernels (120 of ~300 us per block on the longer -- joint -- chain).  It reads dh, dx,
-    // dqkv, dx2 of block i, which block i-1 overwrites: those four scratch buffers exist twice, blocks alternate between the sets,
-    // and the chain waits for dW(i) before block i-2 reuses block i's set.
-    bool dw_async = e->dw_stream && e->scr2_dx && e->scr2_dx2 && e->scr2_dh && e->scr2_dqkv && !e->layer_done && panel_all && S <= 16;
-    for (int i = 0; i < S && dw_async; ++i) dw_async = e->params[i].wtp_fc && e->params[i].wtp_proj;
-    void* const dxs[2] = {e->scr_dx, dw_async ? e->scr2_dx : e->scr_dx};
-    void* const dx2s[2] = {e->scr_dx2, dw_async ? e->scr2_dx2 : e->scr_dx2};
-    void* const dhs[2] = {e->scr_dh, dw_async ? e->scr2_dh : e->scr_dh};
-    void* const dqkvs[2] = {e->scr_dqkv, dw_async ? e->scr2_dqkv : e->scr_dqkv};
-    static thread_local hipEvent_t ev_in[16], ev_done[16];
-    static thread_local bool ev_made = false;
-    if (dw_async && !ev_made) {
-        for (int i = 0; i < 16; ++i) {
-            if (hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming) != hipSuccess) return -3;
-            if (hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming) != hipSuccess) return -3;
-        }
-        ev_made = true;
-    }
-    void* dx = dxs[(S - 1) & 1];      // gradient w.r.t. the residual stream leaving the current layer
+    const bool panel_all = panel_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0;
+    void* dx = e->scr_dx;             // gradient w.r.t. the residual stream leaving the current layer
     if (e->d_stage[S - 1] && panel_all && e->params[S - 1].wtp_fc && e->params[S - 1].wtp_proj) {
         TAN_REQUIRE(e->post_out);
         pend.on = true; pend.layer = -1; pend.dxn = e->d_stage[S - 1]; pend.x = x_last; pend.res = nullptr;
@@ -331,18 +257,12 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         const tan_layer_params& p = e->params[i];
         const tan_layer_bufs& b = e->bufs[i];
         const void* x_in = i == 0 ? e->x0 : e->bufs[i - 1].x_out;
-        const int P = i & 1;
-        dx = dxs[P];
-        void* const dx2 = dx2s[P];
-        void* const scr_dh = dhs[P];
-        void* const scr_dqkv = dqkvs[P];
-        if (dw_async && i + 2 < S)         // block i + 2 used this set: its weight gradients must have read it
-            if (hipStreamWaitEvent((hipStream_t)st, ev_done[i + 2], 0) != hipSuccess) return -3;
+        void* const dx2 = e->scr_dx2;
+        void* const scr_dh = e->scr_dh;
+        void* const scr_dqkv = e->scr_dqkv;
         // ---- MLP branch: x_out = x_mid + c_proj(quickgelu(c_fc(LN2(x_mid))))
-        const bool grouped = grouped_enabled() != 0;       // the four dW GEMMs after the dX chain, in one launch
         bool do_fused = false;                             // d_o = dx2 W_out already produced by the row-panel MLP backward
-        if (!grouped) CK(linear_bwd_w(dt, dx, b.h_act, p.g_w_proj, R, C, 4 * C, e->dw_ws, e->dw_ws_floats, st));
-        if (panel_bwd_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0 && p.wtp_fc && p.wtp_proj) {
+        if (panel_all && p.wtp_fc && p.wtp_proj) {
             // one launch: dh = (dx W_proj) o quickgelu'(h_pre), dxn = dh W_fc, LN2 backward + residual -> dx2, four parameter
             // gradients that are column sums (tan_panel.hip)
             tan_mlp_bwd_desc m{};
@@ -356,9 +276,8 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
                 m.ln1_g = pend.g; m.g_ln1_g = pend.gg; m.g_ln1_b = pend.gb; m.g_dx_colsum = pend.gcol; m.dx_out = dx;
                 m.dqkv = pend.dqkv; m.pwt_in = pend.pwt_in; m.dstage = pend.dstage;      // (the in_proj dX GEMM in front of it, or NULLs)
             }
-            // the out-projection's dX GEMM as the tail of the same launch (TAN_PANEL_DO=0: its own launch below)
-            do_fused = panel_do_enabled() && p.wtp_out != nullptr &&
-                       !((attn_panel_enabled() & 2) && tan_attnblk_supported(e->L, C, H, dt));      // (tan_attnblk_bwd computes d_o itself)
+            // the out-projection's dX GEMM as the tail of the same launch
+            do_fused = p.wtp_out != nullptr;
             if (do_fused) { m.pwt_out = p.wtp_out; m.d_o = e->scr_do; }
             CK(tan_mlp_bwd(&m, st));
             if (pend.on) {          // every gradient of block pend.layer is final now
@@ -368,49 +287,28 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
                     if (err != hipSuccess) return (int)err;
                 }
             }
-            if (!grouped) CK(linear_bwd_w(dt, scr_dh, b.xn2, p.g_w_fc, R, 4 * C, C, e->dw_ws, e->dw_ws_floats, st));
         } else {
             CK(linear_bwd_x(dt, dx, p.w_proj, p.wt_proj, scr_dh, R, C, 4 * C, TAN_ACT_QUICKGELU_GRAD, b.h_pre, nullptr, p.g_b_fc, st));
-            if (!grouped) CK(linear_bwd_w(dt, scr_dh, b.xn2, p.g_w_fc, R, 4 * C, C, e->dw_ws, e->dw_ws_floats, st));
             CK(linear_bwd_x(dt, scr_dh, p.w_fc, p.wt_fc, e->scr_dxn, R, 4 * C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
             CK(tan_layernorm_bwd(e->scr_dxn, b.x_mid, p.ln2_g, b.mean2, b.rstd2, dx, dx2, p.g_ln2_g, p.g_ln2_b, p.g_b_out, e->ln_ws, R, C,
                                  dt, st));
         }
         // ---- attention branch: x_mid = x_in + out_proj(attn(LN1(x_in)))
-        if (!grouped) CK(linear_bwd_w(dt, dx2, b.attn_o, p.g_w_out, R, C, C, e->dw_ws, e->dw_ws_floats, st));
-        if ((attn_panel_enabled() & 2) && panel_enabled() && tan_attnblk_supported(e->L, C, H, dt) && p.wtp_out) {
-            // one launch: d_o = dx2 W_out and the 8 heads' attention backward incl. the in_proj bias column sums (tan_attnblk.hip)
-            tan_attnblk_bwd_desc ab{};
-            ab.B = e->B; ab.L = e->L; ab.C = C; ab.H = H;
-            ab.dx2 = dx2; ab.qkv = b.qkv; ab.lse = b.lse; ab.key_padding_mask = e->key_padding_mask;
-            ab.pwt_out = p.wtp_out; ab.dqkv = scr_dqkv; ab.g_b_qkv = p.g_b_qkv;
-            CK(tan_attnblk_bwd(&ab, st));
-        } else {
-            if (!do_fused) CK(linear_bwd_x(dt, dx2, p.w_out, p.wt_out, e->scr_do, R, C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
-            CK(tan_attn_bwd_bias(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->scr_do, scr_dqkv, p.g_b_qkv, e->B, e->L, H, dt, st));
-        }
-        if (!grouped) CK(linear_bwd_w(dt, scr_dqkv, b.xn1, p.g_w_qkv, R, 3 * C, C, e->dw_ws, e->dw_ws_floats, st));
+        if (!do_fused) CK(linear_bwd_x(dt, dx2, p.w_out, p.wt_out, e->scr_do, R, C, C, TAN_ACT_NONE, nullptr, nullptr, nullptr, st));
+        CK(tan_attn_bwd_bias(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->scr_do, scr_dqkv, p.g_b_qkv, e->B, e->L, H, dt, st));
         // stage i-1 IS this layer's xn1: its gradient joins here
         const void* dstage = i >= 1 ? e->d_stage[i - 1] : nullptr;
-        // block i-1's row-panel MLP backward takes the ln_1 backward as its prologue -- and (TAN_PANEL_IN) this dX GEMM in front of it
+        // block i-1's row-panel MLP backward takes the ln_1 backward as its prologue -- and this dX GEMM in front of it as its head
         const bool ln1_next = i > 0 && panel_all && e->params[i - 1].wtp_fc && e->params[i - 1].wtp_proj;
-        const bool in_fused = ln1_next && (panel_in_enabled() & 1) && p.wtp_qkv != nullptr;
-        // block 0: the same head + ln_1 backward as a launch of its own (64-row panels) instead of the tiled GEMM + LayerNorm backward
-        const bool head_only = i == 0 && panel_all && (panel_in_enabled() & 2) && p.wtp_qkv != nullptr;
-        if (!in_fused && !head_only)
+        const bool in_fused = ln1_next && p.wtp_qkv != nullptr;
+        if (!in_fused)
             CK(linear_bwd_x(dt, scr_dqkv, p.w_qkv, p.wt_qkv, e->scr_dxn, R, 3 * C, C, TAN_ACT_NONE, nullptr, dstage, nullptr, st));
-        if (grouped) {      // dx, scr_dh, dx2, scr_dqkv are all still intact here (LN1 backward below overwrites dx)
+        {                   // dx, scr_dh, dx2, scr_dqkv are all still intact here (LN1 backward below overwrites dx)
             const DwItem items[4] = {{scr_dh, b.xn2, p.g_w_fc, 4 * C, C}, {dx, b.h_act, p.g_w_proj, C, 4 * C},
                                      {scr_dqkv, b.xn1, p.g_w_qkv, 3 * C, C}, {dx2, b.attn_o, p.g_w_out, C, C}};
-            if (dw_async) {
-                if (hipEventRecord(ev_in[i], (hipStream_t)st) != hipSuccess) return -3;
-                if (hipStreamWaitEvent((hipStream_t)e->dw_stream, ev_in[i], 0) != hipSuccess) return -3;
-                CK(linear_bwd_w_group(dt, items, 4, R, e->dw_ws, e->dw_ws_floats, e->dw_stream));
-                if (hipEventRecord(ev_done[i], (hipStream_t)e->dw_stream) != hipSuccess) return -3;
-            } else
             CK(linear_bwd_w_group(dt, items, 4, R, e->dw_ws, e->dw_ws_floats, st));
         }
-        void* dx_in = i == 0 ? e->d_x0 : dxs[(i - 1) & 1];
+        void* dx_in = i == 0 ? e->d_x0 : e->scr_dx;
         float* next_b_proj = i > 0 ? e->params[i - 1].g_b_proj : nullptr;       // dx_in is layer i-1's x_out gradient
         if (ln1_next) {
             // block i-1's row-panel MLP backward does this LayerNorm backward as its prologue (dx2 and scr_dxn / scr_dqkv stay
@@ -420,14 +318,6 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
             pend.mean = b.mean1; pend.rstd = b.rstd1; pend.g = p.ln1_g; pend.gg = p.g_ln1_g; pend.gb = p.g_ln1_b; pend.gcol = next_b_proj;
             continue;
         }
-        if (head_only) {
-            tan_mlp_bwd_desc m{};
-            m.rows = R; m.C = C; m.FF = 4 * C; m.head_only = 1;
-            m.dqkv = scr_dqkv; m.pwt_in = p.wtp_qkv; m.dstage = dstage;
-            m.ln1_x = x_in; m.ln1_res = dx2; m.ln1_mean = b.mean1; m.ln1_rstd = b.rstd1; m.ln1_g = p.ln1_g;
-            m.g_ln1_g = p.g_ln1_g; m.g_ln1_b = p.g_ln1_b; m.g_dx_colsum = next_b_proj; m.dx_out = dx_in;
-            CK(tan_mlp_bwd(&m, st));
-        } else
         CK(tan_layernorm_bwd(e->scr_dxn, x_in, p.ln1_g, b.mean1, b.rstd1, dx2, dx_in, p.g_ln1_g, p.g_ln1_b, next_b_proj, e->ln_ws, R,
                              C, dt, st));
         // every gradient of layer i is final here (g_b_proj[i] was written during iteration i+1 / by the post-LN backward)
@@ -436,8 +326,5 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
             if (err != hipSuccess) return (int)err;
         }
     }
-    if (dw_async)        // the caller sees every gradient on `st` (the last two blocks' launches may still be running)
-        for (int i = 0; i < S && i < 2; ++i)
-            if (hipStreamWaitEvent((hipStream_t)st, ev_done[i], 0) != hipSuccess) return -3;
     return 0;
 }

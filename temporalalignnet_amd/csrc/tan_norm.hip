@@ -667,8 +667,8 @@ extern "C" int tan_layernorm_bwd(const void* dy, const void* x, const float* gam
     const int nblk = (int)min((long)LN_BWD_MAX_BLOCKS, (long)cdiv(rows, ROWS_PER_BLOCK));
     // bf16, C = 512: 256 blocks (one per CU) add their column sums straight into the gradients with f32 atomics -- 393 k atomics per
     // launch instead of a 6-MB partial table and a second kernel; measured inside the step: 7.12 vs 7.16 ms, and with 512 / 1024
-    // blocks the contention on the 1536 addresses costs more than the finalize did (7.28 / 7.5 ms).  TAN_LN_ATOMIC=0: tables.
-    static const int atomic_blocks = [] { const char* e = getenv("TAN_LN_ATOMIC"); return e ? atoi(e) : 256; }();
+    // blocks the contention on the 1536 addresses costs more than the finalize did (7.28 / 7.5 ms).
+    constexpr int atomic_blocks = 256;
     if (dtype == TAN_BF16 && C == 512 && aligned16(dy, x, dres, dx, gamma) && atomic_blocks > 0) {
         const int nb = (int)min((long)atomic_blocks, (long)cdiv(rows, ROWS_PER_BLOCK));
         hipLaunchKernelGGL((ln_bwd_bf16x8_kernel<true, 4>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean,

@@ -87,8 +87,7 @@ extern "C" int tan_adamw_step(float* p, const float* g, float* m, float* v, cons
     const float decay = (float)(1.0 - (double)lr * (double)weight_decay);
     const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
     const float w1 = (float)(1.0 - (double)beta1), w2 = (float)(1.0 - (double)beta2);
-    static const long max_grid = []() { const char* e = getenv("TAN_OPT_GRID"); return e ? atol(e) : 8192L; }();
-    const unsigned grid = (unsigned)min(max_grid, (long)cdiv(n, 256));
+    const unsigned grid = (unsigned)min(8192L, (long)cdiv(n, 256));
     hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, mode, n, decay, w1, (float)beta2, w2, (float)eps,
                        step_size, bc2_sqrt, grad_scale, (bf16_t*)p_bf16, ema, ema_m, (bf16_t*)ema_bf16);
     TAN_LAUNCH_CHECK();

@@ -63,12 +63,9 @@ struct MlpFwdArgs {
     bf16_t* h_pre; bf16_t* h_act; bf16_t* x_out;
     const float* nln_g; const float* nln_b; bf16_t* xn_next; float* nmean; float* nrstd;
     float eps;
-    int rot;
     // optional head (MODE & 2048): x_mid is not read but PRODUCED first, x_mid = x_in + attn_o W_out^T + b_out -- the attention
     // out-projection + bias + residual of the block (tfm_model.py:30-36) where the fused attention launch does not run (L > 80)
     const bf16_t* attn_o; const char* pw_out; const float* b_out; const bf16_t* x_in; bf16_t* x_mid_w;
-    // optional tail (MODE & 4096): qkv = xn_next W_in^T + b_qkv, the NEXT block's attention in-projection, from the xn_next panel
-    const char* pw_in; const float* b_qkv; bf16_t* qkv_out;
 };
 // Backward of the same branch, same schedule with the roles of the two weights exchanged (tan_mlp_bwd):
 //   dh_c = (dx W_proj[:, c]) o quickgelu'(h_pre_c)      "c_fc-like": K = 512 over the resident dx panel, packed W_proj^T tiles
@@ -97,7 +94,6 @@ struct MlpBwdArgs {
     const bf16_t* dqkv;         // [rows][1536]
     const char* pwt_in;         // packed W_in^T [512][1536]  (tiles [512][16])
     const bf16_t* dstage;       // [rows][512] or NULL: the deep-supervision gradient that joins at that ln_1 output
-    int rot;
 };
 
 // Tiles are 16 KiB: c_fc [256 features][32 k], c_proj [512 features][16 k].  A weight fragment is consumed by exactly ONE wave
@@ -121,18 +117,6 @@ constexpr int MLP_KDF = 32, MLP_KDP = 16, MLP_TILE = 16384, MLP_TF = 512 / MLP_K
 #endif
 #ifndef TAN_MLP_D
 #define TAN_MLP_D 4
-#endif
-#ifndef TAN_MLP_BURST
-#define TAN_MLP_BURST 0          // 1: all waves in the same phase, epilogue arithmetic in bursts between MFMA bursts (measured: no gain); 0: the skewed wave groups
-#endif
-#ifndef TAN_MLP_PRIO
-#define TAN_MLP_PRIO 0           // s_setprio of a wave while it is in a c_proj || epilogue phase (0: leave the hardware's oldest-first order)
-#endif
-#ifndef TAN_MLP_PRIO_FC
-#define TAN_MLP_PRIO_FC 0        // the same for the pure-MFMA c_fc phases (both measured: 2 is 3-6 % slower either way)
-#endif
-#ifndef TAN_MLP_BURST_SLEEP
-#define TAN_MLP_BURST_SLEEP 8    // s_sleep units (64 clocks) the second wave group starts an epilogue phase late
 #endif
 constexpr int MLP_D = TAN_MLP_D;                 // weight prefetch distance in steps (4: as fast as 8 once the weights are requested up front, 32 registers less)
 constexpr int MLP_XN_OFF = 0, MLP_H_OFF = 65536, MLP_PRE_OFF = 131072, MLP_LDS = 163840;   // input panel | hidden x2 | pre-activation
@@ -219,7 +203,7 @@ __device__ __forceinline__ void mlp_mma_proj(const MlpWFrags& W, const MlpXFrags
 // issue: the wave's own MFMAs then execute under its VALU work, and the quarter-rate v_exp_f32 / v_rcp_f32 results are consumed one
 // MFMA later):  P1 scale, 2 x exp2;  P2 1 + e, 2 x rcp;  P3 x * r, two packs, stores.  The bias is NOT added here: the accumulator
 // of a chunk starts from it (mlp_init_h).
-struct MlpEpiState { float ce[2]; uint32_t pre[4], act[4]; float cb[4][2]; };      // cb: the burst schedule keeps four half-units in flight
+struct MlpEpiState { float ce[2]; uint32_t pre[4], act[4]; };
 struct MlpBias32 { float b[32]; };       // b_fc[c * 256 + wave * 32 ..]: wave-uniform, through scalar loads
 __device__ __forceinline__ void mlp_bias32_load(MlpBias32& B, const float* b_fc, int c, int wave) {
     pn_cfptr_t bp = (pn_cfptr_t)(uintptr_t)b_fc + c * 256 + wave * 32;
@@ -259,30 +243,12 @@ __device__ __forceinline__ void mlp_epi_p3(MlpEpiState& E, const f32x16 (&acc_h)
     }
 }
 
-// burst schedule: pieces of FOUR half-units J = 4 r .. 4 r + 3 issued together (all exps, all rcps, then the products / packs / store)
-template <int J>
-__device__ __forceinline__ void mlp_epi_b1(MlpEpiState& E, const f32x16 (&acc_h)[MLP_NBH][2]) {
-    constexpr int mb = J >> 3, r = 2 * (J & 7);
-    E.cb[J & 3][0] = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * acc_h[0][mb][r]);
-    E.cb[J & 3][1] = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * acc_h[0][mb][r + 1]);
-}
-template <int J>
-__device__ __forceinline__ void mlp_epi_b2(MlpEpiState& E) {
-    E.cb[J & 3][0] = __builtin_amdgcn_rcpf(1.0f + E.cb[J & 3][0]);
-    E.cb[J & 3][1] = __builtin_amdgcn_rcpf(1.0f + E.cb[J & 3][1]);
-}
-template <int J>
-__device__ __forceinline__ void mlp_epi_b3(MlpEpiState& E, const f32x16 (&acc_h)[MLP_NBH][2], char* lds, int hb, int wave, int lane) {
-    E.ce[0] = E.cb[J & 3][0]; E.ce[1] = E.cb[J & 3][1];
-    mlp_epi_p3<J>(E, acc_h, lds, hb, wave, lane);
-}
-
 // ---- backward chunk epilogue: dh = acc o quickgelu'(h_pre), step J = row block J & 1, register pair q = J >> 1 (both row blocks of
 // a feature pair in adjacent steps: their sum is the lane's share of the c_fc bias gradient).  The pre-activations come straight
 // from HBM in the accumulator's layout (16 consecutive features of a row = two 16-byte loads per row block), issued under the
 // c_fc-like phase of the same chunk.
 struct MlpHPre { uint4 q[2][2]; };       // [row block][8-feature half]
-struct MlpBwdEpi { float x[2], ce[2], cs[16]; uint32_t w[2][4]; float xb[4][2], cb[4][2]; };
+struct MlpBwdEpi { float x[2], ce[2], cs[16]; uint32_t w[2][4]; };
 template <int MB, int HALF>
 __device__ __forceinline__ void mlp_hpre_load(MlpHPre& H, const bf16_t* h_pre, long row0, int c, int wave, int lane) {
     H.q[MB][HALF] = *reinterpret_cast<const uint4*>(h_pre + (row0 + MB * 32 + (lane & 31)) * 2048 + c * 256 + wave * 32 + 16 * (lane >> 5) + 8 * HALF);
@@ -331,22 +297,6 @@ __device__ __forceinline__ void mlp_bepi_p3(MlpBwdEpi& E, const f32x16 (&acc_h)[
     }
 }
 
-template <int J>
-__device__ __forceinline__ void mlp_bepi_b1(MlpBwdEpi& E, const MlpHPre& H) {
-    mlp_bepi_p1<J>(E, H);
-    E.xb[J & 3][0] = E.x[0]; E.xb[J & 3][1] = E.x[1]; E.cb[J & 3][0] = E.ce[0]; E.cb[J & 3][1] = E.ce[1];
-}
-template <int J>
-__device__ __forceinline__ void mlp_bepi_b2(MlpBwdEpi& E) {
-    E.cb[J & 3][0] = __builtin_amdgcn_rcpf(1.0f + E.cb[J & 3][0]);
-    E.cb[J & 3][1] = __builtin_amdgcn_rcpf(1.0f + E.cb[J & 3][1]);
-}
-template <int J>
-__device__ __forceinline__ void mlp_bepi_b3(MlpBwdEpi& E, const f32x16 (&acc_h)[MLP_NBH][2], char* lds, int hb, int wave, int lane) {
-    E.x[0] = E.xb[J & 3][0]; E.x[1] = E.xb[J & 3][1]; E.ce[0] = E.cb[J & 3][0]; E.ce[1] = E.cb[J & 3][1];
-    mlp_bepi_p3<J>(E, acc_h, lds, hb, wave, lane);
-}
-
 // The side outputs (pre-activation and activation chunk, the operands of backward) leave for HBM ONE row-instruction at a time,
 // spread over BOTH phases of the body that follows the chunk's barrier: the four row-instructions of the pre-activation panel under
 // c_fc(c+1) (the panel is rewritten by the next epilogue), the four of the activation panel under c_proj(c) || epilogue(c+1).  As a burst between two barriers (the first version)
@@ -363,20 +313,15 @@ __device__ __forceinline__ void mlp_copy_init(MlpCopy& C, int wave, int lane) {
 }
 // step J of a 16-step phase moving the group's half of ONE panel (ACT: activation panel of chunk cprev, else the pre-activation
 // panel): row-instruction i = J / 4 is read from LDS at J = 4 i and stored at J = 4 i + 1
-template <int J, bool ACT, bool CM = false>
+template <int J, bool ACT>
 __device__ __forceinline__ void mlp_copy_step4(MlpCopy& C, const char* lds, bf16_t* dst, long row0, int cprev, int cdata) {
     constexpr int i = J >> 2;
     if constexpr ((J & 3) == 0) {
         const char* panel = ACT ? lds + MLP_H_OFF + (cprev & 1) * 32768 : lds + MLP_PRE_OFF;
         C.v = *reinterpret_cast<const uint4*>(panel + ((C.lds0 ^ (i << 6)) + i * 2048));      // row & 15 gains 4 i: no carry
     } else if constexpr ((J & 3) == 1) {
-        if constexpr (CM) {    // lab experiment: chunk-major side outputs [chunk][row][256] (a panel's chunk = 32 KiB contiguous)
-            bf16_t* base = dst + (long)cdata * gridDim.x * (64 * 256) + row0 * 256;
-            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + (C.voff >> 12) * 512 + (C.voff & 511) + i * 2048) = C.v;
-        } else {
-            bf16_t* base = dst + row0 * 2048 + cdata * 256;                 // wave-uniform (cdata: the chunk's place in the hidden dimension)
-            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + C.voff + i * 16384) = C.v;
-        }
+        bf16_t* base = dst + row0 * 2048 + cdata * 256;                 // wave-uniform (cdata: the chunk's place in the hidden dimension)
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + C.voff + i * 16384) = C.v;
     }
 }
 // both panels in one 16-step phase (the last one): pair q = J / 2
@@ -545,17 +490,8 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     __shared__ __attribute__((aligned(1024))) char lds[MLP_LDS];
 
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
-#ifdef TAN_PN_WAVE_PERM     // experiment: which hardware waves share a SIMD?  logical wave = (hw & 1) * 4 + (hw >> 1): group = hw & 1
-    const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = (hw_wave & 1) * 4 + (hw_wave >> 1);
-#else
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#endif
     const long row0 = (long)blockIdx.x * PN_ROWS;
-    // The hidden chunks are independent terms of the branch's sum: workgroup w walks them starting at chunk rot(w), so that the
-    // workgroups of an XCD do not all pull the same weight lines through the same L2 channel at the same time (TAN_MLP_ROT)
-    const int rot = a.rot == 1 ? (blockIdx.x & 7) : a.rot == 2 ? ((blockIdx.x >> 3) & 7) : a.rot == 3 ? ((blockIdx.x + (blockIdx.x >> 3)) & 7) : 0;
-    auto CC = [&](int c) __attribute__((always_inline)) { return (c + rot) & 7; };
     const char* const pfc = a.pw_fc;
     const char* const ppj = a.pw_proj;
 
@@ -563,7 +499,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     // miss goes to HBM in the middle of the kernel's own 100 MB of side-output writes and the ring (eight steps) cannot cover that
     // latency: 97-104 us per launch against 72-77 us with the weights resident in the Infinity Cache (tools/lab/mlp_lab.py, E2/E3).
     // So the whole set is requested up front, one dword per 128-byte line spread over the first 64 workgroups, while HBM is quiet.
-    if (!(MODE & (256 | 1024))) {
+    if (!(MODE & 256)) {
         const int L = blockIdx.x * (64 * PN_WAVES) + tid;
         if (L < 32768) {
             const char* q = L < 16384 ? pfc + (long)L * 128 : ppj + (long)(L - 16384) * 128;
@@ -583,7 +519,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     MlpWFrags WQ[D];
     pn_static_for<0, D>([&](auto jc) {
         constexpr int J = decltype(jc)::value;
-        mlp_load_w(WQ[J], pin + (long)(((INP || OUTP) ? 0 : CC(0) * 16) + J) * TILE, wave, lane);
+        mlp_load_w(WQ[J], pin + (long)(((INP || OUTP) ? 0 : (0) * 16) + J) * TILE, wave, lane);
     });
 
     // ---- prologue.  Forward: LN2 of the panel, 64 / PN_WAVES rows per wave (batches of 8), one 16-byte chunk per lane.  Backward:
@@ -633,7 +569,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                 acc_d[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], x1, acc_d[nb][1], 0, 0, 0);
             }
             if constexpr (KT + D < 32) mlp_load_w(W, pin + (long)(KT + D) * TILE, wave, lane);
-            else mlp_load_w(W, pfc + (long)(CC(0) * 16 + KT + D - 32) * TILE, wave, lane);
+            else mlp_load_w(W, pfc + (long)((0) * 16 + KT + D - 32) * TILE, wave, lane);
             __builtin_amdgcn_sched_barrier(0);
         });
 #pragma unroll
@@ -699,7 +635,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                     acc_d[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], x1, acc_d[nb][1], 0, 0, 0);
                 }
                 if constexpr (T + D < 96) mlp_load_w(W, pin + (long)(T + D) * TILE, wave, lane);
-                else if constexpr (!(MODE & 1024)) mlp_load_w(W, pfc + (long)(CC(0) * 16 + T + D - 96) * TILE, wave, lane);   // the ring ends on c_fc(0)'s first tiles
+                else mlp_load_w(W, pfc + (long)(T + D - 96) * TILE, wave, lane);   // the ring ends on c_fc(0)'s first tiles
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
@@ -845,7 +781,6 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
             }
         }
     }
-    if constexpr (BWD && (MODE & 1024) != 0) return;      // head only (block 0: the stack's input gradient is the ln_1 backward's output)
     __syncthreads();
 
     f32x16 acc_o[MLP_NBO][2];      // [feature block of the wave's output features][row block]
@@ -859,7 +794,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     MlpBias32 B32;           // bias of the next chunk: loaded before a slot barrier, consumed right after it (mlp_init_h)
     MlpHPre HP;              // backward: pre-activations of the chunk in the accumulator layout
     MlpBwdEpi BE;
-    if constexpr (!BWD) mlp_bias32_load(B32, a.b_fc, CC(0), wave);
+    if constexpr (!BWD) mlp_bias32_load(B32, a.b_fc, (0), wave);
     static_assert(MLP_NBO == 2 && MLP_WFR == 2, "eight waves");
     MlpXAddr XA;
     mlp_xaddr_init(XA, lds, lane);
@@ -869,14 +804,11 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     __builtin_amdgcn_sched_barrier(0);
 
     const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
-    constexpr bool BURST = TAN_MLP_BURST != 0 && !(MODE & (256 | 128));
     // the two 16-step phases; the flags are compile-time so that every step is ONE basic block (the scheduler interleaves the
     // epilogue half-unit with the MFMAs only inside a block)
     auto fc_phase = [&](int c, auto has_copy) __attribute__((always_inline)) {            // c_fc(c) (|| side outputs of chunk c-1)
         constexpr bool COPY = decltype(has_copy)::value;
         const int hb = c & 1;
-        if constexpr (TAN_MLP_PRIO_FC != 0) __builtin_amdgcn_s_setprio(TAN_MLP_PRIO_FC);
-        struct PrioResetF { __device__ ~PrioResetF() { if (TAN_MLP_PRIO_FC != 0) __builtin_amdgcn_s_setprio(0); } } prio_reset_f;
         pn_static_for<0, 16>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
             MlpXFrags& cur = (J & 1) ? FB : FA;
@@ -889,18 +821,18 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                 // all four together: each is a cold HBM read in the in-order vmcnt queue in front of the weight ring, and the
                 // ring stalls once per batch of them, not once per load
                 if constexpr (J == TAN_HPRE_STEP) {
-                    mlp_hpre_load<0, 0>(HP, a.h_pre, row0, CC(c), wave, lane);
-                    mlp_hpre_load<1, 0>(HP, a.h_pre, row0, CC(c), wave, lane);
-                    mlp_hpre_load<0, 1>(HP, a.h_pre, row0, CC(c), wave, lane);
-                    mlp_hpre_load<1, 1>(HP, a.h_pre, row0, CC(c), wave, lane);
+                    mlp_hpre_load<0, 0>(HP, a.h_pre, row0, (c), wave, lane);
+                    mlp_hpre_load<1, 0>(HP, a.h_pre, row0, (c), wave, lane);
+                    mlp_hpre_load<0, 1>(HP, a.h_pre, row0, (c), wave, lane);
+                    mlp_hpre_load<1, 1>(HP, a.h_pre, row0, (c), wave, lane);
                 }
             } else if constexpr (COPY) {
-                if (!(MODE & (8 | 16))) mlp_copy_step4<J, false, (MODE & 128) != 0>(CP, lds, a.h_pre, row0, c - 1, CC(c - 1));
+                if (!(MODE & (8 | 16))) mlp_copy_step4<J, false>(CP, lds, a.h_pre, row0, c - 1, (c - 1));
             }
             if (!(MODE & 2)) {      // the tile eight steps on: c_fc(c) J+8, else the first half of the next phase that streams
-                const char* src = J + D < 16 ? pfc + (long)(CC(c) * 16 + J + D) * TILE
-                                             : (c == 0 ? pfc + (long)(CC(1) * 16 + J + D - 16) * TILE      // body(0) has no c_proj phase
-                                                       : ppj + (long)(CC(c - 1) * 16 + J + D - 16) * TILE);
+                const char* src = J + D < 16 ? pfc + (long)((c) * 16 + J + D) * TILE
+                                             : (c == 0 ? pfc + (long)((1) * 16 + J + D - 16) * TILE      // body(0) has no c_proj phase
+                                                       : ppj + (long)((c - 1) * 16 + J + D - 16) * TILE);
                 mlp_load_w(WQ[J % D], src, wave, lane);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -910,67 +842,6 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
         constexpr bool PROJ = decltype(has_proj)::value, EPI = decltype(has_epi)::value;
         constexpr bool ARITH = EPI && !(MODE & (8 | 32));
         const int hb = c & 1;
-        // the wave in this phase carries the chunk epilogue next to its MFMAs and is the slot's long pole: let its instructions go
-        // first (the other wave of the SIMD is in a pure-MFMA phase and fills the gaps)
-        if constexpr (TAN_MLP_PRIO != 0 && EPI && PROJ) __builtin_amdgcn_s_setprio(TAN_MLP_PRIO);
-        struct PrioReset { __device__ ~PrioReset() { if (TAN_MLP_PRIO != 0) __builtin_amdgcn_s_setprio(0); } } prio_reset;
-        if constexpr (BURST) {
-            // Burst schedule (all eight waves in the same phase): four rounds of [16 MFMAs of four steps | the arithmetic of four
-            // epilogue half-units].  A wave that waits for the matrix pipe cannot issue its VALU work (in-order issue), so MFMAs and
-            // epilogue pieces alternating one by one ran at the SUM of both waves' MFMA time and the wave's own arithmetic; in bursts,
-            // with the second wave group half a round behind, one wave of a SIMD computes its epilogue pieces while the other has the
-            // matrix pipe to itself.
-            if constexpr (PROJ && ARITH) { if (grp) __builtin_amdgcn_s_sleep(TAN_MLP_BURST_SLEEP); }
-            pn_static_for<0, 4>([&](auto rc) {
-                constexpr int RB = decltype(rc)::value * 4;
-                pn_static_for<0, 4>([&](auto jc) {
-                    constexpr int J = RB + decltype(jc)::value;
-                    MlpXFrags& cur = (J & 1) ? FB : FA;
-                    MlpXFrags& nxt = (J & 1) ? FA : FB;
-                    MlpWFrags& W = WQ[J % D];
-                    if constexpr (PROJ) {
-                        if (!(MODE & 4)) {
-                            if constexpr (J < 15) mlp_load_x_proj<J + 1>(nxt, XA, hb ^ 1);
-                        }
-                        if constexpr (!EPI && !BWD) {
-                            if (!(MODE & (8 | 16))) mlp_copy_step8<J>(CP, lds, a.h_pre, a.h_act, row0, 7, CC(7));
-                        } else {
-                            if (!(MODE & (8 | 16))) mlp_copy_step4<J, true, (MODE & 128) != 0>(CP, lds, a.h_act, row0, c - 1, CC(c - 1));
-                        }
-                        if (!(MODE & 1)) {
-                            acc_o[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[0], cur.f[0], acc_o[0][0], 0, 0, 0);
-                            acc_o[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[0], cur.f[1], acc_o[0][1], 0, 0, 0);
-                            acc_o[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[1], cur.f[0], acc_o[1][0], 0, 0, 0);
-                            acc_o[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[1], cur.f[1], acc_o[1][1], 0, 0, 0);
-                        }
-                        if (!(MODE & 2)) {
-                            if constexpr (J + D < 16) mlp_load_w(W, ppj + (long)(CC(c - 1) * 16 + J + D) * TILE, wave, lane);
-                            else if constexpr (EPI)
-                                mlp_load_w(W, c < 7 ? pfc + (long)(CC(c + 1) * 16 + J + D - 16) * TILE : ppj + (long)(CC(7) * 16 + J + D - 16) * TILE,
-                                           wave, lane);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                if constexpr (ARITH) {
-                    // the round's MFMAs are issued before its arithmetic starts (and the next round's after it ends): pure nodes, tied
-                    // through the registers they produce
-                    if constexpr (PROJ) asm volatile("" : "+v"(acc_o[0][0]), "+v"(acc_o[0][1]), "+v"(acc_o[1][0]), "+v"(acc_o[1][1]), "+v"(acc_h[0][RB >> 3]));
-                    if constexpr (BWD) {
-                        pn_static_for<0, 4>([&](auto jc) { mlp_bepi_b1<RB + decltype(jc)::value>(BE, HP); });
-                        pn_static_for<0, 4>([&](auto jc) { mlp_bepi_b2<RB + decltype(jc)::value>(BE); });
-                        pn_static_for<0, 4>([&](auto jc) { mlp_bepi_b3<RB + decltype(jc)::value>(BE, acc_h, lds, hb, wave, lane); });
-                        if constexpr (PROJ) asm volatile("" : "+v"(acc_o[0][0]), "+v"(BE.w[0][(RB >> 1) & 3]), "+v"(BE.w[1][(RB >> 1) & 3]), "+v"(BE.cs[RB]), "+v"(BE.cs[RB + 3]));
-                    } else {
-                        pn_static_for<0, 4>([&](auto jc) { mlp_epi_b1<RB + decltype(jc)::value>(ES, acc_h); });
-                        pn_static_for<0, 4>([&](auto jc) { mlp_epi_b2<RB + decltype(jc)::value>(ES); });
-                        pn_static_for<0, 4>([&](auto jc) { mlp_epi_b3<RB + decltype(jc)::value>(ES, acc_h, lds, hb, wave, lane); });
-                        if constexpr (PROJ) asm volatile("" : "+v"(acc_o[0][0]), "+v"(ES.pre[0]), "+v"(ES.act[0]), "+v"(ES.pre[3]), "+v"(ES.act[3]));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            });
-        } else
         pn_static_for<0, 16>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
             MlpXFrags& cur = (J & 1) ? FB : FA;
@@ -981,9 +852,9 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                     if constexpr (J < 15) mlp_load_x_proj<J + 1>(nxt, XA, hb ^ 1);
                 }
                 if constexpr (!EPI && !BWD) {       // body(8): the side outputs of chunk 7 under c_proj(7)
-                    if (!(MODE & (8 | 16))) mlp_copy_step8<J>(CP, lds, a.h_pre, a.h_act, row0, 7, CC(7));
+                    if (!(MODE & (8 | 16))) mlp_copy_step8<J>(CP, lds, a.h_pre, a.h_act, row0, 7, (7));
                 } else {                    // the activation panel of chunk c-1 (c_proj(c-1) reads it too; rewritten in body c+1)
-                    if (!(MODE & (8 | 16))) mlp_copy_step4<J, true, (MODE & 128) != 0>(CP, lds, a.h_act, row0, c - 1, CC(c - 1));
+                    if (!(MODE & (8 | 16))) mlp_copy_step4<J, true>(CP, lds, a.h_act, row0, c - 1, (c - 1));
                 }
             }
             // c_proj: W.f[nb] = output features wave*64 + nb*32 .., one k step; the epilogue pieces sit between the MFMAs.  Neither
@@ -1018,9 +889,9 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
             if constexpr (PROJ) {
                 if (!(MODE & 1)) acc_o[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[1], cur.f[1], acc_o[1][1], 0, 0, 0);
                 if (!(MODE & 2)) {  // c_proj(c-1) J+8, else the first half of the next body's first phase
-                    if constexpr (J + D < 16) mlp_load_w(W, ppj + (long)(CC(c - 1) * 16 + J + D) * TILE, wave, lane);
+                    if constexpr (J + D < 16) mlp_load_w(W, ppj + (long)((c - 1) * 16 + J + D) * TILE, wave, lane);
                     else if constexpr (EPI)     // c <= 7: body(c+1) starts with c_fc(c+1), body(8) with c_proj(7)
-                        mlp_load_w(W, c < 7 ? pfc + (long)(CC(c + 1) * 16 + J + D - 16) * TILE : ppj + (long)(CC(7) * 16 + J + D - 16) * TILE,
+                        mlp_load_w(W, c < 7 ? pfc + (long)((c + 1) * 16 + J + D - 16) * TILE : ppj + (long)((7) * 16 + J + D - 16) * TILE,
                                    wave, lane);
                 }
             }
@@ -1066,13 +937,13 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     auto after_epi = [&](int c) __attribute__((always_inline)) {   // after the epilogue of chunk c, before the slot barrier
         if constexpr (BWD) {       // c_fc bias gradient: column sums of the wave's 32 features over the panel's 64 rows
             const float tot = pn_colsum16(BE.cs, lane);
-            if (!(lane & 2)) unsafeAtomicAdd(a.g_b_fc + CC(c) * 256 + wave * 32 + 16 * hi + pn_colsum16_index(lane), tot);
+            if (!(lane & 2)) unsafeAtomicAdd(a.g_b_fc + (c) * 256 + wave * 32 + 16 * hi + pn_colsum16_index(lane), tot);
         } else {
-            mlp_bias32_load(B32, a.b_fc, CC(min(c + 1, 7)), wave);
+            mlp_bias32_load(B32, a.b_fc, (min(c + 1, 7)), wave);
         }
     };
     tick();
-    if (!BURST && grp) slot_barrier();
+    if (grp) slot_barrier();
     // body(0) and body(8) are peeled as straight-line code around the loop: as if / else arms INSIDE the loop every extra variant of
     // a phase cost ~300 spilled registers at the joins
     start_h();
@@ -1095,11 +966,11 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
         if (c < 7) mlp_load_x_fc<0>(FA, XA);                        // fragments of the next body's first step
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (!BURST) slot_barrier();                                      // (slot of the empty phase "c_fc(8)")
+    slot_barrier();                                                  // (slot of the empty phase "c_fc(8)")
     mlp_load_x_proj<0>(FA, XA, 1);                                   // c_proj(7) reads hidden panel 7 & 1
     __builtin_amdgcn_sched_barrier(0);
     tick(); proj_phase(8, T_{}, F_{}); tick();
-    if (!BURST && !grp) slot_barrier();
+    if (!grp) slot_barrier();
     tick();
     if (MODE & 1) {          // stream-only experiment: keep the loaded fragments alive
 #pragma unroll
@@ -1203,57 +1074,6 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                 }
             }
         __syncthreads();
-        if constexpr ((MODE & 4096) != 0) {
-            // ---- tail: qkv = xn_next W_in^T + b_qkv for the next block (a [64 x 512] x [512 x 1536] row-local product on the panel
-            // that is sitting in LDS), three groups of 512 output features (q | k | v), 32 K-steps of 16 each, packed W_in through the
-            // idle weight ring; every group leaves through the (idle) input panel space as whole 1-KiB rows of the [rows][1536] tensor
-            pn_static_for<0, D>([&](auto jc) {
-                constexpr int J = decltype(jc)::value;
-                mlp_load_w(WQ[J], a.pw_in + (long)J * TILE, wave, lane);
-            });
-            pn_panel_copy_out<1024>(xn_panel, a.xn_next + row0 * 512, 512, wave, lane);
-            pn_static_for<0, 3>([&](auto gc) {
-                constexpr int G = decltype(gc)::value;
-                f32x16 acc_q[MLP_NBO][2];
-#pragma unroll
-                for (int i = 0; i < MLP_NBO; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc_zero(acc_q[i][j]);
-                bf16x8 xq[2][2];
-                mlp_load_x_k16<0, MLP_H_OFF - MLP_XN_OFF>(xq[0], XA);
-                pn_static_for<0, 32>([&](auto jc) {
-                    constexpr int KT = decltype(jc)::value, T = G * 32 + KT;
-                    MlpWFrags& W = WQ[T % D];
-                    if constexpr (KT < 31) mlp_load_x_k16<KT + 1, MLP_H_OFF - MLP_XN_OFF>(xq[(KT + 1) & 1], XA);
-                    const bf16x8 x0 = xq[KT & 1][0], x1 = xq[KT & 1][1];
-#pragma unroll
-                    for (int nb = 0; nb < MLP_NBO; ++nb) {
-                        acc_q[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], x0, acc_q[nb][0], 0, 0, 0);
-                        acc_q[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], x1, acc_q[nb][1], 0, 0, 0);
-                    }
-                    if constexpr (T + D < 96) mlp_load_w(W, a.pw_in + (long)(T + D) * TILE, wave, lane);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                if constexpr (G > 0) __syncthreads();          // every wave has copied the previous group's rows out of the panel
-#pragma unroll
-                for (int nb = 0; nb < MLP_NBO; ++nb) {
-                    const int nbase = wave * (32 * MLP_NBO) + nb * 32;
-                    pn_cfptr_t bq = (pn_cfptr_t)(uintptr_t)(a.b_qkv) + G * 512 + nbase;
-#pragma unroll
-                    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                        for (int pp = 0; pp < 2; ++pp) {
-                            float bias[8], v[8];
-                            pn_uniform8(bq + 8 * pp, bq + 16 + 8 * pp, hi, bias);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = acc_q[nb][mb][8 * pp + e] + bias[e];
-                            *reinterpret_cast<uint4*>(pn_panel_slot<1024>(xo_panel, mb * 32 + (lane & 31), ((nbase + 8 * pp) >> 3) + 2 * hi)) = pn_pack8(v);
-                        }
-                }
-                __syncthreads();
-                pn_panel_copy_out<1024>(xo_panel, a.qkv_out + row0 * 1536 + G * 512, 1536, wave, lane);
-            });
-        } else
         pn_panel_copy_out<1024>(xn_panel, a.xn_next + row0 * 512, 512, wave, lane);
     }
 
@@ -1320,12 +1140,6 @@ using namespace tal;
 
 extern "C" int tan_panel_waves(void) { return PN_WAVES; }
 
-// TAN_MLP_ROT: 0 = every workgroup walks the hidden chunks 0..7; 1 / 2 / 3 = start at chunk (w & 7) / ((w >> 3) & 7) / ((w + (w >> 3)) & 7)
-static int mlp_rot() {
-    static const int v = [] { const char* e = getenv("TAN_MLP_ROT"); return e ? atoi(e) : 0; }();
-    return v;
-}
-
 extern "C" int tan_pack_weights(const void* src, void* dst, const tan_pack_entry* table, int n, int max_tiles, void* stream) {
     TAN_REQUIRE(src && dst && table && n > 0 && max_tiles > 0);
     hipLaunchKernelGGL(pack_tiles_kernel, dim3(max_tiles < 64 ? max_tiles : 64, n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
@@ -1348,22 +1162,16 @@ extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
     a.h_pre = (bf16_t*)d->h_pre; a.h_act = (bf16_t*)d->h_act; a.x_out = (bf16_t*)d->x_out;
     a.nln_g = d->nln_g; a.nln_b = d->nln_b; a.xn_next = (bf16_t*)d->xn_next; a.nmean = d->nmean; a.nrstd = d->nrstd;
     a.eps = d->eps;
-    a.rot = mlp_rot();
     a.attn_o = (const bf16_t*)d->attn_o; a.pw_out = (const char*)d->pw_out; a.b_out = d->b_out; a.x_in = (const bf16_t*)d->x_in;
     a.x_mid_w = (bf16_t*)d->x_mid;
-    const bool outp = d->pw_out != nullptr, intail = d->pw_in != nullptr;
+    const bool outp = d->pw_out != nullptr;
     if (outp) TAN_REQUIRE(d->attn_o && d->b_out && d->x_in && d->variant == 0);
-    if (intail) TAN_REQUIRE(outp && d->xn_next && d->b_qkv && d->qkv_out);
-    a.pw_in = (const char*)d->pw_in; a.b_qkv = d->b_qkv; a.qkv_out = (bf16_t*)d->qkv_out;
     const dim3 grid((unsigned)(d->rows / PN_ROWS));
-    const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0 + (outp ? 2.0 * d->rows * 512.0 * 512.0 : 0.0) + (intail ? 2.0 * d->rows * 512.0 * 1536.0 : 0.0));
+    const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0 + (outp ? 2.0 * d->rows * 512.0 * 512.0 : 0.0));
 #define TAN_MLP_LAUNCH(M) hipLaunchKernelGGL((mlp_panel_kernel<M, MlpFwdArgs>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a)
     // inference / the EMA target's forward: the side outputs of the chunk epilogue (h_pre, h_act: 2 x 4 KiB per row... 67 MB per
     // 8192 rows) are never read -- the instantiation without their copy-out (everything else identical)
-    if (outp && intail) {
-        if (no_side) TAN_MLP_LAUNCH(4096 | 2048 | 16);
-        else TAN_MLP_LAUNCH(4096 | 2048);
-    } else if (outp) {
+    if (outp) {
         if (no_side) TAN_MLP_LAUNCH(2048 | 16);
         else TAN_MLP_LAUNCH(2048);
     } else if (no_side && d->variant == 0) {
@@ -1392,21 +1200,6 @@ extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
 
 extern "C" int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream) {
     TAN_REQUIRE(d && d->rows > 0 && d->rows % PN_ROWS == 0 && d->C == 512 && d->FF == 2048);
-    if (d->head_only) {        // dx_out = ln1_res + LN-backward(dqkv W_in + dstage): the head and the ln_1 prologue, nothing else
-        TAN_REQUIRE(d->pwt_in && d->dqkv && !d->ln1_dxn && d->ln1_x && d->ln1_mean && d->ln1_rstd && d->ln1_g && d->dx_out);
-        MlpBwdArgs a{};
-        a.ln1_x = (const bf16_t*)d->ln1_x; a.ln1_res = (const bf16_t*)d->ln1_res;
-        a.ln1_mean = d->ln1_mean; a.ln1_rstd = d->ln1_rstd; a.ln1_g = d->ln1_g;
-        a.g_ln1_g = d->g_ln1_g; a.g_ln1_b = d->g_ln1_b; a.g_dx_colsum = d->g_dx_colsum; a.dx_out = (bf16_t*)d->dx_out;
-        a.dqkv = (const bf16_t*)d->dqkv; a.pwt_in = (const char*)d->pwt_in; a.dstage = (const bf16_t*)d->dstage;
-        a.pw_fc = a.pwt_in; a.pw_proj = a.pwt_in;
-        const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 1536.0 * 512.0);
-        hipLaunchKernelGGL((mlp_panel_kernel<512 | 1024, MlpBwdArgs>), dim3((unsigned)(d->rows / PN_ROWS)), dim3(64 * PN_WAVES), 0,
-                           (hipStream_t)stream, a);
-        prof_end((hipStream_t)stream, rec);
-        TAN_LAUNCH_CHECK();
-        return 0;
-    }
     TAN_REQUIRE((d->dx || d->ln1_dxn || d->pwt_in) && d->h_pre && d->x_mid && d->mean2 && d->rstd2 && d->ln_g && d->pwt_proj && d->pwt_fc && d->dh && d->dx2);
     TAN_REQUIRE(d->g_b_fc && d->g_ln_g && d->g_ln_b && d->g_b_out);
     if (d->ln1_dxn || d->pwt_in) TAN_REQUIRE(d->ln1_x && d->ln1_mean && d->ln1_rstd && d->ln1_g && d->dx_out);
@@ -1423,7 +1216,6 @@ extern "C" int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream) {
     TAN_REQUIRE((d->pwt_out != nullptr) == (d->d_o != nullptr));
     a.pwt_out = (const char*)d->pwt_out; a.d_o = (bf16_t*)d->d_o;
     a.dqkv = (const bf16_t*)d->dqkv; a.pwt_in = (const char*)d->pwt_in; a.dstage = (const bf16_t*)d->dstage;
-    a.rot = mlp_rot();
     const dim3 grid((unsigned)(d->rows / PN_ROWS));
     const int rec = prof_begin((hipStream_t)stream, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0 + (d->pwt_out ? 2.0 * d->rows * 512.0 * 512.0 : 0.0) +
                                                                          (d->pwt_in ? 2.0 * d->rows * 1536.0 * 512.0 : 0.0));

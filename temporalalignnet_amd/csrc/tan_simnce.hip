@@ -41,7 +41,6 @@ struct SimArgs {
     // simnce_res_kernel<1> with the same-video corrections as its tail (instead of a simnce_diag_kernel<true> launch):
     const float* diag;                 // [S, B, T, N] same-video cosines, or null: no corrections in the sweep kernel
     const int* colmap;                 // padded column b*N+k -> column of the sweep, or -1; null: identity
-    int rot;                           // simnce_res_kernel: panels start their column walk at different tiles
     int npanel, nfull;                 // simnce_res_kernel: row panels per stage; items (stage, panel) that are not cut in column halves
     const char* Tp;                    // simnce_res_kernel: fragment-major image of the text features (simnce_pack_text_kernel)
     long tp_stage_stride;              // bytes, or 0 (text features shared by the stages)
@@ -381,7 +380,7 @@ __global__ __launch_bounds__(512) void simnce_res_kernel(SimArgs a) {
     const int nall = (nct - grp + 1) / 2;                      // column tiles of this wave group: grp, grp + 2, ..
     const int kbase = half == 1 ? (nall + 1) / 2 : 0;          // .. of which a half item takes the first or the second part
     const int ngrp = half < 0 ? nall : (half == 0 ? (nall + 1) / 2 : nall / 2);
-    const int rot = ngrp > 0 ? ((a.rot & 1) ? (panel * 7 + s * 3) % ngrp : 0) : 0;
+    const int rot = ngrp > 0 ? (panel * 7 + s * 3) % ngrp : 0;
     if (ngrp > 0) {
         pn_static_for_s<0, RD>([&](auto jc) { constexpr int J = decltype(jc)::value; load_b(ring[J], 2 * (kbase + rot) + grp, J); });
     }
@@ -419,15 +418,14 @@ __global__ __launch_bounds__(512) void simnce_res_kernel(SimArgs a) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], Bf.f[j], acc[i][j], 0, 0, 0);
-            if (!(a.rot & 2)) {          // (lab: bit 1 = no text stream, bit 2 = no tile epilogue -- timing ablations, results undefined)
+            {
                 if constexpr (KS + RD < 32) load_b(Bf, ct_, KS + RD);
                 else if (more) load_b(Bf, ctn_, KS + RD - 32);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
         if (MODE == 0 && a.ekeep) c.dl = a.ekeep + ((((long)s * npanel + panel) * nct + ct_) * 4 + gw) * 4096;
-        if (!(a.rot & 4)) tile_done_res<MODE>(c, acc, rowacc, colrow, ct_);
-        else if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 12345.f) rowacc[0][0] += 1.f;      // keep the MFMAs alive
+        tile_done_res<MODE>(c, acc, rowacc, colrow, ct_);
     }
 
     if (MODE == 0) {
@@ -556,11 +554,8 @@ __global__ __launch_bounds__(256) void simnce_dl_kept_kernel(SimArgs a, int npan
     }
 }
 
-// TAN_SIM_RES=0: the re-staging kernel for every shape (A/B measurements)
-static bool res_enabled(const SimArgs& a) {
-    static const int v = [] { const char* e = getenv("TAN_SIM_RES"); return e ? atoi(e) : 1; }();
-    return v != 0 && a.C == 512;
-}
+// the frame-panel-resident sweep takes C = 512; other channel counts run the re-staging kernel
+static bool res_enabled(const SimArgs& a) { return a.C == 512; }
 
 // colsum[s,c] = sum over row panels of colpart
 __global__ void simnce_col_finalize(const float* __restrict__ colpart, float* __restrict__ colsum, int npanel, long SM) {
@@ -780,8 +775,6 @@ static int simnce_pack_text(SimArgs& a, float* ws_after_diag, hipStream_t st, fl
     char* base = (char*)(((uintptr_t)ws_after_diag + 15) & ~(uintptr_t)15);
     const int nblk = cdiv(a.Mp, 128) * 4;
     const bool shared = a.t_stage_stride == 0;
-    static const int rot = [] { const char* e = getenv("TAN_SIM_ROT"); return e ? atoi(e) : 1; }();
-    a.rot = rot;
     a.Tp = base;
     a.tp_stage_stride = shared ? 0 : (long)nblk * 32 * 1024;
     hipLaunchKernelGGL(simnce_pack_text_kernel, dim3(nblk, shared ? 1 : a.S), dim3(256), 0, st, a.Tt, a.t_stage_stride, base, a.tp_stage_stride, a.Mp, zero, nzero);
@@ -856,11 +849,10 @@ extern "C" int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_strid
                            S, B, T, N, C, tn_blocks, tb_stage_stride, colmap, Mc, phases, nullptr, stream);
 }
 
-// 1 when tan_simnce_fwd_keep / tan_simnce_bwd_dl_kept are available for this channel count (TAN_SIM_KEEP_E=0: never)
+// 1 when tan_simnce_fwd_keep / tan_simnce_bwd_dl_kept are available for this channel count
 extern "C" int tan_simnce_keeps(int C) {
-    static const int v = [] { const char* e = getenv("TAN_SIM_KEEP_E"); return e ? atoi(e) : 1; }();
     SimArgs a{}; a.C = C;
-    return v != 0 && res_enabled(a) ? 1 : 0;
+    return res_enabled(a) ? 1 : 0;
 }
 
 extern "C" long tan_simnce_keep_elems(int S, int R, int Mp) { return (long)S * cdiv(R, 128) * cdiv(Mp, 128) * 16384; }

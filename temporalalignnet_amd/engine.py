@@ -51,9 +51,8 @@ class _AlignerEngine(_WorkspaceMixin):
         wt = f.shadow_t if (self.compute_dtype == torch.bfloat16 and self.transposed_dx) else None
         wp = f.shadow_p if (self.compute_dtype == torch.bfloat16 and self.panel_kernels) else None
         wtp = f.shadow_tp if (wt is not None and wp is not None) else None
-        wpk = getattr(f, "shadow_pk", None) if wp is not None else None
         sig = (f.flat.data_ptr(), f.grad.data_ptr(), wbuf.data_ptr(), wt.data_ptr() if wt is not None else 0,
-               wp.data_ptr() if wp is not None else 0, wtp.data_ptr() if wtp is not None else 0, wpk.data_ptr() if wpk is not None else 0)
+               wp.data_ptr() if wp is not None else 0, wtp.data_ptr() if wtp is not None else 0)
         hit = self._lp_cache.get((prefix, layers))
         if hit is not None and hit[0] == sig:
             return hit[1]
@@ -71,7 +70,6 @@ class _AlignerEngine(_WorkspaceMixin):
                 setattr(arr[i], "wt_" + k[2:], f.ptr(wt, base + v) if wt is not None else None)
                 setattr(arr[i], "wp_" + k[2:], f.ptr(wp, base + v) if wp is not None else None)
                 setattr(arr[i], "wtp_" + k[2:], f.ptr(wtp, base + v) if wtp is not None else None)
-            arr[i].wp_qkv_k16 = f.ptr(wpk, base + m["w_qkv"]) if wpk is not None else None
             for k, v in fm.items():
                 setattr(arr[i], k, f.ptr(f.flat, base + v))
                 setattr(arr[i], "g_" + k, f.ptr(f.grad, base + v))
@@ -82,9 +80,6 @@ class _AlignerEngine(_WorkspaceMixin):
         d = _lib.EncoderDesc()
         d.dtype = ops._dt(x0)
         d.B, d.L, d.C, d.H, d.layers = er.B, er.L, WIDTH, HEADS, er.layers
-        if (self.panel_kernels and self.compute_dtype == torch.bfloat16 and not 48 < er.L <= 80
-                and int(os.environ.get("TAN_PANEL_OUT", "1")) & 2):
-            self._flat.sync_shadow_pk()       # in_proj in the tile format of the MLP forward's tail (first use builds it)
         d.key_padding_mask = _vp(keypad)
         d.x0 = _vp(x0)
         er.params = self._layer_params(er.prefix, er.layers)
@@ -130,12 +125,6 @@ class _AlignerEngine(_WorkspaceMixin):
         d.scr_dh, d.scr_dqkv = _vp(scr["dh"]), _vp(scr["dqkv"])
         d.ln_ws = _vp(scr.ln_ws)
         d.dw_ws, d.dw_ws_floats = _vp(scr.dw_ws), scr.dw_ws.numel()
-        # TAN_DW_STREAM: 1 = the joint stack's weight-gradient launches on their own stream (it is the longer chain), 2 = both stacks'
-        mode = int(os.environ.get("TAN_DW_STREAM", "0"))
-        if self._grad_ready_hook is None and dev.type == "cuda" and (mode >= 2 or (mode == 1 and er.prefix.startswith("joint"))):
-            aux = _lib.role_stream(dev, "dwj" if er.prefix.startswith("joint") else "dwv")
-            d.dw_stream = C.c_void_p(aux.cuda_stream)
-            d.scr2_dx, d.scr2_dx2, d.scr2_dh, d.scr2_dqkv = (_vp(scr[k]) for k in ("dx_b", "dx2_b", "dh_b", "dqkv_b"))
         arr = (C.c_void_p * er.layers)(*[(t.data_ptr() if t is not None else None) for t in d_stage])
         d.d_stage = arr
         d.d_x0 = _vp(d_x0)
@@ -347,7 +336,7 @@ class _AlignerEngine(_WorkspaceMixin):
                                                  WIDTH, ops._stream()), "tan_pos_ln_bwd")
         # ---- weight gradients of the two pre-projections (train/main.py: autograd of tan_model.py:48-49)
         cur = torch.cuda.current_stream()
-        aux = self._side_stream(dev) if os.environ.get("TAN_TAIL_STREAMS", "1") != "0" else None
+        aux = self._side_stream(dev)
         if aux is not None and aux.cuda_stream == cur.cuda_stream:
             aux = None
         d_lang = None
@@ -771,7 +760,7 @@ class _AlignerEngine(_WorkspaceMixin):
                 self._encoder_bwd(ev, run["x0"], run["vmask"], "ln_video_post_enc", dst_v, d_x0)
                 if self._grad_ready_hook is not None:
                     self._grad_ready_hook("video", self._layer_events(ev.prefix, ev.layers))
-        if run.get("em") is not None and os.environ.get("TAN_EMBED_BWD_FUSED", "1") != "0":
+        if run.get("em") is not None:          # the fused front-end ran (TAN_EMBED_FUSED): its backward is fused too
             d_lang = self._embed_bwd_fused(run, d_x0 if any_v else None, d_xj, d_lang_raw if have_lang_raw else None, need_d_lang)
             self._release_ws(ev)
             self._release_ws(ej)
@@ -793,7 +782,7 @@ class _AlignerEngine(_WorkspaceMixin):
         # side stream (idle now) next to the video one (TAN_TAIL_STREAMS=0: one after the other)
         d_lang = None
         cur = torch.cuda.current_stream()
-        aux = self._side_stream(dev) if os.environ.get("TAN_TAIL_STREAMS", "1") != "0" else None
+        aux = self._side_stream(dev)
         if aux is not None and aux.cuda_stream == cur.cuda_stream:
             aux = None
 

@@ -37,7 +37,6 @@ class _Flat:
         self.shadow_t, self.shadow_t_table, self.shadow_epoch, self.shadow_t_epoch = None, None, 0, -1
         # tan_pack_weights images (row-panel kernels) of the same weights / of their transposes, same element offsets
         self.shadow_p, self.shadow_tp, self.pack_table, self.shadow_p_epoch, self.shadow_tp_epoch = None, None, None, -1, -1
-        self.shadow_pk, self.pk_table, self.shadow_pk_epoch = None, None, -1
         self.device = None
         # more per-step images owned by the model (callables, run inside refresh_images_async on the side stream): the LayerNorm'ed
         # position tables of the fused input embeddings
@@ -69,7 +68,6 @@ class _Flat:
         self._views = {}
         self.shadow_t, self.shadow_t_table, self.shadow_t_epoch = None, None, -1
         self.shadow_p, self.shadow_tp, self.pack_table, self.shadow_p_epoch, self.shadow_tp_epoch = None, None, None, -1, -1
-        self.shadow_pk, self.pk_table, self.shadow_pk_epoch = None, None, -1
         self._image_table = None
 
     def _pack_tables(self):
@@ -153,8 +151,6 @@ class _Flat:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             self.sync_shadow_p()
-            if getattr(self, "shadow_pk", None) is not None:
-                self.sync_shadow_pk()
             if backward and self.shadow_t is not None:
                 self.sync_shadow_t()
                 if self.shadow_tp is not None:
@@ -167,29 +163,6 @@ class _Flat:
         ev = getattr(self, "images_event", None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)      # a finished event costs nothing on the GPU
-
-    def sync_shadow_pk(self):
-        """Packed images of in_proj in the [512][16] tile format (q | k | v row groups of 512 features): the in-projection as the TAIL
-        of the row-panel MLP forward, for stacks the one-launch attention branch does not take (L > 80).  Built on first use."""
-        if self.shadow is None:
-            return None
-        if getattr(self, "shadow_pk", None) is None:
-            self.shadow_pk = torch.zeros(self.total, dtype=torch.bfloat16, device=self.shadow.device)
-            self.shadow_pk_epoch = -1
-            ents = []
-            for n in self.names:
-                if ".resblocks." in n and n.endswith("attn.in_proj_weight"):
-                    o, _, (N, K) = self.off[n]
-                    ents.append(_lib.PackEntry(o, o, N, K, 512, 16))
-            arr = (_lib.PackEntry * len(ents))(*ents)
-            self.pk_table = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.shadow.device), len(ents),
-                             max((e.N // 512) * (e.K // 16) for e in ents))
-        if self.shadow_pk_epoch != self.shadow_epoch:
-            tab, n, mx = self.pk_table
-            _lib.check(_lib.lib().tan_pack_weights(_vp(self.shadow), _vp(self.shadow_pk), _vp(tab), C.c_int(n), C.c_int(mx),
-                                                   ops._stream()), "tan_pack_weights")
-            self.shadow_pk_epoch = self.shadow_epoch
-        return self.shadow_pk
 
     def sync_shadow(self):
         if self.shadow is not None and self.shadow_version != self.flat._version:

@@ -438,8 +438,7 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
     N = text_embed.shape[1]
     R, Mp = B * T, B * N
     join_ev = getattr(fused, "join_event", None) if fused is not None else None
-    two_streams = os.environ.get("TAN_LOSS_STREAMS", "1") != "0"
-    if join_ev is not None and (args.learn_agreement or getattr(fused, "global_negatives", False) or not two_streams):
+    if join_ev is not None and (args.learn_agreement or getattr(fused, "global_negatives", False)):
         torch.cuda.current_stream().wait_event(join_ev)      # these paths read the joint features on this stream right away
         join_ev = None
     if fused is None:
@@ -520,7 +519,7 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
         # forward ran on and synchronises producer/consumer streams itself, so the two backward chains (d-logits + the two
         # feature-gradient GEMMs each) overlap as well.
         main = torch.cuda.current_stream()
-        side = _side_stream(dev) if os.environ.get("TAN_LOSS_STREAMS", "1") != "0" else None
+        side = _side_stream(dev)
         if side is not None:
             side.wait_stream(main)
             if join_ev is not None:          # deferred join of the forward: only the joint sweep waits for the joint stack

@@ -93,7 +93,7 @@ class TemporalAligner(_AlignerEngine, nn.Module):
         self._side = None
         self._issuer = None               # helper thread issuing the side-stream stack (see _on_side)
         self._lp_cache = {}
-        self.transposed_dx = os.environ.get("TAN_TRANSPOSED_DX", "1") != "0"   # dX GEMMs read W^T copies (K-contiguous)
+        self.transposed_dx = True         # dX GEMMs read W^T copies (K-contiguous); their packed images feed the row-panel backward
         self.panel_kernels = os.environ.get("TAN_PANEL", "1") != "0"           # row-panel fused kernels (packed weight images)
         self._grad_ready_hook = None      # callable(tag, layer_events) fired inside backward once a stack's backward is enqueued
         # load_state_dict copies into the parameter tensors, whose version counters are not the flat buffer's: the bf16

@@ -133,13 +133,7 @@ class Trainer:
         self.ddp_bucket_layers = max(1, int(os.environ.get("TAN_DDP_BUCKET_LAYERS", "2") if ddp_bucket_layers is None
                                             else ddp_bucket_layers))
         self._comm_streams = {}
-        self._opt_streams = {}
         self._zero_ev = None
-        # TAN_STEP_ASYNC=1 (default): `step` fills the gradient buffer and rebuilds the weight images on a side stream, next to the
-        # next forward's input embeddings, instead of in front of them
-        self.step_async = os.environ.get("TAN_STEP_ASYNC", "1") != "0"
-        # TAN_OPT_OVERLAP=1: `step` issues each gradient bucket's AdamW update next to backward (see step)
-        self.opt_overlap = os.environ.get("TAN_OPT_OVERLAP", "0") != "0"
         # TAN_DDP_MODE: "flat" (default) = ONE all-reduce of the whole flat gradient after backward, what BASELINE.json's north_star
         # states; "buckets" = per-layer-group all-reduces overlapped with backward.  No >1-GPU node was available to pick by
         # measurement, so the default is the north star's; bench.py reports the other mode as an `extra` entry of a multi-GPU run.
@@ -176,12 +170,6 @@ class Trainer:
         b = self.batches_seen if lr_iter is None else lr_iter
         return self.args.lr * lr_multiplier(max(b + getattr(self, "_resume_bump", 0), 1), self.iter_per_epoch, self.args.epochs,
                                             self.warmup)
-
-    def _opt_stream(self, device):
-        st = self._opt_streams.get(device)
-        if st is None:
-            st = self._opt_streams[device] = _lib.role_stream(device, "opt")
-        return st
 
     def _comm_order_stream(self, device):
         """The stream the gradient collectives are issued under: it only ever waits for layer events, so a bucket's all-reduce
@@ -280,7 +268,7 @@ class Trainer:
                 if self.global_negatives:
                     raise _lib.TanHipError(f"global_negatives: {Bn}x{Nn} text columns per rank exceed the fused sweep's limit")
                 fused = False
-        if batch["video"].is_cuda and os.environ.get("TAN_LOSS_STREAMS", "1") != "0":
+        if batch["video"].is_cuda:
             # what get_loss derives from the batch alone (masks, targets, column compaction: ~20 tiny launches) runs on the loss
             # side stream next to the forward instead of between the stacks and the similarity sweeps
             from .loss import prepare_inputs_async
@@ -341,33 +329,10 @@ class Trainer:
                 p.grad.copy_(g)
             off += p.numel()
 
-    def _adamw_range(self, lo, hi, grad_scale, step):
-        """tan_adamw_step over flat[lo:hi) (+ its EMA twin range) on the current stream."""
-        f, st = self._ensure_state()
-        ema = self.model.target._ensure_flat() if self.twin else None
-        _lib.check(_lib.lib().tan_adamw_step(
-            _vp(f.flat[lo:hi]), _vp(f.grad[lo:hi]), _vp(st["m"][lo:hi]), _vp(st["v"][lo:hi]), _vp(st["mode"][lo:hi]), C.c_long(hi - lo),
-            C.c_double(self.current_lr()), C.c_double(self.betas[0]), C.c_double(self.betas[1]), C.c_double(self.eps),
-            C.c_double(self.args.wd), C.c_int(step), C.c_float(grad_scale), _vp(f.shadow[lo:hi]) if f.shadow is not None else None,
-            _vp(ema.flat[lo:hi]) if ema is not None else None, C.c_float(self.model.m if self.twin else 0.0),
-            _vp(ema.shadow[lo:hi]) if (ema is not None and ema.shadow is not None) else None, ops._stream()), "tan_adamw_step")
-
-    def optimizer_step(self, grad_scale=1.0, stepped=None):
-        """`stepped`: sorted [(lo, hi)] flat ranges whose AdamW update `step` already issued next to backward (same step count,
-        learning rate and grad_scale); the rest of the buffer follows here."""
+    def optimizer_step(self, grad_scale=1.0):
         f, st = self._ensure_state()
         a = self.args
         self._lm_allreduce()
-        if stepped:
-            assert a.clip_grad <= 0
-            self.iteration += 1
-            for lo, hi in uncovered_ranges(stepped, f.total):
-                self._adamw_range(lo, hi, grad_scale, self.iteration)
-            f.shadow_epoch += 1
-            if self.twin:
-                self.model.target._ensure_flat().shadow_epoch += 1
-            self._lm_step(grad_scale)
-            return
         if a.clip_grad > 0:                            # per-parameter L2 clip, utils/train_utils.py:3-13 (language model included)
             for p in list(f.params) + [q for _, q in self._lm_params()]:
                 if p.grad is not None:
@@ -483,48 +448,29 @@ class Trainer:
             self.sync_parameters()
         dev0 = self.online._ensure_flat().flat.device
         aside = None
-        if self.step_async and dev0.type == "cuda":
+        if dev0.type == "cuda":          # the gradient fill and the image refresh run on a side stream, next to the forward's first kernels
             from .loss import _side_stream
             aside = _side_stream(dev0)
         self.zero_grad(side=aside)
         world = dist.world_size()
         gscale = 1.0 if self.global_negatives else 1.0 / world
-        pending, done, stepped = [], [], []
-        # AdamW next to backward: a bucket's parameters (+ EMA twin, + bf16 shadows) are updated on a side stream as soon as its
-        # gradient is final (and, with N>1, summed), while earlier layers are still being differentiated -- the update is HBM-bound,
-        # backward is not.  Needs the whole-buffer options off: per-parameter clipping reads finished gradients from torch.
-        early = (self.opt_overlap and self.args.clip_grad <= 0 and not self._accum_open
-                 and not (dist.active() and self.ddp_mode == "flat"))
-        opt = self._opt_stream(self.online._ensure_flat().flat.device) if early else None
+        pending, done = [], []
         if dist.active() and self.ddp_mode == "flat":
             flat = self.online.flat_grad()
-        elif dist.active() or early:
+        elif dist.active():
             flat = self.online.flat_grad()
-            comm = self._comm_order_stream(flat.device) if dist.active() else None
-            if early:
-                self._ensure_state()
+            comm = self._comm_order_stream(flat.device)
 
             def hook(tag, layer_events):
                 for lo, hi, last in self._ddp_buckets(tag, len(layer_events)):
                     # comm waits (on the GPU) for the event of the bucket's lowest layer; the process group's own stream
                     # then waits for comm, i.e. for exactly the layers this bucket covers
-                    work = None
-                    if comm is not None:
-                        _lib.check(_lib.lib().tan_stream_wait_event(C.c_void_p(comm.cuda_stream), C.c_void_p(layer_events[last])),
-                                   "tan_stream_wait_event")
-                        with torch.cuda.stream(comm):
-                            work = dist.allreduce_sum_(flat[lo:hi], async_op=True)
-                        done.append((lo, hi))
-                    if early:
-                        with torch.cuda.stream(opt):
-                            if work is not None:
-                                work.wait()                  # opt waits (on the GPU) for this bucket's all-reduce
-                            else:
-                                _lib.check(_lib.lib().tan_stream_wait_event(C.c_void_p(opt.cuda_stream),
-                                                                            C.c_void_p(layer_events[last])), "tan_stream_wait_event")
-                            self._adamw_range(lo, hi, gscale, self.iteration + 1)
-                        stepped.append((lo, hi))
-                    elif work is not None:
+                    _lib.check(_lib.lib().tan_stream_wait_event(C.c_void_p(comm.cuda_stream), C.c_void_p(layer_events[last])),
+                               "tan_stream_wait_event")
+                    with torch.cuda.stream(comm):
+                        work = dist.allreduce_sum_(flat[lo:hi], async_op=True)
+                    done.append((lo, hi))
+                    if work is not None:
                         pending.append(work)
             self.online._grad_ready_hook = hook
         try:
@@ -543,9 +489,7 @@ class Trainer:
             if ev is not None:
                 ev[1].record()
                 self.comm_events.append(ev)
-        if stepped:
-            torch.cuda.current_stream().wait_stream(opt)
-        self.optimizer_step(grad_scale=gscale, stepped=sorted(stepped))
+        self.optimizer_step(grad_scale=gscale)
         if aside is not None:
             self.online._ensure_flat_nosync().refresh_images_async(aside, backward=True)
             if self.twin:

@@ -154,66 +154,6 @@ def test_attnblk_with_every_key_of_a_video_padded_gives_the_residual_plus_bias()
     assert (x_mid.float().view(B, L, 512)[keep] - rk).abs().max().item() <= 2.0 ** -7 * rk.abs().max().item()
 
 
-@pytest.mark.parametrize("B,L,pad", [(3, 64, False), (5, 80, True), (2, 70, True), (4, 56, True), (128, 80, False)])
-def test_attnblk_bwd_matches_autograd_and_the_unfused_path(B, L, pad):
-    """tan_attnblk_bwd = (out_proj dX GEMM, attention backward with the in_proj bias column sums) of tan_encoder_bwd in one launch:
-    dqkv and g_b_qkv against torch autograd (fp64 on the bf16 tensors the kernels see) and against the two launches it replaces."""
-    _lib, ops = _lib_ops()
-    torch.manual_seed(B * 1000 + L)
-    R = B * L
-    qkv = (torch.randn(R, 1536, device="cuda") * 1.2).to(bf)
-    dx2 = (torch.randn(R, 512, device="cuda") * 0.05).to(bf)
-    w_out = (torch.randn(512, 512, device="cuda") * 512 ** -0.5).to(bf)
-    keypad = None
-    if pad:
-        keypad = torch.zeros(B, L, dtype=torch.uint8, device="cuda")
-        for b in range(B):
-            keypad[b, L - 1 - (b * 5) % 17:] = 1
-        keypad[0, 3] = 1
-    # forward quantities the backward needs (unfused kernels)
-    o = torch.empty(R, 512, device="cuda", dtype=bf)
-    lse = torch.empty(B, 8, L, device="cuda")
-    ops.attn_fwd(qkv, keypad, o, lse, B, L, 8)
-    (pwt_out,) = pack([(w_out.T.contiguous(), 512, 16)])
-    dqkv = torch.full((R, 1536), float("nan"), device="cuda", dtype=bf)
-    g0 = torch.randn(1536, device="cuda")
-    g = g0.clone()
-    d = _lib.AttnBlkBwdDesc()
-    d.B, d.L, d.C, d.H = B, L, 512, 8
-    d.dx2, d.qkv, d.lse = dx2.data_ptr(), qkv.data_ptr(), lse.data_ptr()
-    d.key_padding_mask = keypad.data_ptr() if keypad is not None else None
-    d.pwt_out, d.dqkv, d.g_b_qkv = pwt_out.data_ptr(), dqkv.data_ptr(), g.data_ptr()
-    _lib.check(_lib.lib().tan_attnblk_bwd(C.byref(d), ops._stream()), "tan_attnblk_bwd")
-    torch.cuda.synchronize()
-    assert torch.isfinite(dqkv.float()).all()
-    # autograd reference: d_o = bf16(dx2 W_out), attention backward in fp64
-    d_o = (dx2.float() @ w_out.float()).to(bf)
-    q64 = qkv.double().requires_grad_(True)
-    qv = q64.view(B, L, 3, 8, 64)
-    q, k, v = (qv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-    sc = (q @ k.transpose(-1, -2)) * 0.125
-    if keypad is not None:
-        sc = sc.masked_fill(keypad.bool()[:, None, None, :], float("-inf"))
-    oo = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(R, 512)
-    oo.backward(d_o.double())
-    ref = q64.grad.float()
-    err = (dqkv.float() - ref).abs().max().item()
-    assert err <= 0.03 * ref.abs().max().item() + 1e-4, (err, ref.abs().max().item())
-    close_g = (g - g0 - dqkv.float().sum(0)).abs().max().item()
-    assert close_g <= 2e-3 * (1.0 + dqkv.float().sum(0).abs().max().item()), close_g
-    # the two launches it replaces
-    u_do = torch.empty(R, 512, device="cuda", dtype=bf)
-    ops.gemm(dx2, w_out, u_do, M=R, N=512, K=512, a_kc=True, b_kc=False, ldb=512)
-    u_dqkv = torch.empty_like(dqkv)
-    u_g = g0.clone()
-    ops.attn_bwd(qkv, keypad, o, lse, u_do, u_dqkv, B, L, 8, g_b_qkv=u_g)
-    torch.cuda.synchronize()
-    diff = (u_dqkv.float() - dqkv.float()).abs()
-    assert diff.max().item() <= 2.0 ** -6 * u_dqkv.float().abs().max().item(), diff.max().item()
-    assert (diff > 0).float().mean().item() < 0.05
-    assert (u_g - g).abs().max().item() <= 2e-3 * (1.0 + (u_g - g0).abs().max().item())
-
-
 def test_attnblk_rejects_what_it_cannot_do():
     _lib, ops = _lib_ops()
     d = _lib.AttnBlkDesc()

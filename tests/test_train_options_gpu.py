@@ -86,16 +86,15 @@ def test_gradient_accumulation_follows_the_reference_loop():
 
 @pytest.mark.parametrize("model_kind", ["init", "cotrain"])
 def test_step_boundary_options_do_not_change_the_arithmetic(monkeypatch, model_kind):
-    """`Trainer.step` with the gradient fill / weight-image rebuilds on a side stream (TAN_STEP_ASYNC, default) and with AdamW issued
-    per gradient bucket next to backward (TAN_OPT_OVERLAP), or the weight-gradient launches on their own stream with alternating scratch
-    sets (TAN_DW_STREAM), runs the SAME kernels on the same values as the plain sequence: after three
-    steps in bf16 (where the packed weight images matter) the parameters agree up to the order of the f32 gradient atomics."""
+    """`Trainer.step` with the weight images written by the optimizer launch itself (TAN_OPT_IMAGES, default) and the fused input
+    embeddings (TAN_EMBED_FUSED, default) runs the same arithmetic as AdamW + image rebuilds on the side stream / the unfused
+    front-end launches: after three steps in bf16 the parameters agree up to bf16 rounding of the embeddings and the order of the
+    f32 gradient atomics."""
     kw = dict(model=model_kind, **({"loss_threshold": 0.5} if model_kind == "cotrain" else {}))
     batches = [_batch(40 + i, B=8, T=64) for i in range(3)]
     flats = {}
-    for tag, env in (("plain", {"TAN_STEP_ASYNC": "0", "TAN_OPT_OVERLAP": "0"}), ("async", {"TAN_STEP_ASYNC": "1", "TAN_OPT_OVERLAP": "0"}),
-                     ("overlap", {"TAN_STEP_ASYNC": "1", "TAN_OPT_OVERLAP": "1"}),
-                     ("dwstream", {"TAN_STEP_ASYNC": "1", "TAN_OPT_OVERLAP": "0", "TAN_DW_STREAM": "2"})):
+    for tag, env in (("plain", {"TAN_OPT_IMAGES": "0", "TAN_EMBED_FUSED": "0"}), ("images", {"TAN_OPT_IMAGES": "1", "TAN_EMBED_FUSED": "0"}),
+                     ("fused", {"TAN_OPT_IMAGES": "1", "TAN_EMBED_FUSED": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         tr, _ = _trainer(seed=3, dtype="bf16", **kw)
@@ -108,10 +107,11 @@ def test_step_boundary_options_do_not_change_the_arithmetic(monkeypatch, model_k
         flats[tag] = (tr.online.flat_parameters().clone(), tr.model.target.flat_parameters().clone() if model_kind == "cotrain" else None)
     ref = flats["plain"]
     assert torch.isfinite(ref[0]).all()
-    for tag in ("async", "overlap", "dwstream"):
+    for tag in ("images", "fused"):
         d = (flats[tag][0] - ref[0]).abs()
         # Adam turns atomics-order noise on ~zero gradients into lr-sized (1e-3) updates of a few elements: bounded by the three steps' total
-        assert d.max().item() <= 3.5e-3 and d.mean().item() <= 5e-6, (tag, d.max().item(), d.mean().item())
+        # (the fused front-end adds the position rows in f32 instead of bf16: rounding-level input differences on top of the atomics)
+        assert d.max().item() <= 3.5e-3 and d.mean().item() <= (5e-6 if tag == "images" else 3e-5), (tag, d.max().item(), d.mean().item())
         if ref[1] is not None:
             assert (flats[tag][1] - ref[1]).abs().max().item() <= 3.5e-3, tag
     moved = (ref[0] - _trainer(seed=3, dtype="bf16", **kw)[0].online.flat_parameters()).abs().max().item()

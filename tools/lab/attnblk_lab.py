@@ -72,52 +72,3 @@ for L in ([int(sys.argv[2])] if len(sys.argv) > 2 else [64, 80]):
     tn = timeit(lambda t: fused(t, L, False), ts)
     print(f"B={B} L={L}: unfused {tu:.1f} us ({fl / tu * 1e-6:.0f} TF/s) | fused {tf:.1f} us ({fl / tf * 1e-6:.0f} TF/s) | "
           f"fused, nothing saved {tn:.1f} us")
-
-
-# ---- backward: tan_attnblk_bwd vs out_proj dX GEMM + tan_attn_bwd_bias
-def bwd_fused(t, L):
-    d = _lib.AttnBlkBwdDesc()
-    d.B, d.L, d.C, d.H = B, L, 512, 8
-    d.dx2, d.qkv, d.lse, d.key_padding_mask = t["dx2"].data_ptr(), t["qkv"].data_ptr(), t["lse"].data_ptr(), None
-    d.pwt_out, d.dqkv, d.g_b_qkv = t["pwt_out"].data_ptr(), t["dqkv"].data_ptr(), t["g"].data_ptr()
-    _lib.check(_lib.lib().tan_attnblk_bwd(C.byref(d), ops._stream()), "tan_attnblk_bwd")
-
-
-def bwd_unfused(t, L):
-    R = B * L
-    ops.gemm(t["dx2"], t["w_out"], t["d_o"], M=R, N=512, K=512, a_kc=True, b_kc=True, ldb=512)      # (the W^T-copy form: K-contiguous)
-    ops.attn_bwd(t["qkv"], None, t["o"], t["lse"], t["d_o"], t["dqkv"], B, L, 8, g_b_qkv=t["g"])
-
-
-for L in ([int(sys.argv[2])] if len(sys.argv) > 2 else [64, 80]):
-    ts = make(L)
-    for t in ts:
-        unfused(t, L)
-        R = B * L
-        t["dx2"] = (torch.randn(R, 512, device="cuda") * 0.05).to(bf)
-        t["d_o"], t["dqkv"], t["g"] = torch.empty(R, 512, device="cuda", dtype=bf), torch.empty(R, 1536, device="cuda", dtype=bf), torch.zeros(1536, device="cuda")
-        (t["pwt_out"],) = pack([(t["w_out"].T.contiguous(), 512, 16)])
-    tu = timeit(lambda t: bwd_unfused(t, L), ts)
-    tf = timeit(lambda t: bwd_fused(t, L), ts)
-    print(f"backward B={B} L={L}: out_proj dX + attention backward {tu:.1f} us | fused {tf:.1f} us")
-
-# ---- phase clocks of the backward kernel (workgroup 0)
-for L in ([int(sys.argv[2])] if len(sys.argv) > 2 else [64, 80]):
-    ts = make(L)
-    t = ts[0]
-    unfused(t, L)
-    R = B * L
-    t["dx2"] = (torch.randn(R, 512, device="cuda") * 0.05).to(bf)
-    t["dqkv"], t["g"] = torch.empty(R, 1536, device="cuda", dtype=bf), torch.zeros(1536, device="cuda")
-    (t["pwt_out"],) = pack([(t["w_out"].T.contiguous(), 512, 16)])
-    dbg = torch.zeros(8 * 64, dtype=torch.int64, device="cuda")
-    _lib.lib().tan_attnblk_lab_set_dbg(C.c_void_p(dbg.data_ptr()))
-    for _ in range(3):
-        bwd_fused(t, L)
-    torch.cuda.synchronize()
-    _lib.lib().tan_attnblk_lab_set_dbg(None)
-    d = dbg.view(8, 64).cpu().numpy()
-    names = ["start", "prologue", "GEMM-a loop", "d_o + qkv images"] + [f"hp{h} {n}" for h in range(4) for n in ("phase A", "barrier", "phase B", "park+colsum", "copy/refill")] + ["end"]
-    for w in (0, 5, 7):
-        row = d[w]
-        print(f"L={L} wave {w}: " + ", ".join(f"{names[i]} {int(row[i] - row[i - 1])}" for i in range(1, len(names))) + f" | total {int(row[len(names) - 1] - row[0])}")
