@@ -391,6 +391,14 @@ int tan_encoder_bwd(const tan_encoder_desc* e, void* stream);
  * slices <= 32) they are written as partial tiles and folded by tan_reduce_add, otherwise accumulated with f32 atomics. */
 int tan_linear_wgrad(const void* dy, const void* x, float* gw, long M, int N, int K, float* ws, long ws_floats, int dtype,
                      void* stream);
+/* C_p [M_p, N_p] (=|+=) A_p^T B_p for p < n <= 8 problems sharing the contraction length K (a multiple of 128): A_p [K, lda_p] and
+ * B_p [K, N_p] row-major bf16 -- the contraction runs over ROWS.  256 x 256 tiles (N_p % 256 == 0; M_p ragged: the last tile of A_p's
+ * columns reads up to 255 elements past each row, so the caller pads the END of A_p's buffer by 512 bytes).  out_dtype TAN_BF16: plain
+ * store (split == 1, accumulate == 0); TAN_F32: split == 1 stores or (accumulate) adds in place, split > 1 K slices add with f32
+ * atomics (accumulate must be set; C zeroed by the caller).  This is the kernel behind tan_linear_wgrad_group (the weight gradients
+ * dW = dY^T X of a block, autograd of model/tfm_model.py:21-27) with its full shape range exposed. */
+int tan_gemm_atb(int n, const void* const* A, const void* const* B, void* const* C, const int* lda, const int* M, const int* N, long K,
+                 int out_dtype, int accumulate, int split, void* stream);
 /* The weight gradients of up to four Linear layers over the same M rows (the in_proj, out_proj, c_fc and c_proj of one
  * ResidualAttentionBlock, tfm_model.py:17-27) in ONE launch: gw[i][N[i],K[i]] += dy[i][M,N[i]]^T x[i][M,K[i]].  This is the call
  * tan_encoder_bwd makes per block; not eligible groups (f32, ragged M) run tan_linear_wgrad one by one.               */

@@ -694,7 +694,23 @@ __device__ __forceinline__ void dma256(unsigned voff, const char* base, unsigned
                  : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(base) : "memory");
 }
 
-__global__ __launch_bounds__(256) void gemm_dw256_kernel(GroupedDwArgs ga) {
+// C_p [M_p x N_p] (=|+=) A_p^T B_p for up to eight problems that share the contraction length K: A_p [K x lda_p] and B_p [K x N_p]
+// row-major bf16 (the contraction runs over ROWS: both operands "K-strided").  The weight gradients of a block (tan_encoder_bwd); the
+// general form is exported as tan_gemm_atb.  (Round 4 ran the two feature-gradient GEMMs of the similarity loss on it -- d_tn = dl^T vn,
+// d_vn = (dl^T)^T tn with the transpose written by the d-logits pass: 810 vs 690 TF/s on the GEMMs themselves, but the transposed
+// write made the d-logits pass 50 us longer and the K-sliced d_tn launches quantise badly on 256 CUs: 4.77 vs 4.65 ms per step,
+// removed again.  DESIGN_APPENDIX.md A.9.)
+// mv = valid output rows (M may be ragged: the last 256-row tile reads past the matrix' columns -- into the next row, the caller pads
+// the end of the buffer -- and stores nothing there); out: 0 plain f32 store, 1 f32 read-add-write, 2 f32 atomics (K slices), 3 bf16
+// store through the (then idle) LDS stages as whole rows.
+struct Dw256Args {
+    const bf16_t* A[8]; const bf16_t* B[8]; void* C[8];
+    int M[8], Mv[8], N[8];           // M = row stride of A (elements) = columns of the tile grid's base; Mv <= M valid rows of C
+    int tile_end[8];                 // running sum of tiles
+    int nprob, kchunk, K, out;
+};
+
+__global__ __launch_bounds__(256) void gemm_dw256_kernel(Dw256Args ga) {
     constexpr int NST = 4;
     extern __shared__ __attribute__((aligned(1024))) char lds[];          // NST * D256_STAGE = 128 KiB
     const int tid = threadIdx.x, lane = tid & 63;
@@ -717,10 +733,10 @@ __global__ __launch_bounds__(256) void gemm_dw256_kernel(GroupedDwArgs ga) {
     }
     int p = 0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) p += (i + 1 < ga.nprob && t >= ga.tile_end[i]) ? 1 : 0;
+    for (int i = 0; i < 7; ++i) p += (i + 1 < ga.nprob && t >= ga.tile_end[i]) ? 1 : 0;
     p = __builtin_amdgcn_readfirstlane(p);
     const int t0 = p ? ga.tile_end[p - 1] : 0;
-    const int M = ga.M[p], N = ga.N[p];
+    const int M = ga.M[p], N = ga.N[p], Mv = ga.Mv[p];
     const int ntn = N / 256;
     const int lt = t - t0, n0 = (lt % ntn) * 256, m0 = (lt / ntn) * 256;
     // K slices in groups of 128 rows (four stages), the first K/128 % slices of them one group longer
@@ -817,15 +833,41 @@ __global__ __launch_bounds__(256) void gemm_dw256_kernel(GroupedDwArgs ga) {
     tr_wait256(s0);                      // the read-ahead of a tile past the end: landed, unused
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");     // + the last MFMA's result before the AGPR reads
 
-    float* C = ga.C[p] + (long)(m0 + wm * 128) * N + n0 + wn * 128 + acc_col(lane);
+    if (ga.out == 3) {
+        // bf16 result: the wave's 128 x 128 quarter goes through LDS (rows of 272 B: off the bank period; 34 KiB per wave, the launch
+        // asks for 136 KiB) and leaves as 16-byte vectors, four 256-byte row pieces per instruction
+        __syncthreads();                 // every wave is done reading the stages
+        constexpr int LDW = 136;         // bf16 per LDS row
+        bf16_t* wt = reinterpret_cast<bf16_t*>(lds) + wave * (128 * LDW);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) wt[(i * 32 + acc_row(r, lane)) * LDW + j * 32 + acc_col(lane)] = f2bf(acc[i][j][r]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        bf16_t* C16 = reinterpret_cast<bf16_t*>(ga.C[p]);
+#pragma unroll 4
+        for (int q = lane; q < 128 * 16; q += 64) {
+            const int lr = q >> 4, cc = (q & 15) * 8, grow = m0 + wm * 128 + lr;
+            if (grow < Mv) *reinterpret_cast<uint4*>(C16 + (long)grow * N + n0 + wn * 128 + cc) = *reinterpret_cast<const uint4*>(wt + lr * LDW + cc);
+        }
+        return;
+    }
+    float* C = reinterpret_cast<float*>(ga.C[p]) + (long)(m0 + wm * 128) * N + n0 + wn * 128 + acc_col(lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+            if (m0 + wm * 128 + i * 32 + acc_row(r, lane) >= Mv) continue;
             float* row = C + (long)(i * 32 + acc_row(r, lane)) * N;
-            if (ga.accumulate == 2) {
+            if (ga.out == 2) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) unsafeAtomicAdd(row + j * 32, acc[i][j][r]);
+            } else if (ga.out == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) row[j * 32] = acc[i][j][r];
             } else {
                 float v[4];
 #pragma unroll
@@ -836,28 +878,42 @@ __global__ __launch_bounds__(256) void gemm_dw256_kernel(GroupedDwArgs ga) {
         }
 }
 
-// host side: gw_p += dy_p^T x_p; returns -2 when the group is not eligible
-int gemm_dw256_grouped(int nprob, const void* const* dy, const void* const* x, float* const* gw, const int* Ms, const int* Ns,
-                       long rows, int split, hipStream_t st) {
-    if (nprob < 1 || nprob > 4 || split < 1 || rows % 128 != 0 || rows / 128 < split) return -2;
-    GroupedDwArgs ga{};
+// host side; returns -2 when the group is not eligible.  lda[p] = row stride of A_p (>= Mv[p], multiple of 8), out as Dw256Args.out
+int gemm_atb256(int nprob, const void* const* A, const void* const* B, void* const* C, const int* lda, const int* Mv, const int* Ns,
+                long rows, int out, int split, hipStream_t st) {
+    if (nprob < 1 || nprob > 8 || split < 1 || rows % 128 != 0 || rows / 128 < split) return -2;
+    if ((out == 0 || out == 1 || out == 3) && split != 1) return -2;
+    Dw256Args ga{};
     int tiles = 0;
     for (int p = 0; p < nprob; ++p) {
-        if (Ms[p] % 256 || Ns[p] % 256 || ((uintptr_t)dy[p] | (uintptr_t)x[p] | (uintptr_t)gw[p]) % 16) return -2;
-        ga.A[p] = (const bf16_t*)dy[p]; ga.B[p] = (const bf16_t*)x[p]; ga.C[p] = gw[p];
-        ga.M[p] = Ms[p]; ga.N[p] = Ns[p];
-        tiles += (Ms[p] / 256) * (Ns[p] / 256);
+        if (lda[p] % 8 || Mv[p] < 1 || Mv[p] > lda[p] || Ns[p] % 256 || ((uintptr_t)A[p] | (uintptr_t)B[p] | (uintptr_t)C[p]) % 16) return -2;
+        ga.A[p] = (const bf16_t*)A[p]; ga.B[p] = (const bf16_t*)B[p]; ga.C[p] = C[p];
+        ga.M[p] = lda[p]; ga.Mv[p] = Mv[p]; ga.N[p] = Ns[p];
+        tiles += (int)cdiv(Mv[p], 256) * (Ns[p] / 256);
         ga.tile_end[p] = tiles;
     }
-    for (int p = nprob; p < 4; ++p) { ga.tile_end[p] = tiles; ga.A[p] = ga.A[0]; ga.B[p] = ga.B[0]; ga.C[p] = ga.C[0]; ga.M[p] = ga.M[0]; ga.N[p] = ga.N[0]; }
-    ga.nprob = nprob; ga.K = (int)rows; ga.accumulate = split == 1 ? 1 : 2;       // 1: one slice, plain read-add-write; 2: atomics
-    static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_dw256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * D256_STAGE);
+    for (int p = nprob; p < 8; ++p) { ga.tile_end[p] = tiles; ga.A[p] = ga.A[0]; ga.B[p] = ga.B[0]; ga.C[p] = ga.C[0]; ga.M[p] = ga.M[0]; ga.Mv[p] = ga.Mv[0]; ga.N[p] = ga.N[0]; }
+    ga.nprob = nprob; ga.K = (int)rows; ga.out = out;
+    constexpr int LDS_BF16_EPI = 4 * 128 * 136 * 2;          // the bf16 epilogue parks four 128 x 128 quarters in rows of 136
+    constexpr int LDS_MAX = LDS_BF16_EPI > 4 * D256_STAGE ? LDS_BF16_EPI : 4 * D256_STAGE;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_dw256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
     if (attr != hipSuccess) return (int)attr;
+    const int lds_bytes = out == 3 ? LDS_MAX : 4 * D256_STAGE;
     ga.kchunk = (8 % split == 0 && tiles % (8 / split) == 0) ? split : 0;                 // slices pinned to XCD groups
-    if (ga.kchunk) hipLaunchKernelGGL(gemm_dw256_kernel, dim3(tiles * split), dim3(256), 4 * D256_STAGE, st, ga);
-    else hipLaunchKernelGGL(gemm_dw256_kernel, dim3(tiles, split), dim3(256), 4 * D256_STAGE, st, ga);
+    if (ga.kchunk) hipLaunchKernelGGL(gemm_dw256_kernel, dim3(tiles * split), dim3(256), lds_bytes, st, ga);
+    else hipLaunchKernelGGL(gemm_dw256_kernel, dim3(tiles, split), dim3(256), lds_bytes, st, ga);
     TAN_LAUNCH_CHECK();
     return 0;
+}
+
+// gw_p += dy_p^T x_p (the weight gradients of a block): one K slice adds in place, more add with atomics
+int gemm_dw256_grouped(int nprob, const void* const* dy, const void* const* x, float* const* gw, const int* Ms, const int* Ns,
+                       long rows, int split, hipStream_t st) {
+    if (nprob < 1 || nprob > 4) return -2;
+    for (int p = 0; p < nprob; ++p) if (Ms[p] % 256) return -2;
+    void* C[4];
+    for (int p = 0; p < nprob; ++p) C[p] = gw[p];
+    return gemm_atb256(nprob, dy, x, C, Ms, Ms, Ns, rows, split == 1 ? 1 : 2, split, st);
 }
 
 // The 4-stage / K-step-32 pipeline (three tiles in flight) pays for the K-strided x K-strided weight-gradient GEMMs once the K
@@ -911,3 +967,19 @@ int gemm_glds_try(const tan_gemm_desc* d, hipStream_t st) {
 }
 
 }  // namespace tal
+
+// C_p [M_p x N_p] (=|+=) A_p^T B_p, p < n <= 8: the 256 x 256-tile kernel above behind the C ABI (see include/tan_hip.h)
+extern "C" int tan_gemm_atb(int n, const void* const* A, const void* const* B, void* const* C, const int* lda, const int* M, const int* N,
+                            long K, int out_dtype, int accumulate, int split, void* stream) {
+    TAN_REQUIRE(n >= 1 && n <= 8 && A && B && C && lda && M && N && K > 0 && split >= 1);
+    int out;
+    if (out_dtype == TAN_BF16) { TAN_REQUIRE(!accumulate && split == 1); out = 3; }
+    else if (split > 1) { TAN_REQUIRE(accumulate); out = 2; }
+    else out = accumulate ? 1 : 0;
+    double work = 0;
+    for (int p = 0; p < n; ++p) work += 2.0 * (double)K * M[p] * N[p];
+    const int rec = tal::prof_begin((hipStream_t)stream, TAN_PROF_GEMM_BF16 + 3, work);
+    const int rc = tal::gemm_atb256(n, A, B, C, lda, M, N, K, out, split, (hipStream_t)stream);
+    tal::prof_end((hipStream_t)stream, rec);
+    return rc == -2 ? TAN_ERR_BAD_ARG : rc;
+}

@@ -35,6 +35,22 @@ def _stream():
     return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
+def gemm_atb(As, Bs, Cs, *, lda, M, N, K, accumulate=False, split=1):
+    """C_p [M_p, N_p] (=|+=) A_p^T B_p for up to eight problems (lists of tensors; A_p [K, lda_p], B_p [K, N_p] bf16 row-major, C_p f32
+    or bf16): tan_gemm_atb, the 256 x 256-tile kernel.  lda / M / N: ints (the same for every problem) or lists."""
+    if len(As) > 8:                                    # the kernel takes eight problems per launch
+        sl = lambda v, a, b: v if isinstance(v, int) else v[a:b]                        # noqa: E731
+        for a in range(0, len(As), 8):
+            gemm_atb(As[a:a + 8], Bs[a:a + 8], Cs[a:a + 8], lda=sl(lda, a, a + 8), M=sl(M, a, a + 8), N=sl(N, a, a + 8), K=K,
+                     accumulate=accumulate, split=split)
+        return
+    n = len(As)
+    ints = lambda v: (C.c_int * n)(*([v] * n if isinstance(v, int) else v))          # noqa: E731
+    ptrs = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])                    # noqa: E731
+    _lib.check(_lib.lib().tan_gemm_atb(n, ptrs(As), ptrs(Bs), ptrs(Cs), ints(lda), ints(M), ints(N), K, _dt(Cs[0]), int(accumulate),
+                                       split, _stream()), "tan_gemm_atb")
+
+
 def gemm(A, B, C_out, *, M, N, K, a_kc=True, b_kc=True, lda=None, ldb=None, ldc=None, bias=None, residual=None,
          ldr=None, act=ACT_NONE, aux=None, ldaux=None, accumulate=False, split_k=1, alpha=1.0, batch=1,
          sA=0, sB=0, sC=0, colsum=None):

@@ -208,3 +208,40 @@ def test_gemm_long_contraction_accumulate(M, N, K):
     ref = C0.double() + A.double().t() @ B.double()
     err = (C.double() - ref).abs().max().item()
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("K,Ms,N,out,split", [(256, [256], 256, "f32", 1), (512, [300, 256, 40], 512, "f32", 2), (1280, [8192], 512, "bf16", 1),
+                                             (384, [520] * 6, 256, "bf16", 1), (2048, [1344] * 2, 512, "f32", 4), (128, [64] * 9, 256, "f32", 1)])
+def test_gemm_atb_matches_torch(K, Ms, N, out, split):
+    """tan_gemm_atb: C_p = A_p^T B_p on the 256 x 256-tile kernel -- ragged M (the last tile reads past the rows: padded buffer),
+    several problems per launch, f32 store / in-place add / K slices through atomics, bf16 store."""
+    from temporalalignnet_amd import ops
+    torch.manual_seed(K + len(Ms))
+    n = len(Ms)
+    As, Bs, Cs, refs = [], [], [], []
+    for M in Ms:
+        lda = (M + 7) // 8 * 8
+        buf = torch.zeros(K * lda + 256, device="cuda", dtype=torch.bfloat16)
+        A = buf[:K * lda].view(K, lda)
+        A.copy_((torch.randn(K, lda, device="cuda") * K ** -0.5).bfloat16())
+        B = torch.randn(K, N, device="cuda").bfloat16()
+        As.append(A); Bs.append(B)
+        refs.append(A[:, :M].double().t() @ B.double())
+    ldas = [a.shape[1] for a in As]
+    if out == "bf16":
+        Cs = [torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16) for M in Ms]
+        ops.gemm_atb(As, Bs, Cs, lda=ldas, M=Ms, N=N, K=K)
+        for c, r in zip(Cs, refs):
+            assert torch.isfinite(c.float()).all()
+            assert (c.double() - r).abs().max().item() <= 2.0 ** -7 * r.abs().max().item() + 1e-6
+    else:
+        init = [torch.randn(M, N, device="cuda") for M in Ms]
+        Cs = [c.clone() for c in init]
+        ops.gemm_atb(As, Bs, Cs, lda=ldas, M=Ms, N=N, K=K, accumulate=True, split=split)
+        for c, c0, r in zip(Cs, init, refs):
+            assert (c.double() - (c0.double() + r)).abs().max().item() <= 2e-4 * max(1.0, r.abs().max().item())
+        if split == 1:
+            Cs = [torch.full((M, N), float("nan"), device="cuda") for M in Ms]
+            ops.gemm_atb(As, Bs, Cs, lda=ldas, M=Ms, N=N, K=K)
+            for c, r in zip(Cs, refs):
+                assert (c.double() - r).abs().max().item() <= 2e-4 * max(1.0, r.abs().max().item())
