@@ -133,7 +133,7 @@ def traffic_profile(stage, batch_size, seq_len):
     tag = {(1, 128, 64): "", (2, 128, 64): "stage2_b128_", (1, 32, 256): "cfg4_len256_b32_"}.get((stage, batch_size, seq_len))
     if tag is None:
         return None
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         rel = f"profiles/{rnd}_{tag}pmc_traffic.json"
         path = os.path.join(ROOT, rel)
         if os.path.exists(path):

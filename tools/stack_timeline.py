@@ -1,5 +1,7 @@
 """Where a training step's GPU time is: events on the stream each piece is issued on (the two encoder stacks run on two HIP streams),
-relative to the step's start, averaged over steps.  Tool only.  usage: python tools/stack_timeline.py [--stage 2]"""
+relative to the step's start, averaged over steps.  The steps are NOT synchronised (the host runs ahead as in bench.py's loop; events are
+read after the last step): `step:begin` of step k fires when the main stream has finished step k-1's optimizer launch.
+Tool only.  usage: python tools/stack_timeline.py [--stage 2] [--sync]   (--sync: host waits for every step -- the round-3 behaviour)"""
 import os
 import sys
 import threading
@@ -71,15 +73,21 @@ for _ in range(5):
 torch.cuda.synchronize()
 N = 20
 acc = {}
+per_step = []
 for _ in range(N):
     marks.clear()
     ev("step:begin")
     tr.step(b)
     ev("step:end")
-    torch.cuda.synchronize()
-    t0 = marks[0][1]
-    for tag, e in marks[1:]:
+    if "--sync" in sys.argv:
+        torch.cuda.synchronize()
+    per_step.append(list(marks))
+torch.cuda.synchronize()
+for ms in per_step[3:]:              # (the first steps after the warm-up sync are host-bound)
+    t0 = ms[0][1]
+    for tag, e in ms[1:]:
         acc.setdefault(tag, []).append(t0.elapsed_time(e))
+N = len(per_step) - 3
 print(f"stage {stage}: GPU time since the step's first event [ms], mean of {N} steps")
 for tag, v in sorted(acc.items(), key=lambda kv: sum(kv[1]) / len(kv[1])):
     print(f"{sum(v) / len(v):7.3f}  {tag}")
