@@ -381,3 +381,4 @@ def test_mlp_bwd_rejects_what_it_cannot_do():
     assert _lib.lib().tan_mlp_bwd(C.byref(d), ops._stream()) == -1
     d.rows = 100
     assert _lib.lib().tan_mlp_bwd(C.byref(d), ops._stream()) == -1
+
