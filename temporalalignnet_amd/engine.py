@@ -636,6 +636,82 @@ class _AlignerEngine(_WorkspaceMixin):
             self._release_ws(run.pop("em"))
         return run
 
+    # ------------------------------------------------------------------ forward + backward as two independent chains (no autograd)
+    def _chains_ok(self, video, lang, itp=None):
+        return (self.compute_dtype == torch.bfloat16 and self._embed_fused_ok(video, lang, itp) and not self.use_alignability_head
+                and self._side_stream(video.device) is not None and self._grad_ready_hook is None)
+
+    def _run_chains(self, video, lang, vmask_u8, tmask_u8, family):
+        """Forward AND backward of the aligner under a loss that separates into a dual and a joint term (stage 1: train/loss.py:359-373,
+        loss = (loss_dual + loss_joint) / 2 with batch-independent weights) as TWO chains that never wait for each other:
+            main stream:  video stack forward -> unit features -> family("dual") -> their backward -> video stack backward
+            side stream:  joint stack forward -> unit features -> family("joint") -> their backward -> joint stack backward
+        joined only in front of the embeddings' backward.  Under autograd (`_run_forward` / get_loss / `_run_backward`) every backward
+        kernel waits for the LAST forward kernel: the video stack's backward could not start before the joint stack's forward, the
+        joint similarity sweep and its ~12 small launches were through -- 0.6 ms in which the chip runs one stack's kernels or less.
+        `family(which, vn, tn) -> (v_terms, t_terms, d_vn, d_tn)` runs a family's similarity + NCE forward and backward on the current
+        stream (the upstream gradients of its terms depend on masks only).  Parameter gradients land in the flat gradient buffer as in
+        `_run_backward`.  Returns (v_d, t_d, v_j, t_j)."""
+        self._ensure_flat()
+        self._bind_grads()
+        f = self._flat
+        B, T, _ = video.shape
+        N = lang.shape[1]
+        cd, dev = self.compute_dtype, video.device
+        Se, Sd, Cw = self.num_encoder_layers, self.num_decoder_layers, WIDTH
+        R, Mp, L = B * T, B * N, T + N
+        p_v = self._draw(T, None)
+        p_t = self._draw(N, None) if self.use_text_pos_enc else 0
+        p_j = self._draw(T, None)
+        f.sync_shadow_t()
+        f.sync_shadow_tp()
+        fe = self._embed_fused(video, lang, vmask_u8, tmask_u8, p_v, p_t, p_j, True)
+        em = fe["em"]
+        vn_d = torch.empty(Se, R, Cw, dtype=cd, device=dev)
+        tn_d = torch.empty(1, Mp, Cw, dtype=cd, device=dev)
+        inv = _Blocks(torch.float32, dev, {"vd": Se * R, "vj": Sd * R, "td": Mp, "tj": Sd * Mp})
+        dst_v = torch.empty(Se, R, Cw, dtype=cd, device=dev)
+        d_lang_raw = torch.empty(Mp, Cw, dtype=cd, device=dev)
+        d_x0 = torch.empty(R, Cw, dtype=cd, device=dev)
+        main, side = torch.cuda.current_stream(), self._side_stream(dev)
+        side.wait_stream(main)
+
+        def joint_chain():
+            vn_j = torch.empty(Sd, R, Cw, dtype=cd, device=dev)
+            tn_j = torch.empty(Sd, Mp, Cw, dtype=cd, device=dev)
+            dst_j = torch.empty(Sd, B * L, Cw, dtype=cd, device=dev)
+            d_xj = torch.empty(B * L, Cw, dtype=cd, device=dev)
+            ej = self._run_joint_stack(None, None, vmask_u8, tmask_u8, B, T, N, True, pre=(fe["ej"], fe["xj"], fe["keypad"]))
+            stages = [ej.stage(s) for s in range(Sd)]
+            ops.l2norm_fwd_multi(stages, vn_j, inv["vj"], R, Cw, T, L, 0)
+            ops.l2norm_fwd_multi(stages, tn_j, inv["tj"], Mp, Cw, N, L, T)
+            v_j, t_j, d_vn_j, d_tn_j = family("joint", vn_j, tn_j)
+            dj = [dst_j[s] for s in range(Sd)]
+            ops.l2norm_bwd_multi(d_vn_j, vn_j, inv["vj"], dj, R, Cw, T, L, 0)
+            ops.l2norm_bwd_multi(d_tn_j, tn_j, inv["tj"], dj, Mp, Cw, N, L, T)
+            self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dj, d_xj)
+            return ej, v_j, t_j, d_xj, (vn_j, tn_j, dst_j)
+        fut = self._on_side(side, joint_chain)
+        ev = self._run_video_stack(fe["x0"], vmask_u8, B, T, True, er=fe["ev"])
+        ops.l2norm_fwd_multi([ev.stage(s) for s in range(Se)], vn_d, inv["vd"], R, Cw)
+        ops.l2norm_fwd(fe["lang_raw"], tn_d[0], inv["td"], Mp, Cw)
+        v_d, t_d, d_vn_d, d_tn_d = family("dual", vn_d, tn_d)
+        dv = [dst_v[s] for s in range(Se)]
+        ops.l2norm_bwd_multi(d_vn_d, vn_d, inv["vd"], dv, R, Cw)
+        ops.l2norm_bwd(d_tn_d.view(Mp, Cw), tn_d[0], inv["td"], d_lang_raw, Mp, Cw)
+        self._encoder_bwd(ev, fe["x0"], vmask_u8, "ln_video_post_enc", dv, d_x0)
+        ej, v_j, t_j, d_xj, keep = fut.result()
+        main.wait_stream(side)
+        for t in (d_xj,) + keep:                 # allocated under the side stream, read (or freed) under this one
+            t.record_stream(main)
+        run = {"em": em, "B": B, "T": T, "N": N, "sv_video": fe["sv_video"], "sv_video_j": fe["sv_video_j"], "sv_text": fe["sv_text"],
+               "sv_text_t": fe["sv_text_t"]}
+        self._embed_bwd_fused(run, d_x0, d_xj, d_lang_raw, False)
+        self._release_ws(ev)
+        self._release_ws(ej)
+        self._release_ws(em)
+        return v_d, t_d, v_j, t_j
+
     # ------------------------------------------------------------------ the HIP backward
     def _run_backward(self, run, grads, need_d_lang):
         self._bind_grads()

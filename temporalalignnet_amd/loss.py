@@ -320,6 +320,40 @@ class _FusedNCEFn(torch.autograd.Function):
         return d_vn, d_tn, None, None, None, None, None, None, None
 
 
+class _ManualCtx:
+    """Stand-in for the autograd context of _FusedNCEFn / _NCETail when their forward and backward are driven by hand (Trainer's
+    two-chain step)."""
+    needs_input_grad = (True, True)
+
+    def set_materialize_grads(self, flag):
+        pass
+
+
+def nce_family(vn, tn, tgt, col_invalid, B, T, N, nv, g_v, g_t):
+    """Similarity + multi-positive NCE of ONE family, forward and backward back to back on the current stream (loss.py:240-253 and its
+    autograd): -> (v_terms, t_terms, d_vn, d_tn).  g_v [S, R] / g_t [S, Mc]: d loss / d terms (`nce_term_grads`)."""
+    ctx = _ManualCtx()
+    v_terms, t_terms = _FusedNCEFn.forward(ctx, vn, tn, tgt, col_invalid, None, B, T, N, nv)
+    d_vn, d_tn = _FusedNCEFn.backward(ctx, g_v, g_t)[:2]
+    return v_terms, t_terms, d_vn, d_tn
+
+
+def nce_term_grads(rows_mask, cols_mask, Sd, Sj):
+    """d loss_mean / d (v_d, t_d, v_j, t_j) of _NCETail for loss = (loss_dual + loss_joint) / 2 (loss.py:254-275,359-373): a function of
+    the two masks alone (mean weights 1 / (S count)), so it is known before any similarity is -- what lets a family's backward start
+    as soon as its own forward is through.  -> (g_v_d, g_t_d, g_v_j, g_t_j, counts)."""
+    dev = rows_mask.device
+    R, M = rows_mask.shape[0], cols_mask.shape[0]
+    counts = torch.stack([rows_mask.sum(), cols_mask.sum()])
+    one = torch.ones(1, device=dev)
+    g_v_d, g_t_d = torch.empty(Sd, R, device=dev), torch.empty(Sd, M, device=dev)
+    g_v_j, g_t_j = torch.empty(Sj, R, device=dev), torch.empty(Sj, M, device=dev)
+    _lib.check(_lib.lib().tan_nce_tail_bwd(None, None, _p(one), _p(rows_mask), _p(cols_mask), _p(counts), C.c_int(Sd), C.c_int(Sj),
+                                           C.c_long(R), C.c_long(M), _p(g_v_d), _p(g_t_d), _p(g_v_j), _p(g_t_j), ops._stream()),
+               "tan_nce_tail_bwd")
+    return g_v_d, g_t_d, g_v_j, g_t_j, counts
+
+
 _SIDE = {}
 
 

@@ -268,6 +268,8 @@ class Trainer:
                 if self.global_negatives:
                     raise _lib.TanHipError(f"global_negatives: {Bn}x{Nn} text columns per rank exceed the fused sweep's limit")
                 fused = False
+        if self._chains_eligible(batch, fused):
+            return self._forward_backward_chains(batch)
         if batch["video"].is_cuda:
             # what get_loss derives from the batch alone (masks, targets, column compaction: ~20 tiny launches) runs on the loss
             # side stream next to the forward instead of between the stacks and the similarity sweeps
@@ -301,6 +303,52 @@ class Trainer:
             self._zero_ev = None
         loss_dict["loss"].backward()
         return loss_dict
+
+    def _chains_eligible(self, batch, fused):
+        """Stage 1 ('init': multi-positive NCE only, train/readme.md:10) on the fused bf16 path with rank-local negatives: the loss is
+        (loss_dual + loss_joint) / 2 with weights that depend on the batch's masks only, so the step runs as two chains that never wait
+        for each other (`_AlignerEngine._run_chains`) instead of forward -> loss -> backward under autograd.  TAN_STEP_CHAINS=0: autograd."""
+        a = self.args
+        return (bool(fused) and not self.twin and a.model == "init" and not a.learn_agreement and a.loss_threshold <= 0
+                and not a.use_alignability_head and a.optim_policy != "bce" and not self.global_negatives and "token" not in batch
+                and batch["video"].is_cuda and not batch["text_embed"].requires_grad and os.environ.get("TAN_STEP_CHAINS", "1") != "0"
+                and not (dist.active() and self.ddp_mode != "flat")
+                and self.online._chains_ok(batch["video"], batch["text_embed"]))
+
+    def _forward_backward_chains(self, batch):
+        from .loss import _ManualCtx, _NCETail, nce_family, nce_term_grads, prepare_inputs_async
+        a, m = self.args, self.online
+        video, lang = batch["video"], batch["text_embed"]
+        B, T = video.shape[:2]
+        N = lang.shape[1]
+        dev = video.device
+        Se, Sd = m.num_encoder_layers, m.num_decoder_layers
+        main = torch.cuda.current_stream()
+        # everything the loss derives from the batch alone, incl. the gradients of the NCE terms, on the loss side stream
+        prep = prepare_inputs_async(batch, batch["padding_mask"], batch["text_padding_mask"], T, N, dev, a, batch.get("n_text"),
+                                    want_compaction=True)
+        from .loss import _side_stream
+        ls = _side_stream(dev)
+        with torch.cuda.stream(ls):
+            nv = prep.get("nv")
+            cols_tail = prep["cols_pos_c"] if nv is not None else prep["cols_pos"]
+            g_v_d, g_t_d, g_v_j, g_t_j, _ = nce_term_grads(prep["rows_pos"], cols_tail, Se, Sd)
+            ready = ls.record_event()
+        tgt, ci = prep["tgt"], prep["tpad_u8"].view(B * N)
+
+        def family(which, vn, tn):
+            torch.cuda.current_stream().wait_event(ready)          # (a finished event costs nothing)
+            gv, gt = (g_v_d, g_t_d) if which == "dual" else (g_v_j, g_t_j)
+            return nce_family(vn, tn, tgt, ci, B, T, N, nv, gv, gt)
+        if self._zero_ev is not None:                  # the gradient buffer's fill ran on a side stream
+            main.wait_event(self._zero_ev)
+            self._zero_ev = None
+        tp_bool = batch["_text_pad_bool"] if batch.get("_text_pad_bool") is not None else batch["text_padding_mask"].bool()
+        v_d, t_d, v_j, t_j = m._run_chains(video, lang, m._mask_u8(batch["padding_mask"]), m._mask_u8(tp_bool), family)
+        for t in (g_v_d, g_t_d, g_v_j, g_t_j, cols_tail, prep["rows_pos"], v_j, t_j):
+            t.record_stream(main)
+        loss_dual, loss_joint, loss_mean = _NCETail.forward(_ManualCtx(), v_d, t_d, v_j, t_j, prep["rows_pos"], cols_tail, None)
+        return {"loss-dual": loss_dual, "loss-joint": loss_joint, "loss": loss_mean}
 
     def _lm_allreduce(self):
         """Sum the language model's gradients over ranks in ONE bucket (they live outside the flat buffer).  Must run before

@@ -116,3 +116,34 @@ def test_step_boundary_options_do_not_change_the_arithmetic(monkeypatch, model_k
             assert (flats[tag][1] - ref[1]).abs().max().item() <= 3.5e-3, tag
     moved = (ref[0] - _trainer(seed=3, dtype="bf16", **kw)[0].online.flat_parameters()).abs().max().item()
     assert moved > 1e-3                       # (the three steps did something)
+
+
+@pytest.mark.parametrize("random_pos", [0, 1])
+def test_two_chain_step_matches_the_autograd_step(monkeypatch, random_pos):
+    """Stage 1 in bf16: `Trainer.forward_backward` as two chains that never wait for each other (video stack + dual NCE, joint stack + joint
+    NCE, each forward AND backward on its own stream: `_run_chains`) against forward -> get_loss -> loss.backward() under autograd
+    (TAN_STEP_CHAINS=0): same kernels on the same values -- loss scalars equal, every parameter gradient equal up to the order of the
+    f32 atomics."""
+    import numpy as np
+    outs = {}
+    for tag, env in (("autograd", "0"), ("chains", "1")):
+        monkeypatch.setenv("TAN_STEP_CHAINS", env)
+        tr, _ = _trainer(seed=5, dtype="bf16", model="init")
+        tr.online.random_pos_start = random_pos
+        b = _batch(77, B=8, T=64)
+        b["padding_mask"][2, -6:] = True
+        assert tr._chains_eligible(b, tr.fused_loss) == (env == "1")
+        np.random.seed(3)
+        tr.zero_grad()
+        ld = tr.forward_backward(b)
+        torch.cuda.synchronize()
+        outs[tag] = ({k: float(ld[k]) for k in ("loss", "loss-dual", "loss-joint")}, tr.online.flat_grad().clone(), tr.online._flat)
+    (l0, g0, f), (l1, g1, _) = outs["autograd"], outs["chains"]
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 1e-5 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
+    assert torch.isfinite(g1).all() and g0.abs().max() > 0
+    assert (g1 - g0).norm() <= 2e-3 * g0.norm()
+    for n in f.names:
+        o, k, _ = f.off[n]
+        a, c = g1[o:o + k], g0[o:o + k]
+        assert (a - c).norm() <= 2e-2 * c.norm() + 1e-7, (n, float((a - c).norm()), float(c.norm()))
