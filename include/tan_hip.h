@@ -324,6 +324,9 @@ typedef struct tan_adamw_images_desc {
     const tan_image_entry* table; const long* unit_prefix; int n_entries; long n_units;
     void *p_packed, *p_t, *p_tpacked, *ema_packed;
     const int* rest_idx; long n_rest;
+    long unit_begin, unit_end;   /* only the table's units [unit_begin, unit_end) (unit_end == 0: to n_units): a step may update the matrices whose
+                                    gradients are final early -- e.g. one stack's while the other's backward still runs -- and the rest,
+                                    with rest_idx, in a second call */
 } tan_adamw_images_desc;
 int tan_adamw_step_images(const tan_adamw_images_desc* d, void* stream);
 /* target = m*target + (1-m)*online  (TwinTemporalAligner._momentum_update, tan_model.py:339-344) */

@@ -126,7 +126,7 @@ class AdamwImagesDesc(C.Structure):
         ("p_bf16", C.c_void_p), ("ema", C.c_void_p), ("ema_m", C.c_float), ("ema_bf16", C.c_void_p),
         ("table", C.c_void_p), ("unit_prefix", C.c_void_p), ("n_entries", C.c_int), ("n_units", C.c_long),
         ("p_packed", C.c_void_p), ("p_t", C.c_void_p), ("p_tpacked", C.c_void_p), ("ema_packed", C.c_void_p),
-        ("rest_idx", C.c_void_p), ("n_rest", C.c_long),
+        ("rest_idx", C.c_void_p), ("n_rest", C.c_long), ("unit_begin", C.c_long), ("unit_end", C.c_long),
     ]
 
 

@@ -110,6 +110,7 @@ struct ImgArgs {
     bf16_t* p_lowp; float* ema; float ema_m; bf16_t* ema_lowp;
     const tan_image_entry* table; const long* unit_prefix; int n_entries; long n_units;
     bf16_t *p_packed, *p_t, *p_tpacked, *ema_packed;
+    long unit_begin;
 };
 
 // element offset of the 1-KiB fragment (32 rows x 16 cols at (row0, col0)) of a [rows][cols] matrix packed in tiles [TN][TK]
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void adamw_images_kernel(const ImgArgs A) {
     char* rm = lds;
     char* tr = lds + 64 * IMG_PITCH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long u = blockIdx.x;
+    const long u = A.unit_begin + blockIdx.x;
     int lo = 0, hi = A.n_entries;                         // entry whose unit range holds u (block-uniform binary search)
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (A.unit_prefix[mid] <= u) lo = mid; else hi = mid; }
     const tan_image_entry e = A.table[lo];
@@ -286,9 +287,14 @@ extern "C" int tan_adamw_step_images(const tan_adamw_images_desc* d, void* strea
     A.table = d->table; A.unit_prefix = d->unit_prefix; A.n_entries = d->n_entries; A.n_units = d->n_units;
     A.p_packed = (bf16_t*)d->p_packed; A.p_t = (bf16_t*)d->p_t; A.p_tpacked = (bf16_t*)d->p_tpacked; A.ema_packed = (bf16_t*)d->ema_packed;
     hipStream_t st = (hipStream_t)stream;
-    const unsigned grid = (unsigned)d->n_units;                 // one 64 x 64 block per workgroup
-    hipLaunchKernelGGL(adamw_images_kernel, dim3(grid), dim3(256), 0, st, A);
-    TAN_LAUNCH_CHECK();
+    // one 64 x 64 block per workgroup; [unit_begin, unit_end) of the table's units (unit_end == 0: all of them)
+    const long u1 = d->unit_end > 0 ? d->unit_end : d->n_units;
+    TAN_REQUIRE(d->unit_begin >= 0 && d->unit_begin <= u1 && u1 <= d->n_units);
+    A.unit_begin = d->unit_begin;
+    if (u1 > d->unit_begin) {
+        hipLaunchKernelGGL(adamw_images_kernel, dim3((unsigned)(u1 - d->unit_begin)), dim3(256), 0, st, A);
+        TAN_LAUNCH_CHECK();
+    }
     if (d->n_rest <= 0) return 0;
     const unsigned grid2 = (unsigned)min((long)8192, (long)cdiv(d->n_rest, 256));
     hipLaunchKernelGGL(adamw_rest_kernel, dim3(grid2), dim3(256), 0, st, d->p, d->g, d->m, d->v, d->mode, d->rest_idx, d->n_rest, A.decay, A.w1, A.beta2, A.w2,

@@ -641,7 +641,7 @@ class _AlignerEngine(_WorkspaceMixin):
         return (self.compute_dtype == torch.bfloat16 and self._embed_fused_ok(video, lang, itp) and not self.use_alignability_head
                 and self._side_stream(video.device) is not None and self._grad_ready_hook is None)
 
-    def _run_chains(self, video, lang, vmask_u8, tmask_u8, family):
+    def _run_chains(self, video, lang, vmask_u8, tmask_u8, family, after_video_bwd=None):
         """Forward AND backward of the aligner under a loss that separates into a dual and a joint term (stage 1: train/loss.py:359-373,
         loss = (loss_dual + loss_joint) / 2 with batch-independent weights) as TWO chains that never wait for each other:
             main stream:  video stack forward -> unit features -> family("dual") -> their backward -> video stack backward
@@ -700,6 +700,8 @@ class _AlignerEngine(_WorkspaceMixin):
         ops.l2norm_bwd_multi(d_vn_d, vn_d, inv["vd"], dv, R, Cw)
         ops.l2norm_bwd(d_tn_d.view(Mp, Cw), tn_d[0], inv["td"], d_lang_raw, Mp, Cw)
         self._encoder_bwd(ev, fe["x0"], vmask_u8, "ln_video_post_enc", dv, d_x0)
+        if after_video_bwd is not None:          # every gradient of the video stack's blocks is final (enqueued) here
+            after_video_bwd()
         ej, v_j, t_j, d_xj, keep = fut.result()
         main.wait_stream(side)
         for t in (d_xj,) + keep:                 # allocated under the side stream, read (or freed) under this one

@@ -117,6 +117,10 @@ class _Flat:
             dev = self.shadow.device
             tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
             pre_t = torch.from_numpy(np.asarray(prefix, dtype=np.int64)).to(dev)
+            # (units of the video stack's matrices come first: `Trainer` may update them before the joint stack's backward is through)
+            n_video = sum(1 for n in mats if n.startswith("video_temporal_encoder."))
+            assert all(n.startswith("video_temporal_encoder.") for n in mats[:n_video])
+            self.video_units = prefix[n_video]
             self._image_table = (tab, pre_t, len(ents), prefix[-1], ranges)
         return self._image_table
 

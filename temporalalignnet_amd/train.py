@@ -344,7 +344,10 @@ class Trainer:
             main.wait_event(self._zero_ev)
             self._zero_ev = None
         tp_bool = batch["_text_pad_bool"] if batch.get("_text_pad_bool") is not None else batch["text_padding_mask"].bool()
-        v_d, t_d, v_j, t_j = m._run_chains(video, lang, m._mask_u8(batch["padding_mask"]), m._mask_u8(tp_bool), family)
+        early = None
+        if os.environ.get("TAN_OPT_EARLY", "1") != "0" and getattr(self, "_in_step", False):
+            early = lambda: self.early_video_update(1.0 / dist.world_size())       # noqa: E731
+        v_d, t_d, v_j, t_j = m._run_chains(video, lang, m._mask_u8(batch["padding_mask"]), m._mask_u8(tp_bool), family, early)
         for t in (g_v_d, g_t_d, g_v_j, g_t_j, cols_tail, prep["rows_pos"], v_j, t_j):
             t.record_stream(main)
         loss_dual, loss_joint, loss_mean = _NCETail.forward(_ManualCtx(), v_d, t_d, v_j, t_j, prep["rows_pos"], cols_tail, None)
@@ -389,7 +392,8 @@ class Trainer:
         ema = self.model.target._ensure_flat() if self.twin else None
         self.iteration += 1
         if self._images_in_optimizer(f, ema):
-            self._adamw_images(f, st, ema, grad_scale)
+            u0 = self.__dict__.pop("_early_units", 0)        # units `early_video_update` already stepped (same step count, lr, grad_scale)
+            self._adamw_images(f, st, ema, grad_scale, units=(u0, 0) if u0 else None)
             self._lm_step(grad_scale)
             return
         _lib.check(_lib.lib().tan_adamw_step(
@@ -411,7 +415,8 @@ class Trainer:
         return (f.shadow is not None and on.panel_kernels and on.transposed_dx and os.environ.get("TAN_OPT_IMAGES", "1") != "0"
                 and (ema is None or (ema.shadow is not None and self.model.target.panel_kernels)))
 
-    def _adamw_images(self, f, st, ema, grad_scale):
+    def _adamw_images(self, f, st, ema, grad_scale, units=None, rest=True, step=None):
+        """units = (u0, u1): only those units of the image table (see `early_video_update`); rest: also everything outside the matrices."""
         tab, prefix, n_ent, n_units, ranges = f.image_table()
         if "rest_idx" not in st:                 # every element outside the matrices: the plain kernel's work list
             own = torch.zeros(f.total, dtype=torch.bool, device=f.flat.device)
@@ -424,17 +429,31 @@ class Trainer:
         d.p, d.g, d.m, d.v, d.mode = (t.data_ptr() for t in (f.flat, f.grad, st["m"], st["v"], st["mode"]))
         d.n = f.total
         d.lr, d.beta1, d.beta2, d.eps, d.weight_decay = self.current_lr(), self.betas[0], self.betas[1], self.eps, self.args.wd
-        d.step, d.grad_scale = self.iteration, grad_scale
+        d.step, d.grad_scale = (self.iteration if step is None else step), grad_scale
         d.p_bf16 = f.shadow.data_ptr()
         d.table, d.unit_prefix, d.n_entries, d.n_units = tab.data_ptr(), prefix.data_ptr(), n_ent, n_units
         d.p_packed, d.p_t, d.p_tpacked = f.shadow_p.data_ptr(), f.shadow_t.data_ptr(), f.shadow_tp.data_ptr()
-        d.rest_idx, d.n_rest = st["rest_idx"].data_ptr(), st["rest_idx"].numel()
+        d.rest_idx, d.n_rest = st["rest_idx"].data_ptr(), (st["rest_idx"].numel() if rest else 0)
+        if units is not None:
+            d.unit_begin, d.unit_end = units
         if ema is not None:
             d.ema, d.ema_m, d.ema_bf16, d.ema_packed = ema.flat.data_ptr(), self.model.m, ema.shadow.data_ptr(), ema.shadow_p.data_ptr()
         _lib.check(_lib.lib().tan_adamw_step_images(C.byref(d), ops._stream()), "tan_adamw_step_images")
-        f.images_rewritten()
-        if ema is not None:
-            ema.images_rewritten(transposes=False)
+        if rest:                                 # (the call that completes the step)
+            f.images_rewritten()
+            if ema is not None:
+                ema.images_rewritten(transposes=False)
+
+    def early_video_update(self, grad_scale):
+        """Two-chain step: the video stack's backward is enqueued and its chain (main stream) would idle until the joint chain is
+        through (~0.3 ms) -- AdamW + weight images of the video stack's matrices run there, under the joint stack's last layers
+        (HBM-bound next to MFMA-bound kernels); `optimizer_step` then updates everything else."""
+        f, st = self._ensure_state()
+        if not self._images_in_optimizer(f, None) or self.args.clip_grad > 0 or dist.active() or self._accum_open:
+            return
+        f.image_table()
+        self._early_units = f.video_units
+        self._adamw_images(f, st, None, grad_scale, units=(0, f.video_units), rest=False, step=self.iteration + 1)
 
     def train_iteration(self, batch, idx):
         """One iteration of the reference loop INCLUDING its gradient accumulation (train/main.py:112-139): backward every
@@ -521,10 +540,12 @@ class Trainer:
                     if work is not None:
                         pending.append(work)
             self.online._grad_ready_hook = hook
+        self._in_step = True                   # (forward_backward may hand finished gradients to the optimizer early: only inside step)
         try:
             loss_dict = self.forward_backward(batch)
         finally:
             self.online._grad_ready_hook = None
+            self._in_step = False
         if dist.active():
             ev = None
             if self.time_comm:

@@ -93,8 +93,11 @@ def test_step_boundary_options_do_not_change_the_arithmetic(monkeypatch, model_k
     kw = dict(model=model_kind, **({"loss_threshold": 0.5} if model_kind == "cotrain" else {}))
     batches = [_batch(40 + i, B=8, T=64) for i in range(3)]
     flats = {}
-    for tag, env in (("plain", {"TAN_OPT_IMAGES": "0", "TAN_EMBED_FUSED": "0"}), ("images", {"TAN_OPT_IMAGES": "1", "TAN_EMBED_FUSED": "0"}),
-                     ("fused", {"TAN_OPT_IMAGES": "1", "TAN_EMBED_FUSED": "1"})):
+    # (stage 1 additionally: the two-chain step with the video stack's AdamW issued under the joint stack's backward -- the defaults)
+    for tag, env in (("plain", {"TAN_OPT_IMAGES": "0", "TAN_EMBED_FUSED": "0", "TAN_STEP_CHAINS": "0", "TAN_OPT_EARLY": "0"}),
+                     ("images", {"TAN_OPT_IMAGES": "1", "TAN_EMBED_FUSED": "0", "TAN_STEP_CHAINS": "0", "TAN_OPT_EARLY": "0"}),
+                     ("chains", {"TAN_OPT_IMAGES": "1", "TAN_EMBED_FUSED": "1", "TAN_STEP_CHAINS": "1", "TAN_OPT_EARLY": "0"}),
+                     ("fused", {"TAN_OPT_IMAGES": "1", "TAN_EMBED_FUSED": "1", "TAN_STEP_CHAINS": "1", "TAN_OPT_EARLY": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         tr, _ = _trainer(seed=3, dtype="bf16", **kw)
@@ -107,7 +110,7 @@ def test_step_boundary_options_do_not_change_the_arithmetic(monkeypatch, model_k
         flats[tag] = (tr.online.flat_parameters().clone(), tr.model.target.flat_parameters().clone() if model_kind == "cotrain" else None)
     ref = flats["plain"]
     assert torch.isfinite(ref[0]).all()
-    for tag in ("images", "fused"):
+    for tag in ("images", "chains", "fused"):
         d = (flats[tag][0] - ref[0]).abs()
         # Adam turns atomics-order noise on ~zero gradients into lr-sized (1e-3) updates of a few elements: bounded by the three steps' total
         # (the fused front-end adds the position rows in f32 instead of bf16: rounding-level input differences on top of the atomics)
