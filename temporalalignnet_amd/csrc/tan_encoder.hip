@@ -306,6 +306,14 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         {                   // dx, scr_dh, dx2, scr_dqkv are all still intact here (LN1 backward below overwrites dx)
             const DwItem items[4] = {{scr_dh, b.xn2, p.g_w_fc, 4 * C, C}, {dx, b.h_act, p.g_w_proj, C, 4 * C},
                                      {scr_dqkv, b.xn1, p.g_w_qkv, 3 * C, C}, {dx2, b.attn_o, p.g_w_out, C, C}};
+            if (i == 0 && e->dw0_stream && e->dw0_stream != st) {
+                // block 0: nothing of this stack's backward depends on its weight gradients, and nothing overwrites their operands any more
+                static thread_local hipEvent_t ev = nullptr;
+                if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return -3;
+                if (hipEventRecord(ev, (hipStream_t)st) != hipSuccess) return -3;
+                if (hipStreamWaitEvent((hipStream_t)e->dw0_stream, ev, 0) != hipSuccess) return -3;
+                CK(linear_bwd_w_group(dt, items, 4, R, e->dw_ws, e->dw_ws_floats, e->dw0_stream));
+            } else
             CK(linear_bwd_w_group(dt, items, 4, R, e->dw_ws, e->dw_ws_floats, st));
         }
         void* dx_in = i == 0 ? e->d_x0 : e->scr_dx;

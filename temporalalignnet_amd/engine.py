@@ -112,7 +112,7 @@ class _AlignerEngine(_WorkspaceMixin):
             cache[prefix] = evs
         return evs
 
-    def _encoder_bwd(self, er, x0, keypad, post_name, d_stage, d_x0):
+    def _encoder_bwd(self, er, x0, keypad, post_name, d_stage, d_x0, dw0_stream=None):
         cd, dev, R = x0.dtype, x0.device, er.R
         d = self._enc_desc(er, x0, keypad, post_name)
         self._flat.join_images()
@@ -128,6 +128,8 @@ class _AlignerEngine(_WorkspaceMixin):
         arr = (C.c_void_p * er.layers)(*[(t.data_ptr() if t is not None else None) for t in d_stage])
         d.d_stage = arr
         d.d_x0 = _vp(d_x0)
+        if dw0_stream is not None:         # block 0's weight gradients off the chain (the caller joins that stream)
+            d.dw0_stream = C.c_void_p(dw0_stream.cuda_stream)
         _lib.check(_lib.lib().tan_encoder_bwd(C.byref(d), ops._stream()), "tan_encoder_bwd")
 
     # ------------------------------------------------------------------ embedding front-ends
@@ -675,6 +677,11 @@ class _AlignerEngine(_WorkspaceMixin):
         d_x0 = torch.empty(R, Cw, dtype=cd, device=dev)
         main, side = torch.cuda.current_stream(), self._side_stream(dev)
         side.wait_stream(main)
+        # block 0's weight-gradient launch of each stack -- the last big launch of its backward, feeding only the optimizer -- runs on an
+        # otherwise idle role stream, next to the stack's ln_1 backward and (joint chain) the embeddings' backward
+        dw0 = os.environ.get("TAN_DW0_STREAM", "1") != "0"
+        aux_j = _lib.role_stream(dev, "loss") if dw0 else None
+        aux_v = _lib.role_stream(dev, "opt") if dw0 else None
 
         def joint_chain():
             vn_j = torch.empty(Sd, R, Cw, dtype=cd, device=dev)
@@ -689,7 +696,7 @@ class _AlignerEngine(_WorkspaceMixin):
             dj = [dst_j[s] for s in range(Sd)]
             ops.l2norm_bwd_multi(d_vn_j, vn_j, inv["vj"], dj, R, Cw, T, L, 0)
             ops.l2norm_bwd_multi(d_tn_j, tn_j, inv["tj"], dj, Mp, Cw, N, L, T)
-            self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dj, d_xj)
+            self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dj, d_xj, dw0_stream=aux_j)
             return ej, v_j, t_j, d_xj, (vn_j, tn_j, dst_j)
         fut = self._on_side(side, joint_chain)
         ev = self._run_video_stack(fe["x0"], vmask_u8, B, T, True, er=fe["ev"])
@@ -699,7 +706,9 @@ class _AlignerEngine(_WorkspaceMixin):
         dv = [dst_v[s] for s in range(Se)]
         ops.l2norm_bwd_multi(d_vn_d, vn_d, inv["vd"], dv, R, Cw)
         ops.l2norm_bwd(d_tn_d.view(Mp, Cw), tn_d[0], inv["td"], d_lang_raw, Mp, Cw)
-        self._encoder_bwd(ev, fe["x0"], vmask_u8, "ln_video_post_enc", dv, d_x0)
+        self._encoder_bwd(ev, fe["x0"], vmask_u8, "ln_video_post_enc", dv, d_x0, dw0_stream=aux_v)
+        if aux_v is not None:
+            main.wait_stream(aux_v)                # (the early optimizer launch below reads the video stack's weight gradients)
         if after_video_bwd is not None:          # every gradient of the video stack's blocks is final (enqueued) here
             after_video_bwd()
         ej, v_j, t_j, d_xj, keep = fut.result()
@@ -709,6 +718,8 @@ class _AlignerEngine(_WorkspaceMixin):
         run = {"em": em, "B": B, "T": T, "N": N, "sv_video": fe["sv_video"], "sv_video_j": fe["sv_video_j"], "sv_text": fe["sv_text"],
                "sv_text_t": fe["sv_text_t"]}
         self._embed_bwd_fused(run, d_x0, d_xj, d_lang_raw, False)
+        if aux_j is not None:
+            main.wait_stream(aux_j)                # the joint stack's block-0 weight gradients
         self._release_ws(ev)
         self._release_ws(ej)
         self._release_ws(em)
