@@ -385,12 +385,14 @@ typedef struct tan_encoder_desc {
                                                    outputs (xn1 of layers >= 1, post_out) and x_mid / x_out are written as usual. */
     /* forward only: != 0: bufs[0].xn1 / mean1 / rstd1 already hold the first block's ln_1(x0) (tan_embed_fwd wrote them) */
     int xn1_ready;
-    /* backward only, optional: block 0's grouped weight-gradient launch -- the last big launch of a stack's backward, which only feeds
-     * the optimizer -- goes to this stream (made to wait for the stack's stream first), so that block 0's ln_1 backward and whatever the
-     * caller queues behind tan_encoder_bwd (the embeddings' backward) do not wait for it.  The CALLER joins dw0_stream before it reads
-     * block 0's weight gradients or reuses the scratch buffers.  (Block 0 only: the scratch operands of every other block's launch are
-     * overwritten by the next block's kernels.) */
-    void* dw0_stream;
+    /* backward only, optional: the grouped weight-gradient launches of blocks dw_tail - 1 .. 0 -- the LAST blocks of a stack's backward;
+     * they only feed the optimizer -- go to dw_stream (made to wait for the stack's stream first), so that the stack's remaining dX kernels
+     * and whatever the caller queues behind tan_encoder_bwd (the embeddings' backward) do not wait for them.  Block 0 needs nothing else
+     * (nothing overwrites its operands any more); dw_tail > 1 needs the second set of the four scratch buffers such a launch reads
+     * (scr2_*): the tail blocks alternate between the sets, and a block waits for the launch two blocks above it before it reuses
+     * a set.  The CALLER joins dw_stream before it reads those weight gradients or reuses the scratch buffers. */
+    void* dw_stream; int dw_tail;
+    void *scr2_dx, *scr2_dx2, *scr2_dh, *scr2_dqkv;
 } tan_encoder_desc;
 int tan_encoder_fwd(const tan_encoder_desc* e, void* stream);
 int tan_encoder_bwd(const tan_encoder_desc* e, void* stream);

@@ -208,7 +208,8 @@ class EncoderDesc(C.Structure):
         ("dw_ws", C.c_void_p), ("dw_ws_floats", C.c_long),
         ("d_stage", C.POINTER(C.c_void_p)), ("d_x0", C.c_void_p),
         ("layer_done", C.POINTER(C.c_void_p)),
-        ("no_save", C.c_int), ("xn1_ready", C.c_int), ("dw0_stream", C.c_void_p),
+        ("no_save", C.c_int), ("xn1_ready", C.c_int), ("dw_stream", C.c_void_p), ("dw_tail", C.c_int),
+        ("scr2_dx", C.c_void_p), ("scr2_dx2", C.c_void_p), ("scr2_dh", C.c_void_p), ("scr2_dqkv", C.c_void_p),
     ]
 
 

@@ -235,7 +235,22 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
     struct { bool on; int layer; const void *dxn, *x, *res; const float *mean, *rstd, *g; float *gg, *gb, *gcol;
              const void *dqkv, *pwt_in, *dstage; } pend{};
     const bool panel_all = panel_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0;
-    void* dx = e->scr_dx;             // gradient w.r.t. the residual stream leaving the current layer
+    // the last `tail` blocks' weight-gradient launches on e->dw_stream (see tan_hip.h); tail > 1: those blocks alternate between two
+    // sets of the scratch buffers the launch reads
+    int tail = e->dw_stream && e->dw_stream != st ? (e->dw_tail > 0 ? e->dw_tail : 0) : 0;
+    if (tail > S) tail = S;
+    if (tail > 16) tail = 16;
+    const bool two_sets = e->scr2_dx && e->scr2_dx2 && e->scr2_dh && e->scr2_dqkv;
+    if (tail > 1 && !two_sets) tail = 1;
+    static thread_local hipEvent_t ev_in = nullptr, ev_done[16] = {};
+    if (tail > 0 && !ev_in) {
+        if (hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess) return -3;
+        for (int i = 0; i < 16; ++i)
+            if (hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming) != hipSuccess) return -3;
+    }
+    auto set_b = [&](int i) { return tail > 1 && i < tail && (i & 1); };
+    // gradient w.r.t. the residual stream leaving the current layer (the set of the block that reads it)
+    void* dx = set_b(S - 1) ? e->scr2_dx : e->scr_dx;
     if (e->d_stage[S - 1] && panel_all && e->params[S - 1].wtp_fc && e->params[S - 1].wtp_proj) {
         TAN_REQUIRE(e->post_out);
         pend.on = true; pend.layer = -1; pend.dxn = e->d_stage[S - 1]; pend.x = x_last; pend.res = nullptr;
@@ -257,9 +272,13 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         const tan_layer_params& p = e->params[i];
         const tan_layer_bufs& b = e->bufs[i];
         const void* x_in = i == 0 ? e->x0 : e->bufs[i - 1].x_out;
-        void* const dx2 = e->scr_dx2;
-        void* const scr_dh = e->scr_dh;
-        void* const scr_dqkv = e->scr_dqkv;
+        const bool B_ = set_b(i);
+        dx = B_ ? e->scr2_dx : e->scr_dx;
+        void* const dx2 = B_ ? e->scr2_dx2 : e->scr_dx2;
+        void* const scr_dh = B_ ? e->scr2_dh : e->scr_dh;
+        void* const scr_dqkv = B_ ? e->scr2_dqkv : e->scr_dqkv;
+        if (tail > 1 && i + 2 < tail)      // block i + 2 used this set: its weight-gradient launch must have read it
+            if (hipStreamWaitEvent((hipStream_t)st, ev_done[i + 2], 0) != hipSuccess) return -3;
         // ---- MLP branch: x_out = x_mid + c_proj(quickgelu(c_fc(LN2(x_mid))))
         bool do_fused = false;                             // d_o = dx2 W_out already produced by the row-panel MLP backward
         if (panel_all && p.wtp_fc && p.wtp_proj) {
@@ -306,17 +325,17 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         {                   // dx, scr_dh, dx2, scr_dqkv are all still intact here (LN1 backward below overwrites dx)
             const DwItem items[4] = {{scr_dh, b.xn2, p.g_w_fc, 4 * C, C}, {dx, b.h_act, p.g_w_proj, C, 4 * C},
                                      {scr_dqkv, b.xn1, p.g_w_qkv, 3 * C, C}, {dx2, b.attn_o, p.g_w_out, C, C}};
-            if (i == 0 && e->dw0_stream && e->dw0_stream != st) {
-                // block 0: nothing of this stack's backward depends on its weight gradients, and nothing overwrites their operands any more
-                static thread_local hipEvent_t ev = nullptr;
-                if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return -3;
-                if (hipEventRecord(ev, (hipStream_t)st) != hipSuccess) return -3;
-                if (hipStreamWaitEvent((hipStream_t)e->dw0_stream, ev, 0) != hipSuccess) return -3;
-                CK(linear_bwd_w_group(dt, items, 4, R, e->dw_ws, e->dw_ws_floats, e->dw0_stream));
+            if (i < tail) {
+                // nothing of this stack's backward depends on these weight gradients; their operands stay untouched until the block two
+                // below reuses the set (it waits for ev_done), block 0's for good
+                if (hipEventRecord(ev_in, (hipStream_t)st) != hipSuccess) return -3;
+                if (hipStreamWaitEvent((hipStream_t)e->dw_stream, ev_in, 0) != hipSuccess) return -3;
+                CK(linear_bwd_w_group(dt, items, 4, R, e->dw_ws, e->dw_ws_floats, e->dw_stream));
+                if (hipEventRecord(ev_done[i], (hipStream_t)e->dw_stream) != hipSuccess) return -3;
             } else
             CK(linear_bwd_w_group(dt, items, 4, R, e->dw_ws, e->dw_ws_floats, st));
         }
-        void* dx_in = i == 0 ? e->d_x0 : e->scr_dx;
+        void* dx_in = i == 0 ? e->d_x0 : (set_b(i - 1) ? e->scr2_dx : e->scr_dx);
         float* next_b_proj = i > 0 ? e->params[i - 1].g_b_proj : nullptr;       // dx_in is layer i-1's x_out gradient
         if (ln1_next) {
             // block i-1's row-panel MLP backward does this LayerNorm backward as its prologue (dx2 and scr_dxn / scr_dqkv stay

@@ -112,7 +112,7 @@ class _AlignerEngine(_WorkspaceMixin):
             cache[prefix] = evs
         return evs
 
-    def _encoder_bwd(self, er, x0, keypad, post_name, d_stage, d_x0, dw0_stream=None):
+    def _encoder_bwd(self, er, x0, keypad, post_name, d_stage, d_x0, dw_stream=None, dw_tail=1):
         cd, dev, R = x0.dtype, x0.device, er.R
         d = self._enc_desc(er, x0, keypad, post_name)
         self._flat.join_images()
@@ -128,8 +128,9 @@ class _AlignerEngine(_WorkspaceMixin):
         arr = (C.c_void_p * er.layers)(*[(t.data_ptr() if t is not None else None) for t in d_stage])
         d.d_stage = arr
         d.d_x0 = _vp(d_x0)
-        if dw0_stream is not None:         # block 0's weight gradients off the chain (the caller joins that stream)
-            d.dw0_stream = C.c_void_p(dw0_stream.cuda_stream)
+        if dw_stream is not None:          # the last blocks' weight gradients off the chain (the caller joins that stream)
+            d.dw_stream, d.dw_tail = C.c_void_p(dw_stream.cuda_stream), dw_tail
+            d.scr2_dx, d.scr2_dx2, d.scr2_dh, d.scr2_dqkv = (_vp(scr[k]) for k in ("dx_b", "dx2_b", "dh_b", "dqkv_b"))
         _lib.check(_lib.lib().tan_encoder_bwd(C.byref(d), ops._stream()), "tan_encoder_bwd")
 
     # ------------------------------------------------------------------ embedding front-ends
@@ -677,11 +678,13 @@ class _AlignerEngine(_WorkspaceMixin):
         d_x0 = torch.empty(R, Cw, dtype=cd, device=dev)
         main, side = torch.cuda.current_stream(), self._side_stream(dev)
         side.wait_stream(main)
-        # block 0's weight-gradient launch of each stack -- the last big launch of its backward, feeding only the optimizer -- runs on an
-        # otherwise idle role stream, next to the stack's ln_1 backward and (joint chain) the embeddings' backward
-        dw0 = os.environ.get("TAN_DW0_STREAM", "1") != "0"
-        aux_j = _lib.role_stream(dev, "loss") if dw0 else None
-        aux_v = _lib.role_stream(dev, "opt") if dw0 else None
+        # The weight-gradient launches of the LAST blocks of each stack's backward feed only the optimizer: they run on an otherwise idle
+        # role stream next to the stack's remaining dX kernels and the embeddings' backward (tan_encoder_desc.dw_tail).  Joint chain (the
+        # longer one): blocks 1 and 0; video chain: block 0.  Measured (ms per step, ABBA x2 on one box): none 4.58, (1, 1) 4.50 / 4.44,
+        # (2, 1) 4.40, (3, 1) 4.40, (2, 2) 4.45, (6, 1) 4.47 -- earlier than the last ~0.4 ms of the chain there are no idle CUs to give.
+        tail_j, tail_v = 2, 1
+        aux_j = _lib.role_stream(dev, "loss")
+        aux_v = _lib.role_stream(dev, "opt")
 
         def joint_chain():
             vn_j = torch.empty(Sd, R, Cw, dtype=cd, device=dev)
@@ -696,7 +699,7 @@ class _AlignerEngine(_WorkspaceMixin):
             dj = [dst_j[s] for s in range(Sd)]
             ops.l2norm_bwd_multi(d_vn_j, vn_j, inv["vj"], dj, R, Cw, T, L, 0)
             ops.l2norm_bwd_multi(d_tn_j, tn_j, inv["tj"], dj, Mp, Cw, N, L, T)
-            self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dj, d_xj, dw0_stream=aux_j)
+            self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dj, d_xj, dw_stream=aux_j, dw_tail=tail_j)
             return ej, v_j, t_j, d_xj, (vn_j, tn_j, dst_j)
         fut = self._on_side(side, joint_chain)
         ev = self._run_video_stack(fe["x0"], vmask_u8, B, T, True, er=fe["ev"])
@@ -706,7 +709,7 @@ class _AlignerEngine(_WorkspaceMixin):
         dv = [dst_v[s] for s in range(Se)]
         ops.l2norm_bwd_multi(d_vn_d, vn_d, inv["vd"], dv, R, Cw)
         ops.l2norm_bwd(d_tn_d.view(Mp, Cw), tn_d[0], inv["td"], d_lang_raw, Mp, Cw)
-        self._encoder_bwd(ev, fe["x0"], vmask_u8, "ln_video_post_enc", dv, d_x0, dw0_stream=aux_v)
+        self._encoder_bwd(ev, fe["x0"], vmask_u8, "ln_video_post_enc", dv, d_x0, dw_stream=aux_v, dw_tail=tail_v)
         if aux_v is not None:
             main.wait_stream(aux_v)                # (the early optimizer launch below reads the video stack's weight gradients)
         if after_video_bwd is not None:          # every gradient of the video stack's blocks is final (enqueued) here

@@ -131,7 +131,9 @@ class _WorkspaceMixin:
         scr = self._ws_pool.get(key)
         if scr is None:
             scr = _Blocks(cd, dev, {"dx": R * WIDTH, "dx2": R * WIDTH, "do": R * WIDTH, "dxn": R * WIDTH,
-                                    "dh": R * 4 * WIDTH, "dqkv": R * 3 * WIDTH})
+                                    "dh": R * 4 * WIDTH, "dqkv": R * 3 * WIDTH,
+                                    # second set of what a block's weight-gradient launch reads (tan_encoder_desc.dw_tail > 1)
+                                    "dx_b": R * WIDTH, "dx2_b": R * WIDTH, "dh_b": R * 4 * WIDTH, "dqkv_b": R * 3 * WIDTH})
             n_ws = _lib.lib().tan_layernorm_bwd_ws_floats(C.c_int(WIDTH))
             scr.ln_ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
             scr.dw_ws = torch.empty(32 * 4 * WIDTH * WIDTH, dtype=torch.float32, device=dev)     # split-K partial tiles

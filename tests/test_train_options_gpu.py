@@ -112,9 +112,9 @@ def test_step_boundary_options_do_not_change_the_arithmetic(monkeypatch, model_k
     assert torch.isfinite(ref[0]).all()
     for tag in ("images", "chains", "fused"):
         d = (flats[tag][0] - ref[0]).abs()
-        # Adam turns atomics-order noise on ~zero gradients into lr-sized (1e-3) updates of a few elements: bounded by the three steps' total
+        # Adam turns atomics-order noise on ~zero gradients into lr-sized (1e-3) updates of a few elements: a sign flip is 2 lr per step
         # (the fused front-end adds the position rows in f32 instead of bf16: rounding-level input differences on top of the atomics)
-        assert d.max().item() <= 3.5e-3 and d.mean().item() <= (5e-6 if tag == "images" else 3e-5), (tag, d.max().item(), d.mean().item())
+        assert d.max().item() <= 6.5e-3 and d.mean().item() <= (5e-6 if tag == "images" else 3e-5), (tag, d.max().item(), d.mean().item())
         if ref[1] is not None:
             assert (flats[tag][1] - ref[1]).abs().max().item() <= 3.5e-3, tag
     moved = (ref[0] - _trainer(seed=3, dtype="bf16", **kw)[0].online.flat_parameters()).abs().max().item()
