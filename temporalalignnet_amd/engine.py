@@ -831,8 +831,14 @@ class _AlignerEngine(_WorkspaceMixin):
         if any_j and any_v and side is not None:
             # joint stack backward on the side stream (issued by the helper thread), video stack backward on the main stream
             side.wait_stream(main)
-            fut = self._on_side(side, lambda: self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dst_j, d_xj))
-            self._encoder_bwd(ev, run["x0"], run["vmask"], "ln_video_post_enc", dst_v, d_x0)
+            # the last blocks' weight-gradient launches on idle role streams (see _run_chains); not under a DDP bucket hook, whose layer
+            # events mean "every gradient of the layer is final" on the stack's own stream
+            tail = self._grad_ready_hook is None and dev.type == "cuda"
+            aux_j = _lib.role_stream(dev, "loss") if tail else None
+            aux_v = _lib.role_stream(dev, "opt") if tail else None
+            fut = self._on_side(side, lambda: self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dst_j, d_xj, dw_stream=aux_j,
+                                                                dw_tail=2))
+            self._encoder_bwd(ev, run["x0"], run["vmask"], "ln_video_post_enc", dst_v, d_x0, dw_stream=aux_v, dw_tail=1)
             # DDP: each stack's slice of the flat gradient is final once its backward is enqueued.  Both collectives are issued
             # from THIS thread, video first (every rank must issue them in the same order), each in the stream context whose
             # work it has to wait for; they overlap whatever backward work is still running.
@@ -843,7 +849,9 @@ class _AlignerEngine(_WorkspaceMixin):
                 with torch.cuda.stream(side):
                     self._grad_ready_hook("joint", self._layer_events(ej.prefix, ej.layers))
             main.wait_stream(side)
+            tail_streams = [t for t in (aux_j, aux_v) if t is not None]
         else:
+            tail_streams = []
             if any_j:
                 self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dst_j, d_xj)
                 if self._grad_ready_hook is not None:    # joint-stack gradients are final: DDP starts reducing them now
@@ -854,6 +862,8 @@ class _AlignerEngine(_WorkspaceMixin):
                     self._grad_ready_hook("video", self._layer_events(ev.prefix, ev.layers))
         if run.get("em") is not None:          # the fused front-end ran (TAN_EMBED_FUSED): its backward is fused too
             d_lang = self._embed_bwd_fused(run, d_x0 if any_v else None, d_xj, d_lang_raw if have_lang_raw else None, need_d_lang)
+            for t in tail_streams:
+                main.wait_stream(t)
             self._release_ws(ev)
             self._release_ws(ej)
             self._release_ws(run.get("em"))
@@ -906,6 +916,8 @@ class _AlignerEngine(_WorkspaceMixin):
             cur.wait_stream(aux)
         else:
             d_lang = text_side()
+        for t in tail_streams:
+            cur.wait_stream(t)
         self._release_ws(ev)
         self._release_ws(ej)
         self._release_ws(run.get("em"))
