@@ -554,6 +554,267 @@ __global__ __launch_bounds__(256) void simnce_dl_kept_kernel(SimArgs a, int npan
     }
 }
 
+// ---- d logits AND d v_hat = dl . t_hat from the kept exponentials, one pass ------------------------------------------------------
+// simnce_dl_kept_kernel + the GEMM behind it read the d-logits twice more than needed: the element-wise pass writes them (126 MB per
+// family at B = 128), the [S*R, Mp] x [Mp, 512] GEMM reads them back and runs at ~0.16 of the MFMA peak inside the step (K = Mp is
+// short, its 128 x 128 tiles stage both operands through the LDS).  Here ONE workgroup (8 waves) owns a 128-row panel of a stage and
+// walks its column tiles: the 128 x 128 d-logits tile is built in the LDS exactly as simnce_dl_kept_kernel builds it (row-major, same
+// rounding, same-video corrections applied there), leaves for HBM as whole rows (the text-feature gradient still contracts over the
+// rows of ALL panels: a second kernel), and -- while it is in the LDS -- is the dl operand of the d v_hat MFMAs:
+//   D^T[feature][row] += T^T[feature][col] dl[row][col]^T          (v_mfma_f32_32x32x16_bf16, A = text fragment, B = dl fragment)
+// wave w owns features 64 w .. 64 w + 63 of all 128 rows (8 accumulator tiles), so every text element is pulled from the L2 once per
+// workgroup: the text operand comes from a fragment-major image of the TRANSPOSED unit text features (simnce_pack_textT_kernel:
+// piece (16 columns, 32 features) = one 1-KiB wave-load, lane l = 8 consecutive columns of feature l & 31) through a register ring
+// that runs across tiles, like the sweep's.  The transposed accumulators (a lane owns 4 consecutive features of one row per
+// register quad) leave through the LDS as whole 1-KiB rows of d v_hat.
+// The next tile's exponentials are requested a tile ahead and converted between the MFMA steps of the current one (two tile
+// buffers, ONE barrier per tile).
+constexpr int DV_LD = 136;                          // bf16 per LDS row of a d-logits tile (as simnce_dl_kept_kernel)
+constexpr int DV_TILE_B = 128 * DV_LD * 2;          // 34 KiB
+constexpr int DV_RAW_B = 32768;                     // a tile of kept exponentials as the sweep stored it
+constexpr int DV_OUT_LD = 520;                      // bf16 per LDS row of the d v_hat panel (epilogue)
+constexpr int DV_OFF_RAW = 2 * DV_TILE_B, DV_OFF_RF = DV_OFF_RAW + 2 * DV_RAW_B, DV_OFF_CF = DV_OFF_RF + 512, DV_OFF_CV = DV_OFF_CF + 1024;
+constexpr int DV_LDS_B = DV_OFF_CV + 1024;          // 137.5 KiB (the epilogue's 130-KiB panel overlays the tile buffers)
+static_assert(128 * DV_OUT_LD * 2 <= DV_OFF_RF, "epilogue panel");
+constexpr int DV_RD = 8;                            // text-fragment ring depth (steps of 16 columns): one tile
+
+// Transposed fragment-major text image: piece (column block cb16 of 16, feature block fb of 32) = 1 KiB at ((cb16 * 16 + fb) * 1024),
+// lane l's 16 bytes = Tt[cb16*16 + 8 (l >> 5) + e][fb*32 + (l & 31)], e = 0..7; columns >= Mp are ZERO (they are the K padding of
+// the last tile).  grid (32-column blocks, stages), 256 threads.
+__global__ __launch_bounds__(256) void simnce_pack_textT_kernel(const bf16_t* __restrict__ Tt, long t_stage_stride, char* __restrict__ TpT,
+                                                                long tpt_stage_stride, int Mp) {
+    constexpr int LDT = 520;
+    __shared__ __attribute__((aligned(16))) bf16_t tl[32 * LDT];
+    const int blk = blockIdx.x, st = blockIdx.y, tid = threadIdx.x;
+    const bf16_t* src = Tt + (long)st * t_stage_stride;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = tid + 256 * i, r = q >> 6, ch = q & 63, col = blk * 32 + r;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (col < Mp) v = *reinterpret_cast<const uint4*>(src + (long)col * 512 + ch * 8);
+        *reinterpret_cast<uint4*>(tl + r * LDT + ch * 8) = v;
+    }
+    __syncthreads();
+    char* dst = TpT + (long)st * tpt_stage_stride + (long)blk * 2 * 16 * 1024;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int o = tid + 256 * i, l = o & 63, fb = (o >> 6) & 15, k2 = o >> 10;
+        const bf16_t* g = tl + (k2 * 16 + 8 * (l >> 5)) * LDT + fb * 32 + (l & 31);
+        uint4 u;
+        u.x = (unsigned)g[0] | ((unsigned)g[LDT] << 16);
+        u.y = (unsigned)g[2 * LDT] | ((unsigned)g[3 * LDT] << 16);
+        u.z = (unsigned)g[4 * LDT] | ((unsigned)g[5 * LDT] << 16);
+        u.w = (unsigned)g[6 * LDT] | ((unsigned)g[7 * LDT] << 16);
+        *reinterpret_cast<uint4*>(dst + (long)(k2 * 16 + fb) * 1024 + l * 16) = u;
+    }
+}
+
+__global__ __launch_bounds__(512) void simnce_dl_dvn_kernel(SimArgs a, int npanel, int nct, const char* __restrict__ TpT, long tpt_stage_stride,
+                                                            bf16_t* __restrict__ dvn, int dbg) {
+    extern __shared__ __attribute__((aligned(1024))) char dv_lds[];
+    __shared__ int crange[2];                                 // sweep columns that hold sentences of this panel's videos: [min, max]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // 1-D grid over (stage, row panel) items, a contiguous run of items per XCD (they share a stage's text image behind one L2)
+    int wg = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    }
+    const int s = wg / npanel, panel = wg - s * npanel, m0 = panel * 128;
+    const int R = a.R, Mp = a.Mp, T = a.T, N = a.N;
+    const float inv_tau = 1.0f / S_TAU;
+    float* const rfb = reinterpret_cast<float*>(dv_lds + DV_OFF_RF);           // [128] g_v / rowsum / tau of the panel's rows
+    float* const cfb = reinterpret_cast<float*>(dv_lds + DV_OFF_CF);           // [2][128] g_t / colsum / tau of a tile's columns
+    float* const cvb = reinterpret_cast<float*>(dv_lds + DV_OFF_CV);           // [2][128] 1 = valid column
+    if (tid == 0) { crange[0] = 0x7fffffff; crange[1] = -1; }
+    __syncthreads();
+    if (a.diag) {
+        const int b_lo = m0 / T, b_hi = min(m0 + 127, R - 1) / T;
+        for (int p = b_lo * N + tid; p < (b_hi + 1) * N; p += 512) {
+            const int m = a.colmap ? a.colmap[p] : p;
+            if (m >= 0) { atomicMin(&crange[0], m); atomicMax(&crange[1], m); }
+        }
+    }
+    if (tid < 128) {
+        const long ri = (long)s * R + min(m0 + tid, R - 1);
+        rfb[tid] = a.g_v[ri] / a.rowsum[ri] * inv_tau;
+    }
+    // column factors of tile ct -> cfb / cvb[ct & 1] (threads 0..127; requested half a tile before they are written)
+    float c_gt = 0.f, c_cs = 1.f;
+    int c_inv = 0;
+    auto cols_load = [&](int ct) __attribute__((always_inline)) {
+        if (tid < 128) {
+            const int col = min(ct * 128 + tid, Mp - 1);
+            const long ci = (long)s * Mp + col;
+            c_gt = a.g_t[ci]; c_cs = a.colsum[ci]; c_inv = a.col_invalid[col];
+        }
+    };
+    auto cols_put = [&](int ct) __attribute__((always_inline)) {
+        if (tid < 128) {
+            cfb[(ct & 1) * 128 + tid] = c_gt / c_cs * inv_tau;
+            cvb[(ct & 1) * 128 + tid] = c_inv ? 0.f : 1.f;
+        }
+    };
+    // The kept exponentials of a tile travel HBM -> LDS by LDS-DMA (no registers, requested a whole tile ahead): thread `tid` owns the
+    // four 16-byte units tid + 512 n of the tile as the sweep stored it (wave quadrant n of the sweep, its accumulator tile ij,
+    // register half qh) = 2 column sets (n & 1) x 2 row sets (n >> 1) of 8 rows, and reads back exactly the bytes its own wave
+    // requested: the wait for them is the wave's own vmcnt (every later load of the ring is behind them in the in-order queue).
+    // (Issued from inline asm: told about an LDS-DMA write, hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS read it cannot tell
+    // apart from the destination -- the conversion's and the row pieces' -- which drains the ring at every step.  Loads the compiler
+    // does not count only make its own vmcnt waits more conservative: the queue is in order.)
+    const char* Eb = reinterpret_cast<const char*>(a.ekeep) + (((long)s * npanel + panel) * nct) * (long)DV_RAW_B;
+    const unsigned raw_lds0 = (unsigned)(uintptr_t)(dv_lds + DV_OFF_RAW) + (unsigned)wave * 1024u;
+    auto raw_request = [&](int ct) __attribute__((always_inline)) {
+        const char* src = Eb + (long)ct * DV_RAW_B;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(raw_lds0 + (unsigned)((ct & 1) * DV_RAW_B + n * 8192)));
+            const unsigned voff = (unsigned)(tid * 16 + n * 8192);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(dst), "s"(src) : "memory");
+        }
+    };
+    const int ij = (tid >> 7) & 3, qh = (tid >> 6) & 1;
+    const int colb = (ij & 1) * 32 + (lane & 31);                              // + 64 (n & 1)
+    const int rowb = (ij >> 1) * 32 + 16 * qh + 4 * (lane >> 5);               // + 64 (n >> 1) + 8 (j >> 1) + (2 j & 3) + h
+    // one 16-byte unit: 8 rows (two float4 of row factors) of one column -> the row-major bf16 tile
+    auto convert_unit = [&](int ct, int n) __attribute__((always_inline)) {
+        const int cs = n & 1, rs = n >> 1;
+        const uint4 ev = *reinterpret_cast<const uint4*>(dv_lds + DV_OFF_RAW + (ct & 1) * DV_RAW_B + (n * 512 + tid) * 16);
+        const float cf = cfb[(ct & 1) * 128 + cs * 64 + colb], ok = cvb[(ct & 1) * 128 + cs * 64 + colb];
+        const float4 r0 = *reinterpret_cast<const float4*>(rfb + rs * 64 + rowb), r1 = *reinterpret_cast<const float4*>(rfb + rs * 64 + rowb + 8);
+        const float rf[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        const unsigned w[4] = {ev.x, ev.y, ev.z, ev.w};
+        bf16_t* tp = reinterpret_cast<bf16_t*>(dv_lds + (ct & 1) * DV_TILE_B) + (rs * 64 + rowb) * DV_LD + cs * 64 + colb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ro = 8 * (j >> 1) + ((2 * j) & 3);
+            const unsigned pk = f2bf2(__uint_as_float(w[j] << 16) * ((ok != 0.f ? rf[2 * j] : 0.f) + cf),
+                                       __uint_as_float(w[j] & 0xffff0000u) * ((ok != 0.f ? rf[2 * j + 1] : 0.f) + cf));
+            tp[ro * DV_LD] = (bf16_t)(pk & 0xffffu);
+            tp[(ro + 1) * DV_LD] = (bf16_t)(pk >> 16);
+        }
+    };
+    // same-video corrections of tile ct in the LDS (simnce_diag_kernel<true>'s arithmetic; block-uniform condition: 1-2 tiles of a panel)
+    auto diag_tile = [&](int ct) __attribute__((always_inline)) {
+        const int c0 = ct * 128;
+        bf16_t* tb = reinterpret_cast<bf16_t*>(dv_lds + (ct & 1) * DV_TILE_B);
+        if (a.diag && crange[0] <= c0 + 127 && crange[1] >= c0) {
+            const int nrow = min(128, R - m0);
+            for (int i = tid; i < nrow * N; i += 512) {
+                const int lr = i / N, k = i - lr * N, row = m0 + lr;
+                const int b = row / T, t = row - b * T;
+                const int m = a.colmap ? a.colmap[b * N + k] : b * N + k;
+                if (m < c0 || m >= c0 + 128 || m >= Mp) continue;
+                bf16_t* out = tb + lr * DV_LD + (m - c0);
+                if (a.row_leak && a.row_leak[row]) { *out = 0; continue; }
+                if (a.tgt[((long)b * T + t) * N + k] == 0.f) continue;
+                const long ri = (long)s * R + row, ci = (long)s * Mp + m;
+                const float e = __expf((a.diag[(((long)s * a.B + b) * T + t) * N + k] - 1.0f) * inv_tau);
+                const float pv = a.possum_v[ri], pt = a.possum_t[ci];
+                float corr = 0.f;
+                if (!a.col_invalid[m] && pv > 0.f) corr += a.g_v[ri] / pv;
+                if (pt > 0.f) corr += a.g_t[ci] / pt;
+                *out = f2bf(bf2f(*out) - e * corr * inv_tau);
+            }
+            __syncthreads();
+        }
+    };
+    // one 16-byte row piece of tile ct -> dl (Mp % 8 == 0: the host checks)
+    auto store_unit = [&](int ct, int i) __attribute__((always_inline)) {
+        const int q = tid + 512 * i, lr = q >> 4, cc = (q & 15) * 8, row = m0 + lr, col = ct * 128 + cc;
+        const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(dv_lds + (ct & 1) * DV_TILE_B) + lr * DV_LD + cc);
+        if (row < R && col < Mp) *reinterpret_cast<uint4*>(a.dl + ((long)s * R + row) * Mp + col) = v;
+    };
+
+    struct BT { bf16x8 f[2]; };
+    BT ring[DV_RD];
+    const char* Tps = TpT + (long)s * tpt_stage_stride + (long)wave * 2048 + lane * 16;
+    const int nk = nct * 8;
+    auto load_bt = [&](BT& dst, int kk) __attribute__((always_inline)) {
+        const char* p = Tps + (long)kk * 16384;
+        dst.f[0] = *reinterpret_cast<const bf16x8*>(p);
+        dst.f[1] = *reinterpret_cast<const bf16x8*>(p + 1024);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
+
+    // ---- prologue: tile 0 converted, tile 1 requested, the ring filled behind them
+    raw_request(0);
+    cols_load(0);
+    cols_put(0);
+    if (nct > 1) { raw_request(1); cols_load(1); cols_put(1); }
+    pn_static_for_s<0, DV_RD>([&](auto jc) { constexpr int J = decltype(jc)::value; load_bt(ring[J], min(J, nk - 1)); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                    // rfb, cfb[0]
+#pragma unroll
+    for (int n = 0; n < 4; ++n) convert_unit(0, n);
+    __syncthreads();
+    diag_tile(0);
+
+    typedef __attribute__((address_space(3))) const bf16x8* lds_frag_t;
+    for (int ct = 0; ct < nct; ++ct) {
+        const unsigned abase = (unsigned)(uintptr_t)(dv_lds + (ct & 1) * DV_TILE_B) + ((lane & 31) * DV_LD + 8 * (lane >> 5)) * 2;
+        bf16x8 af[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) af[rb] = *(lds_frag_t)(uintptr_t)(abase + rb * 32 * DV_LD * 2);
+        // Per tile and wave: [step 0] the exponentials of tile ct + 2 are requested IN FRONT of the step's ring load -- that load is
+        // waited for at step 0 of the next tile, and the queue is in order, so the conversion of tile ct + 1 [steps 1-4] finds its
+        // bytes landed (requested a tile ago) without a wait of its own; [steps 4-7] tile ct leaves for HBM one row piece per step;
+        // column factors of tile ct + 2: requested at step 1, put at step 7 (read behind the tile's barrier).
+        pn_static_for_s<0, 8>([&](auto jc) {
+            constexpr int KS = decltype(jc)::value;
+            BT& Bt = ring[KS % DV_RD];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[rb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bt.f[j], af[rb], acc[rb][j], 0, 0, 0);
+                if constexpr (KS < 7) { if (!(dbg & 16)) af[rb] = *(lds_frag_t)(uintptr_t)(abase + (rb * 32 * DV_LD + (KS + 1) * 16) * 2); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (KS == 0) {
+                if (ct + 2 < nct && !(dbg & 4)) raw_request(ct + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (KS == 1) { if (ct + 2 < nct) cols_load(ct + 2); }
+            if constexpr (KS >= 1 && KS <= 4) { if (ct + 1 < nct && !(dbg & 1)) convert_unit(ct + 1, KS - 1); }
+            if constexpr (KS >= 4) { if (!(dbg & 2)) store_unit(ct, KS - 4); }
+            if constexpr (KS == 7) { if (ct + 2 < nct) cols_put(ct + 2); }
+            if (!(dbg & 8)) load_bt(Bt, min(ct * 8 + KS + DV_RD, nk - 1));
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        __syncthreads();
+        if (ct + 1 < nct) diag_tile(ct + 1);
+    }
+
+    // ---- epilogue: acc[rb][j][r] = d v_hat[row rb*32 + (lane & 31)][feature 64 wave + 32 j + acc_row(r, lane)] -> LDS rows -> 16-byte stores
+    bf16_t* outp = reinterpret_cast<bf16_t*>(dv_lds);          // (every wave is behind the last tile's barrier: the tile buffers are free)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 u;
+                u.x = f2bf2(acc[rb][j][4 * g], acc[rb][j][4 * g + 1]);
+                u.y = f2bf2(acc[rb][j][4 * g + 2], acc[rb][j][4 * g + 3]);
+                *reinterpret_cast<uint2*>(outp + (rb * 32 + (lane & 31)) * DV_OUT_LD + wave * 64 + j * 32 + 8 * g + 4 * (lane >> 5)) = u;
+            }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int q = tid + 512 * i, lr = q >> 6, ch = q & 63;
+        if (m0 + lr < R)
+            *reinterpret_cast<uint4*>(dvn + ((long)s * R + m0 + lr) * 512 + ch * 8) = *reinterpret_cast<const uint4*>(outp + lr * DV_OUT_LD + ch * 8);
+    }
+}
+
 // the frame-panel-resident sweep takes C = 512; other channel counts run the re-staging kernel
 static bool res_enabled(const SimArgs& a) { return a.C == 512; }
 
@@ -871,10 +1132,11 @@ static int simnce_bwd_impl(const void* vn, const void* tn, long t_stage_stride, 
                            const unsigned char* col_invalid, const unsigned char* row_leak, const float* rowsum,
                            const float* colsum, const float* possum_v, const float* possum_t, const float* g_v, const float* g_t,
                            void* dl, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks, long tb_stage_stride,
-                           const int* colmap, int Mc, int phases, const void* ekeep, void* stream) {
+                           const int* colmap, int Mc, int phases, const void* ekeep, void* dvn, void* stream) {
     TAN_REQUIRE(vn && tn && tgt && col_invalid && rowsum && colsum && possum_v && possum_t && g_v && g_t && dl && ws);
     TAN_REQUIRE(!colmap || (tn_blocks && Mc > 0 && Mc <= B * N));
     if (phases == 0) phases = TAN_SIM_SWEEP | TAN_SIM_DIAG;
+    TAN_REQUIRE(!dvn || (ekeep && (phases & TAN_SIM_SWEEP) && (uintptr_t)dvn % 16 == 0));
     SimArgs a{};
     a.V = (const bf16_t*)vn; a.Tt = (const bf16_t*)tn; a.t_stage_stride = t_stage_stride;
     a.tgt = tgt; a.col_invalid = col_invalid; a.row_leak = row_leak;
@@ -891,6 +1153,23 @@ static int simnce_bwd_impl(const void* vn, const void* tn, long t_stage_stride, 
         const bool tail = (phases & TAN_SIM_DIAG) != 0;
         if (tail && !(phases & TAN_SIM_DIAG_KEEP) && (rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;
         a.ekeep = (bf16_t*)ekeep; a.diag = tail ? diag : nullptr; a.colmap = colmap;
+        if (dvn && a.Mp % 8) return TAN_ERR_BAD_ARG;          // (16-byte row pieces of dl)
+        if (dvn) {          // d logits + d v_hat in one pass; the transposed text image takes the place of the sweep's (not read again)
+            const int npanel = cdiv(a.R, 128), nct = cdiv(a.Mp, 128);
+            char* TpT = (char*)(((uintptr_t)(diag + (long)S * B * T * N) + 15) & ~(uintptr_t)15);
+            const bool shared = a.t_stage_stride == 0;
+            const long tpt_stride = shared ? 0 : (long)nct * 128 * 1024;
+            hipLaunchKernelGGL(simnce_pack_textT_kernel, dim3(nct * 4, shared ? 1 : S), dim3(256), 0, st, a.Tt, a.t_stage_stride, TpT, tpt_stride, a.Mp);
+            TAN_LAUNCH_CHECK();
+            static const hipError_t attr = hipFuncSetAttribute((const void*)simnce_dl_dvn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DV_LDS_B);
+            if (attr != hipSuccess) return (int)attr;
+            const int prec = prof_begin(st, TAN_PROF_GEMM_BF16 + 1, 2.0 * S * a.R * (double)a.Mp * C);
+            static const int dbg = getenv("TAN_DVN_DBG") ? atoi(getenv("TAN_DVN_DBG")) : 0;
+            hipLaunchKernelGGL(simnce_dl_dvn_kernel, dim3(npanel * S), dim3(512), DV_LDS_B, st, a, npanel, nct, (const char*)TpT, tpt_stride, (bf16_t*)dvn, dbg);
+            prof_end(st, prec);
+            TAN_LAUNCH_CHECK();
+            return 0;
+        }
         hipLaunchKernelGGL(simnce_dl_kept_kernel, dim3(cdiv(a.R, 128) * cdiv(a.Mp, 128), S), dim3(256), 0, st, a, cdiv(a.R, 128), cdiv(a.Mp, 128));
         TAN_LAUNCH_CHECK();
         return 0;
@@ -925,7 +1204,7 @@ extern "C" int tan_simnce_bwd_dl(const void* vn, const void* tn, long t_stage_st
                                  void* dl, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks, long tb_stage_stride,
                                  const int* colmap, int Mc, int phases, void* stream) {
     return simnce_bwd_impl(vn, tn, t_stage_stride, tgt, col_invalid, row_leak, rowsum, colsum, possum_v, possum_t, g_v, g_t, dl, ws,
-                           S, B, T, N, C, tn_blocks, tb_stage_stride, colmap, Mc, phases, nullptr, stream);
+                           S, B, T, N, C, tn_blocks, tb_stage_stride, colmap, Mc, phases, nullptr, nullptr, stream);
 }
 
 extern "C" int tan_simnce_bwd_dl_kept(const void* e_keep, const void* vn, const void* tn, long t_stage_stride, const float* tgt,
@@ -935,5 +1214,19 @@ extern "C" int tan_simnce_bwd_dl_kept(const void* e_keep, const void* vn, const 
                                       long tb_stage_stride, const int* colmap, int Mc, int phases, void* stream) {
     TAN_REQUIRE(e_keep);
     return simnce_bwd_impl(vn, tn, t_stage_stride, tgt, col_invalid, row_leak, rowsum, colsum, possum_v, possum_t, g_v, g_t, dl, ws,
-                           S, B, T, N, C, tn_blocks, tb_stage_stride, colmap, Mc, phases, e_keep, stream);
+                           S, B, T, N, C, tn_blocks, tb_stage_stride, colmap, Mc, phases, e_keep, nullptr, stream);
+}
+
+// tan_simnce_bwd_dl_kept that ALSO returns d v_hat [S, R, C] = dl . t_hat (bf16; C = 512): the d-logits tile feeds the MFMAs while it
+// is in the LDS (simnce_dl_dvn_kernel), so the [S*R, Mp] x [Mp, C] GEMM and its read of the d-logits are gone.  dl is still written
+// (row-major [S, R, Mp]) for the text-feature gradient.  Overwrites the sweep's text image in `ws` (tan_simnce_ws_floats).
+extern "C" int tan_simnce_bwd_dl_dvn_kept(const void* e_keep, const void* vn, const void* tn, long t_stage_stride, const float* tgt,
+                                          const unsigned char* col_invalid, const unsigned char* row_leak, const float* rowsum,
+                                          const float* colsum, const float* possum_v, const float* possum_t, const float* g_v,
+                                          const float* g_t, void* dl, void* d_vn, float* ws, int S, int B, int T, int N, int C,
+                                          const void* tn_blocks, long tb_stage_stride, const int* colmap, int Mc, int phases, void* stream) {
+    TAN_REQUIRE(e_keep && d_vn && C == 512);
+    if (phases == 0) phases = TAN_SIM_SWEEP | TAN_SIM_DIAG;
+    return simnce_bwd_impl(vn, tn, t_stage_stride, tgt, col_invalid, row_leak, rowsum, colsum, possum_v, possum_t, g_v, g_t, dl, ws,
+                           S, B, T, N, C, tn_blocks, tb_stage_stride, colmap, Mc, phases, e_keep, d_vn, stream);
 }

@@ -23,6 +23,9 @@ from torch.nn.utils.rnn import pad_sequence
 
 from . import _lib, ops
 
+# A/B switch of the one-pass d-logits + d_vn kernel (tan_simnce_bwd_dl_dvn_kept); 0 = element-wise pass + GEMM
+_FUSED_DVN = os.environ.get("TAN_FUSED_DVN", "1") != "0"
+
 _KIND = {"i": 0, "u": 1, "keep": 2, "keep-joint": 3}
 
 
@@ -295,13 +298,18 @@ class _FusedNCEFn(torch.autograd.Function):
                     _p(g_t), _p(dl), _p(ws), C.c_int(S), C.c_int(B), C.c_int(T), C.c_int(N),
                     C.c_int(Cw), _p(tn) if compact else None, C.c_long(0 if shared else Mp * Cw),
                     _p(colmap), C.c_int(Mc), C.c_int(1 | 2 | 16), ops._stream())      # SWEEP | DIAG | DIAG_KEEP: `ws` still holds the forward's same-video blocks
-        if ekeep is not None:
-            _lib.check(_lib.lib().tan_simnce_bwd_dl_kept(_p(ekeep), *bwd_args), "tan_simnce_bwd_dl_kept")
-        else:
-            _lib.check(_lib.lib().tan_simnce_bwd_dl(*bwd_args), "tan_simnce_bwd_dl")
         d_vn = torch.empty_like(vn)
-        ops.gemm(dl, tn_run, d_vn, M=R, N=Cw, K=Mc, a_kc=True, b_kc=False, lda=Mc, ldb=Cw, batch=S, sA=R * Mc,
-                 sB=0 if shared else Mc * Cw, sC=R * Cw)
+        if ekeep is not None and vn.dtype == torch.bfloat16 and Mc % 8 == 0 and _FUSED_DVN:
+            # d logits and d_vn = dl . tn_run in one pass over the kept exponentials (the tile is the MFMA operand while it is in the LDS)
+            _lib.check(_lib.lib().tan_simnce_bwd_dl_dvn_kept(_p(ekeep), *bwd_args[:13], _p(d_vn), *bwd_args[13:]),
+                       "tan_simnce_bwd_dl_dvn_kept")
+        else:
+            if ekeep is not None:
+                _lib.check(_lib.lib().tan_simnce_bwd_dl_kept(_p(ekeep), *bwd_args), "tan_simnce_bwd_dl_kept")
+            else:
+                _lib.check(_lib.lib().tan_simnce_bwd_dl(*bwd_args), "tan_simnce_bwd_dl")
+            ops.gemm(dl, tn_run, d_vn, M=R, N=Cw, K=Mc, a_kc=True, b_kc=False, lda=Mc, ldb=Cw, batch=S, sA=R * Mc,
+                     sB=0 if shared else Mc * Cw, sC=R * Cw)
         if shared:       # one text feature for every stage: contract over (stage, row) in a single split-K GEMM
             acc = torch.zeros(Mc, Cw, device=dev)
             ops.gemm(dl, vn, acc, M=Mc, N=Cw, K=S * R, a_kc=False, b_kc=False, lda=Mc, ldb=Cw, accumulate=True,

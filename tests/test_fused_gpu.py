@@ -177,3 +177,49 @@ def test_kept_exponentials_match_the_recomputing_backward(S, B, T, N, shared, co
     for a, c in ((dv0, dv1), (dt0, dt1)):
         assert torch.isfinite(a).all()
         assert (a - c).norm().item() <= 6e-3 * c.norm().item() + 1e-6, (a - c).norm().item() / c.norm().item()
+
+
+@pytest.mark.parametrize("S,B,T,N,shared,compact,leak", [(2, 3, 70, 5, False, False, False), (3, 4, 64, 9, True, True, True),
+                                                         (1, 5, 40, 16, False, True, False), (2, 6, 64, 30, True, False, True),
+                                                         (2, 40, 64, 10, False, True, False), (3, 24, 64, 16, True, False, False)])
+def test_one_pass_dlogits_and_dvn_match_the_pass_plus_gemm(S, B, T, N, shared, compact, leak):
+    """tan_simnce_bwd_dl_dvn_kept (d logits + d_vn = dl . tn in one pass: the tile is the MFMA operand while it is in the LDS) against
+    tan_simnce_bwd_dl_kept + the GEMM it replaces, same kept exponentials.  d_tn is computed from the d-logits either path wrote by the
+    same GEMM (equal up to the run-to-run last-bit noise of the sweep's atomically summed row sums); d_vn differs by the f32 summation
+    order only (one bf16 ulp)."""
+    from temporalalignnet_amd import _lib, loss as L
+    if not _lib.lib().tan_simnce_keeps(512):
+        pytest.skip("kept-exponentials path not available")
+    g = torch.Generator(device="cpu").manual_seed(4321 + S + B)
+    R, Mp, Cw = B * T, B * N, 512
+    vn = torch.nn.functional.normalize(torch.randn(S, R, Cw, generator=g), dim=-1).cuda().bfloat16()
+    tn = torch.nn.functional.normalize(torch.randn(1 if shared else S, Mp, Cw, generator=g), dim=-1).cuda().bfloat16()
+    tgt = (torch.rand(B, T, N, generator=g) < 0.15).float().cuda()
+    tpad = torch.zeros(B, N, dtype=torch.bool)
+    for b in range(B):
+        tpad[b, max(1, N - (b % N)):] = True
+    col_invalid = tpad.view(-1).to(torch.uint8).cuda()
+    row_leak = None
+    if leak:
+        row_leak = torch.zeros(R, dtype=torch.uint8)
+        row_leak[T - 3:T] = 1; row_leak[R - 2:] = 1
+        row_leak = row_leak.cuda()
+    prep = L.compaction_prep(col_invalid, int((~tpad).sum())) if compact else None
+    outs, gv, gt = [], None, None
+    keep_flag = L._FUSED_DVN
+    try:
+        for fused in (True, False):
+            L._FUSED_DVN = fused
+            v = vn.clone().requires_grad_(True); t = tn.clone().requires_grad_(True)
+            v_terms, t_terms = L._FusedNCEFn.apply(v, t, tgt, col_invalid, row_leak, B, T, N, prep)
+            if gv is None:
+                gv = torch.randn(v_terms.shape, generator=g).cuda(); gt = torch.randn(t_terms.shape, generator=g).cuda()
+            (v_terms * gv).sum().add((t_terms * gt).sum()).backward()
+            outs.append((v.grad.float(), t.grad.float()))
+    finally:
+        L._FUSED_DVN = keep_flag
+    (dv0, dt0), (dv1, dt1) = outs
+    assert torch.isfinite(dv0).all() and torch.isfinite(dt0).all()
+    assert (dt0 - dt1).norm().item() <= 2e-4 * dt1.norm().item() + 1e-7       # (two forward sweeps: their row sums meet in f32 atomics)
+    assert (dv0 - dv1).norm().item() <= 3e-3 * dv1.norm().item() + 1e-7, (dv0 - dv1).norm().item() / dv1.norm().item()
+    assert (dv0 - dv1).abs().max().item() <= 1e-2 * dv1.abs().max().item() + 1e-7
