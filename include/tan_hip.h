@@ -224,6 +224,7 @@ int tan_masked_quantile(const float* x, const unsigned char* invalid, int n, flo
 #define TAN_SIM_TERMS 4
 #define TAN_SIM_ACC_ROWS 8
 #define TAN_SIM_DIAG_KEEP 16
+#define TAN_SIM_CORR_KEEP 32 /* (tan_simnce_bwd_dl_dvn_kept) `ws` already holds the correction array of these upstream gradients */
 long tan_simnce_ws_floats(int S, int B, int T, int N);
 int tan_simnce_max_cols(void);   /* most text columns (B*N, or Mc when compacted) one sweep accepts: callers fall back to tan_nce_* above it */
 int tan_simnce_fwd(const void* vn, const void* tn, long t_stage_stride, const float* tgt, const unsigned char* col_invalid,
@@ -261,7 +262,6 @@ int tan_simnce_bwd_dl_dvn_kept(const void* e_keep, const void* vn, const void* t
                                const float* possum_v, const float* possum_t, const float* g_v, const float* g_t, void* dl, void* d_vn,
                                float* ws, int S, int B, int T, int N, int C, const void* tn_blocks, long tb_stage_stride,
                                const int* colmap, int Mc, int phases, void* stream);
-
 /* NCE tail (loss.py:236-237,254-275).  tan_pos_masks: rows_pos[b*T+t] = 1 if frame t of video b has a positive among its
  * unpadded sentences, cols_pos[b*N+k] = 1 if sentence k is unpadded and has a positive frame (tgt [B,T,N] f32, text_pad [B,N]).
  * tan_nce_tail_fwd: out2[0] = (mean(v_d | rows_mask) + mean(t_d | cols_mask)) / 2, out2[1] the same for the joint terms and

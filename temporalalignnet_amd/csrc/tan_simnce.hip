@@ -40,6 +40,7 @@ struct SimArgs {
     bf16_t* ekeep;                     // [S, R, Mp] or null: simnce_res_kernel<0> also stores every e = exp((cos - 1)/tau) (bf16)
     // simnce_res_kernel<1> with the same-video corrections as its tail (instead of a simnce_diag_kernel<true> launch):
     const float* diag;                 // [S, B, T, N] same-video cosines, or null: no corrections in the sweep kernel
+    const float* corr;                 // [S, R, N] same-video corrections of the d-logits (simnce_corr_kernel), or null (simnce_dl_dvn_kernel)
     const int* colmap;                 // padded column b*N+k -> column of the sweep, or -1; null: identity
     int npanel, nfull;                 // simnce_res_kernel: row panels per stage; items (stage, panel) that are not cut in column halves
     const char* Tp;                    // simnce_res_kernel: fragment-major image of the text features (simnce_pack_text_kernel)
@@ -554,6 +555,58 @@ __global__ __launch_bounds__(256) void simnce_dl_kept_kernel(SimArgs a, int npan
     }
 }
 
+// Same-video corrections of the d-logits as a dense [S, R, N] f32 array (entry (row b*T + t, sentence k) = column colmap[b*N + k] of
+// the sweep): what simnce_diag_kernel<true> subtracts -- e (g_v / possum_v [valid column] + g_t / possum_t) / tau on positives -- 0
+// where nothing changes, +inf where the entry is to be zeroed (leaked frames).  The one-pass kernels apply it to their tiles in the
+// LDS from here: looked up entry by entry inside them, each of the ~8 dependent loads (target, cosine, sums, upstream gradients)
+// paid a memory latency per tile -- 7 us a tile, measured with the workgroup's phase clocks.  One block per (video, stage).
+__global__ __launch_bounds__(256) void simnce_corr_kernel(const float* __restrict__ diag, const float* __restrict__ tgt,
+                                                          const unsigned char* __restrict__ col_invalid, const unsigned char* __restrict__ row_leak,
+                                                          const float* __restrict__ possum_v, const float* __restrict__ possum_t,
+                                                          const float* __restrict__ g_v, const float* __restrict__ g_t, float* __restrict__ corr,
+                                                          int B, int T, int N, const int* __restrict__ colmap, int Mp) {
+    const int b = blockIdx.x, s = blockIdx.y;
+    const int R = B * T;
+    const float inv_tau = 1.0f / S_TAU;
+    const float* blk = diag + ((long)s * B + b) * T * N;
+    const float* tg = tgt + (long)b * T * N;
+    float* out = corr + ((long)s * B + b) * T * N;
+    constexpr int U = 4;
+    for (int i0 = threadIdx.x; i0 < T * N; i0 += 256 * U) {
+        int cc[U]; long r[U], c[U]; bool in[U], leak[U];
+        float tgv[U], bl[U], pv[U], gv[U], pt[U], gt[U]; unsigned char inval[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int i = min(i0 + j * 256, T * N - 1);
+            const int t = i / N, k = i - t * N;
+            const int m = colmap ? colmap[b * N + k] : b * N + k;
+            in[j] = m >= 0 && m < Mp;
+            cc[j] = min(max(m, 0), Mp - 1);
+            r[j] = (long)s * R + b * T + t;
+            c[j] = (long)s * Mp + cc[j];
+            leak[j] = row_leak && row_leak[b * T + t];
+            tgv[j] = tg[i]; bl[j] = blk[i]; inval[j] = col_invalid[cc[j]];
+            pv[j] = possum_v[r[j]]; gv[j] = g_v[r[j]]; pt[j] = possum_t[c[j]]; gt[j] = g_t[c[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            if (i0 + j * 256 >= T * N) continue;
+            float v = 0.f;
+            if (in[j]) {
+                if (leak[j]) v = INFINITY;
+                else if (tgv[j] != 0.f) {
+                    const float e = __expf((bl[j] - 1.0f) * inv_tau);
+                    float cr = 0.f;
+                    if (!inval[j] && pv[j] > 0.f) cr += gv[j] / pv[j];
+                    if (pt[j] > 0.f) cr += gt[j] / pt[j];
+                    v = e * cr * inv_tau;
+                }
+            }
+            out[i0 + j * 256] = v;
+        }
+    }
+}
+
 // ---- d logits AND d v_hat = dl . t_hat from the kept exponentials, one pass ------------------------------------------------------
 // simnce_dl_kept_kernel + the GEMM behind it read the d-logits twice more than needed: the element-wise pass writes them (126 MB per
 // family at B = 128), the [S*R, Mp] x [Mp, 512] GEMM reads them back and runs at ~0.16 of the MFMA peak inside the step (K = Mp is
@@ -573,10 +626,18 @@ constexpr int DV_LD = 136;                          // bf16 per LDS row of a d-l
 constexpr int DV_TILE_B = 128 * DV_LD * 2;          // 34 KiB
 constexpr int DV_RAW_B = 32768;                     // a tile of kept exponentials as the sweep stored it
 constexpr int DV_OUT_LD = 520;                      // bf16 per LDS row of the d v_hat panel (epilogue)
-constexpr int DV_OFF_RAW = 2 * DV_TILE_B, DV_OFF_RF = DV_OFF_RAW + 2 * DV_RAW_B, DV_OFF_CF = DV_OFF_RF + 512, DV_OFF_CV = DV_OFF_CF + 1024;
-constexpr int DV_LDS_B = DV_OFF_CV + 1024;          // 137.5 KiB (the epilogue's 130-KiB panel overlays the tile buffers)
-static_assert(128 * DV_OUT_LD * 2 <= DV_OFF_RF, "epilogue panel");
+constexpr int DV_MAX_N = 32;                        // sentences per video the LDS-resident correction arrays hold
+constexpr int DV_OFF_RAW = 2 * DV_TILE_B, DV_OFF_RF = DV_OFF_RAW + 2 * DV_RAW_B, DV_OFF_CORR = DV_OFF_RF + 512;
+constexpr int DV_OFF_MCOL = DV_OFF_CORR + 128 * DV_MAX_N * 4;
+constexpr int DV_LDS_B = DV_OFF_MCOL + 128 * DV_MAX_N * 2;          // 156.5 KiB (the epilogue's 130-KiB panel overlays the tile buffers)
 constexpr int DV_RD = 8;                            // text-fragment ring depth (steps of 16 columns): one tile
+
+// a wave-uniform 64-bit value the compiler may hold in VGPRs -> SGPRs (the "s" operands of inline asm)
+__device__ __forceinline__ const char* sgpr_ptr(const char* p) {
+    const unsigned long long v = (unsigned long long)(uintptr_t)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const char*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
 
 // Transposed fragment-major text image: piece (column block cb16 of 16, feature block fb of 32) = 1 KiB at ((cb16 * 16 + fb) * 1024),
 // lane l's 16 bytes = Tt[cb16*16 + 8 (l >> 5) + e][fb*32 + (l & 31)], e = 0..7; columns >= Mp are ZERO (they are the K padding of
@@ -610,7 +671,7 @@ __global__ __launch_bounds__(256) void simnce_pack_textT_kernel(const bf16_t* __
 }
 
 __global__ __launch_bounds__(512) void simnce_dl_dvn_kernel(SimArgs a, int npanel, int nct, const char* __restrict__ TpT, long tpt_stage_stride,
-                                                            bf16_t* __restrict__ dvn, int dbg) {
+                                                            bf16_t* __restrict__ dvn) {
     extern __shared__ __attribute__((aligned(1024))) char dv_lds[];
     __shared__ int crange[2];                                 // sweep columns that hold sentences of this panel's videos: [min, max]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -625,37 +686,27 @@ __global__ __launch_bounds__(512) void simnce_dl_dvn_kernel(SimArgs a, int npane
     const int R = a.R, Mp = a.Mp, T = a.T, N = a.N;
     const float inv_tau = 1.0f / S_TAU;
     float* const rfb = reinterpret_cast<float*>(dv_lds + DV_OFF_RF);           // [128] g_v / rowsum / tau of the panel's rows
-    float* const cfb = reinterpret_cast<float*>(dv_lds + DV_OFF_CF);           // [2][128] g_t / colsum / tau of a tile's columns
-    float* const cvb = reinterpret_cast<float*>(dv_lds + DV_OFF_CV);           // [2][128] 1 = valid column
+    float* const corrL = reinterpret_cast<float*>(dv_lds + DV_OFF_CORR);       // [128][N] corrections of the panel's same-video entries (a.corr)
+    short* const mL = reinterpret_cast<short*>(dv_lds + DV_OFF_MCOL);          // [128][N] their sweep columns, or -1
     if (tid == 0) { crange[0] = 0x7fffffff; crange[1] = -1; }
     __syncthreads();
-    if (a.diag) {
-        const int b_lo = m0 / T, b_hi = min(m0 + 127, R - 1) / T;
-        for (int p = b_lo * N + tid; p < (b_hi + 1) * N; p += 512) {
-            const int m = a.colmap ? a.colmap[p] : p;
-            if (m >= 0) { atomicMin(&crange[0], m); atomicMax(&crange[1], m); }
+    const int nrow = min(128, R - m0);
+    if (a.corr) {
+        // the panel's rows of the correction array and their columns, once: the per-tile pass below touches the LDS only
+        const float* cp = a.corr + ((long)s * R + m0) * N;
+        for (int i = tid; i < nrow * N; i += 512) {
+            const int lr = i / N, k = i - lr * N, bv = (m0 + lr) / T;
+            int m = a.colmap ? a.colmap[bv * N + k] : bv * N + k;
+            const float v = cp[i];
+            if (m < 0 || m >= Mp) m = -1;
+            corrL[i] = v; mL[i] = (short)m;
+            if (m >= 0 && v != 0.f) { atomicMin(&crange[0], m); atomicMax(&crange[1], m); }
         }
     }
     if (tid < 128) {
         const long ri = (long)s * R + min(m0 + tid, R - 1);
         rfb[tid] = a.g_v[ri] / a.rowsum[ri] * inv_tau;
     }
-    // column factors of tile ct -> cfb / cvb[ct & 1] (threads 0..127; requested half a tile before they are written)
-    float c_gt = 0.f, c_cs = 1.f;
-    int c_inv = 0;
-    auto cols_load = [&](int ct) __attribute__((always_inline)) {
-        if (tid < 128) {
-            const int col = min(ct * 128 + tid, Mp - 1);
-            const long ci = (long)s * Mp + col;
-            c_gt = a.g_t[ci]; c_cs = a.colsum[ci]; c_inv = a.col_invalid[col];
-        }
-    };
-    auto cols_put = [&](int ct) __attribute__((always_inline)) {
-        if (tid < 128) {
-            cfb[(ct & 1) * 128 + tid] = c_gt / c_cs * inv_tau;
-            cvb[(ct & 1) * 128 + tid] = c_inv ? 0.f : 1.f;
-        }
-    };
     // The kept exponentials of a tile travel HBM -> LDS by LDS-DMA (no registers, requested a whole tile ahead): thread `tid` owns the
     // four 16-byte units tid + 512 n of the tile as the sweep stored it (wave quadrant n of the sweep, its accumulator tile ij,
     // register half qh) = 2 column sets (n & 1) x 2 row sets (n >> 1) of 8 rows, and reads back exactly the bytes its own wave
@@ -666,7 +717,7 @@ __global__ __launch_bounds__(512) void simnce_dl_dvn_kernel(SimArgs a, int npane
     const char* Eb = reinterpret_cast<const char*>(a.ekeep) + (((long)s * npanel + panel) * nct) * (long)DV_RAW_B;
     const unsigned raw_lds0 = (unsigned)(uintptr_t)(dv_lds + DV_OFF_RAW) + (unsigned)wave * 1024u;
     auto raw_request = [&](int ct) __attribute__((always_inline)) {
-        const char* src = Eb + (long)ct * DV_RAW_B;
+        const char* src = sgpr_ptr(Eb + (long)ct * DV_RAW_B);
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(raw_lds0 + (unsigned)((ct & 1) * DV_RAW_B + n * 8192)));
@@ -679,11 +730,23 @@ __global__ __launch_bounds__(512) void simnce_dl_dvn_kernel(SimArgs a, int npane
     const int ij = (tid >> 7) & 3, qh = (tid >> 6) & 1;
     const int colb = (ij & 1) * 32 + (lane & 31);                              // + 64 (n & 1)
     const int rowb = (ij >> 1) * 32 + 16 * qh + 4 * (lane >> 5);               // + 64 (n >> 1) + 8 (j >> 1) + (2 j & 3) + h
+    // column factors of this thread's two column sets of a tile: requested a tile and a half before the conversion uses them (6 registers)
+    float cgt[2], ccs[2];
+    int cinv[2];
+    auto cols_load = [&](int ct) __attribute__((always_inline)) {
+#pragma unroll
+        for (int cs = 0; cs < 2; ++cs) {
+            const int col = min(ct * 128 + cs * 64 + colb, Mp - 1);
+            const long ci = (long)s * Mp + col;
+            cgt[cs] = a.g_t[ci]; ccs[cs] = a.colsum[ci]; cinv[cs] = a.col_invalid[col];
+        }
+    };
     // one 16-byte unit: 8 rows (two float4 of row factors) of one column -> the row-major bf16 tile
     auto convert_unit = [&](int ct, int n) __attribute__((always_inline)) {
         const int cs = n & 1, rs = n >> 1;
         const uint4 ev = *reinterpret_cast<const uint4*>(dv_lds + DV_OFF_RAW + (ct & 1) * DV_RAW_B + (n * 512 + tid) * 16);
-        const float cf = cfb[(ct & 1) * 128 + cs * 64 + colb], ok = cvb[(ct & 1) * 128 + cs * 64 + colb];
+        const float cf = cgt[cs] / ccs[cs] * inv_tau;
+        const bool ok = !cinv[cs];
         const float4 r0 = *reinterpret_cast<const float4*>(rfb + rs * 64 + rowb), r1 = *reinterpret_cast<const float4*>(rfb + rs * 64 + rowb + 8);
         const float rf[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
         const unsigned w[4] = {ev.x, ev.y, ev.z, ev.w};
@@ -691,33 +754,24 @@ __global__ __launch_bounds__(512) void simnce_dl_dvn_kernel(SimArgs a, int npane
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ro = 8 * (j >> 1) + ((2 * j) & 3);
-            const unsigned pk = f2bf2(__uint_as_float(w[j] << 16) * ((ok != 0.f ? rf[2 * j] : 0.f) + cf),
-                                       __uint_as_float(w[j] & 0xffff0000u) * ((ok != 0.f ? rf[2 * j + 1] : 0.f) + cf));
+            const unsigned pk = f2bf2(__uint_as_float(w[j] << 16) * ((ok ? rf[2 * j] : 0.f) + cf),
+                                       __uint_as_float(w[j] & 0xffff0000u) * ((ok ? rf[2 * j + 1] : 0.f) + cf));
             tp[ro * DV_LD] = (bf16_t)(pk & 0xffffu);
             tp[(ro + 1) * DV_LD] = (bf16_t)(pk >> 16);
         }
     };
-    // same-video corrections of tile ct in the LDS (simnce_diag_kernel<true>'s arithmetic; block-uniform condition: 1-2 tiles of a panel)
+    // same-video corrections of tile ct in the LDS (simnce_diag_kernel<true>'s arithmetic on the precomputed values; block-uniform
+    // condition: 1-2 tiles of a panel)
     auto diag_tile = [&](int ct) __attribute__((always_inline)) {
         const int c0 = ct * 128;
         bf16_t* tb = reinterpret_cast<bf16_t*>(dv_lds + (ct & 1) * DV_TILE_B);
-        if (a.diag && crange[0] <= c0 + 127 && crange[1] >= c0) {
-            const int nrow = min(128, R - m0);
+        if (a.corr && crange[0] <= c0 + 127 && crange[1] >= c0) {
             for (int i = tid; i < nrow * N; i += 512) {
-                const int lr = i / N, k = i - lr * N, row = m0 + lr;
-                const int b = row / T, t = row - b * T;
-                const int m = a.colmap ? a.colmap[b * N + k] : b * N + k;
-                if (m < c0 || m >= c0 + 128 || m >= Mp) continue;
-                bf16_t* out = tb + lr * DV_LD + (m - c0);
-                if (a.row_leak && a.row_leak[row]) { *out = 0; continue; }
-                if (a.tgt[((long)b * T + t) * N + k] == 0.f) continue;
-                const long ri = (long)s * R + row, ci = (long)s * Mp + m;
-                const float e = __expf((a.diag[(((long)s * a.B + b) * T + t) * N + k] - 1.0f) * inv_tau);
-                const float pv = a.possum_v[ri], pt = a.possum_t[ci];
-                float corr = 0.f;
-                if (!a.col_invalid[m] && pv > 0.f) corr += a.g_v[ri] / pv;
-                if (pt > 0.f) corr += a.g_t[ci] / pt;
-                *out = f2bf(bf2f(*out) - e * corr * inv_tau);
+                const float v = corrL[i];
+                const int m = mL[i];
+                if (v == 0.f || m < c0 || m >= c0 + 128) continue;
+                bf16_t* out = tb + (i / N) * DV_LD + (m - c0);
+                *out = v == INFINITY ? (bf16_t)0 : f2bf(bf2f(*out) - v);
             }
             __syncthreads();
         }
@@ -726,7 +780,7 @@ __global__ __launch_bounds__(512) void simnce_dl_dvn_kernel(SimArgs a, int npane
     auto store_unit = [&](int ct, int i) __attribute__((always_inline)) {
         const int q = tid + 512 * i, lr = q >> 4, cc = (q & 15) * 8, row = m0 + lr, col = ct * 128 + cc;
         const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(dv_lds + (ct & 1) * DV_TILE_B) + lr * DV_LD + cc);
-        if (row < R && col < Mp) *reinterpret_cast<uint4*>(a.dl + ((long)s * R + row) * Mp + col) = v;
+        if (a.dl && row < R && col < Mp) *reinterpret_cast<uint4*>(a.dl + ((long)s * R + row) * Mp + col) = v;
     };
 
     struct BT { bf16x8 f[2]; };
@@ -747,14 +801,14 @@ __global__ __launch_bounds__(512) void simnce_dl_dvn_kernel(SimArgs a, int npane
 
     // ---- prologue: tile 0 converted, tile 1 requested, the ring filled behind them
     raw_request(0);
+    if (nct > 1) raw_request(1);
     cols_load(0);
-    cols_put(0);
-    if (nct > 1) { raw_request(1); cols_load(1); cols_put(1); }
     pn_static_for_s<0, DV_RD>([&](auto jc) { constexpr int J = decltype(jc)::value; load_bt(ring[J], min(J, nk - 1)); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                    // rfb, cfb[0]
+    __syncthreads();                                    // rfb, corrL, mL, crange
 #pragma unroll
     for (int n = 0; n < 4; ++n) convert_unit(0, n);
+    if (nct > 1) cols_load(1);
     __syncthreads();
     diag_tile(0);
 
@@ -766,8 +820,7 @@ __global__ __launch_bounds__(512) void simnce_dl_dvn_kernel(SimArgs a, int npane
         for (int rb = 0; rb < 4; ++rb) af[rb] = *(lds_frag_t)(uintptr_t)(abase + rb * 32 * DV_LD * 2);
         // Per tile and wave: [step 0] the exponentials of tile ct + 2 are requested IN FRONT of the step's ring load -- that load is
         // waited for at step 0 of the next tile, and the queue is in order, so the conversion of tile ct + 1 [steps 1-4] finds its
-        // bytes landed (requested a tile ago) without a wait of its own; [steps 4-7] tile ct leaves for HBM one row piece per step;
-        // column factors of tile ct + 2: requested at step 1, put at step 7 (read behind the tile's barrier).
+        // bytes landed (requested a tile ago) without a wait of its own; [steps 4-7] tile ct leaves for HBM one row piece per step.
         pn_static_for_s<0, 8>([&](auto jc) {
             constexpr int KS = decltype(jc)::value;
             BT& Bt = ring[KS % DV_RD];
@@ -775,18 +828,17 @@ __global__ __launch_bounds__(512) void simnce_dl_dvn_kernel(SimArgs a, int npane
             for (int rb = 0; rb < 4; ++rb) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[rb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bt.f[j], af[rb], acc[rb][j], 0, 0, 0);
-                if constexpr (KS < 7) { if (!(dbg & 16)) af[rb] = *(lds_frag_t)(uintptr_t)(abase + (rb * 32 * DV_LD + (KS + 1) * 16) * 2); }
+                if constexpr (KS < 7) af[rb] = *(lds_frag_t)(uintptr_t)(abase + (rb * 32 * DV_LD + (KS + 1) * 16) * 2);
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (KS == 0) {
-                if (ct + 2 < nct && !(dbg & 4)) raw_request(ct + 2);
+                if (ct + 2 < nct) raw_request(ct + 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (KS == 1) { if (ct + 2 < nct) cols_load(ct + 2); }
-            if constexpr (KS >= 1 && KS <= 4) { if (ct + 1 < nct && !(dbg & 1)) convert_unit(ct + 1, KS - 1); }
-            if constexpr (KS >= 4) { if (!(dbg & 2)) store_unit(ct, KS - 4); }
-            if constexpr (KS == 7) { if (ct + 2 < nct) cols_put(ct + 2); }
-            if (!(dbg & 8)) load_bt(Bt, min(ct * 8 + KS + DV_RD, nk - 1));
+            if constexpr (KS >= 1 && KS <= 4) { if (ct + 1 < nct) convert_unit(ct + 1, KS - 1); }
+            if constexpr (KS >= 4) store_unit(ct, KS - 4);
+            if constexpr (KS == 5) { if (ct + 2 < nct) cols_load(ct + 2); }
+            load_bt(Bt, min(ct * 8 + KS + DV_RD, nk - 1));
             __builtin_amdgcn_sched_barrier(0);
         });
         __syncthreads();
@@ -953,11 +1005,26 @@ extern "C" int tan_simnce_max_cols(void) {
     return res_enabled(a) ? S_MAXCOLS_RES : S_MAXCOLS;       // (C = 512, what the aligner runs; other channel counts: 2048)
 }
 
+static long simnce_corr_floats(int S, int B, int T, int N) { return (long)S * B * T * N + 128 * 32 + 8; }
+
 extern "C" long tan_simnce_ws_floats(int S, int B, int T, int N) {
     const long R = (long)B * T, Mp = (long)B * N;
     // column partials (two per row panel) + same-video blocks + the fragment-major text image of the resident sweep (bf16, per stage,
     // columns rounded up to 128)
-    return 2 * (long)cdiv(R, 128) * S * Mp + (long)S * B * T * N + (long)S * cdiv(Mp, 128) * 128 * 512 / 2 + 4;
+    // ... + the same-video corrections of the one-pass backward kernels ([S, R, N] f32, simnce_corr_kernel; slack for its 1-KiB LDS-DMA pieces)
+    return 2 * (long)cdiv(R, 128) * S * Mp + (long)S * B * T * N + (long)S * cdiv(Mp, 128) * 128 * 512 / 2 + 4 + simnce_corr_floats(S, B, T, N);
+}
+// where the corrections live in `ws` (behind the text image; 16-byte aligned)
+static float* simnce_corr_ptr(float* ws, int S, int B, int T, int N) {
+    const long R = (long)B * T, Mp = (long)B * N;
+    float* p = ws + 2 * (long)cdiv(R, 128) * S * Mp + (long)S * B * T * N + (long)S * cdiv(Mp, 128) * 128 * 512 / 2 + 4;
+    return (float*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+}
+static int simnce_corr_launch(const SimArgs& a, const float* diag, float* corr, hipStream_t st) {
+    hipLaunchKernelGGL(simnce_corr_kernel, dim3(a.B, a.S), dim3(256), 0, st, diag, a.tgt, a.col_invalid, a.row_leak, (const float*)a.possum_v,
+                       a.possum_t, a.g_v, a.g_t, corr, a.B, a.T, a.N, a.colmap, a.Mp);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 static int simnce_common(SimArgs& a, int S, int B, int T, int N, int C) {
@@ -1133,7 +1200,7 @@ static int simnce_bwd_impl(const void* vn, const void* tn, long t_stage_stride, 
                            const float* colsum, const float* possum_v, const float* possum_t, const float* g_v, const float* g_t,
                            void* dl, float* ws, int S, int B, int T, int N, int C, const void* tn_blocks, long tb_stage_stride,
                            const int* colmap, int Mc, int phases, const void* ekeep, void* dvn, void* stream) {
-    TAN_REQUIRE(vn && tn && tgt && col_invalid && rowsum && colsum && possum_v && possum_t && g_v && g_t && dl && ws);
+    TAN_REQUIRE(vn && tn && tgt && col_invalid && rowsum && colsum && possum_v && possum_t && g_v && g_t && (dl || dvn) && ws);
     TAN_REQUIRE(!colmap || (tn_blocks && Mc > 0 && Mc <= B * N));
     if (phases == 0) phases = TAN_SIM_SWEEP | TAN_SIM_DIAG;
     TAN_REQUIRE(!dvn || (ekeep && (phases & TAN_SIM_SWEEP) && (uintptr_t)dvn % 16 == 0));
@@ -1153,7 +1220,12 @@ static int simnce_bwd_impl(const void* vn, const void* tn, long t_stage_stride, 
         const bool tail = (phases & TAN_SIM_DIAG) != 0;
         if (tail && !(phases & TAN_SIM_DIAG_KEEP) && (rc = simnce_diag_blocks(a, (const bf16_t*)tn_blocks, tb_stage_stride, diag, st))) return rc;
         a.ekeep = (bf16_t*)ekeep; a.diag = tail ? diag : nullptr; a.colmap = colmap;
-        if (dvn && a.Mp % 8) return TAN_ERR_BAD_ARG;          // (16-byte row pieces of dl)
+        if (dvn && tail) {          // the corrections as a dense array (once per backward: TAN_SIM_CORR_KEEP = the other one-pass call made it)
+            float* corr = simnce_corr_ptr(ws, S, B, T, N);
+            if (!(phases & TAN_SIM_CORR_KEEP) && (rc = simnce_corr_launch(a, diag, corr, st))) return rc;
+            a.corr = corr;
+        }
+        if (dvn && (a.Mp % 8 || N > DV_MAX_N || a.Mp > 32767)) return TAN_ERR_BAD_ARG;          // (16-byte row pieces of dl; corrections in the LDS)
         if (dvn) {          // d logits + d v_hat in one pass; the transposed text image takes the place of the sweep's (not read again)
             const int npanel = cdiv(a.R, 128), nct = cdiv(a.Mp, 128);
             char* TpT = (char*)(((uintptr_t)(diag + (long)S * B * T * N) + 15) & ~(uintptr_t)15);
@@ -1164,8 +1236,7 @@ static int simnce_bwd_impl(const void* vn, const void* tn, long t_stage_stride, 
             static const hipError_t attr = hipFuncSetAttribute((const void*)simnce_dl_dvn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DV_LDS_B);
             if (attr != hipSuccess) return (int)attr;
             const int prec = prof_begin(st, TAN_PROF_GEMM_BF16 + 1, 2.0 * S * a.R * (double)a.Mp * C);
-            static const int dbg = getenv("TAN_DVN_DBG") ? atoi(getenv("TAN_DVN_DBG")) : 0;
-            hipLaunchKernelGGL(simnce_dl_dvn_kernel, dim3(npanel * S), dim3(512), DV_LDS_B, st, a, npanel, nct, (const char*)TpT, tpt_stride, (bf16_t*)dvn, dbg);
+            hipLaunchKernelGGL(simnce_dl_dvn_kernel, dim3(npanel * S), dim3(512), DV_LDS_B, st, a, npanel, nct, (const char*)TpT, tpt_stride, (bf16_t*)dvn);
             prof_end(st, prec);
             TAN_LAUNCH_CHECK();
             return 0;

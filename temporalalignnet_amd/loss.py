@@ -292,6 +292,7 @@ class _FusedNCEFn(torch.autograd.Function):
         compact = idx is not None
         g_v = torch.zeros(S, R, device=dev) if g_v is None else g_v.contiguous()
         g_t = torch.zeros(S, Mc, device=dev) if g_t is None else g_t.contiguous()           # [S, Mc]: compacted order, like t_terms
+        fusable = ekeep is not None and vn.dtype == torch.bfloat16 and Mc % 8 == 0 and N <= 32 and Mc < 32768
         dl = torch.empty(S, R, Mc, dtype=torch.bfloat16, device=dev)
         bwd_args = (_p(vn), _p(tn_run), C.c_long(0 if shared else Mc * Cw), _p(tgt), _p(ci_run),
                     _p(row_leak), _p(rowsum), _p(colsum), _p(possum_v), _p(possum_t), _p(g_v),
@@ -299,7 +300,7 @@ class _FusedNCEFn(torch.autograd.Function):
                     C.c_int(Cw), _p(tn) if compact else None, C.c_long(0 if shared else Mp * Cw),
                     _p(colmap), C.c_int(Mc), C.c_int(1 | 2 | 16), ops._stream())      # SWEEP | DIAG | DIAG_KEEP: `ws` still holds the forward's same-video blocks
         d_vn = torch.empty_like(vn)
-        if ekeep is not None and vn.dtype == torch.bfloat16 and Mc % 8 == 0 and _FUSED_DVN:
+        if fusable and _FUSED_DVN:
             # d logits and d_vn = dl . tn_run in one pass over the kept exponentials (the tile is the MFMA operand while it is in the LDS)
             _lib.check(_lib.lib().tan_simnce_bwd_dl_dvn_kept(_p(ekeep), *bwd_args[:13], _p(d_vn), *bwd_args[13:]),
                        "tan_simnce_bwd_dl_dvn_kept")

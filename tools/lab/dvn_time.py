@@ -1,4 +1,5 @@
-"""Stand-alone time of the loss backward (d-logits [+ d_vn]) at the headline shape, for TAN_DVN_DBG ablations: prints ms per call."""
+"""Stand-alone time of the loss backward at the headline shape: element-wise d-logits pass + two GEMMs against the one-pass d-logits +
+d_vn kernel + one GEMM; prints ms per call (run under `rocprofv3 --kernel-trace --stats` for the kernels' own durations)."""
 import sys, torch
 from temporalalignnet_amd import loss as L
 sys.path.insert(0, "tools/lab")
@@ -13,8 +14,8 @@ for b in range(B):
     tpad[b, max(1, 4 + (b * 7) % 13):] = True
 col_invalid = tpad.view(-1).to(torch.uint8).cuda()
 prep = L.compaction_prep(col_invalid, int((~tpad).sum()))
-for fused in (False, True):
-    L._FUSED_DVN = fused
+for fused in (0, 1):
+    L._FUSED_DVN = fused >= 1
     ts = []
     for it in range(8):
         ctx = L._ManualCtx()
@@ -26,4 +27,4 @@ for fused in (False, True):
         L._FusedNCEFn.backward(ctx, gv, gt)
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
-    print("fused" if fused else "base ", "Mc", prep[0].shape[0], "backward ms:", " ".join(f"{t:.3f}" for t in ts[2:]))
+    print(("base ", "dvn  ")[fused], "Mc", prep[0].shape[0], "backward ms:", " ".join(f"{t:.3f}" for t in ts[2:]))
