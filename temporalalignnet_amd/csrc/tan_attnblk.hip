@@ -132,7 +132,7 @@ template <int NRB16>
 __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void attnblk_fwd_kernel(AbFwdArgs a) {
     static_assert(PN_WAVES == 8, "eight waves");
     constexpr int NKB = (NRB16 + 1) / 2, LP = 32 * NKB, XROWS = 16 * NRB16, D = AB_D;
-    constexpr int XP_OFF = 0, IMG_OFF = XROWS * 1024, IMG_B = LP * 128, BIAS_OFF = IMG_OFF + 6 * IMG_B, LDS_B = BIAS_OFF + LP * 4;
+    constexpr int XP_OFF = 0, IMG_OFF = XROWS * 1024, IMG_B = LP * 128, BIAS_OFF = IMG_OFF + 6 * IMG_B, BQ_OFF = BIAS_OFF + LP * 4, LDS_B = BQ_OFF + 1536 * 4;
     static_assert(LDS_B <= 163840, "LDS budget");
     __shared__ __attribute__((aligned(1024))) char lds[LDS_B];
 
@@ -164,6 +164,9 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void attnblk_fwd_kerne
         float* bias = reinterpret_cast<float*>(lds + BIAS_OFF);
         const unsigned char* kp = a.keypad ? a.keypad + (long)blockIdx.x * L : nullptr;
         for (int j = tid; j < LP; j += 64 * PN_WAVES) bias[j] = (j >= L || (kp && kp[j])) ? -INFINITY : 0.f;
+        // the in_proj bias (6 KiB): every GEMM-a starts from it, and a global load there is an exposed L2 round trip per head pair
+        for (int j = tid; j < 1536 / 4; j += 64 * PN_WAVES)
+            reinterpret_cast<float4*>(lds + BQ_OFF)[j] = reinterpret_cast<const float4*>(a.b_qkv)[j];
         if constexpr (LP > XROWS) {                 // image rows GEMM-a never writes: zero once (V rows must be finite)
             constexpr int PER = (LP - XROWS) * 8;     // 16-byte chunks per image
             for (int i = tid; i < 6 * PER; i += 64 * PN_WAVES)
@@ -183,23 +186,24 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void attnblk_fwd_kerne
     const float* bias = reinterpret_cast<const float*>(lds + BIAS_OFF);
     const bool saving = a.qkv != nullptr;
 
-    // Side outputs (k, v and O rows of a head pair: operands of the backward) leave for HBM one 1-KiB piece (8 image rows) per
-    // GEMM-a step of the NEXT head pair, read from LDS one step before it is stored: a CU stores ~10-14 B/clk, i.e. the 48-72 KiB
-    // of a head pair take 4-6k cycles of store issue -- as a burst next to the attention (first version) they cost 12 us of a 47 us
-    // launch; dealt between the MFMAs of a 16-step phase the SIMD's other wave computes under them.  (The q rows go out from the
-    // attention wave itself, before O overwrites them.)
-    constexpr int PPI = LP / 8, NPW = 6 * PPI / PN_WAVES;        // pieces per image, pieces per wave (6 | 9)
+    // Side outputs (operands of the backward).  Every vector-memory operation of a wave completes IN ORDER, so a store issued between
+    // the steps of a GEMM sits in front of the weight ring's next loads until the chip's write path has acknowledged it: the 256-320 KiB
+    // a video saves cost 12-20 us of a 48-75 us launch dealt into GEMM-a's steps (round 3).  Now: the q rows leave from the attention
+    // wave itself before O overwrites them (as before); the k and v images of a head pair -- final once GEMM-a's epilogue has written
+    // them -- leave DURING THE ATTENTION PHASE from the waves that have no attention unit (4 of 8 at L <= 64, 2 of 8 at L <= 80: their
+    // ring loads for GEMM-b are already in flight, and the next ones are issued a whole attention phase later); only the O images
+    // (2 x LP rows) still leave one 1-KiB piece per GEMM-a step of the NEXT head pair, read from LDS one step before they are stored.
+    constexpr int PPI = LP / 8, NPW = 2 * PPI / PN_WAVES;        // pieces per image, O pieces per wave (2 | 3)
+    constexpr int NIDLE = PN_WAVES - 2 * NKB, NKV = 4 * PPI / NIDLE;           // waves without an attention unit, k / v pieces per such wave (8 | 24)
+    static_assert(2 * PPI % PN_WAVES == 0 && 4 * PPI % NIDLE == 0, "piece split");
     uint4 cpv;
     auto copy_read = [&](int i, int ln) __attribute__((always_inline)) {
-        const int g = wave + PN_WAVES * i, im = g / PPI, row = (g % PPI) * 8 + (ln >> 3), chunk = ln & 7;
-        cpv = *reinterpret_cast<const uint4*>(lds + IMG_OFF + im * IMG_B + row * 128 + ((chunk ^ img_swz(row)) << 4));
+        const int g = wave + PN_WAVES * i, j = g / PPI, row = (g % PPI) * 8 + (ln >> 3), chunk = ln & 7;
+        cpv = *reinterpret_cast<const uint4*>(lds + IMG_OFF + (j * 3) * IMG_B + row * 128 + ((chunk ^ img_swz(row)) << 4));
     };
     auto copy_store = [&](int i, int ln, int hp_prev) __attribute__((always_inline)) {
-        const int g = wave + PN_WAVES * i, im = g / PPI, row = (g % PPI) * 8 + (ln >> 3), chunk = ln & 7;
-        const int j = im / 3, which = im % 3, h = 2 * hp_prev + j;
-        bf16_t* dst = which == 0 ? a.attn_o + (row0 + row) * C + h * 64 + chunk * 8
-                                 : a.qkv + (row0 + row) * (3 * C) + which * C + h * 64 + chunk * 8;
-        if (row < L) *reinterpret_cast<uint4*>(dst) = cpv;
+        const int g = wave + PN_WAVES * i, j = g / PPI, row = (g % PPI) * 8 + (ln >> 3), chunk = ln & 7;
+        if (row < L) *reinterpret_cast<uint4*>(a.attn_o + (row0 + row) * C + (2 * hp_prev + j) * 64 + chunk * 8) = cpv;
     };
 
     f32x4_t acc_a[3][NRB16];
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void attnblk_fwd_kerne
 #pragma unroll
         for (int fb = 0; fb < 3; ++fb) {
             const int p = 3 * wave + fb, which = (p >> 2) % 3, j = p / 12, fblk = p & 3;
-            const float4 bv = *reinterpret_cast<const float4*>(a.b_qkv + which * C + (2 * hp + j) * 64 + fblk * 16 + 4 * xq);
+            const float4 bv = *reinterpret_cast<const float4*>(lds + BQ_OFF + (which * C + (2 * hp + j) * 64 + fblk * 16 + 4 * xq) * 4);
 #pragma unroll
             for (int rb = 0; rb < NRB16; ++rb) { acc_a[fb][rb][0] = bv.x; acc_a[fb][rb][1] = bv.y; acc_a[fb][rb][2] = bv.z; acc_a[fb][rb][3] = bv.w; }
         }
@@ -272,8 +276,20 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void attnblk_fwd_kerne
         }
         __syncthreads();
 
-        // ---- attention: one (head, 32-query block) unit per wave
-        if (wave < 2 * NKB) {
+        // ---- attention: one (head, 32-query block) unit per wave; the other waves move this head pair's k and v rows out
+        if (wave >= 2 * NKB) {
+            if (saving) {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+#pragma unroll 4
+                for (int i = 0; i < NKV; ++i) {
+                    const int g = (wave - 2 * NKB) + NIDLE * i, im = g / PPI, j = im >> 1, which = 1 + (im & 1);
+                    const int row = (g % PPI) * 8 + (ln >> 3), chunk = ln & 7;
+                    const uint4 v = *reinterpret_cast<const uint4*>(lds + IMG_OFF + (j * 3 + which) * IMG_B + row * 128 + ((chunk ^ img_swz(row)) << 4));
+                    if (row < L) *reinterpret_cast<uint4*>(a.qkv + (row0 + row) * (3 * C) + which * C + (2 * hp + j) * 64 + chunk * 8) = v;
+                }
+            }
+        } else {
             int ln = lane;
             asm volatile("" : "+v"(ln));
             const int j = wave / NKB, q0 = (wave % NKB) * 32, h = 2 * hp + j;
@@ -316,7 +332,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void attnblk_fwd_kerne
 #pragma unroll
             for (int p = 0; p < 2; ++p)
                 resq[nb][mb][p] = *reinterpret_cast<const uint4*>(a.x_in + (row0 + min(mb * 32 + (lane & 31), L - 1)) * C + wave * 64 + nb * 32 + (2 * hi + p) * 8);
-    if (saving) {          // the last head pair's side outputs
+    if (saving) {          // the last head pair's O rows
 #pragma unroll 1
         for (int i = 0; i < NPW; ++i) { copy_read(i, lane); copy_store(i, lane, 3); }
     }
