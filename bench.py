@@ -276,7 +276,7 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
                     "gemm_ms_per_step": round(tms / sampled, 3), "algorithmic_gflop_per_step": round(twork / sampled / 1e9, 1),
                     "step_frac": round(twork / sampled / (elapsed / steps) / 1e12 / peak, 4),
                     "timer": f"HIP events on each launch's own stream, {sampled} of the {steps} timed steps (one in {min(timer_every, steps)}), "
-                             f"every {stride}-th launch in it (a kind's time = its sampled time x all its work / its sampled work; `isolated` brackets every launch)",
+                             f"every {stride}-th launch OF EACH KIND in it (a kind's time = its sampled time x all its work / its sampled work; `isolated` brackets every launch)",
                     "concurrency": "2 HIP streams (video || joint stack): durations include co-running kernels",
                     "isolated": iso,
                     "by_kernel": [{**x, "ms_per_step": round(x["ms_per_step"], 3), "tflops": round(x["tflops"], 1)} for x in kinds]}

@@ -10,7 +10,7 @@ struct ProfState {
     bool on = false;
     int cap = 0;
     std::atomic<int> n{0};           // launches are issued from two host threads (main + side-stream helper)
-    std::atomic<int> seen{0};        // every eligible launch, timed or not
+    std::atomic<int> seen[TAN_PROF_NKINDS];      // every eligible launch of a kind, timed or not
     int stride = 1;                  // time every stride-th eligible launch (the ~8-14 us an event pair costs add up over ~60 launches)
     std::atomic<long long> all_mflop[TAN_PROF_NKINDS], all_cnt[TAN_PROF_NKINDS];      // work / launches of EVERY eligible launch
     std::vector<hipEvent_t> ev;      // 2 per record
@@ -23,7 +23,9 @@ int prof_begin(hipStream_t st, int kind, double work) {
     ProfState& p = g_prof;
     if (!p.on || p.n.load(std::memory_order_relaxed) >= p.cap) return -1;
     if (kind >= 0 && kind < TAN_PROF_NKINDS) { p.all_mflop[kind].fetch_add((long long)(work * 1e-6)); p.all_cnt[kind].fetch_add(1); }
-    if (p.stride > 1 && p.seen.fetch_add(1) % p.stride != 0) return -1;
+    // every stride-th launch OF ITS KIND (a global count left kinds with two launches per step unsampled in some runs, and the line's
+    // FLOP total with them)
+    if (p.stride > 1 && kind >= 0 && kind < TAN_PROF_NKINDS && p.seen[kind].fetch_add(1) % p.stride != 0) return -1;
     const int i = p.n.fetch_add(1);
     if (i >= p.cap) return -1;
     p.kind[i] = kind;
@@ -65,7 +67,7 @@ extern "C" int tan_prof_collect_all(double* work_by_kind, long* count_by_kind, i
 
 extern "C" int tan_prof_stride(int stride) {
     g_prof.stride = stride < 1 ? 1 : stride;
-    g_prof.seen = 0;
+    for (int k = 0; k < TAN_PROF_NKINDS; ++k) g_prof.seen[k] = 0;
     return 0;
 }
 
