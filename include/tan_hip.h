@@ -255,8 +255,9 @@ int tan_simnce_bwd_dl_kept(const void* e_keep, const void* vn, const void* tn, l
 /* tan_simnce_bwd_dl_kept that also returns d_vn [S, R, C] (bf16) = dl . t_hat, the gradient of the unit video features
  * (the autograd of tan_model.py:116-119,136-139's einsum towards its first operand): the 128 x 128 d-logits tiles are the MFMA operand
  * while they are in the LDS, so the [S*R, Mp] x [Mp, C] GEMM behind the element-wise pass and its read of the d-logits go away.  dl is
- * still written (the text-feature gradient contracts it over the rows).  C = 512 (tan_simnce_keeps), sweep columns % 8 == 0;
- * overwrites the sweep's text image inside `ws`.                                                                                                          */
+ * still written (the text-feature gradient contracts it over the rows; dl = NULL: not written).  C = 512 (tan_simnce_keeps), sweep
+ * columns % 8 == 0 and < 32768, N <= 32; overwrites the sweep's text image inside `ws` and (unless phases has TAN_SIM_CORR_KEEP)
+ * builds the dense same-video correction array there.                                                                                                          */
 int tan_simnce_bwd_dl_dvn_kept(const void* e_keep, const void* vn, const void* tn, long t_stage_stride, const float* tgt,
                                const unsigned char* col_invalid, const unsigned char* row_leak, const float* rowsum, const float* colsum,
                                const float* possum_v, const float* possum_t, const float* g_v, const float* g_t, void* dl, void* d_vn,
