@@ -31,6 +31,16 @@ from .tfm_model import TemporalEncoder, _LayerNormParams, _LinearParams, get_pos
 from .workspace import HEADS, WIDTH
 
 
+def _local_bert():
+    """HuggingFace BertModel('bert-base-uncased') from local files only (tan_model.py:38), or None."""
+    import os
+    try:
+        from transformers import BertModel
+        return BertModel.from_pretrained(os.environ.get("TAN_BERT_PATH", "bert-base-uncased"), local_files_only=True)
+    except Exception:          # noqa: BLE001  (no local weights / no transformers: the embeddings come from the caller)
+        return None
+
+
 class TemporalAligner(_AlignerEngine, nn.Module):
     def __init__(self, num_encoder_layers=2, num_decoder_layers=2, sim="cos", language_model="word2vec",
                  pos_enc="learned", use_text_pos_enc=0, return_dual_feature=1, random_pos_start=1,
@@ -55,9 +65,15 @@ class TemporalAligner(_AlignerEngine, nn.Module):
             self.bert = Word2VecModel(compute_dtype=compute_dtype)
         elif language_model in (None, "none"):
             self.bert = None
+        elif language_model == "bert":
+            # tan_model.py:37-38,41,49: 768-d sentence embeddings into text_pre_proj.  forward() never calls the language model
+            # (train/main.py:47-79 embeds the text first) and the BERT encoder is outside this path (f1 is the
+            # Word2Vec model): `self.bert` is HuggingFace's BertModel when a local copy of the weights is available
+            # (TAN_BERT_PATH or the HF cache; no download is attempted), else None -- the caller then passes [B, N, 768] embeddings
+            self.bert = _local_bert()
         else:
-            raise NotImplementedError(f"language_model={language_model!r}: only 'word2vec' (tan_model.py:39-40) or None")
-        text_embed_dim = 512
+            raise NotImplementedError(f"language_model={language_model!r}: 'word2vec' (tan_model.py:39-40), 'bert' (:37-38) or None")
+        text_embed_dim = {"bert": 768}.get(language_model, 512)           # tan_model.py:41
 
         self.video_temporal_encoder = TemporalEncoder(width=WIDTH, layers=num_encoder_layers, heads=HEADS)
         self.joint_temporal_encoder = TemporalEncoder(width=WIDTH, layers=num_decoder_layers, heads=HEADS)

@@ -503,10 +503,32 @@ def g12_retrieval():
     save("g12_compute_metrics", x=x, **{k: np.asarray(v) for k, v in ref_retr.compute_metrics(x).items()})
 
 
+def g13_bert_width():
+    """G13: language_model='bert' (tan_model.py:37-41,49: 768-d sentence embeddings into text_pre_proj): E1D2 T=16 B=3, every output
+    of TemporalAligner.forward.  The pretrained BertModel is not available offline and forward() never calls it (train/main.py embeds
+    the text first): `BertModel.from_pretrained` is shimmed to a parameter-less stub, like the Word2Vec class above."""
+    class _Bert:
+        @staticmethod
+        def from_pretrained(name):
+            return _NoLM()
+    keep = ref_tan.BertModel
+    ref_tan.BertModel = _Bert
+    try:
+        m = ref_tan.TemporalAligner(num_encoder_layers=1, num_decoder_layers=2, use_alignability_head=1, language_model="bert")
+    finally:
+        ref_tan.BertModel = keep
+    load_params(m, synth.make_params(113, 1, 2, True, d_text=768))
+    batch = synth.make_batch(23, B=3, T=16, n_min=2, n_max=6, d_text=768, video_pad_tail=2)
+    np.random.seed(77)
+    with torch.no_grad():
+        out = ref_forward(m, batch)
+    save("g13_bert_width", **{k: v.numpy() for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     table = {"g1": g1_forward_small, "g2": g2_forward_e6d6, "g3": g3_loss_init, "g4": g4_loss_cotrain,
              "g5": g5_train_steps, "g6": g6_eval_harness, "g7": g7_long_and_interp, "g8": g8_word2vec, "g9": g9_htm_loader, "g10": g10_sine_pos,
-             "g11": g11_text_pos_and_sine, "g12": g12_retrieval}
+             "g11": g11_text_pos_and_sine, "g12": g12_retrieval, "g13": g13_bert_width}
     for w in which:
         table[w]()

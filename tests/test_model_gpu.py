@@ -43,6 +43,37 @@ def test_g1_forward_matches_reference_golden(golden):
 
 
 @gpu
+def test_g13_bert_width_matches_reference_golden(golden):
+    """language_model='bert' (tan_model.py:37-41,49): the aligner takes 768-d sentence embeddings (fp32 forward against the reference's
+    outputs; a bf16 train step through the fused input embeddings and their backward runs and gives finite gradients)."""
+    from temporalalignnet_amd.tan_model import TemporalAligner
+    g = golden("g13_bert_width")
+    b = synth.make_batch(23, B=3, T=16, n_min=2, n_max=6, d_text=768, video_pad_tail=2)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_params(113, 1, 2, True, d_text=768).items()}
+    outs = {}
+    for dtype in ("fp32", "bf16"):
+        m = TemporalAligner(num_encoder_layers=1, num_decoder_layers=2, use_alignability_head=1, language_model="bert", compute_dtype=dtype)
+        assert m.text_pre_proj.weight.shape == (512, 768)
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected and all(k.startswith("bert.") for k in missing), (missing, unexpected)
+        m.cuda()
+        np.random.seed(77)
+        if dtype == "fp32":
+            with torch.no_grad():
+                out = hip_forward(m, b)
+            assert set(out) == set(g.files)
+            for k in g.files:
+                np.testing.assert_allclose(out[k].cpu().numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+        else:
+            out = hip_forward(m, b)
+            (out["logits_dual"].float().square().mean() + out["logits_joint"].float().square().mean()).backward()
+            gw = m.text_pre_proj.weight.grad
+            assert gw is not None and gw.shape == (512, 768) and torch.isfinite(gw).all() and gw.abs().sum() > 0
+            for k in ("logits_dual", "logits_joint"):
+                assert np.abs(out[k].detach().float().cpu().numpy() - g[k]).max() < 3e-2, k
+
+
+@gpu
 def test_g2_forward_e6d6_matches_reference_golden(golden):
     g = golden("g2_forward_e6d6")
     b = synth.make_batch(12, B=2, T=64, n_min=8, n_max=12)

@@ -55,6 +55,18 @@ def test_g2_forward_e6d6(golden):
         np.testing.assert_allclose(out[k].numpy(), g[k], err_msg=k, **TOL)
 
 
+def test_g13_bert_width_text_pre_proj(golden):
+    """language_model='bert' (tan_model.py:37-41,49): 768-d sentence embeddings; the oracle is shape-agnostic in text_pre_proj."""
+    g = golden("g13_bert_width")
+    b = synth.make_batch(23, B=3, T=16, n_min=2, n_max=6, d_text=768, video_pad_tail=2)
+    p = {k: torch.from_numpy(v) for k, v in synth.make_params(113, 1, 2, True, d_text=768).items()}
+    np.random.seed(77)
+    out = fwd(p, b, 1, 2, random_pos_start=True)
+    assert set(out) == set(g.files)
+    for k in g.files:
+        np.testing.assert_allclose(out[k].numpy(), g[k], err_msg=k, **TOL)
+
+
 def test_g11_text_pos_enc_and_sine(golden):
     """The two constructor branches of tan_model.py:60-62,212-228 (previously unpinned)."""
     b = synth.make_batch(21, B=3, T=16, n_min=2, n_max=6, video_pad_tail=2)
