@@ -267,3 +267,39 @@ def test_full_size_forward_and_loss_match_the_cpu_oracle():
         l16, _ = _loss(mb, _batch(), fused=True)
     for k in ("loss", "loss-dual", "loss-joint"):
         assert abs(l16[k].item() - float(ref_loss[k])) < 1e-2 * abs(float(ref_loss[k])), (k, l16[k].item(), float(ref_loss[k]))
+
+
+def test_full_size_gradients_match_the_cpu_oracle():
+    """... and the backward: every parameter gradient of the stage-1 loss at B = 128 against torch autograd through the oracle (fp32 mode:
+    max error 2e-3 of the tensor's largest entry, the tolerance of the fixture-size test; bf16 mode with the fused loss -- the
+    benchmarked configuration, two-chain step kernels included -- cosine >= 0.99 per tensor)."""
+    from oracle import loss_ref, tan_ref, train_ref
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    b_np = synth.make_batch(21, B=B, T=T, n_min=4, n_max=16)
+    p = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in synth.make_params(7, E, D, False).items()}
+    t = train_ref.to_torch_batch(b_np)
+    ref = tan_ref.forward(p, t["video"], t["text_embed"], t["padding_mask"], t["text_padding_mask"].bool(), E=E, D=D,
+                          use_alignability_head=False)
+    ref_loss, _ = loss_ref.get_loss(b_np, t["video"], t["text_embed"], t["padding_mask"], t["text_padding_mask"], ref,
+                                    loss_ref.default_args(model="init"), t["abs_text_pos"])
+    ref_loss["loss"].backward()
+    del ref
+    for dtype, fused in (("fp32", False), ("bf16", True)):
+        m = _model(dtype)
+        l, _ = _loss(m, _batch(), fused=fused)
+        l["loss"].backward()
+        worst = ("", 0.0)
+        for name, prm in m.named_parameters():
+            want = p[name].grad
+            if want is None or want.abs().max().item() == 0:
+                continue
+            got = prm.grad.float().cpu()
+            if dtype == "fp32":
+                err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
+                worst = max(worst, (name, err), key=lambda x: x[1])
+                assert err < 2e-3, (name, err)
+            else:
+                cos = torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0).item()
+                assert cos >= 0.99, (name, cos)
+        del m
+        torch.cuda.empty_cache()
