@@ -303,3 +303,42 @@ def test_full_size_gradients_match_the_cpu_oracle():
                 assert cos >= 0.99, (name, cos)
         del m
         torch.cuda.empty_cache()
+
+
+def test_stage2_full_size_self_labelling_matches_the_cpu_oracle():
+    """BASELINE configs[2] (stage-2 co-training, E6D6, B = 128 per GPU) against the oracle at full size: two oracle forwards (online,
+    EMA) + its cotrain get_loss (threshold 0.5, agreement 'keep', alignability head).  HIP fp32: the arg-max window positions of the
+    self-labelling (north star: bit-exact alignable argmax indices) and the agreement targets of every real sentence, the threshold
+    mask and the loss entries."""
+    from oracle import loss_ref, tan_ref, train_ref
+    from temporalalignnet_amd.loss import get_loss
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    b_np = synth.make_batch(23, B=B, T=T, n_min=4, n_max=16)
+    t = train_ref.to_torch_batch(b_np)
+    args = loss_ref.default_args(model="cotrain", loss_threshold=0.5, temporal_agreement_type="keep")
+    with torch.no_grad():
+        outs = {}
+        for tag, seed in (("", 7), ("ema-", 8)):
+            p = {k: torch.from_numpy(v) for k, v in synth.make_params(seed, E, D, True).items()}
+            o = tan_ref.forward(p, t["video"], t["text_embed"], t["padding_mask"], t["text_padding_mask"].bool(), E=E, D=D,
+                                use_alignability_head=True)
+            outs.update({tag + k: v for k, v in o.items()})
+        ref, raux = loss_ref.get_loss(b_np, t["video"], t["text_embed"], t["padding_mask"], t["text_padding_mask"], outs, args,
+                                      t["abs_text_pos"])
+    del outs
+    tr, b = _cotrain_setup("fp32", False)
+    with torch.no_grad():
+        kw = dict(video_padding_mask=b["padding_mask"], lang_padding_mask=b["text_padding_mask"].bool(), fused=False)
+        lg = tr.model.online(b["video"], b["text_embed"], **kw)
+        le = tr.model.target(b["video"], b["text_embed"], **kw)
+        ld, aux = get_loss(b, b["video"], b["text_embed"], b["padding_mask"], b["text_padding_mask"],
+                           {**lg, **{f"ema-{k}": v for k, v in le.items()}}, tr.args, b["abs_text_pos"], return_aux=True)
+    valid = ~torch.as_tensor(b_np["text_padding_mask"]).bool().numpy()                 # [B, N]
+    pos, want = aux["max_position_dual"].cpu().numpy(), raux["max_position_dual"].numpy()
+    assert (pos == want)[valid].all(), ((pos != want) & valid).sum()
+    full = raux["agreement_self_tgt"].numpy()                                          # [B,T,B,N]
+    diag = np.stack([full[i, :, i, :] for i in range(B)])
+    got = aux["agreement_tgt"].cpu().numpy()
+    assert got.shape == diag.shape and ((got != 0) == (diag != 0)).all()
+    for k in ("loss", "loss-dual", "loss-joint", "loss-joint-bce", "loss-total", "confidence-ratio", "alignability_top1"):
+        assert abs(ld[k].item() - float(ref[k])) <= 2e-4 * max(1.0, abs(float(ref[k]))), (k, ld[k].item(), float(ref[k]))
