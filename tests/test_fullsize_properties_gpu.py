@@ -342,3 +342,56 @@ def test_stage2_full_size_self_labelling_matches_the_cpu_oracle():
     assert got.shape == diag.shape and ((got != 0) == (diag != 0)).all()
     for k in ("loss", "loss-dual", "loss-joint", "loss-joint-bce", "loss-total", "confidence-ratio", "alignability_top1"):
         assert abs(ld[k].item() - float(ref[k])) <= 2e-4 * max(1.0, abs(float(ref[k]))), (k, ld[k].item(), float(ref[k]))
+
+
+def test_len256_full_size_matches_the_cpu_oracle():
+    """BASELINE configs[3] (len = 256: video stack L = 256, joint stack L = 272, B = 32 -- the mid-length attention kernels and the
+    row-panel MLP head / tail variants that only this configuration runs) against the oracle at full size: fp32 logits, the stage-1 loss,
+    and every parameter gradient (fp32 within 2e-3 of each tensor's largest entry; bf16 + fused loss cosine >= 0.99)."""
+    from oracle import loss_ref, tan_ref, train_ref
+    from temporalalignnet_amd.loss import get_loss
+    from temporalalignnet_amd.tan_model import TemporalAligner
+    from temporalalignnet_amd.train import default_args, to_device_batch
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    Bl, Tl = 32, 256
+    b_np = synth.make_batch(29, B=Bl, T=Tl, n_min=4, n_max=16)
+    p = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in synth.make_params(9, E, D, False).items()}
+    t = train_ref.to_torch_batch(b_np)
+    ref = tan_ref.forward(p, t["video"], t["text_embed"], t["padding_mask"], t["text_padding_mask"].bool(), E=E, D=D,
+                          use_alignability_head=False)
+    ref_loss, _ = loss_ref.get_loss(b_np, t["video"], t["text_embed"], t["padding_mask"], t["text_padding_mask"], ref,
+                                    loss_ref.default_args(model="init"), t["abs_text_pos"])
+    ref_loss["loss"].backward()
+    ref = {k: v.detach() for k, v in ref.items() if k.startswith("logits")}
+    b = to_device_batch(b_np)
+    for dtype, fused in (("fp32", False), ("bf16", True)):
+        m = TemporalAligner(num_encoder_layers=E, num_decoder_layers=D, use_alignability_head=0, language_model=None,
+                            compute_dtype=dtype, random_pos_start=0)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(9, E, D, False).items()})
+        m.cuda()
+        out = m(b["video"], b["text_embed"], b["padding_mask"], b["text_padding_mask"].bool(), b["_tgt_raw"], fused=fused)
+        if fused:
+            out["_fused"].n_text_valid = b["n_text"]
+        l = get_loss(b, b["video"], b["text_embed"], b["padding_mask"], b["text_padding_mask"], out, default_args(model="init", seq_len=Tl),
+                     b["abs_text_pos"])
+        l["loss"].backward()
+        tol = 1e-4 if dtype == "fp32" else 1e-2
+        for k in ("loss", "loss-dual", "loss-joint"):
+            assert abs(l[k].item() - float(ref_loss[k].detach())) < tol * abs(float(ref_loss[k].detach())), (dtype, k, l[k].item(), float(ref_loss[k].detach()))
+        if dtype == "fp32":
+            for k in ("logits_dual", "logits_joint"):
+                err = (out[k].detach().cpu() - ref[k]).abs().max().item()
+                assert err < 2e-4, (k, err)
+        for name, prm in m.named_parameters():
+            want = p[name].grad
+            if want is None or want.abs().max().item() == 0:
+                continue
+            got = prm.grad.float().cpu()
+            if dtype == "fp32":
+                err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
+                assert err < 2e-3, (name, err)
+            else:
+                cos = torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0).item()
+                assert cos >= 0.99, (name, cos)
+        del m, out, l
+        torch.cuda.empty_cache()
