@@ -145,7 +145,7 @@ def traffic_profile(stage, batch_size, seq_len):
 
 
 def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, timer_every, ddp_mode=None, global_negatives=None,
-               with_lm=False):
+               with_lm=False, grad_dtype=None):
     """One configuration: W untimed + K timed steps between barriers; returns the result fields (no printing)."""
     from temporalalignnet_amd import _lib, dist, synth
     from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
@@ -160,6 +160,8 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
                       global_negatives=gneg)
     if ddp_mode is not None:
         trainer.ddp_mode = ddp_mode
+    if grad_dtype is not None:
+        trainer.ddp_grad_dtype = grad_dtype
     trainer.time_comm = dist.active()
     trainer.batches_seen = 1000                                          # past warm-up: non-zero learning rate
     trainer.iteration = 1000
@@ -213,7 +215,8 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
         comm = {"world_size_seen_by_backend": tdist.get_world_size(), "backend": tdist.get_backend(),
                 "ddp_mode": "global-negatives (feature all-gather + text-gradient reduce-scatter) + " + trainer.ddp_mode
                 if gneg else trainer.ddp_mode,
-                "gradient_bytes_per_step": alone[2], "collectives_per_step": alone[1],
+                "gradient_bytes_per_step": alone[2], "collectives_per_step": alone[1], "collectives_last_step": trainer.last_collectives,
+                "gradient_wire_dtype": trainer.ddp_grad_dtype, "two_chain_step": bool(getattr(trainer, "_last_step_chains", False)),
                 "allreduce_ms_per_step_alone": round(alone[0], 3),
                 "exposed_comm_ms_per_step": round(sum(exposed) / max(len(exposed), 1), 3),
                 "exposed_comm_ms_per_step_max_over_ranks": round(dist.max_over_ranks(sum(exposed) / max(len(exposed), 1), dev), 3),
@@ -330,7 +333,9 @@ def main():
         # reference's step also runs the sentence embedder (row f1): a fourth entry starts from token ids.
         for st, bs, sl, lm, tag in ((2, 128, 64, False, "configs[2] on 1 GPU: E6D6 len=64 stage-2 co-training, B=128"),
                                     (1, 32, 256, False, "configs[3]: len=256 (joint L=272), B=32"),
-                                    (1, 128, 64, True, "configs[1] with the language model in the step (tokens -> Word2Vec -> aligner)")):
+                                    (1, 128, 64, True, "configs[1] with the language model in the step (tokens -> Word2Vec -> aligner)"),
+                                    (1, 16, 64, False, "configs[1] at B_local=16 (SURVEY 8(d) config 3's small-batch point, stage 1)"),
+                                    (2, 16, 64, False, "configs[2]: stage-2 co-training at B_local=16 (global 128 at 8 GPUs)")):
             r, _ = run_config(a, world, rank, dev, st, bs, sl, a.extra_steps, 3, 5, with_lm=lm)
             r["name"] = tag
             extra.append(r)
@@ -338,13 +343,17 @@ def main():
         # Multi-GPU (or TAN_FORCE_DIST=1): the variants the first hardware scaling run has to decide between, in the same run --
         # the other gradient-reduction mode, global negatives, and BASELINE configs[2] (stage-2 co-training) at B_local 128 / 16
         # (SURVEY 8(d) config 3).  The headline line keeps the default mode; n_gpus == 1 without TAN_FORCE_DIST prints none of this.
-        other = "buckets" if os.environ.get("TAN_DDP_MODE", "flat") == "flat" else "flat"
-        for kw, tag in ((dict(stage=1, bs=128, ddp_mode=other), f"configs[1], gradient reduction mode '{other}' (TAN_DDP_MODE)"),
-                        (dict(stage=1, bs=128, gneg=True), "configs[1] with global negatives (row f3)"),
-                        (dict(stage=2, bs=128), "configs[2]: stage-2 co-training, B_local=128"),
-                        (dict(stage=2, bs=16), "configs[2]: stage-2 co-training, B_local=16 (global 128 at 8 GPUs)")):
+        cur = os.environ.get("TAN_DDP_MODE", "flat")
+        others = [m for m in ("flat", "buckets", "single") if m != cur]
+        variants = [(dict(stage=1, bs=128, ddp_mode=m), f"configs[1], gradient reduction mode '{m}' (TAN_DDP_MODE)") for m in others]
+        variants += [(dict(stage=1, bs=128, grad_dtype="bf16"), "configs[1], gradient on the wire as bf16 (TAN_DDP_GRAD_DTYPE=bf16: 80 MB per step)"),
+                     (dict(stage=1, bs=16), "configs[1] at B_local=16 (SURVEY 8(d) config 3's small-batch point, stage 1)"),
+                     (dict(stage=1, bs=128, gneg=True), "configs[1] with global negatives (row f3)"),
+                     (dict(stage=2, bs=128), "configs[2]: stage-2 co-training, B_local=128"),
+                     (dict(stage=2, bs=16), "configs[2]: stage-2 co-training, B_local=16 (global 128 at 8 GPUs)")]
+        for kw, tag in variants:
             r, _ = run_config(a, world, rank, dev, kw["stage"], kw["bs"], 64, a.extra_steps, 5, 5, ddp_mode=kw.get("ddp_mode"),
-                              global_negatives=kw.get("gneg", False))
+                              global_negatives=kw.get("gneg", False), grad_dtype=kw.get("grad_dtype"))
             r["name"] = tag
             extra.append(r)
     if rank == 0:

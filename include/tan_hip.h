@@ -32,7 +32,7 @@ extern "C" {
 #define TAN_ACT_RELU 3           /* C = max(acc+bias, 0)  (Word2VecModel fc1, model/word2vec_model.py:86) */
 
 int tan_version(void);
-/* sizeof(tan_gemm_desc | tan_layer_params | tan_layer_bufs | tan_encoder_desc) for which = 0..3 (binding self-check) */
+/* sizeof(tan_gemm_desc | tan_layer_params | tan_layer_bufs | tan_encoder_desc | tan_simfam_desc) for which = 0..4 (binding self-check) */
 int tan_abi_sizeof(int which);
 
 /* Optional in-stream kernel timer (bench.py's `roofline` line): while enabled every tan_gemm / tan_attn_* launch is
@@ -263,6 +263,47 @@ int tan_simnce_bwd_dl_dvn_kept(const void* e_keep, const void* vn, const void* t
                                const float* possum_v, const float* possum_t, const float* g_v, const float* g_t, void* dl, void* d_vn,
                                float* ws, int S, int B, int T, int N, int C, const void* tn_blocks, long tb_stage_stride,
                                const int* colmap, int Mc, int phases, void* stream);
+/* ---- one feature FAMILY (dual or joint) of the logits-free NCE, from the stacks' stage outputs to their gradients --------------
+ * Everything between an encoder stack's forward and its backward in the training step, for one family of tan_model.py:116-119
+ * (dual: video stack stages x the one text embedding) or :136-139 (joint: video rows x text rows of the joint stack's stages), with
+ * loss.py:240-253 and its autograd:
+ *   tan_simfam_fwd  L2-normalise the stage rows (video: one launch, or inside the sweep's panel load with TAN_SIMFAM_NORM_IN_SWEEP;
+ *                   text: normalise + column compaction + both fragment-major text images in ONE launch), the statistics sweep keeping
+ *                   its exponentials (tan_simnce_fwd_keep's kernel), and ONE finishing launch: same-video cosine blocks, column sums
+ *                   over the row panels, positives / leaked frames, v_terms / t_terms -- and, when g_v / g_t are already known (the
+ *                   two-chain step: they depend on the batch's masks only), the same-video corrections of the backward.
+ *   tan_simfam_bwd  d logits + d v_hat in one pass over the kept exponentials whose epilogue applies the L2-normalisation's backward
+ *                   and stores straight into the stacks' stage-gradient rows (d v_hat never exists in HBM); the text-feature gradient
+ *                   GEMM d t_hat = dl^T v_hat (f32, split-K); one launch that gathers it back to the padded sentence order, applies
+ *                   the normalisation's backward and stores the text stage-gradient rows.
+ * 6-7 launches per family and step instead of 18.  bf16, C = 512, N <= 32, Mc % 8 == 0, Mc <= tan_simnce_max_cols(), S <= 8.
+ * Row addressing: video row r = b*T + t of stage s lives at x_video.p[s] + ((r / T) * v_grp_rows + v_off + r % T) * C (video stack:
+ * v_grp_rows = T; joint stack: T + N); padded sentence m = b*N + k at x_text.p[st] + ((m / N) * t_grp_rows + t_off + m % N) * C;
+ * d_video / d_text are addressed the same way.  St = 1: one text embedding for all stages (dual), St = S: per stage (joint).
+ * Column compaction as tan_simnce_fwd: idx [Mc] (sweep column -> padded sentence), colmap [B*N] (or both NULL: Mc = B*N, identity).
+ * Saved between the two calls (caller-owned): vn [S,R,C], inv_v [S,R], tn [St,Mc,C], inv_t [St,Mc], rowsum / possum_v [S,R],
+ * colsum / possum_t [S,Mc], e_keep (tan_simnce_keep_elems), ws (tan_simfam_ws_bytes).                                              */
+#define TAN_SIMFAM_NORM_IN_SWEEP 1   /* flags: the sweep normalises its frame panel itself and writes vn / inv_v (no separate launch) */
+#define TAN_SIMFAM_CORR_DONE 2       /* (set by tan_simfam_fwd when g_v / g_t were given) ws holds the corrections: bwd skips that launch */
+typedef struct tan_simfam_desc {
+    int S, St, B, T, N, C, Mc, flags;
+    tan_ptr8 x_video; long v_grp_rows, v_off;
+    tan_ptr8 x_text; long t_grp_rows, t_off;
+    const long* idx; const int* colmap; const unsigned char* col_invalid;   /* [Mc] | [B*N] | [Mc] pad flags of the sweep's columns */
+    const float* tgt; const unsigned char* row_leak;                        /* [B,T,N] f32 | [B*T] or NULL */
+    void* vn; float* inv_v; void* tn; float* inv_t;
+    float *rowsum, *colsum, *possum_v, *possum_t;
+    void* e_keep; void* ws;
+    float *v_terms, *t_terms;                                               /* out: [S,R], [S,Mc] */
+    const float *g_v, *g_t;                                                 /* d loss / d terms: [S,R], [S,Mc] (fwd: optional) */
+    void* dl; float* d_tn_acc;                                              /* bwd scratch: [S,R,Mc] bf16, [St,Mc,C] f32 */
+    tan_ptr8 d_video; tan_ptr8 d_text;                                      /* out: stage-gradient rows (addressed like x_*) */
+    int dtn_split_k;                                                        /* K slices of the text-gradient GEMM (0: default) */
+} tan_simfam_desc;
+long tan_simfam_ws_bytes(int S, int St, int B, int T, int N, int Mc);
+int tan_simfam_fwd(tan_simfam_desc* d, void* stream);
+int tan_simfam_bwd(tan_simfam_desc* d, void* stream);
+
 /* NCE tail (loss.py:236-237,254-275).  tan_pos_masks: rows_pos[b*T+t] = 1 if frame t of video b has a positive among its
  * unpadded sentences, cols_pos[b*N+k] = 1 if sentence k is unpadded and has a positive frame (tgt [B,T,N] f32, text_pad [B,N]).
  * tan_nce_tail_fwd: out2[0] = (mean(v_d | rows_mask) + mean(t_d | cols_mask)) / 2, out2[1] the same for the joint terms and

@@ -50,6 +50,7 @@ extern "C" int tan_abi_sizeof(int which) {
         case 1: return (int)sizeof(tan_layer_params);
         case 2: return (int)sizeof(tan_layer_bufs);
         case 3: return (int)sizeof(tan_encoder_desc);
+        case 4: return (int)sizeof(tan_simfam_desc);
         default: return TAN_ERR_BAD_ARG;
     }
 }

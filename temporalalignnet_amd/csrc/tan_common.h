@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/tan_hip.h"
 
 namespace tal {
@@ -171,5 +173,19 @@ int prof_begin(hipStream_t st, int kind, double work);
 void prof_end(hipStream_t st, int rec);
 
 inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize for a kernel that launches with more than 48 KiB of dynamic LDS: once per DEVICE (a
+// function attribute belongs to the device's copy of the code object) and safe under concurrent first calls (`done` = one bit per
+// device id, set only after the attribute call succeeded; a plain `static bool` was neither -- ADVICE r4).
+inline hipError_t ensure_dyn_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 }  // namespace tal

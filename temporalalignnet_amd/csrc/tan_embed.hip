@@ -203,12 +203,8 @@ extern "C" int tan_embed_fwd(const tan_embed_desc* d, int nprob, void* stream) {
         work += 2.0 * (double)s.rows * 512.0 * s.K;
     }
     const int lds_bytes = EMB_ROWS * (maxK > 512 ? maxK : 512) * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)embed_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return -3;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_done{0};
+    if (ensure_dyn_lds((const void*)embed_fwd_kernel, 160 * 1024, lds_done) != hipSuccess) return -3;
     const int rec = prof_begin((hipStream_t)stream, TAN_PROF_GEMM_BF16, work);
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(blk), dim3(512), lds_bytes, (hipStream_t)stream, A);
     prof_end((hipStream_t)stream, rec);

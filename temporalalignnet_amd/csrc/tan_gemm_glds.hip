@@ -903,7 +903,8 @@ int gemm_atb256(int nprob, const void* const* A, const void* const* B, void* con
     ga.nprob = nprob; ga.K = (int)rows; ga.out = out;
     constexpr int LDS_BF16_EPI = 4 * 128 * 136 * 2;          // the bf16 epilogue parks four 128 x 128 quarters in rows of 136
     constexpr int LDS_MAX = LDS_BF16_EPI > 4 * D256_STAGE ? LDS_BF16_EPI : 4 * D256_STAGE;
-    static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_dw256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+    static std::atomic<unsigned long long> lds_done{0};
+        const hipError_t attr = ensure_dyn_lds((const void*)gemm_dw256_kernel, LDS_MAX, lds_done);
     if (attr != hipSuccess) return (int)attr;
     const int lds_bytes = out == 3 ? LDS_MAX : 4 * D256_STAGE;
     ga.kchunk = (8 % split == 0 && tiles % (8 / split) == 0) ? split : 0;                 // slices pinned to XCD groups

@@ -24,6 +24,7 @@ constexpr int S_MAXCOLS_RES = 8192;   // column limit of the resident sweep (col
 typedef const void __attribute__((address_space(1)))* sgptr_t;
 typedef void __attribute__((address_space(3)))* slptr_t;
 
+struct FamPtrs { void* p[8]; };
 struct SimArgs {
     const bf16_t* V;      // [S, R, C] unit video features
     const bf16_t* Tt;     // [S or 1, Mp, C] unit text features
@@ -45,6 +46,11 @@ struct SimArgs {
     int npanel, nfull;                 // simnce_res_kernel: row panels per stage; items (stage, panel) that are not cut in column halves
     const char* Tp;                    // simnce_res_kernel: fragment-major image of the text features (simnce_pack_text_kernel)
     long tp_stage_stride;              // bytes, or 0 (text features shared by the stages)
+    // simnce_res_kernel<0> normalising its frame panel itself (tan_simfam_fwd, TAN_SIMFAM_NORM_IN_SWEEP): the panel is staged from the
+    // stack's RAW stage rows (frame r of stage s at xraw.p[s] + ((r / T) * x_grp_rows + x_off + r % T) * C), L2-normalised in the LDS with
+    // l2n_fwd_kernel's arithmetic, and written to V / inv_v for the backward -- inv_v == null: V holds unit features already
+    FamPtrs xraw; long x_grp_rows, x_off;
+    float* inv_v;
 };
 
 // K-contiguous 128-row operand tile, same image as tan_gemm_glds.hip (slot = chunk ^ ((row >> 1) & 7))
@@ -385,9 +391,62 @@ __global__ __launch_bounds__(512) void simnce_res_kernel(SimArgs a) {
     if (ngrp > 0) {
         pn_static_for_s<0, RD>([&](auto jc) { constexpr int J = decltype(jc)::value; load_b(ring[J], 2 * (kbase + rot) + grp, J); });
     }
+    if (MODE == 0 && a.inv_v) {
+        // raw stage rows -> LDS (same image as s_stage; a row's address goes through the stack's row grouping)
+        const bf16_t* X = reinterpret_cast<const bf16_t*>(a.xraw.p[s]);
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) s_stage(V, Cw, m0, R, (grp * 4 + kt) * 64, lds + (grp * 4 + kt) * S_TILE, gw, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int kt = 0; kt < 4; ++kt) {
+            char* tile = lds + (grp * 4 + kt) * S_TILE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int piece = gw * 4 + i;
+                const int row = piece * 8 + (lane >> 3), slot = lane & 7;
+                const int chunk = slot ^ ((row >> 1) & 7);
+                const int gr = min(m0 + row, R - 1);
+                const long sr = (long)(gr / a.T) * a.x_grp_rows + a.x_off + gr % a.T;
+                __builtin_amdgcn_global_load_lds((sgptr_t)(X + sr * Cw + (grp * 4 + kt) * 64 + chunk * 8), (slptr_t)(tile + piece * 1024), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // x / |x| in place, one wave per row, lane l = elements 8 l .. 8 l + 7 (one 16-byte LDS access each way: element e of row r lives
+        // in K tile e / 64 at r * 128 + (((e % 64) / 8) ^ ((r >> 1) & 7)) * 16), and the unit row leaves for HBM as ONE 1-KiB store per
+        // row -- 8-byte pieces (l2n_fwd_kernel's lane layout) made the 128 KiB a workgroup keeps store-issue bound: +40 us per sweep
+        bf16_t* vout = const_cast<bf16_t*>(V);
+#pragma unroll 1
+        for (int i0 = 0; i0 < 16; i0 += 4) {
+            uint4 raw[4];
+            char* ap[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wave * 16 + i0 + j;
+                ap[j] = lds + (lane >> 3) * S_TILE + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) * 16);
+                raw[j] = *reinterpret_cast<const uint4*>(ap[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wave * 16 + i0 + j;
+                const unsigned w[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(w[e] << 16); x[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+                float q = ((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) + ((x[4] * x[4] + x[5] * x[5]) + (x[6] * x[6] + x[7] * x[7]));
+                const float inv = 1.0f / sqrtf(wave_sum(q));
+                uint4 y;
+                y.x = f2bf2(x[0] * inv, x[1] * inv); y.y = f2bf2(x[2] * inv, x[3] * inv);
+                y.z = f2bf2(x[4] * inv, x[5] * inv); y.w = f2bf2(x[6] * inv, x[7] * inv);
+                *reinterpret_cast<uint4*>(ap[j]) = y;
+                if (m0 + row < R) {
+                    *reinterpret_cast<uint4*>(vout + (long)(m0 + row) * Cw + lane * 8) = y;
+                    if (lane == 0) a.inv_v[(long)s * R + m0 + row] = inv;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) s_stage(V, Cw, m0, R, (grp * 4 + kt) * 64, lds + (grp * 4 + kt) * S_TILE, gw, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
     bf16x8 afA[2], afB[2];
 #pragma unroll
@@ -564,13 +623,16 @@ __global__ __launch_bounds__(256) void simnce_corr_kernel(const float* __restric
                                                           const unsigned char* __restrict__ col_invalid, const unsigned char* __restrict__ row_leak,
                                                           const float* __restrict__ possum_v, const float* __restrict__ possum_t,
                                                           const float* __restrict__ g_v, const float* __restrict__ g_t, float* __restrict__ corr,
-                                                          int B, int T, int N, const int* __restrict__ colmap, int Mp) {
+                                                          int B, int T, int N, const int* __restrict__ colmap, int Mp,
+                                                          float* __restrict__ zero = nullptr, long nzero = 0) {
     const int b = blockIdx.x, s = blockIdx.y;
     const int R = B * T;
     const float inv_tau = 1.0f / S_TAU;
     const float* blk = diag + ((long)s * B + b) * T * N;
     const float* tg = tgt + (long)b * T * N;
     float* out = corr + ((long)s * B + b) * T * N;
+    if (zero)      // (tan_simfam_bwd: the f32 accumulator of the text-feature gradient GEMM, a memset launch otherwise)
+        for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < nzero; i += (long)gridDim.x * gridDim.y * 256) zero[i] = 0.f;
     constexpr int U = 4;
     for (int i0 = threadIdx.x; i0 < T * N; i0 += 256 * U) {
         int cc[U]; long r[U], c[U]; bool in[U], leak[U];
@@ -670,8 +732,13 @@ __global__ __launch_bounds__(256) void simnce_pack_textT_kernel(const bf16_t* __
     }
 }
 
+// `l2` (tan_simfam_bwd): the backward of the L2 normalisation v_hat = x / |x| as the epilogue -- dx = (d v_hat - v_hat <v_hat, d v_hat>) / |x|
+// from the bf16 d v_hat panel in the LDS, stored straight into the stack's stage-gradient rows: d v_hat never exists in HBM and the
+// l2n_bwd launch (read d v_hat + v_hat, write dx: 150 MB per family at B = 128) is gone.  Same per-lane element order and reduction as
+// l2n_bwd_kernel (tan_norm.hip).
+struct FamL2 { FamPtrs dx; const float* inv; int grp; long dst_grp_rows, dst_off; };
 __global__ __launch_bounds__(512) void simnce_dl_dvn_kernel(SimArgs a, int npanel, int nct, const char* __restrict__ TpT, long tpt_stage_stride,
-                                                            bf16_t* __restrict__ dvn) {
+                                                            bf16_t* __restrict__ dvn, FamL2 l2) {
     extern __shared__ __attribute__((aligned(1024))) char dv_lds[];
     __shared__ int crange[2];                                 // sweep columns that hold sentences of this panel's videos: [min, max]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -846,6 +913,16 @@ __global__ __launch_bounds__(512) void simnce_dl_dvn_kernel(SimArgs a, int npane
     }
 
     // ---- epilogue: acc[rb][j][r] = d v_hat[row rb*32 + (lane & 31)][feature 64 wave + 32 j + acc_row(r, lane)] -> LDS rows -> 16-byte stores
+    // (with `l2`: the unit rows and norms the normalisation's backward needs are requested NOW, so that their HBM latency passes under
+    // the parking of the accumulators; wave w finishes rows 16 w .. 16 w + 15, lane l = elements 8 l .. 8 l + 7)
+    uint4 yv[16];
+    float invl = 0.f;
+    if (l2.inv) {
+        const bf16_t* Y = a.V + ((long)s * R + m0) * 512 + lane * 8;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) yv[i] = *reinterpret_cast<const uint4*>(Y + (long)min(wave * 16 + i, nrow - 1) * 512);
+        invl = l2.inv[(long)s * R + m0 + min(wave * 16 + (lane & 15), nrow - 1)];
+    }
     bf16_t* outp = reinterpret_cast<bf16_t*>(dv_lds);          // (every wave is behind the last tile's barrier: the tile buffers are free)
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
@@ -859,6 +936,30 @@ __global__ __launch_bounds__(512) void simnce_dl_dvn_kernel(SimArgs a, int npane
                 *reinterpret_cast<uint2*>(outp + (rb * 32 + (lane & 31)) * DV_OUT_LD + wave * 64 + j * 32 + 8 * g + 4 * (lane >> 5)) = u;
             }
     __syncthreads();
+    if (l2.inv) {
+        bf16_t* dxs = reinterpret_cast<bf16_t*>(l2.dx.p[s]);
+        auto unpack = [](const uint4& u, float (&x)[8]) __attribute__((always_inline)) {
+            const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(w[e] << 16); x[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+        };
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int lr = wave * 16 + i, row = m0 + lr;
+            float d[8], y[8];
+            unpack(*reinterpret_cast<const uint4*>(outp + lr * DV_OUT_LD + lane * 8), d);
+            unpack(yv[i], y);
+            float dot = ((d[0] * y[0] + d[1] * y[1]) + (d[2] * y[2] + d[3] * y[3])) + ((d[4] * y[4] + d[5] * y[5]) + (d[6] * y[6] + d[7] * y[7]));
+            dot = wave_sum(dot);
+            const float inv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(invl), i));
+            uint4 o;
+            o.x = f2bf2((d[0] - y[0] * dot) * inv, (d[1] - y[1] * dot) * inv); o.y = f2bf2((d[2] - y[2] * dot) * inv, (d[3] - y[3] * dot) * inv);
+            o.z = f2bf2((d[4] - y[4] * dot) * inv, (d[5] - y[5] * dot) * inv); o.w = f2bf2((d[6] - y[6] * dot) * inv, (d[7] - y[7] * dot) * inv);
+            if (row < R)                                             // (wave-uniform)
+                *reinterpret_cast<uint4*>(dxs + ((long)(row / l2.grp) * l2.dst_grp_rows + l2.dst_off + row % l2.grp) * 512 + lane * 8) = o;
+        }
+        return;
+    }
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
         const int q = tid + 512 * i, lr = q >> 6, ch = q & 63;
@@ -1233,10 +1334,11 @@ static int simnce_bwd_impl(const void* vn, const void* tn, long t_stage_stride, 
             const long tpt_stride = shared ? 0 : (long)nct * 128 * 1024;
             hipLaunchKernelGGL(simnce_pack_textT_kernel, dim3(nct * 4, shared ? 1 : S), dim3(256), 0, st, a.Tt, a.t_stage_stride, TpT, tpt_stride, a.Mp);
             TAN_LAUNCH_CHECK();
-            static const hipError_t attr = hipFuncSetAttribute((const void*)simnce_dl_dvn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DV_LDS_B);
+            static std::atomic<unsigned long long> lds_done{0};
+        const hipError_t attr = ensure_dyn_lds((const void*)simnce_dl_dvn_kernel, DV_LDS_B, lds_done);
             if (attr != hipSuccess) return (int)attr;
             const int prec = prof_begin(st, TAN_PROF_GEMM_BF16 + 1, 2.0 * S * a.R * (double)a.Mp * C);
-            hipLaunchKernelGGL(simnce_dl_dvn_kernel, dim3(npanel * S), dim3(512), DV_LDS_B, st, a, npanel, nct, (const char*)TpT, tpt_stride, (bf16_t*)dvn);
+            hipLaunchKernelGGL(simnce_dl_dvn_kernel, dim3(npanel * S), dim3(512), DV_LDS_B, st, a, npanel, nct, (const char*)TpT, tpt_stride, (bf16_t*)dvn, FamL2{});
             prof_end(st, prec);
             TAN_LAUNCH_CHECK();
             return 0;
@@ -1300,4 +1402,440 @@ extern "C" int tan_simnce_bwd_dl_dvn_kept(const void* e_keep, const void* vn, co
     if (phases == 0) phases = TAN_SIM_SWEEP | TAN_SIM_DIAG;
     return simnce_bwd_impl(vn, tn, t_stage_stride, tgt, col_invalid, row_leak, rowsum, colsum, possum_v, possum_t, g_v, g_t, dl, ws,
                            S, B, T, N, C, tn_blocks, tb_stage_stride, colmap, Mc, phases, e_keep, d_vn, stream);
+}
+
+// =================================================================================================================================
+// One feature family from the stacks' stage outputs to their stage gradients (tan_simfam_fwd / tan_simfam_bwd, include/tan_hip.h).
+// What ran between a stack's forward and its backward in the training step was 18 launches per family (l2n_fwd x 2, a gather,
+// pack_text, the sweep, col_finalize, blocks, diag, terms2 | corr, pack_textT, the one-pass d-logits + d v_hat kernel, fill, GEMM,
+// cast, rows_gather, l2n_bwd x 2), eleven of them 5-35 us of latency each on the critical chain of the stack (~230 us per family,
+// profiles/r04_*kernel_stats.csv).  Here: [l2n_fwd of the frame rows] -> text -> sweep -> finish | one-pass kernel with the
+// normalisation's backward as its epilogue -> GEMM -> text gradient.
+namespace tal {
+
+struct FamText {
+    FamPtrs xs;                       // raw text rows per text stage
+    long grp_rows, off;               // padded sentence m = b*N + k -> row (m / N) * grp_rows + off + m % N
+    int N, Mc;
+    const long long* idx;             // [Mc] sweep column -> padded sentence, or null (identity)
+    bf16_t* tn; float* inv_t;         // [St, Mc, 512], [St, Mc]
+    char* Tp; char* TpT; long img_stage_stride;
+    float* zero; long nzero;
+};
+
+// Unit text features of the sweep's columns in ONE launch: gather (column compaction) + L2 normalisation (l2n_fwd_kernel's arithmetic) +
+// the fragment-major image of the statistics sweep (simnce_pack_text_kernel's format) + the transposed one of the one-pass backward
+// (simnce_pack_textT_kernel's).  One block per 32 columns and text stage; also zeroes the sweep's row sums.
+__global__ __launch_bounds__(256) void simfam_text_kernel(FamText a) {
+    constexpr int LDT = 520;
+    __shared__ __attribute__((aligned(16))) bf16_t tl[32 * LDT];
+    const int blk = blockIdx.x, st = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (a.zero)
+        for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nzero; i += (long)gridDim.x * gridDim.y * 256) a.zero[i] = 0.f;
+    const bf16_t* xs = reinterpret_cast<const bf16_t*>(a.xs.p[st]);
+    float4 v[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int cs = min(blk * 32 + w * 8 + i, a.Mc - 1);          // columns past Mc repeat the last one (Tp) / are zero (TpT)
+        const long m = a.idx ? (long)a.idx[cs] : (long)cs;
+        const bf16_t* x = xs + ((m / a.N) * a.grp_rows + a.off + m % a.N) * 512;
+        v[i][0] = ld4(x + lane * 4);
+        v[i][1] = ld4(x + 256 + lane * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) q += (v[i][j].x * v[i][j].x + v[i][j].y * v[i][j].y) + (v[i][j].z * v[i][j].z + v[i][j].w * v[i][j].w);
+        const float inv = 1.0f / sqrtf(wave_sum(q));
+        const int r = w * 8 + i, c = blk * 32 + r;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float4 y = make_float4(v[i][j].x * inv, v[i][j].y * inv, v[i][j].z * inv, v[i][j].w * inv);
+            st4(tl + r * LDT + j * 256 + lane * 4, y);
+            if (c < a.Mc) st4(a.tn + ((long)st * a.Mc + c) * 512 + j * 256 + lane * 4, y);
+        }
+        if (lane == 0 && c < a.Mc) a.inv_t[(long)st * a.Mc + c] = inv;
+    }
+    __syncthreads();
+    {   // piece (column block blk, k step ks): lane l = tn[blk*32 + (l & 31)][16 ks + 8 (l >> 5) ..]
+        char* dst = a.Tp + (long)st * a.img_stage_stride + (long)blk * 32 * 1024 + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ks = w * 8 + i;
+            *reinterpret_cast<uint4*>(dst + (long)ks * 1024) = *reinterpret_cast<const uint4*>(tl + (lane & 31) * LDT + 16 * ks + 8 * (lane >> 5));
+        }
+    }
+    {   // piece (column block of 16, feature block fb of 32): lane l = tn[cb16*16 + 8 (l >> 5) + e][fb*32 + (l & 31)], e = 0..7
+        char* dst = a.TpT + (long)st * a.img_stage_stride + (long)blk * 2 * 16 * 1024;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int o = tid + 256 * i, l = o & 63, fb = (o >> 6) & 15, k2 = o >> 10;
+            const int r0 = k2 * 16 + 8 * (l >> 5);
+            const bf16_t* g = tl + r0 * LDT + fb * 32 + (l & 31);
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (blk * 32 + r0 < a.Mc) {                                  // (Mc % 8 == 0: eight columns are all in or all out)
+                u.x = (unsigned)g[0] | ((unsigned)g[LDT] << 16);
+                u.y = (unsigned)g[2 * LDT] | ((unsigned)g[3 * LDT] << 16);
+                u.z = (unsigned)g[4 * LDT] | ((unsigned)g[5 * LDT] << 16);
+                u.w = (unsigned)g[6 * LDT] | ((unsigned)g[7 * LDT] << 16);
+            }
+            *reinterpret_cast<uint4*>(dst + (long)(k2 * 16 + fb) * 1024 + l * 16) = u;
+        }
+    }
+}
+
+struct FamFin {
+    const bf16_t* vn; const bf16_t* tn; long tn_stage_stride;        // [S, R, 512]; [St, Mc, 512], stride Mc*512 or 0
+    const float* colpart; int nparts;                                // [nparts, S, Mc] column partials of the sweep (two per row panel)
+    float* diag;                                                     // [S, B, T, N] same-video cosines (kept for the fallback kernels)
+    const float* tgt; const unsigned char* col_invalid; const unsigned char* row_leak; const int* colmap;
+    float *rowsum, *colsum, *possum_v, *possum_t, *v_terms, *t_terms;
+    const float *g_v, *g_t; float* corr;                             // optional: the backward's same-video corrections [S, R, N]
+    float* zero; long nzero;
+    int S, B, T, N, Mc; long R;
+    float log_cols, log_rows;
+};
+
+// Everything between the statistics sweep and the loss terms in ONE launch, one block per (video, stage): the same-video cosine block
+// by MFMA from global fragments (simnce_blocks_kernel), the column sums of the video's sentences over the sweep's row-panel partials
+// (simnce_col_finalize), positives and leaked frames (simnce_diag_kernel<false>), v_terms / t_terms (simnce_terms2) and -- when the
+// upstream gradients of the terms are known already -- the dense correction array of the backward (simnce_corr_kernel).  The cosine
+// block stays in the LDS: the four kernels this replaces each re-read it entry by entry behind dependent global loads.  Blocks past
+// the videos take the sweep's filler columns (compaction pads up to a multiple of 64; no sentence owns them).
+__global__ __launch_bounds__(256) void simfam_finish_kernel(FamFin a) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = blockIdx.y;
+    const int B = a.B, T = a.T, N = a.N, Mc = a.Mc, S = a.S;
+    const long R = a.R;
+    const float inv_tau = 1.0f / S_TAU, shift = 1.0f / S_TAU;
+    if (a.zero)
+        for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nzero; i += (long)gridDim.x * gridDim.y * 256) a.zero[i] = 0.f;
+    if ((int)blockIdx.x >= B) {                 // filler columns: their sums must be defined (g_t = 0 there, but 0 / garbage may be NaN)
+        const int c = ((int)blockIdx.x - B) * 256 + tid;
+        if (c < Mc && a.col_invalid[c]) {
+            float cs = 0.f;
+            for (int p = 0; p < a.nparts; ++p) cs += a.colpart[((long)p * S + s) * Mc + c];
+            a.colsum[(long)s * Mc + c] = cs;
+            a.possum_t[(long)s * Mc + c] = 0.f;
+            a.t_terms[(long)s * Mc + c] = (logf(cs) + shift) - (-6e4f + a.log_rows);
+        }
+        return;
+    }
+    const int b = blockIdx.x, TN = T * N;
+    float* dg = fsm;                            // [T][N] cosines
+    float* ev = dg + TN;                        // [T][N] e of the entries that count (positives; every entry of a leaked frame)
+    float* accRl = ev + TN;                     // [T] possum_v
+    float* parts = accRl + T;                   // [8][32] column partial sums
+    float* colf = parts + 256;                  // [32] x {colsum, possum_t, g_t}
+    int* ccs = reinterpret_cast<int*>(colf + 96);                     // [32] sweep column of sentence k, or -1
+    unsigned char* validk = reinterpret_cast<unsigned char*>(ccs + 32);   // [32] column takes part in the row sums
+    unsigned char* leakf = validk + 32;                                // [T]
+    if (tid < 32) {
+        int cc = -1;
+        if (tid < N) { cc = a.colmap ? a.colmap[b * N + tid] : b * N + tid; if (cc >= Mc) cc = -1; }
+        ccs[tid] = cc;
+        validk[tid] = cc >= 0 && !a.col_invalid[cc];
+    }
+    for (int t = tid; t < T; t += 256) leakf[t] = a.row_leak && a.row_leak[(long)b * T + t];
+    // ---- same-video cosines: one wave per (32 frames, 32 sentences) unit, both operands straight from global memory
+    const int nrb = (T + 31) / 32, nnb = (N + 31) / 32;
+    for (int u = wave; u < nrb * nnb; u += 4) {
+        const int t0 = (u % nrb) * 32, n0 = (u / nrb) * 32, hi8 = 8 * (lane >> 5);
+        const int n = n0 + (lane & 31);
+        int ccn = -1;
+        if (n < N) ccn = a.colmap ? a.colmap[b * N + n] : b * N + n;
+        if (ccn >= Mc) ccn = -1;
+        const bf16_t* arow = a.vn + ((long)s * R + (long)b * T + min(t0 + (lane & 31), T - 1)) * 512 + hi8;
+        const bf16_t* brow = a.tn + (long)s * a.tn_stage_stride + (long)max(ccn, 0) * 512 + hi8;
+        f32x16 acc;
+        acc_zero(acc);
+#pragma unroll 16
+        for (int ks = 0; ks < 512; ks += 16) {
+            const bf16x8 fa = *reinterpret_cast<const bf16x8*>(arow + ks);
+            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(brow + ks);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+        }
+        float* out = a.diag + ((long)s * B + b) * TN;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + acc_row(r, lane), nn = n0 + acc_col(lane);
+            if (t < T && nn < N) { dg[t * N + nn] = acc[r]; out[t * N + nn] = acc[r]; }
+        }
+    }
+    __syncthreads();
+    // ---- column partial sums of this video's sentences (fixed order: deterministic)
+    {
+        const int k = tid & 31, p0 = tid >> 5;
+        float cs = 0.f;
+        if (k < N && ccs[k] >= 0)
+            for (int p = p0; p < a.nparts; p += 8) cs += a.colpart[((long)p * S + s) * Mc + ccs[k]];
+        parts[p0 * 32 + k] = cs;
+    }
+    // ---- e of the entries that count
+    const float* tg = a.tgt + (long)b * TN;
+    for (int i = tid; i < TN; i += 256) {
+        const int t = i / N, k = i - t * N;
+        const bool counts = ccs[k] >= 0 && (leakf[t] || tg[i] != 0.f);
+        ev[i] = counts ? __expf((dg[i] - 1.0f) * inv_tau) : 0.f;
+    }
+    __syncthreads();
+    // ---- rows: positives among the valid columns (or, for a leaked frame, everything the sweep added that reads -6e4 in the reference)
+    for (int t = tid; t < T; t += 256) {
+        float sum = 0.f;
+        for (int k = 0; k < N; ++k) sum += validk[k] ? ev[t * N + k] : 0.f;
+        const long ri = (long)s * R + (long)b * T + t;
+        const bool leak = leakf[t];
+        const float pv = leak ? 0.f : sum;
+        float rs = a.rowsum[ri];
+        if (leak) { rs -= sum; a.rowsum[ri] = rs; }
+        a.possum_v[ri] = pv;
+        accRl[t] = pv;
+        a.v_terms[ri] = (logf(rs) + shift) - (pv > 0.f ? logf(pv) + shift : -6e4f + a.log_cols);
+    }
+    // ---- columns
+    if (tid < N && ccs[tid] >= 0) {
+        const int k = tid, cc = ccs[k];
+        float cs = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) cs += parts[p * 32 + k];
+        float acc = 0.f, lost = 0.f;
+        for (int t = 0; t < T; ++t) { const float e = ev[t * N + k]; if (leakf[t]) lost += e; else acc += e; }
+        cs -= lost;
+        const long ci = (long)s * Mc + cc;
+        a.colsum[ci] = cs;
+        a.possum_t[ci] = acc;
+        a.t_terms[ci] = (logf(cs) + shift) - (acc > 0.f ? logf(acc) + shift : -6e4f + a.log_rows);
+        colf[k] = cs; colf[32 + k] = acc; colf[64 + k] = a.g_t ? a.g_t[ci] : 0.f;
+    }
+    if (!a.g_v) return;
+    __syncthreads();
+    // ---- the backward's same-video corrections (simnce_corr_kernel's values)
+    float* out = a.corr + ((long)s * B + b) * TN;
+    for (int i = tid; i < TN; i += 256) {
+        const int t = i / N, k = i - t * N;
+        float v = 0.f;
+        if (ccs[k] >= 0) {
+            if (leakf[t]) v = INFINITY;
+            else if (ev[i] != 0.f) {
+                const float pv = accRl[t], pt = colf[32 + k];
+                float cr = 0.f;
+                if (validk[k] && pv > 0.f) cr += a.g_v[(long)s * R + (long)b * T + t] / pv;
+                if (pt > 0.f) cr += colf[64 + k] / pt;
+                v = ev[i] * cr * inv_tau;
+            }
+        }
+        out[i] = v;
+    }
+}
+
+struct FamTB {
+    const float* acc;                 // [St, Mc, 512] f32 text-feature gradient (split-K sums)
+    const bf16_t* tn; const float* inv_t; const int* colmap;
+    FamPtrs dx; long grp_rows, off;
+    int N, Mc; long Mp;
+};
+
+// The text-feature gradient back in the padded sentence order (rows_gather_kernel), through the L2 normalisation's backward
+// (l2n_bwd_kernel's arithmetic on the bf16-rounded gradient), into the text rows of the stage gradients; dropped sentences get zeros.
+__global__ __launch_bounds__(256) void simfam_text_bwd_kernel(FamTB a) {
+    const int lane = threadIdx.x & 63, st = blockIdx.y;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= a.Mp) return;
+    const int cc = a.colmap ? a.colmap[m] : (int)m;
+    bf16_t* dx = reinterpret_cast<bf16_t*>(a.dx.p[st]) + ((m / a.N) * a.grp_rows + a.off + m % a.N) * 512 + lane * 4;
+    if (cc < 0 || cc >= a.Mc) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        st4(dx, z); st4(dx + 256, z);
+        return;
+    }
+    const float* ap = a.acc + ((long)st * a.Mc + cc) * 512 + lane * 4;
+    const bf16_t* yp = a.tn + ((long)st * a.Mc + cc) * 512 + lane * 4;
+    float4 d[2], y[2];
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float4 f = ld4(ap + j * 256);
+        const unsigned lo = f2bf2(f.x, f.y), hi = f2bf2(f.z, f.w);          // (the gradient as the bf16 tensor it used to be)
+        d[j] = make_float4(__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u));
+        y[j] = ld4(yp + j * 256);
+        dot += (d[j].x * y[j].x + d[j].y * y[j].y) + (d[j].z * y[j].z + d[j].w * y[j].w);
+    }
+    dot = wave_sum(dot);
+    const float inv = a.inv_t[(long)st * a.Mc + cc];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        st4(dx + j * 256, make_float4((d[j].x - y[j].x * dot) * inv, (d[j].y - y[j].y * dot) * inv, (d[j].z - y[j].z * dot) * inv,
+                                      (d[j].w - y[j].w * dot) * inv));
+}
+
+struct FamWs { float* colpart; float* diag; float* corr; char* Tp; char* TpT; long img_stage_stride; long bytes; };
+static FamWs simfam_ws(void* ws, int S, int St, int B, int T, int N, int Mc) {
+    auto up = [](long v) { return (v + 255) & ~255L; };
+    const long R = (long)B * T, npanel = cdiv(R, 128), nblk = (long)cdiv(Mc, 128) * 4;
+    FamWs w;
+    char* p = (char*)ws;
+    long o = 0;
+    w.colpart = (float*)(p + o); o += up(2 * npanel * S * (long)Mc * 4);
+    w.diag = (float*)(p + o);    o += up((long)S * R * N * 4);
+    w.corr = (float*)(p + o);    o += up(((long)S * R * N + 128 * 32 + 8) * 4);
+    w.img_stage_stride = nblk * 32 * 1024;
+    w.Tp = p + o;                o += up((long)St * w.img_stage_stride);
+    w.TpT = p + o;               o += up((long)St * w.img_stage_stride);
+    w.bytes = o;
+    return w;
+}
+
+static int simfam_check(const tan_simfam_desc* d) {
+    TAN_REQUIRE(d && d->S >= 1 && d->S <= 8 && (d->St == 1 || d->St == d->S) && d->B > 0 && d->T > 0 && d->N > 0 && d->N <= DV_MAX_N);
+    TAN_REQUIRE(d->C == 512 && d->Mc > 0 && d->Mc % 8 == 0 && d->Mc <= S_MAXCOLS_RES && d->Mc <= 32767);
+    TAN_REQUIRE((d->idx != nullptr) == (d->colmap != nullptr));
+    TAN_REQUIRE(d->idx || d->Mc == d->B * d->N);
+    TAN_REQUIRE(d->col_invalid && d->tgt && d->vn && d->inv_v && d->tn && d->inv_t && d->rowsum && d->colsum && d->possum_v && d->possum_t);
+    TAN_REQUIRE(d->e_keep && d->ws && ((uintptr_t)d->ws % 256) == 0 && ((uintptr_t)d->vn % 16) == 0 && ((uintptr_t)d->tn % 16) == 0);
+    for (int s = 0; s < d->S; ++s) TAN_REQUIRE(d->x_video.p[s] && ((uintptr_t)d->x_video.p[s] % 16) == 0);
+    for (int s = 0; s < d->St; ++s) TAN_REQUIRE(d->x_text.p[s] && ((uintptr_t)d->x_text.p[s] % 16) == 0);
+    return 0;
+}
+
+static void simfam_args(const tan_simfam_desc* d, const FamWs& w, SimArgs& a) {
+    a.V = (const bf16_t*)d->vn; a.Tt = (const bf16_t*)d->tn; a.t_stage_stride = d->St == 1 ? 0 : (long)d->Mc * 512;
+    a.tgt = d->tgt; a.col_invalid = d->col_invalid; a.row_leak = d->row_leak;
+    a.rowsum = d->rowsum; a.possum_v = d->possum_v; a.colpart = w.colpart;
+    a.S = d->S; a.B = d->B; a.T = d->T; a.N = d->N; a.C = 512; a.R = d->B * d->T; a.Mp = d->Mc;
+    a.ekeep = (bf16_t*)d->e_keep; a.colmap = d->colmap;
+    a.npanel = cdiv(a.R, 128); a.nfull = a.npanel * d->S;
+    a.Tp = w.Tp; a.tp_stage_stride = d->St == 1 ? 0 : w.img_stage_stride;
+}
+
+}  // namespace tal
+
+extern "C" long tan_simfam_ws_bytes(int S, int St, int B, int T, int N, int Mc) {
+    return simfam_ws(nullptr, S, St, B, T, N, Mc).bytes;
+}
+
+extern "C" int tan_simfam_fwd(tan_simfam_desc* d, void* stream) {
+    int rc = simfam_check(d);
+    if (rc) return rc;
+    TAN_REQUIRE(d->v_terms && d->t_terms && (!d->g_v == !d->g_t));
+    hipStream_t st = (hipStream_t)stream;
+    const int S = d->S, St = d->St, B = d->B, T = d->T, N = d->N, Mc = d->Mc;
+    const long R = (long)B * T;
+    const FamWs w = simfam_ws(d->ws, S, St, B, T, N, Mc);
+    d->flags &= ~TAN_SIMFAM_CORR_DONE;
+    // ---- unit frame features (tan_model.py:116,136)
+    if (!(d->flags & TAN_SIMFAM_NORM_IN_SWEEP)) {
+        if ((rc = tan_l2norm_fwd_multi(&d->x_video, d->vn, d->inv_v, S, R, 512, T, (int)d->v_grp_rows, (int)d->v_off, TAN_BF16, stream))) return rc;
+    }
+    // ---- unit text features of the sweep's columns + both text images; zero the row sums
+    {
+        FamText t{};
+        for (int s = 0; s < St; ++s) t.xs.p[s] = (void*)d->x_text.p[s];
+        t.grp_rows = d->t_grp_rows; t.off = d->t_off; t.N = N; t.Mc = Mc; t.idx = (const long long*)d->idx;
+        t.tn = (bf16_t*)d->tn; t.inv_t = d->inv_t; t.Tp = w.Tp; t.TpT = w.TpT; t.img_stage_stride = w.img_stage_stride;
+        t.zero = d->rowsum; t.nzero = (long)S * R;
+        hipLaunchKernelGGL(simfam_text_kernel, dim3(cdiv(Mc, 128) * 4, St), dim3(256), 0, st, t);
+        TAN_LAUNCH_CHECK();
+    }
+    // ---- the statistics sweep, exponentials kept (simnce_res_kernel<0>)
+    SimArgs a{};
+    simfam_args(d, w, a);
+    if (d->flags & TAN_SIMFAM_NORM_IN_SWEEP) {       // the sweep stages the RAW stage rows and normalises its panel in the LDS
+        for (int s = 0; s < S; ++s) a.xraw.p[s] = (void*)d->x_video.p[s];
+        a.x_grp_rows = d->v_grp_rows; a.x_off = d->v_off; a.inv_v = d->inv_v;
+    }
+    {
+        const int prec = prof_begin(st, TAN_PROF_SIMNCE, 2.0 * S * R * (double)Mc * 512);
+        hipLaunchKernelGGL((simnce_res_kernel<0>), dim3(a.nfull), dim3(512), 0, st, a);
+        prof_end(st, prec);
+        TAN_LAUNCH_CHECK();
+    }
+    // ---- same-video blocks, column sums, positives, terms (+ the backward's corrections when its upstream gradients are known)
+    {
+        FamFin f{};
+        f.vn = (const bf16_t*)d->vn; f.tn = (const bf16_t*)d->tn; f.tn_stage_stride = a.t_stage_stride;
+        f.colpart = w.colpart; f.nparts = 2 * a.npanel; f.diag = w.diag;
+        f.tgt = d->tgt; f.col_invalid = d->col_invalid; f.row_leak = d->row_leak; f.colmap = d->colmap;
+        f.rowsum = d->rowsum; f.colsum = d->colsum; f.possum_v = d->possum_v; f.possum_t = d->possum_t;
+        f.v_terms = d->v_terms; f.t_terms = d->t_terms;
+        f.S = S; f.B = B; f.T = T; f.N = N; f.Mc = Mc; f.R = R;
+        f.log_cols = logf((float)Mc); f.log_rows = logf((float)R);
+        if (d->g_v) {
+            TAN_REQUIRE(d->d_tn_acc);
+            f.g_v = d->g_v; f.g_t = d->g_t; f.corr = w.corr;
+            f.zero = d->d_tn_acc; f.nzero = (long)St * Mc * 512;
+        }
+        const size_t lds = sizeof(float) * (2 * (size_t)T * N + T + 256 + 96) + 4 * 32 + 32 + (size_t)T + 16;
+        TAN_REQUIRE(lds <= 160 * 1024);
+        static std::atomic<unsigned long long> lds_done{0};
+        const hipError_t attr = ensure_dyn_lds((const void*)simfam_finish_kernel, 160 * 1024, lds_done);
+        if (attr != hipSuccess) return (int)attr;
+        const int nfill = d->colmap ? (int)cdiv(Mc, 256) : 0;
+        hipLaunchKernelGGL(simfam_finish_kernel, dim3(B + nfill, S), dim3(256), lds, st, f);
+        TAN_LAUNCH_CHECK();
+        if (d->g_v) d->flags |= TAN_SIMFAM_CORR_DONE;
+    }
+    return 0;
+}
+
+extern "C" int tan_simfam_bwd(tan_simfam_desc* d, void* stream) {
+    int rc = simfam_check(d);
+    if (rc) return rc;
+    TAN_REQUIRE(d->g_v && d->g_t && d->dl && d->d_tn_acc && ((uintptr_t)d->dl % 16) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int S = d->S, St = d->St, B = d->B, T = d->T, N = d->N, Mc = d->Mc;
+    const long R = (long)B * T;
+    for (int s = 0; s < S; ++s) TAN_REQUIRE(d->d_video.p[s]);
+    for (int s = 0; s < St; ++s) TAN_REQUIRE(d->d_text.p[s]);
+    const FamWs w = simfam_ws(d->ws, S, St, B, T, N, Mc);
+    SimArgs a{};
+    simfam_args(d, w, a);
+    a.colsum = d->colsum; a.possum_t = d->possum_t; a.g_v = d->g_v; a.g_t = d->g_t; a.dl = (bf16_t*)d->dl;
+    a.diag = w.diag; a.corr = w.corr;
+    if (!(d->flags & TAN_SIMFAM_CORR_DONE)) {
+        hipLaunchKernelGGL(simnce_corr_kernel, dim3(B, S), dim3(256), 0, st, (const float*)w.diag, a.tgt, a.col_invalid, a.row_leak,
+                           (const float*)a.possum_v, a.possum_t, a.g_v, a.g_t, w.corr, B, T, N, a.colmap, Mc, d->d_tn_acc, (long)St * Mc * 512);
+        TAN_LAUNCH_CHECK();
+    }
+    // ---- d logits + d v_hat in one pass, the normalisation's backward as the epilogue -> the stack's stage-gradient rows
+    {
+        const int npanel = a.npanel, nct = cdiv(Mc, 128);
+        FamL2 l2{};
+        for (int s = 0; s < S; ++s) l2.dx.p[s] = (void*)d->d_video.p[s];
+        l2.inv = d->inv_v; l2.grp = T; l2.dst_grp_rows = d->v_grp_rows; l2.dst_off = d->v_off;
+        static std::atomic<unsigned long long> lds_done{0};
+        const hipError_t attr = ensure_dyn_lds((const void*)simnce_dl_dvn_kernel, DV_LDS_B, lds_done);
+        if (attr != hipSuccess) return (int)attr;
+        const int prec = prof_begin(st, TAN_PROF_GEMM_BF16 + 1, 2.0 * S * R * (double)Mc * 512);
+        hipLaunchKernelGGL(simnce_dl_dvn_kernel, dim3(npanel * S), dim3(512), DV_LDS_B, st, a, npanel, nct, (const char*)w.TpT,
+                           St == 1 ? 0L : w.img_stage_stride, (bf16_t*)nullptr, l2);
+        prof_end(st, prec);
+        TAN_LAUNCH_CHECK();
+    }
+    // ---- d t_hat[st] (+)= dl[s]^T v_hat[s]  (f32, K slices meet in atomics; the accumulator was zeroed with the corrections)
+    {
+        tan_gemm_desc g{};
+        g.dtype = TAN_BF16; g.out_dtype = TAN_F32;
+        g.M = Mc; g.N = 512; g.a_kc = 0; g.b_kc = 0;
+        g.A = d->dl; g.lda = Mc; g.B = d->vn; g.ldb = 512; g.C = d->d_tn_acc; g.ldc = 512;
+        g.accumulate = 1; g.alpha = 1.0f;
+        if (St == 1) {
+            g.K = (int)(S * R); g.batch = 1;
+            g.split_k = d->dtn_split_k > 0 ? d->dtn_split_k : (int)((S * R / 512) < 1 ? 1 : ((S * R / 512) > 8 ? 8 : (S * R / 512)));
+        } else {
+            g.K = (int)R; g.batch = S; g.sA = R * Mc; g.sB = R * 512; g.sC = (long)Mc * 512;
+            g.split_k = d->dtn_split_k > 0 ? d->dtn_split_k : 1;
+        }
+        if ((rc = tan_gemm(&g, stream))) return rc;
+    }
+    // ---- back to the padded sentence order, through the normalisation's backward, into the text rows of the stage gradients
+    {
+        FamTB t{};
+        t.acc = d->d_tn_acc; t.tn = (const bf16_t*)d->tn; t.inv_t = d->inv_t; t.colmap = d->colmap;
+        for (int s = 0; s < St; ++s) t.dx.p[s] = (void*)d->d_text.p[s];
+        t.grp_rows = d->t_grp_rows; t.off = d->t_off; t.N = N; t.Mc = Mc; t.Mp = (long)B * N;
+        hipLaunchKernelGGL(simfam_text_bwd_kernel, dim3(cdiv(t.Mp, 4), St), dim3(256), 0, st, t);
+        TAN_LAUNCH_CHECK();
+    }
+    return 0;
 }

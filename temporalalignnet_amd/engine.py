@@ -451,7 +451,8 @@ class _AlignerEngine(_WorkspaceMixin):
 
     def _embed_fused_ok(self, video, lang, itp):
         return (self.compute_dtype == torch.bfloat16 and self.panel_kernels and not itp and video.shape[-1] % 128 == 0
-                and lang.shape[-1] % 128 == 0 and video.shape[-1] <= 2048 and os.environ.get("TAN_EMBED_FUSED", "1") != "0")
+                and lang.shape[-1] % 128 == 0 and video.shape[-1] <= 2048 and lang.shape[-1] <= 2048      # (tan_embed_fwd: K <= 2048 for both)
+                and os.environ.get("TAN_EMBED_FUSED", "1") != "0")
 
     @staticmethod
     def _feature_operand(x):
@@ -472,8 +473,9 @@ class _AlignerEngine(_WorkspaceMixin):
         L, R, Mp = T + N, B * T, B * N
         cd, dev = self.compute_dtype, video.device
         video, lang = self._feature_operand(video), self._feature_operand(lang)
-        ev = self._take_ws("video_temporal_encoder", self.num_encoder_layers, B, T, cd, dev)
-        ej = self._take_ws("joint_temporal_encoder", self.num_decoder_layers, B, L, cd, dev)
+        alt = bool(self.__dict__.get("_ws_alternate"))
+        ev = self._take_ws("video_temporal_encoder", self.num_encoder_layers, B, T, cd, dev, alternate=alt)
+        ej = self._take_ws("joint_temporal_encoder", self.num_decoder_layers, B, L, cd, dev, alternate=alt)
         em = self._take_emb(B, T, N, Dv, Dt, cd, dev)
         pv = self._pos_ln_full("temporal_pos_embed")
         pt = self._pos_ln_full("text_temporal_pos_embed") if self.use_text_pos_enc else None
@@ -642,9 +644,9 @@ class _AlignerEngine(_WorkspaceMixin):
     # ------------------------------------------------------------------ forward + backward as two independent chains (no autograd)
     def _chains_ok(self, video, lang, itp=None):
         return (self.compute_dtype == torch.bfloat16 and self._embed_fused_ok(video, lang, itp) and not self.use_alignability_head
-                and self._side_stream(video.device) is not None and self._grad_ready_hook is None)
+                and self._side_stream(video.device) is not None)
 
-    def _run_chains(self, video, lang, vmask_u8, tmask_u8, family, after_video_bwd=None):
+    def _run_chains(self, video, lang, vmask_u8, tmask_u8, family, after_video_bwd=None, after_joint_bwd=None, pipe=None):
         """Forward AND backward of the aligner under a loss that separates into a dual and a joint term (stage 1: train/loss.py:359-373,
         loss = (loss_dual + loss_joint) / 2 with batch-independent weights) as TWO chains that never wait for each other:
             main stream:  video stack forward -> unit features -> family("dual") -> their backward -> video stack backward
@@ -652,12 +654,21 @@ class _AlignerEngine(_WorkspaceMixin):
         joined only in front of the embeddings' backward.  Under autograd (`_run_forward` / get_loss / `_run_backward`) every backward
         kernel waits for the LAST forward kernel: the video stack's backward could not start before the joint stack's forward, the
         joint similarity sweep and its ~12 small launches were through -- 0.6 ms in which the chip runs one stack's kernels or less.
-        `family(which, vn, tn) -> (v_terms, t_terms, d_vn, d_tn)` runs a family's similarity + NCE forward and backward on the current
-        stream (the upstream gradients of its terms depend on masks only).  Parameter gradients land in the flat gradient buffer as in
-        `_run_backward`.  Returns (v_d, t_d, v_j, t_j)."""
+        `family(which, x_video, v_grp, x_text, t_grp, d_video, d_text) -> (v_terms, t_terms)` runs a family's L2 normalisation,
+        similarity + NCE forward and backward from the stack's stage outputs to its stage gradients on the current stream
+        (`loss.nce_family_stages`; the upstream gradients of its terms depend on masks only).  Parameter gradients land in the flat
+        gradient buffer as in `_run_backward`.  Returns (v_d, t_d, v_j, t_j).
+        `pipe` (a dict, `Trainer.step` with TAN_STEP_PIPELINE): steps are pipelined across their boundary.  In: the events the previous
+        step left in `_Flat.pending` -- "dw_v" / "dw_j" (a stack's last weight-gradient launches: they read the activation workspaces this
+        step is about to overwrite: the workspaces alternate between two sets instead of waiting), "video" / "joint" (the optimizer launch
+        of a stack's matrices behind them: that stack's forward waits for it, and only for it) -- and "zero" (the gradient fill: the first
+        backward kernel of each chain waits for it).  Out: the same events of THIS step, and the main stream is NOT joined with the
+        streams that carry them: the embeddings and the video stack of the next step run under the joint stack's last weight gradients
+        and optimizer launch."""
         self._ensure_flat()
         self._bind_grads()
         f = self._flat
+        prev = f.pending if pipe is not None else {}
         B, T, _ = video.shape
         N = lang.shape[1]
         cd, dev = self.compute_dtype, video.device
@@ -668,11 +679,15 @@ class _AlignerEngine(_WorkspaceMixin):
         p_j = self._draw(T, None)
         f.sync_shadow_t()
         f.sync_shadow_tp()
-        fe = self._embed_fused(video, lang, vmask_u8, tmask_u8, p_v, p_t, p_j, True)
+        # (pipelined: the stacks' activation workspaces alternate between two sets -- the previous step's last weight-gradient launches
+        #  still read theirs; each stack waits for its own optimizer launch, which is behind those on the same stream)
+        self._ws_alternate = pipe is not None
+        try:
+            fe = self._embed_fused(video, lang, vmask_u8, tmask_u8, p_v, p_t, p_j, True)
+        finally:
+            self._ws_alternate = False
         em = fe["em"]
-        vn_d = torch.empty(Se, R, Cw, dtype=cd, device=dev)
-        tn_d = torch.empty(1, Mp, Cw, dtype=cd, device=dev)
-        inv = _Blocks(torch.float32, dev, {"vd": Se * R, "vj": Sd * R, "td": Mp, "tj": Sd * Mp})
+        zero_ev = pipe.get("zero") if pipe is not None else None
         dst_v = torch.empty(Se, R, Cw, dtype=cd, device=dev)
         d_lang_raw = torch.empty(Mp, Cw, dtype=cd, device=dev)
         d_x0 = torch.empty(R, Cw, dtype=cd, device=dev)
@@ -685,44 +700,63 @@ class _AlignerEngine(_WorkspaceMixin):
         tail_j, tail_v = 2, 1
         aux_j = _lib.role_stream(dev, "loss")
         aux_v = _lib.role_stream(dev, "opt")
+        # data parallel with gradient buckets: a layer's event must mean "every gradient of the layer is final" on the stack's own stream,
+        # so the weight gradients stay on the chains; the bucket all-reduces are issued by the hook, from THIS thread, video first
+        hook = self._grad_ready_hook
+        dw_j, dw_v = (None, None) if hook is not None else (aux_j, aux_v)
 
         def joint_chain():
-            vn_j = torch.empty(Sd, R, Cw, dtype=cd, device=dev)
-            tn_j = torch.empty(Sd, Mp, Cw, dtype=cd, device=dev)
             dst_j = torch.empty(Sd, B * L, Cw, dtype=cd, device=dev)
             d_xj = torch.empty(B * L, Cw, dtype=cd, device=dev)
+            if prev.get("joint") is not None:      # the joint stack's weights of this step
+                torch.cuda.current_stream().wait_event(prev["joint"])
             ej = self._run_joint_stack(None, None, vmask_u8, tmask_u8, B, T, N, True, pre=(fe["ej"], fe["xj"], fe["keypad"]))
             stages = [ej.stage(s) for s in range(Sd)]
-            ops.l2norm_fwd_multi(stages, vn_j, inv["vj"], R, Cw, T, L, 0)
-            ops.l2norm_fwd_multi(stages, tn_j, inv["tj"], Mp, Cw, N, L, T)
-            v_j, t_j, d_vn_j, d_tn_j = family("joint", vn_j, tn_j)
             dj = [dst_j[s] for s in range(Sd)]
-            ops.l2norm_bwd_multi(d_vn_j, vn_j, inv["vj"], dj, R, Cw, T, L, 0)
-            ops.l2norm_bwd_multi(d_tn_j, tn_j, inv["tj"], dj, Mp, Cw, N, L, T)
-            self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dj, d_xj, dw_stream=aux_j, dw_tail=tail_j)
-            return ej, v_j, t_j, d_xj, (vn_j, tn_j, dst_j)
+            # frame rows b*L + t and sentence rows b*L + T + k of the SAME stage buffers (tan_model.py:207-209), and of their gradients
+            v_j, t_j = family("joint", stages, (L, 0), stages, (L, T), dj, dj)
+            if zero_ev is not None:
+                torch.cuda.current_stream().wait_event(zero_ev)
+            self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dj, d_xj, dw_stream=dw_j, dw_tail=tail_j)
+            return ej, v_j, t_j, d_xj, (dst_j,)
         fut = self._on_side(side, joint_chain)
+        if prev.get("video") is not None:
+            main.wait_event(prev["video"])
         ev = self._run_video_stack(fe["x0"], vmask_u8, B, T, True, er=fe["ev"])
-        ops.l2norm_fwd_multi([ev.stage(s) for s in range(Se)], vn_d, inv["vd"], R, Cw)
-        ops.l2norm_fwd(fe["lang_raw"], tn_d[0], inv["td"], Mp, Cw)
-        v_d, t_d, d_vn_d, d_tn_d = family("dual", vn_d, tn_d)
         dv = [dst_v[s] for s in range(Se)]
-        ops.l2norm_bwd_multi(d_vn_d, vn_d, inv["vd"], dv, R, Cw)
-        ops.l2norm_bwd(d_tn_d.view(Mp, Cw), tn_d[0], inv["td"], d_lang_raw, Mp, Cw)
-        self._encoder_bwd(ev, fe["x0"], vmask_u8, "ln_video_post_enc", dv, d_x0, dw_stream=aux_v, dw_tail=tail_v)
-        if aux_v is not None:
-            main.wait_stream(aux_v)                # (the early optimizer launch below reads the video stack's weight gradients)
-        if after_video_bwd is not None:          # every gradient of the video stack's blocks is final (enqueued) here
-            after_video_bwd()
+        v_d, t_d = family("dual", [ev.stage(s) for s in range(Se)], (T, 0), [fe["lang_raw"]], (N, 0), dv, [d_lang_raw])
+        if zero_ev is not None:
+            main.wait_event(zero_ev)
+        self._encoder_bwd(ev, fe["x0"], vmask_u8, "ln_video_post_enc", dv, d_x0, dw_stream=dw_v, dw_tail=tail_v)
+        if hook is not None:
+            hook("video", self._layer_events(ev.prefix, ev.layers))
+        out_ev = {"dw_v": aux_v.record_event() if dw_v is not None else None}
+        if after_video_bwd is not None:          # every gradient of the video stack's blocks is final (enqueued) here: its all-reduce (data
+            aux_v.wait_stream(main)                # parallel) and the optimizer launch of its matrices go BEHIND the block-0 weight gradients on
+            with torch.cuda.stream(aux_v):         # their stream: this one is free for the embeddings' backward as soon as the joint chain is through
+                after_video_bwd()
+        out_ev["video"] = aux_v.record_event()
         ej, v_j, t_j, d_xj, keep = fut.result()
+        if hook is not None:
+            with torch.cuda.stream(side):
+                hook("joint", self._layer_events(ej.prefix, ej.layers))
+        out_ev["dw_j"] = aux_j.record_event() if dw_j is not None else None
+        if after_joint_bwd is not None:          # (issued from this thread like everything that may be a collective: same order on every rank)
+            aux_j.wait_stream(side)
+            with torch.cuda.stream(aux_j):
+                after_joint_bwd()
         main.wait_stream(side)
         for t in (d_xj,) + keep:                 # allocated under the side stream, read (or freed) under this one
             t.record_stream(main)
         run = {"em": em, "B": B, "T": T, "N": N, "sv_video": fe["sv_video"], "sv_video_j": fe["sv_video_j"], "sv_text": fe["sv_text"],
                "sv_text_t": fe["sv_text_t"]}
         self._embed_bwd_fused(run, d_x0, d_xj, d_lang_raw, False)
-        if aux_j is not None:
-            main.wait_stream(aux_j)                # the joint stack's block-0 weight gradients
+        out_ev["joint"] = aux_j.record_event()
+        if pipe is not None:                       # the next step waits for each of them where it needs it (`_Flat.pending`)
+            pipe["out"] = out_ev
+        else:
+            main.wait_stream(aux_v)                # the stacks' last weight gradients (and the optimizer launches behind them)
+            main.wait_stream(aux_j)
         self._release_ws(ev)
         self._release_ws(ej)
         self._release_ws(em)

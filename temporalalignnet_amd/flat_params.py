@@ -41,6 +41,19 @@ class _Flat:
         # more per-step images owned by the model (callables, run inside refresh_images_async on the side stream): the LayerNorm'ed
         # position tables of the fused input embeddings
         self.image_hooks = []
+        # Events of work that `Trainer.step` left running on its role streams when it returned (the stacks' last weight-gradient launches
+        # and the optimizer launches behind them: the NEXT step waits for each exactly where it needs it).  Anything else that touches the
+        # buffers goes through `drain()` first -- `_ensure_flat()` calls it -- which makes the current stream wait for all of them.
+        self.pending = {}
+        self.in_step = False
+
+    def drain(self):
+        if self.pending and not self.in_step:
+            cur = torch.cuda.current_stream()
+            for e in self.pending.values():
+                if e is not None:
+                    cur.wait_event(e)
+            self.pending = {}
 
     def bound(self):
         p0, pl = self.params[0], self.params[-1]
@@ -74,7 +87,7 @@ class _Flat:
         """device tables of tan_pack_entry for the MLP weights of every block ([out, in]) and for their transposes ([in, out])"""
         if self.pack_table is None:
             names = [n for n in self.names if ".resblocks." in n and len(self.off[n][2]) == 2]
-            pre = [n for n in ("video_pre_proj.weight", "text_pre_proj.weight") if n in self.off]     # tan_embed_fwd's operands
+            pre = self._packable_pre()                                                                # tan_embed_fwd's operands
 
             def table(transposed):
                 ents, mx = [], 0
@@ -95,6 +108,13 @@ class _Flat:
             self.pack_table = (table(False), table(True))
         return self.pack_table
 
+    def _packable_pre(self):
+        """The pre-projection matrices that get a packed image: feature widths in whole 64-blocks (what `image_table` and the packer
+        tile by).  Other widths (a constructor argument: SURVEY 8(d) config 5) train through the tiled-GEMM front-end -- the fused
+        embedding launch asks for multiples of 128 (`_embed_fused_ok`) -- and are stepped with the rest of the parameters."""
+        return [n for n in ("video_pre_proj.weight", "text_pre_proj.weight")
+                if n in self.off and self.off[n][2][0] % 64 == 0 and self.off[n][2][1] % 64 == 0]
+
     def image_table(self):
         """For tan_adamw_step_images: (device table of tan_image_entry, device unit prefix, n entries, n units, [(lo, hi)] flat ranges
         of the matrices) over every matrix that has a packed image -- the optimizer launch then writes the shadow, the W^T copies and
@@ -104,7 +124,7 @@ class _Flat:
             import numpy as np
             ents, prefix, ranges = [], [0], []
             mats = [n for n in self.names if ".resblocks." in n and len(self.off[n][2]) == 2]
-            pre = [n for n in ("video_pre_proj.weight", "text_pre_proj.weight") if n in self.off]
+            pre = self._packable_pre()
             for n in mats + pre:
                 o, k, (N, K) = self.off[n]
                 assert N % 64 == 0 and K % 64 == 0, (n, N, K)
@@ -121,6 +141,7 @@ class _Flat:
             n_video = sum(1 for n in mats if n.startswith("video_temporal_encoder."))
             assert all(n.startswith("video_temporal_encoder.") for n in mats[:n_video])
             self.video_units = prefix[n_video]
+            self.mats_units = prefix[len(mats)]            # ... then the joint stack's; the pre-projections are the last units
             self._image_table = (tab, pre_t, len(ents), prefix[-1], ranges)
         return self._image_table
 
@@ -162,6 +183,12 @@ class _Flat:
             for hook in self.image_hooks:
                 hook()
             self.images_event = side.record_event()
+
+    def run_image_hooks(self):
+        """the model's per-step images on the CURRENT stream (a pipelined step: the side stream still carries an optimizer launch)"""
+        for hook in self.image_hooks:
+            hook()
+        self.images_event = None
 
     def join_images(self):
         ev = getattr(self, "images_event", None)

@@ -347,6 +347,87 @@ def nce_family(vn, tn, tgt, col_invalid, B, T, N, nv, g_v, g_t):
     return v_terms, t_terms, d_vn, d_tn
 
 
+_SIMFAM = os.environ.get("TAN_SIMFAM", "1") != "0"
+# the statistics sweep L2-normalises its frame panel itself (TAN_SIMFAM_NORM_IN_SWEEP); 0 = a separate l2n_fwd launch in front of it
+_SIMFAM_NORM = os.environ.get("TAN_SIMFAM_NORM", "1") != "0"
+
+
+def simfam_ok(S, N, Mc, dtype):
+    """Shapes `tan_simfam_fwd / bwd` take (include/tan_hip.h): bf16, <= 8 stages, <= 32 sentences per video, sweep columns a multiple
+    of 8 within the resident sweep's limit."""
+    return (_SIMFAM and dtype == torch.bfloat16 and S <= 8 and N <= 32 and Mc % 8 == 0 and Mc < 32768
+            and Mc <= _lib.lib().tan_simnce_max_cols())
+
+
+def _ptr8(tensors):
+    p = _lib.Ptr8()
+    for i, t in enumerate(tensors):
+        p.p[i] = t.data_ptr()
+    return p
+
+
+def nce_family_stages(x_video, v_grp, x_text, t_grp, d_video, d_text, tgt, col_invalid, B, T, N, nv, g_v, g_t, split_k=0):
+    """Similarity + multi-positive NCE of ONE family from the stacks' stage OUTPUTS to their stage GRADIENTS, forward and backward
+    back to back on the current stream (tan_model.py:116-119 / 136-139, loss.py:240-253 and their autograd) -> (v_terms, t_terms).
+      x_video  list of S stage buffers; frame row r = b*T + t at row (r // T) * v_grp[0] + v_grp[1] + r % T
+      x_text   list of 1 (dual: the text embedding) or S (joint: the stack's stages) buffers; sentence m = b*N + k at row
+               (m // N) * t_grp[0] + t_grp[1] + m % N
+      d_video / d_text  where the gradients go, addressed the same way (every row is written: dropped sentences get zeros)
+      nv       column compaction (idx, colmap, pad flags of the sweep's columns) or None
+      g_v [S, R] / g_t [S, Mc]  d loss / d terms (`nce_term_grads`)
+    Six to seven launches through `tan_simfam_fwd / tan_simfam_bwd` (18 before); shapes those do not take run the same arithmetic as
+    separate launches (`nce_family` between L2-normalisation launches)."""
+    S, St = len(x_video), len(x_text)
+    R, Mp = B * T, B * N
+    dev, cd, Cw = x_video[0].device, x_video[0].dtype, x_video[0].shape[-1]
+    Mc = nv[0].shape[0] if nv is not None else Mp
+    if not (simfam_ok(S, N, Mc, cd) and Cw == 512 and St in (1, S)):
+        vn = torch.empty(S, R, Cw, dtype=cd, device=dev)
+        tn = torch.empty(St, Mp, Cw, dtype=cd, device=dev)
+        inv_v, inv_t = torch.empty(S * R, device=dev), torch.empty(St * Mp, device=dev)
+        ops.l2norm_fwd_multi(x_video, vn, inv_v, R, Cw, T, v_grp[0], v_grp[1])
+        ops.l2norm_fwd_multi(x_text, tn, inv_t, Mp, Cw, N, t_grp[0], t_grp[1])
+        v_terms, t_terms, d_vn, d_tn = nce_family(vn, tn, tgt, col_invalid, B, T, N, nv, g_v, g_t)
+        ops.l2norm_bwd_multi(d_vn, vn, inv_v, d_video, R, Cw, T, v_grp[0], v_grp[1])
+        ops.l2norm_bwd_multi(d_tn.view(St, Mp, Cw), tn, inv_t, d_text, Mp, Cw, N, t_grp[0], t_grp[1])
+        return v_terms, t_terms
+    L = _lib.lib()
+    bf = torch.bfloat16
+    d = _lib.SimFamDesc()
+    d.S, d.St, d.B, d.T, d.N, d.C, d.Mc, d.flags = S, St, B, T, N, Cw, Mc, (1 if _SIMFAM_NORM else 0)
+    d.x_video, d.v_grp_rows, d.v_off = _ptr8(x_video), v_grp[0], v_grp[1]
+    d.x_text, d.t_grp_rows, d.t_off = _ptr8(x_text), t_grp[0], t_grp[1]
+    if nv is not None:
+        d.idx, d.colmap, d.col_invalid = nv[0].data_ptr(), nv[1].data_ptr(), nv[2].data_ptr()
+    else:
+        d.col_invalid = col_invalid.data_ptr()
+    d.tgt = tgt.data_ptr()
+    # one f32 block (saved sums, terms, norms, the text-gradient accumulator; pieces 16-byte aligned) + the bf16 tensors
+    sizes = [S * R] * 4 + [S * Mc] * 3 + [St * Mc, St * Mc * Cw]
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + (n + 3) // 4 * 4)
+    f32 = torch.empty(offs[-1], device=dev)
+    rowsum, possum_v, inv_v, v_terms, colsum, possum_t, t_terms, inv_t, acc = (f32[a:a + n] for a, n in zip(offs, sizes))
+    vn = torch.empty(S, R, Cw, dtype=bf, device=dev)
+    tn = torch.empty(St, Mc, Cw, dtype=bf, device=dev)
+    ekeep = torch.empty(L.tan_simnce_keep_elems(S, R, Mc), dtype=bf, device=dev)
+    dl = torch.empty(S, R, Mc, dtype=bf, device=dev)
+    ws = torch.empty(L.tan_simfam_ws_bytes(S, St, B, T, N, Mc), dtype=torch.uint8, device=dev)
+    d.vn, d.inv_v, d.tn, d.inv_t = vn.data_ptr(), inv_v.data_ptr(), tn.data_ptr(), inv_t.data_ptr()
+    d.rowsum, d.colsum, d.possum_v, d.possum_t = rowsum.data_ptr(), colsum.data_ptr(), possum_v.data_ptr(), possum_t.data_ptr()
+    d.e_keep, d.ws = ekeep.data_ptr(), ws.data_ptr()
+    d.v_terms, d.t_terms = v_terms.data_ptr(), t_terms.data_ptr()
+    d.g_v, d.g_t = g_v.data_ptr(), g_t.data_ptr()
+    d.dl, d.d_tn_acc = dl.data_ptr(), acc.data_ptr()
+    d.d_video, d.d_text = _ptr8(d_video), _ptr8(d_text)
+    d.dtn_split_k = split_k
+    st = ops._stream()
+    _lib.check(L.tan_simfam_fwd(C.byref(d), st), "tan_simfam_fwd")
+    _lib.check(L.tan_simfam_bwd(C.byref(d), st), "tan_simfam_bwd")
+    return v_terms.view(S, R), t_terms.view(S, Mc)
+
+
 def nce_term_grads(rows_mask, cols_mask, Sd, Sj):
     """d loss_mean / d (v_d, t_d, v_j, t_j) of _NCETail for loss = (loss_dual + loss_joint) / 2 (loss.py:254-275,359-373): a function of
     the two masks alone (mean weights 1 / (S count)), so it is known before any similarity is -- what lets a family's backward start

@@ -116,6 +116,13 @@ class TemporalAligner(_AlignerEngine, nn.Module):
         # shadow (and the W^T copies built from it) must be rebuilt from the f32 masters on the next forward
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_shadow())
 
+    def state_dict(self, *args, **kwargs):
+        """nn.Module.state_dict behind the work a pipelined training step may have left on its role streams (`_Flat.pending`)."""
+        f = self.__dict__.get("_flat")
+        if f is not None:
+            f.drain()
+        return super().state_dict(*args, **kwargs)
+
     def invalidate_shadow(self):
         """Call after writing parameters in place other than through the optimizer kernel / load_state_dict (e.g.
         `p.data.copy_(...)`): the next forward re-casts the bf16 shadow weights from the f32 masters."""
@@ -159,6 +166,7 @@ class TemporalAligner(_AlignerEngine, nn.Module):
                 raise _lib.TanHipError("TemporalAligner parameters are on the CPU: the HIP path has no CPU fallback; "
                                        "call .cuda() first")
             f.bind(want_shadow=self.compute_dtype == torch.bfloat16)
+        f.drain()             # (work a pipelined training step left on its role streams; a no-op inside that step and otherwise)
         f.sync_shadow()
         if self.panel_kernels:
             f.sync_shadow_p()

@@ -109,6 +109,79 @@ def uncovered_ranges(done, total):
     return out
 
 
+class _GradReducer:
+    """The gradient collectives of ONE data-parallel step (the reference idiom end2end/main_nce.py:142-158,283): which
+    ranges of the flat gradient have been summed over ranks, and the asynchronous ones still in flight per stack.  Every collective is
+    issued from the main host thread in an order that depends on the configuration only (video pieces, joint pieces, remainder):
+    identical on every rank."""
+
+    def __init__(self, tr):
+        self.tr, self.flat, self.mode = tr, tr.online.flat_grad(), tr.ddp_mode
+        self.done, self.pending, self.n = [], {}, 0
+        self.wire = None
+        if tr.ddp_grad_dtype == "bf16":
+            w = tr.__dict__.get("_wire")
+            if w is None or w.numel() != self.flat.numel() or w.device != self.flat.device:
+                w = tr._wire = torch.empty(self.flat.numel(), dtype=torch.bfloat16, device=self.flat.device)
+            self.wire = w
+
+    def reduce(self, lo, hi, async_op=False, tag=None):
+        """all-reduce(SUM) of flat[lo:hi] under the current stream context (asynchronous: completed by `wait(tag)`)"""
+        piece, after = self.flat[lo:hi], None
+        if self.wire is not None:
+            w = self.wire[lo:hi]
+            ops.cast(piece, w)
+            work = dist.allreduce_sum_(w, async_op=async_op)
+            after = lambda: ops.cast(w, piece)       # noqa: E731
+        else:
+            work = dist.allreduce_sum_(piece, async_op=async_op)
+        self.done.append((lo, hi))
+        self.n += 1
+        if async_op:
+            self.pending.setdefault(tag, []).append((work, after))
+        elif after is not None:
+            after()
+
+    def wait(self, tag):
+        """the current stream waits for the asynchronous collectives issued under `tag`"""
+        for work, after in self.pending.pop(tag, []):
+            if work is not None:
+                work.wait()
+            if after is not None:
+                after()
+
+    def hook(self, tag, layer_events):
+        """'buckets': called once a stack's backward is enqueued -- one asynchronous all-reduce per bucket, each made to wait (on the
+        GPU) only for the event of its lowest layer"""
+        tr = self.tr
+        comm = tr._comm_order_stream(self.flat.device)
+        for lo, hi, last in tr._ddp_buckets(tag, len(layer_events)):
+            # comm waits (on the GPU) for the event of the bucket's lowest layer; the process group's own stream
+            # then waits for comm, i.e. for exactly the layers this bucket covers
+            _lib.check(_lib.lib().tan_stream_wait_event(C.c_void_p(comm.cuda_stream), C.c_void_p(layer_events[last])),
+                       "tan_stream_wait_event")
+            with torch.cuda.stream(comm):
+                self.reduce(lo, hi, async_op=True, tag=tag)
+
+    def stack_done(self, which):
+        """Two-chain step, on the stream that carries the stack's last weight gradients: the stack's slice of the gradient is summed
+        over ranks once this returns (in stream order) -- its optimizer launch may follow."""
+        if self.mode == "buckets":
+            self.wait(which)
+        elif self.mode == "flat":
+            prefix = {"video": "video_temporal_encoder.", "joint": "joint_temporal_encoder."}[which]
+            self.reduce(*self.tr.online.flat_range(prefix))
+            return True
+        return self.mode == "buckets"
+
+    def finish(self):
+        for lo, hi in uncovered_ranges(self.done, self.flat.numel()):        # whatever has not been reduced yet
+            self.reduce(lo, hi)
+        for tag in list(self.pending):
+            self.wait(tag)
+        return self.n
+
+
 class Trainer:
     def __init__(self, model, args, *, betas=(0.9, 0.999), eps=1e-8, iter_per_epoch=None, warmup=1000, fused_loss=None,
                  global_negatives=False, ddp_bucket_layers=None):
@@ -134,10 +207,23 @@ class Trainer:
                                             else ddp_bucket_layers))
         self._comm_streams = {}
         self._zero_ev = None
-        # TAN_DDP_MODE: "flat" (default) = ONE all-reduce of the whole flat gradient after backward, what BASELINE.json's north_star
-        # states; "buckets" = per-layer-group all-reduces overlapped with backward.  No >1-GPU node was available to pick by
-        # measurement, so the default is the north star's; bench.py reports the other mode as an `extra` entry of a multi-GPU run.
+        # TAN_DDP_MODE -- how the flat gradient (39.9 M f32) is summed over ranks each step:
+        #   "flat" (default)  ONE logical all-reduce of the whole gradient, what BASELINE.json's north_star states, issued in contiguous
+        #                     pieces as they become final: in the two-chain step the video stack's 45 % when its chain ends (under the
+        #                     joint stack's last layers), the joint stack's 47 % when that ends, the remaining 8 % behind the embeddings'
+        #                     backward; each stack's optimizer launch follows its piece.  Under autograd (stage 2): one call after backward.
+        #   "single"          literally one call after backward (the A/B of the above)
+        #   "buckets"         an all-reduce per `ddp_bucket_layers` layers behind per-layer events, overlapped with backward (the
+        #                     reference idiom's DistributedDataParallel, end2end/main_nce.py:283); works in both step schedules
+        # No >1-GPU node was available to pick by measurement: bench.py reports the other modes as `extra` entries of a multi-GPU run.
         self.ddp_mode = os.environ.get("TAN_DDP_MODE", "flat")
+        # TAN_DDP_GRAD_DTYPE=bf16: the gradient crosses xGMI as bf16 (80 MB instead of 160), rounded once before and summed in f32 after
+        self.ddp_grad_dtype = os.environ.get("TAN_DDP_GRAD_DTYPE", "f32")
+        # TAN_STEP_PIPELINE (default 1): the two-chain step does not join its role streams when it returns -- the stacks' last weight
+        # gradients and optimizer launches run under the NEXT step's embeddings and video stack (`_run_chains`, `_Flat.pending`)
+        self.pipeline = os.environ.get("TAN_STEP_PIPELINE", "1") != "0"
+        self._ddp = None                  # the step's _GradReducer while `step` runs with more than one rank
+        self.last_collectives = 0
         self._params_synced = False
         # bench.py: with `time_comm` set, every step records two events on the compute stream around the part of the step that
         # WAITS for gradient collectives (the remainder all-reduce and the joins of the asynchronous buckets): their distance is
@@ -217,6 +303,9 @@ class Trainer:
         f = self.online._ensure_flat()
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
+            for e in f.pending.values():          # (a pipelined step: the optimizer launches that still read the gradient)
+                if e is not None:
+                    side.wait_event(e)
             with torch.cuda.stream(side):
                 f.grad.zero_()
                 self._zero_ev = side.record_event()
@@ -268,7 +357,8 @@ class Trainer:
                 if self.global_negatives:
                     raise _lib.TanHipError(f"global_negatives: {Bn}x{Nn} text columns per rank exceed the fused sweep's limit")
                 fused = False
-        if self._chains_eligible(batch, fused):
+        self._last_step_chains = self._chains_eligible(batch, fused)
+        if self._last_step_chains:
             return self._forward_backward_chains(batch)
         if batch["video"].is_cuda:
             # what get_loss derives from the batch alone (masks, targets, column compaction: ~20 tiny launches) runs on the loss
@@ -312,11 +402,10 @@ class Trainer:
         return (bool(fused) and not self.twin and a.model == "init" and not a.learn_agreement and a.loss_threshold <= 0
                 and not a.use_alignability_head and a.optim_policy != "bce" and not self.global_negatives and "token" not in batch
                 and batch["video"].is_cuda and not batch["text_embed"].requires_grad and os.environ.get("TAN_STEP_CHAINS", "1") != "0"
-                and not (dist.active() and self.ddp_mode != "flat")
                 and self.online._chains_ok(batch["video"], batch["text_embed"]))
 
     def _forward_backward_chains(self, batch):
-        from .loss import _ManualCtx, _NCETail, nce_family, nce_term_grads, prepare_inputs_async
+        from .loss import _ManualCtx, _NCETail, nce_family_stages, nce_term_grads, prepare_inputs_async
         a, m = self.args, self.online
         video, lang = batch["video"], batch["text_embed"]
         B, T = video.shape[:2]
@@ -336,21 +425,39 @@ class Trainer:
             ready = ls.record_event()
         tgt, ci = prep["tgt"], prep["tpad_u8"].view(B * N)
 
-        def family(which, vn, tn):
+        def family(which, x_video, v_grp, x_text, t_grp, d_video, d_text):
             torch.cuda.current_stream().wait_event(ready)          # (a finished event costs nothing)
             gv, gt = (g_v_d, g_t_d) if which == "dual" else (g_v_j, g_t_j)
-            return nce_family(vn, tn, tgt, ci, B, T, N, nv, gv, gt)
-        if self._zero_ev is not None:                  # the gradient buffer's fill ran on a side stream
+            return nce_family_stages(x_video, v_grp, x_text, t_grp, d_video, d_text, tgt, ci, B, T, N, nv, gv, gt)
+        pipe = None
+        if getattr(self, "_in_step", False) and self.online._flat.in_step:
+            pipe = {"zero": self._zero_ev}               # (each chain waits for the fill in front of its first backward kernel)
+        elif self._zero_ev is not None:                  # the gradient buffer's fill ran on a side stream
             main.wait_event(self._zero_ev)
-            self._zero_ev = None
+        self._zero_ev = None
         tp_bool = batch["_text_pad_bool"] if batch.get("_text_pad_bool") is not None else batch["text_padding_mask"].bool()
-        early = None
-        if os.environ.get("TAN_OPT_EARLY", "1") != "0" and getattr(self, "_in_step", False):
-            early = lambda: self.early_video_update(1.0 / dist.world_size())       # noqa: E731
-        v_d, t_d, v_j, t_j = m._run_chains(video, lang, m._mask_u8(batch["padding_mask"]), m._mask_u8(tp_bool), family, early)
+        early_v = early_j = None
+        if getattr(self, "_in_step", False):
+            early = os.environ.get("TAN_OPT_EARLY", "1") != "0" and self._early_ok()
+            ddp, gs = self._ddp, 1.0 / dist.world_size()
+
+            def stack_done(which):
+                # (main host thread, current stream = the one that carries the stack's last weight gradients) data parallel: the stack's
+                # slice of the gradient is summed over ranks first; then its matrices may be stepped
+                reduced = ddp.stack_done(which) if ddp is not None else True
+                if early and reduced:
+                    self.early_update(which, gs)
+            if early or ddp is not None:
+                early_v, early_j = (lambda: stack_done("video")), (lambda: stack_done("joint"))       # noqa: E731
+        v_d, t_d, v_j, t_j = m._run_chains(video, lang, m._mask_u8(batch["padding_mask"]), m._mask_u8(tp_bool), family, early_v, early_j,
+                                           pipe=pipe)
         for t in (g_v_d, g_t_d, g_v_j, g_t_j, cols_tail, prep["rows_pos"], v_j, t_j):
             t.record_stream(main)
+        # the masked means of the four term tensors (loss.py:254-275): behind the embeddings' backward on this stream -- in a pipelined
+        # step it runs while the stream would wait for the stacks' last weight gradients anyway
         loss_dual, loss_joint, loss_mean = _NCETail.forward(_ManualCtx(), v_d, t_d, v_j, t_j, prep["rows_pos"], cols_tail, None)
+        if pipe is not None:
+            self._pipe_out = pipe["out"]
         return {"loss-dual": loss_dual, "loss-joint": loss_joint, "loss": loss_mean}
 
     def _lm_allreduce(self):
@@ -392,7 +499,11 @@ class Trainer:
         ema = self.model.target._ensure_flat() if self.twin else None
         self.iteration += 1
         if self._images_in_optimizer(f, ema):
-            u0 = self.__dict__.pop("_early_units", 0)        # units `early_video_update` already stepped (same step count, lr, grad_scale)
+            early = self.__dict__.pop("_early", ())          # stacks `early_update` already stepped (same step count, lr, grad_scale)
+            u0 = 0
+            if early:
+                assert "video" in early, early              # (units: video stack, joint stack, pre-projections)
+                u0 = f.mats_units if "joint" in early else f.video_units
             self._adamw_images(f, st, ema, grad_scale, units=(u0, 0) if u0 else None)
             self._lm_step(grad_scale)
             return
@@ -415,14 +526,18 @@ class Trainer:
         return (f.shadow is not None and on.panel_kernels and on.transposed_dx and os.environ.get("TAN_OPT_IMAGES", "1") != "0"
                 and (ema is None or (ema.shadow is not None and self.model.target.panel_kernels)))
 
-    def _adamw_images(self, f, st, ema, grad_scale, units=None, rest=True, step=None):
-        """units = (u0, u1): only those units of the image table (see `early_video_update`); rest: also everything outside the matrices."""
-        tab, prefix, n_ent, n_units, ranges = f.image_table()
+    def _adamw_tables(self, f, st):
+        tabs = f.image_table()
         if "rest_idx" not in st:                 # every element outside the matrices: the plain kernel's work list
             own = torch.zeros(f.total, dtype=torch.bool, device=f.flat.device)
-            for lo, hi in ranges:
+            for lo, hi in tabs[4]:
                 own[lo:hi] = True
             st["rest_idx"] = (~own).nonzero().flatten().to(torch.int32)
+        return tabs
+
+    def _adamw_images(self, f, st, ema, grad_scale, units=None, rest=True, step=None):
+        """units = (u0, u1): only those units of the image table (see `early_update`); rest: also everything outside the matrices."""
+        tab, prefix, n_ent, n_units, ranges = self._adamw_tables(f, st)
         if ema is not None:
             ema.sync_shadow_p()                  # (allocates the twin's packed image on first use)
         d = _lib.AdamwImagesDesc()
@@ -444,16 +559,26 @@ class Trainer:
             if ema is not None:
                 ema.images_rewritten(transposes=False)
 
-    def early_video_update(self, grad_scale):
-        """Two-chain step: the video stack's backward is enqueued and its chain (main stream) would idle until the joint chain is
-        through (~0.3 ms) -- AdamW + weight images of the video stack's matrices run there, under the joint stack's last layers
-        (HBM-bound next to MFMA-bound kernels); `optimizer_step` then updates everything else."""
+    def _early_ok(self):
         f, st = self._ensure_state()
-        if not self._images_in_optimizer(f, None) or self.args.clip_grad > 0 or dist.active() or self._accum_open:
-            return
-        f.image_table()
-        self._early_units = f.video_units
-        self._adamw_images(f, st, None, grad_scale, units=(0, f.video_units), rest=False, step=self.iteration + 1)
+        # (data parallel: a stack is stepped behind the all-reduce of its slice -- `_GradReducer.stack_done`; not in 'single' mode)
+        ok = (self._images_in_optimizer(f, None) and not self.args.clip_grad > 0 and not self._accum_open
+              and (not dist.active() or (self._ddp is not None and self.ddp_mode in ("flat", "buckets"))))
+        if ok:
+            self._adamw_tables(f, st)        # (built here, by ONE thread: the two early launches are issued from two host threads)
+            self._early = set()
+        return ok
+
+    def early_update(self, which, grad_scale):
+        """Two-chain step: AdamW + weight images of ONE stack's matrices as soon as that stack's backward is enqueued, on the stream
+        that carries the stack's last weight-gradient launches (`_run_chains`): the video stack's under the joint stack's last layers
+        (its chain ends ~0.25 ms earlier), the joint stack's next to the embeddings' backward -- HBM-bound launches next to MFMA-bound /
+        small ones; `optimizer_step` then updates what is left (the pre-projections and everything outside the matrices).  The units of
+        the image table are ordered video stack, joint stack, pre-projections.  (Called from the two host threads that issue the chains.)"""
+        f, st = self._ensure_state()
+        lo, hi = (0, f.video_units) if which == "video" else (f.video_units, f.mats_units)
+        self._adamw_images(f, st, None, grad_scale, units=(lo, hi), rest=False, step=self.iteration + 1)
+        self._early.add(which)
 
     def train_iteration(self, batch, idx):
         """One iteration of the reference loop INCLUDING its gradient accumulation (train/main.py:112-139): backward every
@@ -503,66 +628,98 @@ class Trainer:
             cache[key] = out
         return cache[key]
 
+    def _will_chain(self, batch):
+        """Whether `forward_backward` will take the two-chain path for this batch (decided before the step touches anything)."""
+        if "token" in batch or not batch["video"].is_cuda:
+            return False
+        fused = self.fused_loss
+        if fused:
+            Bn, Nn = batch["text_embed"].shape[:2]
+            cols = Bn * Nn
+            if batch.get("n_text") is not None and not self.global_negatives:
+                cols = min(cols, (batch["n_text"] + 63) // 64 * 64)
+            fused = cols <= _lib.lib().tan_simnce_max_cols()
+        return self._chains_eligible(batch, fused)
+
     def step(self, batch):
-        """One optimizer step on an already device-resident batch (see to_device_batch).  With N>1 ranks the flat gradient
-        is summed over RCCL in buckets that overlap backward: `tan_encoder_bwd` records an event per layer, and as soon as a
-        stack's backward is ENQUEUED the hook below issues one asynchronous all-reduce per `ddp_bucket_layers` layers
-        (~25 MB at 2 layers), each made to wait -- on the GPU -- only for the event of its lowest layer, so the reduction of
-        layers 5,4 runs while layers 3..0 are still being differentiated.  Order of issue is fixed (video buckets last layer
-        first, then joint buckets: identical on every rank); the few remaining tensors (embeddings, projections, heads,
-        post-LNs) follow at the end in one call."""
+        """One optimizer step on an already device-resident batch (see to_device_batch): zero_grad -> forward -> loss -> backward ->
+        [gradient all-reduce] -> AdamW, train/main.py:81-122.
+        With N>1 ranks the flat gradient is summed over RCCL (`_GradReducer`, TAN_DDP_MODE): in pieces behind the two chains, in
+        buckets behind per-layer events recorded inside `tan_encoder_bwd`, or in one call; the order of issue is fixed and identical
+        on every rank.
+        Stage 1 (the two-chain step) is PIPELINED across the step boundary (TAN_STEP_PIPELINE): this call returns with the stacks' last
+        weight-gradient launches and the optimizer launches of their matrices still running on their role streams; their events wait
+        in `_Flat.pending`, the next step waits for each where it needs it, anything else that touches the parameters goes through
+        `_ensure_flat()` / `state_dict()`, which wait for all of them."""
+        if getattr(self, "_poisoned", None):
+            raise _lib.TanHipError(self._poisoned)
         if not self._params_synced:
             self.sync_parameters()
-        dev0 = self.online._ensure_flat().flat.device
-        aside = None
-        if dev0.type == "cuda":          # the gradient fill and the image refresh run on a side stream, next to the forward's first kernels
-            from .loss import _side_stream
-            aside = _side_stream(dev0)
-        self.zero_grad(side=aside)
-        world = dist.world_size()
-        gscale = 1.0 if self.global_negatives else 1.0 / world
-        pending, done = [], []
-        if dist.active() and self.ddp_mode == "flat":
-            flat = self.online.flat_grad()
-        elif dist.active():
-            flat = self.online.flat_grad()
-            comm = self._comm_order_stream(flat.device)
-
-            def hook(tag, layer_events):
-                for lo, hi, last in self._ddp_buckets(tag, len(layer_events)):
-                    # comm waits (on the GPU) for the event of the bucket's lowest layer; the process group's own stream
-                    # then waits for comm, i.e. for exactly the layers this bucket covers
-                    _lib.check(_lib.lib().tan_stream_wait_event(C.c_void_p(comm.cuda_stream), C.c_void_p(layer_events[last])),
-                               "tan_stream_wait_event")
-                    with torch.cuda.stream(comm):
-                        work = dist.allreduce_sum_(flat[lo:hi], async_op=True)
-                    done.append((lo, hi))
-                    if work is not None:
-                        pending.append(work)
-            self.online._grad_ready_hook = hook
-        self._in_step = True                   # (forward_backward may hand finished gradients to the optimizer early: only inside step)
+        fl = self.online._flat
+        piped = self.pipeline and fl.bound() and self._will_chain(batch)
+        fl.in_step = piped                     # (a pipelined step waits for what the previous one left running itself, piece by piece)
+        self._pipe_out = None
         try:
-            loss_dict = self.forward_backward(batch)
+            dev0 = self.online._ensure_flat().flat.device        # (not pipelined: waits for everything pending)
+            aside = None
+            if dev0.type == "cuda":      # the gradient fill and the image refresh run on a side stream, next to the forward's first kernels
+                from .loss import _side_stream
+                aside = _side_stream(dev0)
+            self.zero_grad(side=aside)
+            world = dist.world_size()
+            gscale = 1.0 if self.global_negatives else 1.0 / world
+            self._ddp = None
+            if dist.active():
+                self._ddp = _GradReducer(self)
+                if self.ddp_mode == "buckets":
+                    self.online._grad_ready_hook = self._ddp.hook
+            self._in_step = True               # (forward_backward may hand finished gradients to the optimizer early: only inside step)
+            try:
+                loss_dict = self.forward_backward(batch)
+            except BaseException:
+                self._ddp = None
+                if self.__dict__.pop("_early", None):
+                    # `early_update` has already stepped a stack's matrices with this step's count: the parameters are half way between
+                    # two steps and a retried step would apply AdamW to them twice (ADVICE r4) -- say so instead of going on
+                    self._poisoned = ("a training step failed after the early optimizer launch of a stack: parameters are inconsistent; "
+                                      "reload a checkpoint")
+                raise
+            finally:
+                self.online._grad_ready_hook = None
+                self._in_step = False
+            out_ev = self._pipe_out
+            if out_ev is not None:
+                # a pipelined two-chain step: what is left for this stream is the remainder of the gradient reduction and the small
+                # optimizer launch (pre-projections + everything outside the matrices) -- behind the stacks' last weight-gradient
+                # launches, not behind the optimizer launches that follow those on their streams
+                # (the last weight-gradient launches only write matrix gradients, which the early launches step; without those this launch
+                #  steps the matrices too and waits for them.  Single-call data parallelism reduces everything here: same)
+                if not self.__dict__.get("_early"):
+                    cur = torch.cuda.current_stream()
+                    for k in ("video", "joint"):
+                        cur.wait_event(out_ev[k])
+                fl.pending = {}                # (every event of the previous step has been waited for inside this one)
+            if self._ddp is not None:
+                ev = None
+                if self.time_comm:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                self.last_collectives = self._ddp.finish()
+                self._ddp = None
+                if ev is not None:
+                    ev[1].record()
+                    self.comm_events.append(ev)
+            self.optimizer_step(grad_scale=gscale)
+            if out_ev is not None:
+                fl.run_image_hooks()           # the LayerNorm'ed position tables: one small launch, on this stream
+                fl.pending = dict(out_ev)
+            elif aside is not None:
+                self.online._ensure_flat_nosync().refresh_images_async(aside, backward=True)
+                if self.twin:
+                    self.model.target._ensure_flat_nosync().refresh_images_async(aside, backward=False)
         finally:
-            self.online._grad_ready_hook = None
-            self._in_step = False
-        if dist.active():
-            ev = None
-            if self.time_comm:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()
-            for lo, hi in uncovered_ranges(done, flat.numel()):              # whatever the hooks did not cover
-                dist.allreduce_sum_(flat[lo:hi])
-            for w in pending:
-                w.wait()
-            if ev is not None:
-                ev[1].record()
-                self.comm_events.append(ev)
-        self.optimizer_step(grad_scale=gscale)
-        if aside is not None:
-            self.online._ensure_flat_nosync().refresh_images_async(aside, backward=True)
-            if self.twin:
-                self.model.target._ensure_flat_nosync().refresh_images_async(aside, backward=False)
+            fl.in_step = False
+            self._pipe_out = None
         self.batches_seen += 1
         self._resume_bump = 0
         return loss_dict
@@ -574,8 +731,11 @@ class Trainer:
         if not dist.active():
             return None
         flat = self.online.flat_grad()
-        if self.ddp_mode == "flat":
+        if self.ddp_mode == "single" or (self.ddp_mode == "flat" and not self.__dict__.get("_last_step_chains")):
             ranges = [(0, flat.numel())]
+        elif self.ddp_mode == "flat":
+            ranges = [self.online.flat_range("video_temporal_encoder."), self.online.flat_range("joint_temporal_encoder.")]
+            ranges += uncovered_ranges(sorted(ranges), flat.numel())
         else:
             ranges = []
             for tag, layers in (("video", self.online.num_encoder_layers), ("joint", self.online.num_decoder_layers)):

@@ -94,12 +94,17 @@ class _WorkspaceMixin:
                     self._ws_lru.pop(old)
                     self._ws_pool.pop(old, None)          # tensors return to the caching allocator (stream-ordered reuse)
 
-    def _take_ws(self, prefix, layers, B, L, cd, dev):
+    def _take_ws(self, prefix, layers, B, L, cd, dev, alternate=False):
+        """alternate: two workspaces per shape, handed out in turn (a pipelined training step: the previous step's last weight-gradient
+        launches still read its activations while this step's first kernels write theirs)"""
         key = (prefix, layers, B, L, cd, dev)
         self._pool_touch(key)
         with self._ws_lock:
             pool = self._ws_pool.setdefault(key, [])
-            er = pool.pop() if pool else None
+            if alternate:
+                er = pool.pop(0) if len(pool) >= 2 else None
+            else:
+                er = pool.pop() if pool else None
         if er is None:
             er = _EncRun(self, prefix, layers, B, L, cd, dev)
         er.pool_key = key

@@ -1,6 +1,8 @@
 """bench.py's multi-GPU plumbing driven on ONE GPU (TAN_FORCE_DIST=1: the NCCL process group exists and every collective of the step runs
 at world size 1) -- so that the first 8-GPU driver run cannot die on plumbing: the JSON line carries `comm`, the default gradient
-reduction is the north star's single all-reduce ('flat'), and `extra` holds the other mode, global negatives and both stage-2 batches."""
+reduction is the north star's one logical all-reduce of the whole gradient ('flat': in the two-chain step issued in contiguous pieces as
+they become final), and `extra` holds the other modes ('buckets', 'single'), the bf16 wire dtype, global negatives, the stage-1 B_local = 16
+point and both stage-2 batches."""
 import json
 import os
 import subprocess
@@ -23,12 +25,20 @@ def test_bench_line_under_forced_dist_has_comm_and_every_variant():
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     comm = d["comm"]
     assert comm["world_size_seen_by_backend"] == 1 and comm["backend"] == "nccl"
-    assert comm["ddp_mode"] == "flat" and comm["collectives_per_step"] == 1           # ONE all-reduce of the flat gradient per step
-    assert comm["gradient_bytes_per_step"] > 150e6
+    # ONE logical all-reduce of the flat gradient per step: every element once, in <= 4 contiguous pieces (video stack, joint stack,
+    # and what surrounds them in the flat buffer), on the two-chain step that the single-GPU line times
+    assert comm["ddp_mode"] == "flat" and comm["two_chain_step"] and 1 <= comm["collectives_per_step"] <= 4
+    assert comm["collectives_last_step"] == comm["collectives_per_step"]
+    assert 150e6 < comm["gradient_bytes_per_step"] < 170e6 and comm["gradient_wire_dtype"] == "f32"
     names = [e["name"] for e in d["extra"]]
-    assert any("'buckets'" in n for n in names) and any("global negatives" in n for n in names)
-    assert any("B_local=128" in n for n in names) and any("B_local=16" in n for n in names)
+    assert any("'buckets'" in n for n in names) and any("'single'" in n for n in names) and any("global negatives" in n for n in names)
+    assert any("as bf16" in n for n in names)
+    assert any("B_local=128" in n for n in names) and sum("B_local=16" in n for n in names) == 2
     for e in d["extra"]:
         assert e["value"] > 0 and e["comm"]["world_size_seen_by_backend"] == 1
     bk = next(e for e in d["extra"] if "'buckets'" in e["name"])
-    assert bk["comm"]["ddp_mode"] == "buckets" and bk["comm"]["collectives_per_step"] > 1
+    assert bk["comm"]["ddp_mode"] == "buckets" and bk["comm"]["collectives_per_step"] > 4 and bk["comm"]["two_chain_step"]
+    sg = next(e for e in d["extra"] if "'single'" in e["name"])
+    assert sg["comm"]["collectives_per_step"] == 1 and sg["comm"]["collectives_last_step"] == 1
+    b16 = next(e for e in d["extra"] if "as bf16" in e["name"])
+    assert b16["comm"]["gradient_wire_dtype"] == "bf16"

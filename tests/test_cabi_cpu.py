@@ -23,6 +23,7 @@ def test_ctypes_mirrors_have_the_c_layout():
     assert L.tan_abi_sizeof(1) == C.sizeof(_lib.LayerParams)
     assert L.tan_abi_sizeof(2) == C.sizeof(_lib.LayerBufs)
     assert L.tan_abi_sizeof(3) == C.sizeof(_lib.EncoderDesc)
+    assert L.tan_abi_sizeof(4) == C.sizeof(_lib.SimFamDesc)
 
 
 def test_bad_arguments_are_rejected_without_touching_a_device():

@@ -84,7 +84,8 @@ def test_overlapped_bucketed_allreduce_with_a_simulated_identical_peer(one_rank_
     monkeypatch.setattr(dist, "allreduce_sum_", fake_allreduce)
     monkeypatch.setattr(dist, "world_size", lambda: 2)
     tr2 = Trainer(model, args, ddp_bucket_layers=bucket_layers)
-    tr2.ddp_mode = "buckets"                     # (the default is 'flat': one all-reduce after backward, tested below)
+    tr2.ddp_mode = "buckets"                     # (the default is 'flat': the whole gradient in contiguous pieces, tested below)
+    assert tr2._chains_eligible(batch, tr2.fused_loss)          # the bucket hook rides the two-chain step (round 5)
     ld1 = tr2.step(batch)
     g1 = tr2.online.flat_grad().clone()
     p1 = tr2.online._flat.flat.clone()
@@ -110,8 +111,8 @@ def test_overlapped_bucketed_allreduce_with_a_simulated_identical_peer(one_rank_
     assert (dp > 0.1 * lr).float().mean() < 0.01
 
 
-def test_flat_mode_is_one_allreduce_of_the_whole_gradient(one_rank_rccl, monkeypatch):
-    """The default data-parallel mode (BASELINE north_star: a single RCCL all-reduce of the gradients per step)."""
+def test_single_mode_is_one_allreduce_of_the_whole_gradient(one_rank_rccl, monkeypatch):
+    """TAN_DDP_MODE=single: literally one RCCL all-reduce of the gradients per step, after backward."""
     from temporalalignnet_amd import dist
     Trainer, model, args, batch = _setup(2)
     calls = []
@@ -124,7 +125,59 @@ def test_flat_mode_is_one_allreduce_of_the_whole_gradient(one_rank_rccl, monkeyp
     monkeypatch.setattr(dist, "allreduce_sum_", counting)
     tr = Trainer(model, args)
     assert tr.ddp_mode == "flat"
+    tr.ddp_mode = "single"
     ld = tr.step(batch)
     torch.cuda.synchronize()
-    assert calls == [(tr.online.flat_grad().numel(), False)]
+    assert calls == [(tr.online.flat_grad().numel(), False)] and tr.last_collectives == 1
     assert ld["loss"].item() == ld["loss"].item()
+
+
+@pytest.mark.parametrize("wire", ["f32", "bf16"])
+def test_flat_mode_reduces_every_element_once_in_pieces_behind_the_chains(one_rank_rccl, monkeypatch, wire):
+    """The default mode (BASELINE north_star: one all-reduce of the gradients per step) on the two-chain step: the video stack's slice
+    is reduced when its chain ends, the joint stack's when that ends, what is left behind the embeddings' backward -- with a simulated
+    identical peer (see above) the flat gradient must come out exactly twice the single-process one in every parameter tensor, and the
+    parameters (each stack stepped right behind its piece) must equal the single-process step's.  wire = bf16: TAN_DDP_GRAD_DTYPE."""
+    from temporalalignnet_amd import dist
+    Trainer, model, args, batch = _setup(3)
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+    tr = Trainer(model, args)
+    ld0 = tr.step(batch)
+    g0, p0 = tr.online.flat_grad().clone(), tr.online._flat.flat.clone()
+    model.load_state_dict(state0)
+    calls = []
+    real = dist.allreduce_sum_
+
+    def fake_allreduce(t, async_op=False):
+        assert not async_op
+        real(t)                                    # the real RCCL collective, one rank (the current stream waits for it)
+        t.mul_(2.0)                                # the identical peer's contribution
+        calls.append((t.numel(), t.dtype, torch.cuda.current_stream().cuda_stream))
+        return None
+    monkeypatch.setattr(dist, "_FORCE", True)
+    monkeypatch.setattr(dist, "allreduce_sum_", fake_allreduce)
+    monkeypatch.setattr(dist, "world_size", lambda: 2)
+    tr2 = Trainer(model, args)
+    tr2.ddp_grad_dtype = wire
+    assert tr2.ddp_mode == "flat" and tr2._chains_eligible(batch, tr2.fused_loss)
+    ld1 = tr2.step(batch)
+    g1, p1 = tr2.online.flat_grad().clone(), tr2.online._flat.flat.clone()
+    torch.cuda.synchronize()
+    f = tr2.online._flat
+    lo_v, hi_v = tr2.online.flat_range("video_temporal_encoder.")
+    lo_j, hi_j = tr2.online.flat_range("joint_temporal_encoder.")
+    assert [c[0] for c in calls[:2]] == [hi_v - lo_v, hi_j - lo_j]      # the two stacks first, each on the stream of its last dW launches
+    assert calls[0][2] != calls[1][2] and 3 <= len(calls) <= 4 == tr2.last_collectives + (4 - len(calls))
+    assert sum(c[0] for c in calls) == g1.numel()                        # every element reduced exactly once
+    assert all(c[1] == (torch.bfloat16 if wire == "bf16" else torch.float32) for c in calls)
+    assert abs(ld0["loss"].item() - ld1["loss"].item()) <= 1e-5 * max(1.0, abs(ld0["loss"].item()))
+    tol = 1e-3 if wire == "f32" else 6e-3                                # (bf16: 2^-9 relative rounding per element)
+    assert (g1 - 2 * g0).norm() <= tol * (2 * g0).norm()
+    for n in f.names:                                                    # ... in EVERY parameter tensor, however small
+        o, k, _ = f.off[n]
+        a, b = g1[o:o + k], 2 * g0[o:o + k]
+        assert (a - b).norm() <= 2e-2 * b.norm() + 1e-7, (n, float((a - b).norm()), float(b.norm()))
+    lr = tr2.current_lr()
+    dp = (p1 - p0).abs()
+    assert dp.max() <= 2.1 * lr + 1e-7
+    assert (dp > 0.1 * lr).float().mean() < 0.01

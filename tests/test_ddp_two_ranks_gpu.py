@@ -34,8 +34,9 @@ def _setup(seed_batch, kind, layers, bucket):
 def _worker(rank, world, port, out_dir, kind, layers, bucket, backend="gloo", mode="buckets"):
     sys.path.insert(0, ROOT)
     local = rank if backend == "nccl" else 0                # RCCL: one GPU per rank; gloo: both ranks share cuda:0
+    mode, _, wire = mode.partition("+")                      # "flat+bf16": TAN_DDP_GRAD_DTYPE
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local),
-                      TAN_DDP_MODE=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      TAN_DDP_MODE=mode, TAN_DDP_GRAD_DTYPE=wire or "f32", HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as tdist
     from temporalalignnet_amd import dist
     torch.cuda.set_device(local)
@@ -59,7 +60,10 @@ def _two_gpus():
 
 
 @pytest.mark.parametrize("kind,layers,bucket,backend,mode", [
-    ("init", 2, 1, "gloo", "buckets"), ("cotrain", 3, 2, "gloo", "buckets"), ("init", 2, 1, "gloo", "flat"),
+    # stage 1 ('init') runs the two-chain step in every mode (round 5): bucket hooks behind the chains' layer events, the flat gradient in
+    # pieces with each stack stepped behind its piece, the single call, and the bf16 wire; stage 2 the autograd step
+    ("init", 2, 1, "gloo", "buckets"), ("cotrain", 3, 2, "gloo", "buckets"), ("init", 2, 1, "gloo", "flat"), ("init", 2, 1, "gloo", "single"),
+    ("init", 2, 2, "gloo", "flat+bf16"), ("cotrain", 3, 2, "gloo", "flat"),
     # the same through RCCL over xGMI, one GPU per rank -- runs wherever the box has two GPUs (self-skips on the 1-GPU pool)
     ("init", 2, 1, "nccl", "buckets"), ("cotrain", 3, 2, "nccl", "buckets"), ("cotrain", 3, 2, "nccl", "flat")])
 def test_two_ranks_equal_one_process_with_both_batches(tmp_path, kind, layers, bucket, backend, mode):
@@ -67,6 +71,7 @@ def test_two_ranks_equal_one_process_with_both_batches(tmp_path, kind, layers, b
         pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
     ctx = mp.get_context("spawn")
     port = 29600 + (os.getpid() + layers + 7 * len(mode) + 13 * len(backend)) % 1000
+    wire_bf16 = mode.endswith("+bf16")
     procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), kind, layers, bucket, backend, mode)) for r in range(2)]
     for p in procs:
         p.start()
@@ -91,7 +96,7 @@ def test_two_ranks_equal_one_process_with_both_batches(tmp_path, kind, layers, b
     for n in f.names:                                        # every parameter tensor: summed over the two ranks, once
         o, k, _ = f.off[n]
         a, b = r0["grad"][o:o + k], g[o:o + k]
-        assert (a - b).norm() <= 2e-2 * b.norm() + 1e-7, (n, float((a - b).norm()), float(b.norm()))
+        assert (a - b).norm() <= (3e-2 if wire_bf16 else 2e-2) * b.norm() + 1e-7, (n, float((a - b).norm()), float(b.norm()))
     lr = tr.current_lr()
     dp = (r0["param"] - f.flat.cpu()).abs()
     # Adam with zero moments at step 2001: |update| = lr * 0.1 / sqrt(0.001 / (1 - 0.999**2001)) = 2.94 lr, so a noise-level gradient

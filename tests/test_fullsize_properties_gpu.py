@@ -395,3 +395,92 @@ def test_len256_full_size_matches_the_cpu_oracle():
                 assert cos >= 0.99, (name, cos)
         del m, out, l
         torch.cuda.empty_cache()
+
+
+def _step_trainer(lr=1e-4):
+    from temporalalignnet_amd.train import Trainer, default_args
+    args = default_args(model="init", num_encoder_layers=E, num_decoder_layers=D, lr=lr, wd=1e-5)
+    return Trainer(_model("bf16"), args)
+
+
+def test_benchmarked_step_at_full_size_matches_the_plain_step_the_oracle_and_itself(monkeypatch):
+    """The step `bench.py` times -- `Trainer.step` at B = 128, E6D6, bf16 with every default (two chains without autograd between them,
+    the family launches of the loss, dW tails on idle streams, the early AdamW of the video stack, AdamW writing the weight images) -- at
+    the benchmarked size (stream-ordering bugs are size-dependent; at B = 8 every kernel is over before its
+    consumer is enqueued).  train/main.py:81-122.
+      (i)   three steps against the same three steps with autograd + one AdamW launch + image rebuilds (TAN_STEP_CHAINS / TAN_OPT_EARLY /
+            TAN_OPT_IMAGES = 0): parameters equal up to the order of the f32 gradient atomics (the bound of the B = 8 test);
+      (ii)  the flat gradient of step 1, captured before the optimizer, against torch autograd through the CPU oracle: NORM-relative
+            per tensor (a race corrupting 1 % of a tensor fails this; a cosine bound would not);
+      (iii) the same three steps 20 times in a row from the same state with ONE synchronisation at the end: every repetition equal to
+            the first up to the atomics' order."""
+    from oracle import loss_ref, tan_ref, train_ref
+    batches = [_batch(21 + i) for i in range(3)]
+
+    def three_steps(tr, init, reps=1):
+        outs = []
+        for _ in range(reps):
+            f = tr.online._ensure_flat()       # (waits for what the previous, pipelined, step left on its role streams)
+            f.flat.copy_(init)
+            tr.online.invalidate_shadow()
+            st = tr._ensure_state()[1]
+            st["m"].zero_(); st["v"].zero_()
+            tr.iteration = tr.batches_seen = 0
+            for b in batches:
+                tr.step(b)
+            outs.append(tr.online.flat_parameters().clone())       # (waits for what the pipelined step left on its role streams)
+        torch.cuda.synchronize()
+        return outs
+
+    flats = {}
+    for tag, env in (("plain", "0"), ("bench", "1")):
+        for k in ("TAN_STEP_CHAINS", "TAN_OPT_EARLY", "TAN_OPT_IMAGES"):
+            monkeypatch.setenv(k, env)
+        tr = _step_trainer(lr=1e-3)          # (lr 1e-3: three steps move the parameters by ~3e-3, the atomics' noise stays what it is)
+        init = tr.online._ensure_flat().flat.clone()
+        assert tr._chains_eligible(batches[0], tr.fused_loss) == (env == "1")
+        flats[tag] = three_steps(tr, init, reps=20 if tag == "bench" else 1)
+        if tag == "bench":
+            # ---- (ii) the gradient of step 1 on the chain path, before any optimizer launch
+            tr.online._ensure_flat().flat.copy_(init)
+            tr.online.invalidate_shadow()
+            tr.zero_grad()
+            ld = tr.forward_backward(batches[0])
+            torch.cuda.synchronize()
+            grads = {n: p.grad.float().cpu().clone() for n, p in tr.online.named_parameters() if p.grad is not None}
+            loss_hip = float(ld["loss"])
+        del tr
+        torch.cuda.empty_cache()
+    ref = flats["plain"][0]
+    assert torch.isfinite(ref).all() and (ref - init).abs().max().item() > 1e-3
+    # ---- (i)
+    d = (flats["bench"][0] - ref).abs()
+    assert d.max().item() <= 6.5e-3 and d.mean().item() <= 3e-5, (d.max().item(), d.mean().item())
+    # ---- (iii)
+    for i, f in enumerate(flats["bench"][1:]):
+        dd = (f - flats["bench"][0]).abs()
+        assert dd.max().item() <= 6.5e-3 and dd.mean().item() <= 3e-5, (i + 1, dd.max().item(), dd.mean().item())
+    # ---- (ii) against the oracle
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    b_np = synth.make_batch(21, B=B, T=T, n_min=4, n_max=16)
+    p = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in synth.make_params(7, E, D, False).items()}
+    t = train_ref.to_torch_batch(b_np)
+    out = tan_ref.forward(p, t["video"], t["text_embed"], t["padding_mask"], t["text_padding_mask"].bool(), E=E, D=D,
+                          use_alignability_head=False)
+    ref_loss, _ = loss_ref.get_loss(b_np, t["video"], t["text_embed"], t["padding_mask"], t["text_padding_mask"], out,
+                                    loss_ref.default_args(model="init"), t["abs_text_pos"])
+    ref_loss["loss"].backward()
+    assert abs(loss_hip - float(ref_loss["loss"])) < 1e-2 * abs(float(ref_loss["loss"]))
+    worst = ("", 0.0)
+    for name, want in ((n, v.grad) for n, v in p.items()):
+        if want is None or want.abs().max().item() == 0:
+            continue
+        rel = (grads[name] - want).norm().item() / want.norm().item()
+        worst = max(worst, (name, rel), key=lambda x: x[1])
+        assert rel <= _BF16_GRAD_REL, (name, rel)
+    print("worst norm-relative gradient error of the bf16 chain step vs the fp32 oracle:", worst)
+
+
+# bf16 activations / weights against the fp32 oracle, per parameter tensor, ||g_hip - g_ref|| / ||g_ref|| at B = 128 (measured: see the
+# print above; a tensor with 1 % of its entries corrupted by a race reads >= 0.1)
+_BF16_GRAD_REL = 0.06
