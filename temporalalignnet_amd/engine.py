@@ -363,7 +363,7 @@ class _AlignerEngine(_WorkspaceMixin):
         video_c = sv_v["video_c"]
         Dv = video_c.shape[-1]
         ops.gemm(em["dproj_v"], video_c, self._g("video_pre_proj.weight"), M=WIDTH, N=Dv, K=R, a_kc=False, b_kc=False,
-                 lda=WIDTH, ldb=Dv, accumulate=True, split_k=max(1, min(32, R // 1024)))
+                 lda=WIDTH, ldb=Dv, accumulate=True, split_k=max(1, min(32, R // 1024)))      # (K slices of 256 rows: +0.03 ms per step, ABBA x2)
         if nprob == 2:
             if aux is not None:
                 cur.wait_stream(aux)
@@ -704,6 +704,9 @@ class _AlignerEngine(_WorkspaceMixin):
         # so the weight gradients stay on the chains; the bucket all-reduces are issued by the hook, from THIS thread, video first
         hook = self._grad_ready_hook
         dw_j, dw_v = (None, None) if hook is not None else (aux_j, aux_v)
+        # (Measured in round 5 and not kept: the optimizer launch of a stack's UPPER layers -- whose weight gradients ride the chain -- on a
+        #  third stream as soon as the lowest of them is differentiated.  The step's boundary shrinks by 0.07 ms and the backward grows by
+        #  as much: 4.290 vs 4.271 ms, ABBA x2 of 60 steps.  HBM-bound launches next to the stacks' kernels cost what they save.)
 
         def joint_chain():
             dst_j = torch.empty(Sd, B * L, Cw, dtype=cd, device=dev)

@@ -357,6 +357,8 @@ class Trainer:
                 if self.global_negatives:
                     raise _lib.TanHipError(f"global_negatives: {Bn}x{Nn} text columns per rank exceed the fused sweep's limit")
                 fused = False
+        if self.online.compute_dtype == torch.bfloat16 and batch["video"].is_cuda:
+            batch = self._pad_sentence_slots(batch)          # (whole 64-row panels for the joint stack: both step schedules)
         self._last_step_chains = self._chains_eligible(batch, fused)
         if self._last_step_chains:
             return self._forward_backward_chains(batch)
@@ -403,6 +405,36 @@ class Trainer:
                 and not a.use_alignability_head and a.optim_policy != "bce" and not self.global_negatives and "token" not in batch
                 and batch["video"].is_cuda and not batch["text_embed"].requires_grad and os.environ.get("TAN_STEP_CHAINS", "1") != "0"
                 and self.online._chains_ok(batch["video"], batch["text_embed"]))
+
+    @staticmethod
+    def _pad_sentence_slots(batch):
+        """Small batches: the row-panel kernels take stacks of B * (T + N) rows in whole 64-row panels (at B = 128 every N does; at
+        B = 16 only N % 4 == 0, and the joint stack fell back to LayerNorm + tiled-GEMM launches for the other three quarters of the
+        batches).  Up to three more PADDED sentence slots per video make the row count fit: a padded sentence is masked as an attention
+        key and dropped from the loss (train/main.py:61-65 pads to the longest video of the batch the same way), so nothing a real row
+        or the loss sees changes."""
+        video, lang = batch["video"], batch["text_embed"]
+        B, T, N = video.shape[0], video.shape[1], lang.shape[1]
+        if (B * (T + N)) % 64 == 0:
+            return batch
+        extra = next((e for e in (1, 2, 3) if (B * (T + N + e)) % 64 == 0), 0)
+        if not extra:
+            return batch
+        out = dict(batch)
+        out["text_embed"] = torch.cat([lang, lang[:, -1:].expand(-1, extra, -1)], 1)
+        tp = batch["text_padding_mask"]
+        out["text_padding_mask"] = torch.cat([tp, torch.ones(B, extra, dtype=tp.dtype, device=tp.device)], 1)
+        if batch.get("_text_pad_bool") is not None:
+            pb = batch["_text_pad_bool"]
+            out["_text_pad_bool"] = torch.cat([pb, torch.ones(B, extra, dtype=torch.bool, device=pb.device)], 1)
+        tr_ = batch.get("_tgt_raw")
+        if tr_ is None:
+            tr_, _, _ = get_mask_from_time(batch["start"], batch["end"], T, N, device=video.device)
+        out["_tgt_raw"] = torch.cat([tr_, torch.zeros(B, extra, tr_.shape[2], dtype=tr_.dtype, device=tr_.device)], 1)
+        ap = batch.get("abs_text_pos")
+        if torch.is_tensor(ap):
+            out["abs_text_pos"] = torch.cat([ap, torch.zeros(B, extra, ap.shape[2], dtype=ap.dtype, device=ap.device)], 1)
+        return out
 
     def _forward_backward_chains(self, batch):
         from .loss import _ManualCtx, _NCETail, nce_family_stages, nce_term_grads, prepare_inputs_async

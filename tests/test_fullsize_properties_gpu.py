@@ -483,4 +483,4 @@ def test_benchmarked_step_at_full_size_matches_the_plain_step_the_oracle_and_its
 
 # bf16 activations / weights against the fp32 oracle, per parameter tensor, ||g_hip - g_ref|| / ||g_ref|| at B = 128 (measured: see the
 # print above; a tensor with 1 % of its entries corrupted by a race reads >= 0.1)
-_BF16_GRAD_REL = 0.06
+_BF16_GRAD_REL = 0.03        # (measured 0.012: joint_temporal_encoder.resblocks.4.attn.in_proj_weight)

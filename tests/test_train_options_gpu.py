@@ -150,3 +150,32 @@ def test_two_chain_step_matches_the_autograd_step(monkeypatch, random_pos):
         o, k, _ = f.off[n]
         a, c = g1[o:o + k], g0[o:o + k]
         assert (a - c).norm() <= 2e-2 * c.norm() + 1e-7, (n, float((a - c).norm()), float(c.norm()))
+
+
+def test_small_batch_pads_sentence_slots_to_whole_row_panels():
+    """B = 16 with N = 15 sentences per video: 16 * (64 + 15) rows are not whole 64-row panels; the two-chain step adds ONE padded
+    sentence slot per video (masked as a key, dropped from the loss) so that the joint stack runs the row-panel kernels -- loss and
+    gradients equal the unpadded step's (the fallback launches) up to bf16 rounding of another kernel path."""
+    import numpy as np
+    from temporalalignnet_amd import synth
+    from temporalalignnet_amd.train import Trainer, to_device_batch
+    b_np = synth.make_batch(61, B=16, T=64, n_min=4, n_max=15)
+    assert b_np["text_embed"].shape[1] == 15
+    b = to_device_batch(b_np)
+    padded = Trainer._pad_sentence_slots(b)
+    assert padded["text_embed"].shape[1] == 16 and padded["_tgt_raw"].shape[1] == 16 and bool(padded["text_padding_mask"][:, 15].all())
+    assert Trainer._pad_sentence_slots(padded) is padded
+    outs = []
+    for pad in (True, False):
+        tr, _ = _trainer(seed=9, dtype="bf16", model="init")
+        if not pad:
+            tr._pad_sentence_slots = lambda batch: batch
+        assert tr._chains_eligible(b, tr.fused_loss)
+        np.random.seed(1)
+        tr.zero_grad()
+        ld = tr.forward_backward(b)
+        torch.cuda.synchronize()
+        outs.append((float(ld["loss"]), tr.online.flat_grad().clone()))
+    (l1, g1), (l0, g0) = outs
+    assert abs(l1 - l0) <= 2e-3 * abs(l0), (l1, l0)
+    assert (g1 - g0).norm() <= 3e-2 * g0.norm(), float((g1 - g0).norm() / g0.norm())
