@@ -296,9 +296,9 @@ typedef struct tan_simfam_desc {
     void* e_keep; void* ws;
     float *v_terms, *t_terms;                                               /* out: [S,R], [S,Mc] */
     const float *g_v, *g_t;                                                 /* d loss / d terms: [S,R], [S,Mc] (fwd: optional) */
-    void* dl; float* d_tn_acc;                                              /* bwd scratch: [S,R,Mc] bf16, [St,Mc,C] f32 */
+    void* dl; float* d_tn_acc;                                              /* bwd scratch: [S,R,Mc] bf16 + 256 elements of slack, [St,Mc,C] f32 */
     tan_ptr8 d_video; tan_ptr8 d_text;                                      /* out: stage-gradient rows (addressed like x_*) */
-    int dtn_split_k;                                                        /* K slices of the text-gradient GEMM (0: default) */
+    int dtn_split_k;   /* K slices of the text-gradient GEMM; 0: default (St = 1: 8 slices of tan_gemm; St = S: 2 of tan_gemm_atb), < 0: -n slices of tan_gemm_atb */
 } tan_simfam_desc;
 long tan_simfam_ws_bytes(int S, int St, int B, int T, int N, int Mc);
 int tan_simfam_fwd(tan_simfam_desc* d, void* stream);

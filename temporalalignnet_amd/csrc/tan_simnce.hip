@@ -1813,7 +1813,24 @@ extern "C" int tan_simfam_bwd(tan_simfam_desc* d, void* stream) {
         TAN_LAUNCH_CHECK();
     }
     // ---- d t_hat[st] (+)= dl[s]^T v_hat[s]  (f32, K slices meet in atomics; the accumulator was zeroed with the corrections)
-    {
+    // Per-stage text features (the joint family): S problems [Mc x 512] under an R-long contraction on the 256 x 256-tile kernel
+    // (tan_gemm_atb), two K slices -- 4.154 vs 4.185 ms per step against the 128 x 128-tile GEMM (ABBA x2 of 60 steps; three slices
+    // 4.163; the shared-text problem of the dual family, one [Mc x 512] output under S*R rows, is equal or slower there with 16 / 21).
+    bool done = false;
+    const int atb_split = d->dtn_split_k < 0 ? -d->dtn_split_k : (d->dtn_split_k == 0 && St > 1 ? 2 : 0);
+    const long Kc = St == 1 ? (long)S * R : R;
+    if (atb_split > 0 && Kc % 128 == 0 && Kc / 128 >= atb_split && Mc % 8 == 0) {
+        const void* A[8]; const void* Bm[8]; void* Cm[8]; int lda[8], Mv[8], Ns[8];
+        const int np = St == 1 ? 1 : S;
+        for (int p = 0; p < np; ++p) {
+            A[p] = (const bf16_t*)d->dl + (long)p * R * Mc; Bm[p] = (const bf16_t*)d->vn + (long)p * R * 512;
+            Cm[p] = d->d_tn_acc + (long)p * Mc * 512; lda[p] = Mc; Mv[p] = Mc; Ns[p] = 512;
+        }
+        rc = tan_gemm_atb(np, A, Bm, Cm, lda, Mv, Ns, Kc, TAN_F32, 1, atb_split, stream);
+        if (rc == 0) done = true;
+        else if (rc != TAN_ERR_BAD_ARG) return rc;
+    }
+    if (!done) {
         tan_gemm_desc g{};
         g.dtype = TAN_BF16; g.out_dtype = TAN_F32;
         g.M = Mc; g.N = 512; g.a_kc = 0; g.b_kc = 0;

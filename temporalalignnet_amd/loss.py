@@ -412,7 +412,7 @@ def nce_family_stages(x_video, v_grp, x_text, t_grp, d_video, d_text, tgt, col_i
     vn = torch.empty(S, R, Cw, dtype=bf, device=dev)
     tn = torch.empty(St, Mc, Cw, dtype=bf, device=dev)
     ekeep = torch.empty(L.tan_simnce_keep_elems(S, R, Mc), dtype=bf, device=dev)
-    dl = torch.empty(S, R, Mc, dtype=bf, device=dev)
+    dl = torch.empty(S * R * Mc + 256, dtype=bf, device=dev)      # (+ slack: the 256-wide tiles of tan_gemm_atb read past a ragged Mc)
     ws = torch.empty(L.tan_simfam_ws_bytes(S, St, B, T, N, Mc), dtype=torch.uint8, device=dev)
     d.vn, d.inv_v, d.tn, d.inv_t = vn.data_ptr(), inv_v.data_ptr(), tn.data_ptr(), inv_t.data_ptr()
     d.rowsum, d.colsum, d.possum_v, d.possum_t = rowsum.data_ptr(), colsum.data_ptr(), possum_v.data_ptr(), possum_t.data_ptr()
@@ -421,7 +421,7 @@ def nce_family_stages(x_video, v_grp, x_text, t_grp, d_video, d_text, tgt, col_i
     d.g_v, d.g_t = g_v.data_ptr(), g_t.data_ptr()
     d.dl, d.d_tn_acc = dl.data_ptr(), acc.data_ptr()
     d.d_video, d.d_text = _ptr8(d_video), _ptr8(d_text)
-    d.dtn_split_k = split_k          # (0: 8 K slices for the shared text embedding, 1 per stage otherwise; 2 / 4 / 16 measured equal or slower in the step)
+    d.dtn_split_k = split_k          # (0: the library's choice -- include/tan_hip.h)
     st = ops._stream()
     _lib.check(L.tan_simfam_fwd(C.byref(d), st), "tan_simfam_fwd")
     _lib.check(L.tan_simfam_bwd(C.byref(d), st), "tan_simfam_bwd")
