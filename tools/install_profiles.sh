@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy what tools/refresh_profiles.sh wrote under gpurun_out/refresh/ over profiles/<round>_*:  tools/install_profiles.sh r03
 set -e
-R=${1:-r04}; S=gpurun_out/refresh; P=profiles
+R=${1:-r05}; S=gpurun_out/refresh; P=profiles
 cp $S/bench.json                        $P/${R}_bench_e6d6_b128_bf16.json
 cp $S/kernel_stats.csv                  $P/${R}_bench_e6d6_b128_bf16_kernel_stats.csv
 cp $S/under_rocprof.json                $P/${R}_bench_e6d6_b128_bf16_under_rocprof.json

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates profiles/ on an MI355X box: run as  gpurun -- 'bash tools/refresh_profiles.sh'  (writes under gpurun_out/refresh/);
-# then copy gpurun_out/refresh/* over profiles/r03_*.  Counters are collected in their own passes (--pmc with --kernel-trace only).
+# then `bash tools/install_profiles.sh r05` copies gpurun_out/refresh/* over profiles/r05_*.  Counters are collected in their own passes (--pmc with --kernel-trace only).
 set -x
 R=$PWD; O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
-python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $R/bench.py --steps 10 --warmup 3 --settle-s 0 --no-cpu-baseline --no-extra > $O/under_rocprof.json 2> $O/under_rocprof.err
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
@@ -35,5 +35,5 @@ python $R/tools/pmc_summary.py $(find /tmp/pmc2_FETCH_SIZE -name "*counter_colle
 cd $R
 python tools/stack_timeline.py > $O/stack_timeline.txt 2>/dev/null
 python tools/stack_timeline.py --stage 2 >> $O/stack_timeline.txt 2>/dev/null
-bash tools/batch_sweep.sh 64 96 112 128 144 160 > $O/batch_sweep.txt 2>/dev/null
+bash tools/batch_sweep2.sh 16 32 64 96 112 128 144 160 > $O/batch_sweep.txt 2>/dev/null
 tail -1 $O/bench.json | cut -c1-400
