@@ -98,8 +98,8 @@ struct DwItem { const void* dy; const void* x; float* gw; int N, K; };
 
 constexpr int DW256_SPLIT = 2;
 
-int linear_bwd_w_group(int dt, const DwItem* it, int n, long M, float* ws, long ws_floats, void* st) {
-    if (const int s256 = dt == TAN_BF16 ? DW256_SPLIT : 0) {
+int linear_bwd_w_group(int dt, const DwItem* it, int n, long M, float* ws, long ws_floats, void* st, int split = 0) {
+    if (const int s256 = dt == TAN_BF16 ? (split > 0 ? split : DW256_SPLIT) : 0) {
         bool ok = M % 128 == 0 && M / 128 >= s256;
         for (int i = 0; i < n; ++i) ok = ok && it[i].N % 256 == 0 && it[i].K % 256 == 0;
         if (ok) {
@@ -330,6 +330,8 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
                 // below reuses the set (it waits for ev_done), block 0's for good
                 if (hipEventRecord(ev_in, (hipStream_t)st) != hipSuccess) return -3;
                 if (hipStreamWaitEvent((hipStream_t)e->dw_stream, ev_in, 0) != hipSuccess) return -3;
+                // (more K slices for the LAST of these launches, which runs next to a draining chip: 4 slices +0.03 ms per step, 8 slices
+                //  +0.08, ABBA x2 of 60 steps, round 5)
                 CK(linear_bwd_w_group(dt, items, 4, R, e->dw_ws, e->dw_ws_floats, e->dw_stream));
                 if (hipEventRecord(ev_done[i], (hipStream_t)e->dw_stream) != hipSuccess) return -3;
             } else

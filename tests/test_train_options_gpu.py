@@ -179,3 +179,57 @@ def test_small_batch_pads_sentence_slots_to_whole_row_panels():
     (l1, g1), (l0, g0) = outs
     assert abs(l1 - l0) <= 2e-3 * abs(l0), (l1, l0)
     assert (g1 - g0).norm() <= 3e-2 * g0.norm(), float((g1 - g0).norm() / g0.norm())
+
+
+def test_reads_after_a_pipelined_step_wait_for_its_optimizer_launches():
+    """`Trainer.step` (stage 1) returns with the optimizer launches of the stacks' matrices still running on the trainer's role streams
+    (DESIGN.md section 3.7).  Whatever reads parameters through this package afterwards -- a forward, `state_dict()`,
+    `flat_parameters()` -- must see the STEPPED parameters without the caller synchronising: compared with the same read after a
+    device-wide synchronisation."""
+    tr, _ = _trainer(seed=11, dtype="bf16", model="init")
+    assert tr.pipeline
+    b = _batch(91, B=16, T=64)
+    for _ in range(2):
+        tr.step(b)
+    assert tr.online._flat.pending                                # (events of the last step are waiting)
+    m = tr.online
+    with torch.no_grad():
+        feat_now = m.get_visual_feature(b["video"], b["padding_mask"]).clone()        # no synchronisation in between
+    assert not m._flat.pending
+    flat_now = m.flat_parameters().clone()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        feat_sync = m.get_visual_feature(b["video"], b["padding_mask"])
+    assert torch.equal(feat_now, feat_sync) and torch.equal(flat_now, m.flat_parameters())
+    tr.step(b)
+    sd = {k: v.clone() for k, v in tr.model.state_dict().items()}                     # state_dict(): the same rule
+    torch.cuda.synchronize()
+    for k, v in tr.model.state_dict().items():
+        assert torch.equal(sd[k], v), k
+
+
+def test_padded_sentence_slots_do_not_change_stage2():
+    """The same padding in the co-training step (EMA forward, self-labelling, thresholds, alignability head with abs_text_pos): every
+    entry of the loss dict equal to the unpadded step's up to the bf16 rounding of another kernel path."""
+    from temporalalignnet_amd import synth
+    from temporalalignnet_amd.train import Trainer, to_device_batch
+    b = to_device_batch(synth.make_batch(63, B=16, T=64, n_min=4, n_max=15))
+    assert b["text_embed"].shape[1] == 15
+    outs = []
+    for pad in (True, False):
+        tr, _ = _trainer(seed=13, dtype="bf16", model="cotrain", loss_threshold=0.5)
+        tr.model._copy_param()
+        if not pad:
+            tr._pad_sentence_slots = lambda batch: batch
+        tr.zero_grad()
+        ld = tr.forward_backward(b)
+        torch.cuda.synchronize()
+        outs.append(({k: float(v) for k, v in ld.items()}, tr.online.flat_grad().clone()))
+    (l1, g1), (l0, g0) = outs
+    assert set(l1) == set(l0)
+    for k in l0:
+        # (fractions of the ~160 real sentences -- confidence-ratio, alignability_top1 -- move in steps of 1 / 160: a borderline sentence
+        #  may fall the other way when another kernel path rounds its bf16 features differently)
+        tol = 2.0 / 160 if k in ("confidence-ratio", "alignability_top1") else 5e-3 * max(1.0, abs(l0[k]))
+        assert abs(l1[k] - l0[k]) <= tol, (k, l1[k], l0[k])
+    assert (g1 - g0).norm() <= 5e-2 * g0.norm(), float((g1 - g0).norm() / g0.norm())
