@@ -378,6 +378,9 @@ __global__ __launch_bounds__(512) void simnce_res_kernel(SimArgs a) {
     BF ring[RD];
     const char* Tp = a.Tp + (long)s * a.tp_stage_stride;
     auto load_b = [&](BF& dst, int ct, int ks) __attribute__((always_inline)) {       // columns ct*128 + wn*64 + j*32 .., k = 16 ks ..
+        // (Timing-only ablation, round 5: the wm = 1 waves re-reading one L1-resident piece -- HALF the L2 -> CU text stream -- takes the
+        //  sweep from 108.2 to 105.9 us stand-alone and leaves the step where it is: the loop is not bound by that stream, and a
+        //  128 x 64 wave tile that halves it would buy nothing.)
         const char* pb = Tp + ((long)((ct * 4 + wn * 2) * 32 + ks)) * 1024 + lane * 16;
         dst.f[0] = *reinterpret_cast<const bf16x8*>(pb);
         dst.f[1] = *reinterpret_cast<const bf16x8*>(pb + 32 * 1024);

@@ -646,7 +646,7 @@ class _AlignerEngine(_WorkspaceMixin):
         return (self.compute_dtype == torch.bfloat16 and self._embed_fused_ok(video, lang, itp) and not self.use_alignability_head
                 and self._side_stream(video.device) is not None)
 
-    def _run_chains(self, video, lang, vmask_u8, tmask_u8, family, after_video_bwd=None, after_joint_bwd=None, pipe=None):
+    def _run_chains(self, video, lang, vmask_u8, tmask_u8, family, after_video_bwd=None, after_joint_bwd=None, pipe=None, mid=None):
         """Forward AND backward of the aligner under a loss that separates into a dual and a joint term (stage 1: train/loss.py:359-373,
         loss = (loss_dual + loss_joint) / 2 with batch-independent weights) as TWO chains that never wait for each other:
             main stream:  video stack forward -> unit features -> family("dual") -> their backward -> video stack backward
@@ -708,6 +708,10 @@ class _AlignerEngine(_WorkspaceMixin):
         #  third stream as soon as the lowest of them is differentiated.  The step's boundary shrinks by 0.07 ms and the backward grows by
         #  as much: 4.290 vs 4.271 ms, ABBA x2 of 60 steps.  HBM-bound launches next to the stacks' kernels cost what they save.)
 
+        import threading
+        joint_terms, joint_ready = [], threading.Event()      # the joint family's terms as soon as its launches are enqueued (for `mid`)
+        self._joint_terms = (joint_terms, joint_ready)
+
         def joint_chain():
             dst_j = torch.empty(Sd, B * L, Cw, dtype=cd, device=dev)
             d_xj = torch.empty(B * L, Cw, dtype=cd, device=dev)
@@ -718,6 +722,8 @@ class _AlignerEngine(_WorkspaceMixin):
             dj = [dst_j[s] for s in range(Sd)]
             # frame rows b*L + t and sentence rows b*L + T + k of the SAME stage buffers (tan_model.py:207-209), and of their gradients
             v_j, t_j = family("joint", stages, (L, 0), stages, (L, T), dj, dj)
+            joint_terms.append((v_j, t_j, torch.cuda.current_stream().record_event()))
+            joint_ready.set()
             if zero_ev is not None:
                 torch.cuda.current_stream().wait_event(zero_ev)
             self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dj, d_xj, dw_stream=dw_j, dw_tail=tail_j)
@@ -728,6 +734,7 @@ class _AlignerEngine(_WorkspaceMixin):
         ev = self._run_video_stack(fe["x0"], vmask_u8, B, T, True, er=fe["ev"])
         dv = [dst_v[s] for s in range(Se)]
         v_d, t_d = family("dual", [ev.stage(s) for s in range(Se)], (T, 0), [fe["lang_raw"]], (N, 0), dv, [d_lang_raw])
+        self._dual_terms = (v_d, t_d)
         if zero_ev is not None:
             main.wait_event(zero_ev)
         self._encoder_bwd(ev, fe["x0"], vmask_u8, "ln_video_post_enc", dv, d_x0, dw_stream=dw_v, dw_tail=tail_v)
@@ -739,6 +746,8 @@ class _AlignerEngine(_WorkspaceMixin):
             with torch.cuda.stream(aux_v):         # their stream: this one is free for the embeddings' backward as soon as the joint chain is through
                 after_video_bwd()
         out_ev["video"] = aux_v.record_event()
+        if mid is not None:                      # (main stream, behind the video stack's backward: e.g. the loss's masked means, which
+            mid()                                #  would otherwise sit between the embeddings' backward and the optimizer launch)
         ej, v_j, t_j, d_xj, keep = fut.result()
         if hook is not None:
             with torch.cuda.stream(side):

@@ -481,13 +481,27 @@ class Trainer:
                     self.early_update(which, gs)
             if early or ddp is not None:
                 early_v, early_j = (lambda: stack_done("video")), (lambda: stack_done("joint"))       # noqa: E731
+        tail = {}
+
+        def loss_tail():
+            # the masked means of the four term tensors (loss.py:254-275), on the main stream right behind the video stack's backward:
+            # the joint family's terms were final ~1.5 ms earlier on their stream; issued at the end of the step the launch sat between
+            # the embeddings' backward and the optimizer launch (4.126 -> 4.078 ms per step, ABBA x2 of 60 steps)
+            terms, ready = m._joint_terms
+            if not ready.wait(timeout=60.0):
+                raise _lib.TanHipError("the joint chain did not reach its loss family")
+            v_j_, t_j_, ev_j = terms[0]
+            main.wait_event(ev_j)
+            v_d_, t_d_ = m._dual_terms
+            for t in (v_j_, t_j_):
+                t.record_stream(main)
+            tail["out"] = _NCETail.forward(_ManualCtx(), v_d_, t_d_, v_j_, t_j_, prep["rows_pos"], cols_tail, None)
         v_d, t_d, v_j, t_j = m._run_chains(video, lang, m._mask_u8(batch["padding_mask"]), m._mask_u8(tp_bool), family, early_v, early_j,
-                                           pipe=pipe)
+                                           pipe=pipe, mid=loss_tail)
+        m._joint_terms = m._dual_terms = None
         for t in (g_v_d, g_t_d, g_v_j, g_t_j, cols_tail, prep["rows_pos"], v_j, t_j):
             t.record_stream(main)
-        # the masked means of the four term tensors (loss.py:254-275): behind the embeddings' backward on this stream -- in a pipelined
-        # step it runs while the stream would wait for the stacks' last weight gradients anyway
-        loss_dual, loss_joint, loss_mean = _NCETail.forward(_ManualCtx(), v_d, t_d, v_j, t_j, prep["rows_pos"], cols_tail, None)
+        loss_dual, loss_joint, loss_mean = tail["out"]
         if pipe is not None:
             self._pipe_out = pipe["out"]
         return {"loss-dual": loss_dual, "loss-joint": loss_joint, "loss": loss_mean}

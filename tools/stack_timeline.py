@@ -46,6 +46,10 @@ def wrap(cls, name, tagfn):
 
 wrap(TemporalAligner, "_encoder_fwd", lambda self, er, *a, **k: ("ema " if self is not tr.online else "") + "fwd " + er.prefix.split("_")[0])
 wrap(TemporalAligner, "_encoder_bwd", lambda self, er, *a, **k: "bwd " + er.prefix.split("_")[0])
+if "--boundary" in sys.argv:      # the pieces between the end of the stacks' backward and the next step's stacks (stage 1, pipelined step)
+    wrap(TemporalAligner, "_embed_bwd_fused", lambda self, *a, **k: "embed bwd")
+    wrap(TemporalAligner, "_embed_fused", lambda self, *a, **k: "embed fwd")
+    wrap(Trainer, "early_update", lambda self, which, *a, **k: "adamw " + which)
 orig_gl = TR.get_loss
 
 
