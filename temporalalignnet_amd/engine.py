@@ -646,7 +646,7 @@ class _AlignerEngine(_WorkspaceMixin):
         return (self.compute_dtype == torch.bfloat16 and self._embed_fused_ok(video, lang, itp) and not self.use_alignability_head
                 and self._side_stream(video.device) is not None)
 
-    def _run_chains(self, video, lang, vmask_u8, tmask_u8, family, after_video_bwd=None, after_joint_bwd=None, pipe=None, mid=None):
+    def _run_chains(self, video, lang, vmask_u8, tmask_u8, family, after_video_bwd=None, after_joint_bwd=None, pipe=None, mid=None, need_d_lang=False):
         """Forward AND backward of the aligner under a loss that separates into a dual and a joint term (stage 1: train/loss.py:359-373,
         loss = (loss_dual + loss_joint) / 2 with batch-independent weights) as TWO chains that never wait for each other:
             main stream:  video stack forward -> unit features -> family("dual") -> their backward -> video stack backward
@@ -762,7 +762,7 @@ class _AlignerEngine(_WorkspaceMixin):
             t.record_stream(main)
         run = {"em": em, "B": B, "T": T, "N": N, "sv_video": fe["sv_video"], "sv_video_j": fe["sv_video_j"], "sv_text": fe["sv_text"],
                "sv_text_t": fe["sv_text_t"]}
-        self._embed_bwd_fused(run, d_x0, d_xj, d_lang_raw, False)
+        self._chain_d_lang = self._embed_bwd_fused(run, d_x0, d_xj, d_lang_raw, need_d_lang)      # [B, N, Dt] f32 or None
         out_ev["joint"] = aux_j.record_event()
         if pipe is not None:                       # the next step waits for each of them where it needs it (`_Flat.pending`)
             pipe["out"] = out_ev

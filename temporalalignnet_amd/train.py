@@ -340,13 +340,19 @@ class Trainer:
                 C.c_float(grad_scale), None, _vp(ema.data) if ema is not None else None,
                 C.c_float(self.model.m if self.twin else 0.0), None, ops._stream()), "tan_adamw_step")
 
-    def forward_backward(self, batch):
-        a, m = self.args, self.model
-        if "token" in batch and self.online.bert is not None:      # sentence embeddings from the language model (main.py:55-65)
+    def _embed_tokens(self, batch):
+        """sentence embeddings from the language model (train/main.py:55-65) when the batch carries token ids; idempotent"""
+        if "token" in batch and self.online.bert is not None and not batch.get("_lm_embedded"):
             batch = dict(batch)
-            batch["text_embed"], batch["text_padding_mask"] = embed_sentences(m, batch["token"])
+            batch["text_embed"], batch["text_padding_mask"] = embed_sentences(self.model, batch["token"])
             batch["_text_pad_bool"] = None
             batch["n_text"] = int(sum(t.shape[0] for t in batch["token"]))
+            batch["_lm_embedded"] = True
+        return batch
+
+    def forward_backward(self, batch):
+        a, m = self.args, self.model
+        batch = self._embed_tokens(batch)
         fused = self.fused_loss
         if fused:       # the logits-free sweep keeps one LDS accumulator per text column: beyond its limit use materialised logits
             Bn, Nn = batch["text_embed"].shape[:2]
@@ -402,8 +408,8 @@ class Trainer:
         for each other (`_AlignerEngine._run_chains`) instead of forward -> loss -> backward under autograd.  TAN_STEP_CHAINS=0: autograd."""
         a = self.args
         return (bool(fused) and not self.twin and a.model == "init" and not a.learn_agreement and a.loss_threshold <= 0
-                and not a.use_alignability_head and a.optim_policy != "bce" and not self.global_negatives and "token" not in batch
-                and batch["video"].is_cuda and not batch["text_embed"].requires_grad and os.environ.get("TAN_STEP_CHAINS", "1") != "0"
+                and not a.use_alignability_head and a.optim_policy != "bce" and not self.global_negatives
+                and batch["video"].is_cuda and os.environ.get("TAN_STEP_CHAINS", "1") != "0"
                 and self.online._chains_ok(batch["video"], batch["text_embed"]))
 
     @staticmethod
@@ -497,8 +503,12 @@ class Trainer:
                 t.record_stream(main)
             tail["out"] = _NCETail.forward(_ManualCtx(), v_d_, t_d_, v_j_, t_j_, prep["rows_pos"], cols_tail, None)
         v_d, t_d, v_j, t_j = m._run_chains(video, lang, m._mask_u8(batch["padding_mask"]), m._mask_u8(tp_bool), family, early_v, early_j,
-                                           pipe=pipe, mid=loss_tail)
+                                           pipe=pipe, mid=loss_tail, need_d_lang=lang.requires_grad)
         m._joint_terms = m._dual_terms = None
+        if lang.requires_grad:
+            # the step started from token ids: the sentence embeddings' gradient (the embeddings' backward produced it) goes on through
+            # the language model under autograd (index_select of `embed_sentences`, Word2VecModel's HIP nodes), on this stream
+            lang.backward(m.__dict__.pop("_chain_d_lang").to(lang.dtype))
         for t in (g_v_d, g_t_d, g_v_j, g_t_j, cols_tail, prep["rows_pos"], v_j, t_j):
             t.record_stream(main)
         loss_dual, loss_joint, loss_mean = tail["out"]
@@ -676,7 +686,7 @@ class Trainer:
 
     def _will_chain(self, batch):
         """Whether `forward_backward` will take the two-chain path for this batch (decided before the step touches anything)."""
-        if "token" in batch or not batch["video"].is_cuda:
+        if not batch["video"].is_cuda or "text_embed" not in batch:
             return False
         fused = self.fused_loss
         if fused:
@@ -702,6 +712,7 @@ class Trainer:
         if not self._params_synced:
             self.sync_parameters()
         fl = self.online._flat
+        batch = self._embed_tokens(batch)      # (the language model's forward, when the step starts from token ids: before anything is decided)
         piped = self.pipeline and fl.bound() and self._will_chain(batch)
         fl.in_step = piped                     # (a pipelined step waits for what the previous one left running itself, piece by piece)
         self._pipe_out = None

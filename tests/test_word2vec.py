@@ -126,3 +126,40 @@ def test_trainer_updates_language_model_from_tokens():
         assert (after[n] - before[n]).abs().max().item() > 1e-5, n
     assert (model.target.bert.fc1.weight - tgt_before).abs().max().item() > 0        # EMA follows
     assert (model.target.bert.fc1.weight - after["fc1.weight"]).abs().max().item() > 0
+
+
+@pytest.mark.gpu
+def test_token_step_on_two_chains_matches_the_autograd_step(monkeypatch):
+    """Stage 1 starting from token ids (train/main.py:55-65) in bf16: the two-chain step hands the sentence embeddings' gradient -- the
+    embeddings' backward produces it -- back to the language model under autograd; against forward -> get_loss -> loss.backward()
+    (TAN_STEP_CHAINS=0): loss, every aligner gradient and the gradients of fc1 / fc2 of the sentence embedder."""
+    from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
+    from temporalalignnet_amd.word2vec_model import Word2VecModel
+    args = default_args(model="init", num_encoder_layers=2, num_decoder_layers=2, lr=1e-3)
+    b_np = synth.make_batch(51, B=8, T=64, n_min=4, n_max=16)
+    ids, _ = synth.w2v_tokens(52, int(b_np["n_per"].sum()), V)
+    outs = {}
+    for tag, env in (("autograd", "0"), ("chains", "1")):
+        monkeypatch.setenv("TAN_STEP_CHAINS", env)
+        torch.manual_seed(3)
+        model = build_model(args, compute_dtype="bf16", random_pos_start=0)
+        model.bert = Word2VecModel(num_embeddings=V)
+        model.cuda()
+        b = to_device_batch(b_np)
+        b["token"] = [t.cuda() for t in torch.split(torch.from_numpy(ids), [int(n) for n in b_np["n_per"]])]
+        tr = Trainer(model, args)
+        eb = tr._embed_tokens(b)
+        assert eb["text_embed"].requires_grad and tr._chains_eligible(tr._pad_sentence_slots(eb), tr.fused_loss) == (env == "1")
+        tr.zero_grad()
+        ld = tr.forward_backward(b)
+        torch.cuda.synchronize()
+        outs[tag] = (float(ld["loss"]), tr.online.flat_grad().clone(),
+                     {n: p.grad.detach().clone() for n, p in model.bert.named_parameters() if p.grad is not None})
+        losses = [float(tr.step(b)["loss"]) for _ in range(3)]           # ... and the whole step trains (pipelined boundary included)
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    (l0, g0, lm0), (l1, g1, lm1) = outs["autograd"], outs["chains"]
+    assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0))
+    assert (g1 - g0).norm() <= 2e-3 * g0.norm()
+    assert set(lm0) == set(lm1) and {"fc1.weight", "fc2.weight"} <= set(lm1)
+    for n in lm0:
+        assert (lm1[n] - lm0[n]).norm() <= 2e-2 * lm0[n].norm() + 1e-7, (n, float((lm1[n] - lm0[n]).norm()), float(lm0[n].norm()))
