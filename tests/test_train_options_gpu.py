@@ -233,3 +233,29 @@ def test_padded_sentence_slots_do_not_change_stage2():
         tol = 2.0 / 160 if k in ("confidence-ratio", "alignability_top1") else 5e-3 * max(1.0, abs(l0[k]))
         assert abs(l1[k] - l0[k]) <= tol, (k, l1[k], l0[k])
     assert (g1 - g0).norm() <= 5e-2 * g0.norm(), float((g1 - g0).norm() / g0.norm())
+
+
+@pytest.mark.parametrize("E,D,B,T", [(1, 1, 32, 16), (1, 2, 8, 64), (3, 1, 8, 64)])
+def test_pipelined_chain_steps_on_shallow_and_uneven_stacks(monkeypatch, E, D, B, T):
+    """BASELINE configs[0]'s shape (E1D1, len = 16, 32 videos) and uneven stacks through the pipelined two-chain step: stacks shallower
+    than the dW tails (the joint chain moves its last TWO blocks' weight gradients off the chain), early optimizer launches of unequal
+    unit ranges, alternating workspaces -- five steps against the same five under autograd with one optimizer launch."""
+    from temporalalignnet_amd.train import Trainer, build_model, default_args
+    batches = [_batch(70 + i, B=B, T=T) for i in range(5)]
+    flats = {}
+    for tag, env in (("plain", "0"), ("bench", "1")):
+        for k in ("TAN_STEP_CHAINS", "TAN_OPT_EARLY", "TAN_OPT_IMAGES", "TAN_STEP_PIPELINE"):
+            monkeypatch.setenv(k, env)
+        args = default_args(model="init", num_encoder_layers=E, num_decoder_layers=D, lr=1e-3, wd=1e-2)
+        torch.manual_seed(17)
+        tr = Trainer(build_model(args, compute_dtype="bf16", random_pos_start=0).cuda(), args, iter_per_epoch=50, warmup=5)
+        tr.iteration = tr.batches_seen = 10
+        assert tr.pipeline == (env == "1")
+        for b in batches:
+            assert tr._chains_eligible(tr._pad_sentence_slots(b), tr.fused_loss) == (env == "1")
+            ld = tr.step(b)
+        flats[tag] = tr.online.flat_parameters().clone()
+        assert torch.isfinite(ld["loss"]).item() and torch.isfinite(flats[tag]).all()
+    d = (flats["bench"] - flats["plain"]).abs()
+    # (Adam turns atomics-order noise on ~zero gradients into lr-sized updates of a few elements: the bound of the B = 8 test, five steps)
+    assert d.max().item() <= 1.1e-2 and d.mean().item() <= 5e-5, (d.max().item(), d.mean().item())
