@@ -1179,6 +1179,18 @@ extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
     } else
     switch (d->variant) {
 #ifdef TAN_PANEL_LAB
+        case 1: TAN_MLP_LAUNCH(1); break;
+        case 87: TAN_MLP_LAUNCH(87); break;
+        case 86: TAN_MLP_LAUNCH(86); break;
+        case 19: TAN_MLP_LAUNCH(19); break;
+        case 23: TAN_MLP_LAUNCH(23); break;
+        case 7: TAN_MLP_LAUNCH(7); break;
+        case 4: TAN_MLP_LAUNCH(4); break;
+        case 6: TAN_MLP_LAUNCH(6); break;
+        case 22: TAN_MLP_LAUNCH(22); break;
+        case 20: TAN_MLP_LAUNCH(20); break;
+        case 17: TAN_MLP_LAUNCH(17); break;
+        case 18: TAN_MLP_LAUNCH(18); break;
         case 2: TAN_MLP_LAUNCH(2); break;
         case 8: TAN_MLP_LAUNCH(8); break;
         case 32: TAN_MLP_LAUNCH(32); break;
