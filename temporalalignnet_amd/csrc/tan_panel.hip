@@ -118,6 +118,9 @@ constexpr int MLP_KDF = 32, MLP_KDP = 16, MLP_TILE = 16384, MLP_TF = 512 / MLP_K
 #ifndef TAN_MLP_D
 #define TAN_MLP_D 4
 #endif
+#ifndef TAN_MLP_BALANCED
+#define TAN_MLP_BALANCED 1
+#endif
 constexpr int MLP_D = TAN_MLP_D;                 // weight prefetch distance in steps (4: as fast as 8 once the weights are requested up front, 32 registers less)
 constexpr int MLP_XN_OFF = 0, MLP_H_OFF = 65536, MLP_PRE_OFF = 131072, MLP_LDS = 163840;   // input panel | hidden x2 | pre-activation
 static_assert(PN_WAVES == 8, "eight waves: two groups of four, one wave of each per SIMD");
@@ -203,7 +206,7 @@ __device__ __forceinline__ void mlp_mma_proj(const MlpWFrags& W, const MlpXFrags
 // issue: the wave's own MFMAs then execute under its VALU work, and the quarter-rate v_exp_f32 / v_rcp_f32 results are consumed one
 // MFMA later):  P1 scale, 2 x exp2;  P2 1 + e, 2 x rcp;  P3 x * r, two packs, stores.  The bias is NOT added here: the accumulator
 // of a chunk starts from it (mlp_init_h).
-struct MlpEpiState { float ce[2]; uint32_t pre[4], act[4]; };
+struct MlpEpiState { float ce[2][2]; uint32_t pre[4], act[4]; };      // ce[unit & 1]: two half-units may be in flight (balanced slots)
 struct MlpBias32 { float b[32]; };       // b_fc[c * 256 + wave * 32 ..]: wave-uniform, through scalar loads
 __device__ __forceinline__ void mlp_bias32_load(MlpBias32& B, const float* b_fc, int c, int wave) {
     pn_cfptr_t bp = (pn_cfptr_t)(uintptr_t)b_fc + c * 256 + wave * 32;
@@ -221,20 +224,22 @@ __device__ __forceinline__ void mlp_init_h(f32x16 (&acc_h)[MLP_NBH][2], const Ml
 }
 template <int J>
 __device__ __forceinline__ void mlp_epi_p1(MlpEpiState& E, const f32x16 (&acc_h)[MLP_NBH][2]) {
-    constexpr int mb = J >> 3, r = 2 * (J & 7);
-    E.ce[0] = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * acc_h[0][mb][r]);
-    E.ce[1] = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * acc_h[0][mb][r + 1]);
+    constexpr int mb = J >> 3, r = 2 * (J & 7), u = J & 1;
+    E.ce[u][0] = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * acc_h[0][mb][r]);
+    E.ce[u][1] = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * acc_h[0][mb][r + 1]);
 }
+template <int J>
 __device__ __forceinline__ void mlp_epi_p2(MlpEpiState& E) {
-    E.ce[0] = __builtin_amdgcn_rcpf(1.0f + E.ce[0]);
-    E.ce[1] = __builtin_amdgcn_rcpf(1.0f + E.ce[1]);
+    constexpr int u = J & 1;
+    E.ce[u][0] = __builtin_amdgcn_rcpf(1.0f + E.ce[u][0]);
+    E.ce[u][1] = __builtin_amdgcn_rcpf(1.0f + E.ce[u][1]);
 }
 template <int J>
 __device__ __forceinline__ void mlp_epi_p3(MlpEpiState& E, const f32x16 (&acc_h)[MLP_NBH][2], char* lds, int hb, int wave, int lane) {
-    constexpr int mb = J >> 3, r = 2 * (J & 7), w = J & 3;
+    constexpr int mb = J >> 3, r = 2 * (J & 7), w = J & 3, u = J & 1;
     const float x0 = acc_h[0][mb][r], x1 = acc_h[0][mb][r + 1];
     E.pre[w] = f2bf2(x0, x1);
-    E.act[w] = f2bf2(x0 * E.ce[0], x1 * E.ce[1]);       // QuickGELU: x * sigmoid(1.702 x)
+    E.act[w] = f2bf2(x0 * E.ce[u][0], x1 * E.ce[u][1]);       // QuickGELU: x * sigmoid(1.702 x)
     if constexpr (w == 3) {
         const int ch = (wave * 32 >> 3) + 2 * (lane >> 5) + ((J & 7) >> 2), m = mb * 32 + (lane & 31);
         *reinterpret_cast<uint4*>(pn_panel_slot<512>(lds + MLP_H_OFF + hb * 32768, m, ch)) = make_uint4(E.act[0], E.act[1], E.act[2], E.act[3]);
@@ -248,7 +253,7 @@ __device__ __forceinline__ void mlp_epi_p3(MlpEpiState& E, const f32x16 (&acc_h)
 // from HBM in the accumulator's layout (16 consecutive features of a row = two 16-byte loads per row block), issued under the
 // c_fc-like phase of the same chunk.
 struct MlpHPre { uint4 q[2][2]; };       // [row block][8-feature half]
-struct MlpBwdEpi { float x[2], ce[2], cs[16]; uint32_t w[2][4]; };
+struct MlpBwdEpi { float x[2][2], ce[2][2], cs[16]; uint32_t w[2][4]; };      // x / ce [unit & 1]
 template <int MB, int HALF>
 __device__ __forceinline__ void mlp_hpre_load(MlpHPre& H, const bf16_t* h_pre, long row0, int c, int wave, int lane) {
     H.q[MB][HALF] = *reinterpret_cast<const uint4*>(h_pre + (row0 + MB * 32 + (lane & 31)) * 2048 + c * 256 + wave * 32 + 16 * (lane >> 5) + 8 * HALF);
@@ -263,24 +268,26 @@ __device__ __forceinline__ float pn_half32_sum(float v) {      // sum over the 3
 }
 template <int J>
 __device__ __forceinline__ void mlp_bepi_p1(MlpBwdEpi& E, const MlpHPre& H) {
-    constexpr int mb = J & 1, q = J >> 1;
+    constexpr int mb = J & 1, q = J >> 1, un = J & 1;
     const uint4 u = H.q[mb][q >> 2];
     const uint32_t wd = (q & 3) == 0 ? u.x : (q & 3) == 1 ? u.y : (q & 3) == 2 ? u.z : u.w;
-    E.x[0] = __uint_as_float(wd << 16);
-    E.x[1] = __uint_as_float(wd & 0xffff0000u);
-    E.ce[0] = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * E.x[0]);
-    E.ce[1] = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * E.x[1]);
+    E.x[un][0] = __uint_as_float(wd << 16);
+    E.x[un][1] = __uint_as_float(wd & 0xffff0000u);
+    E.ce[un][0] = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * E.x[un][0]);
+    E.ce[un][1] = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * E.x[un][1]);
 }
+template <int J>
 __device__ __forceinline__ void mlp_bepi_p2(MlpBwdEpi& E) {
-    E.ce[0] = __builtin_amdgcn_rcpf(1.0f + E.ce[0]);       // s = sigmoid(1.702 x)
-    E.ce[1] = __builtin_amdgcn_rcpf(1.0f + E.ce[1]);
+    constexpr int un = J & 1;
+    E.ce[un][0] = __builtin_amdgcn_rcpf(1.0f + E.ce[un][0]);       // s = sigmoid(1.702 x)
+    E.ce[un][1] = __builtin_amdgcn_rcpf(1.0f + E.ce[un][1]);
 }
 template <int J>
 __device__ __forceinline__ void mlp_bepi_p3(MlpBwdEpi& E, const f32x16 (&acc_h)[MLP_NBH][2], char* lds, int hb, int wave, int lane) {
-    constexpr int mb = J & 1, q = J >> 1;
+    constexpr int mb = J & 1, q = J >> 1, un = J & 1;
     // quickgelu'(x) = s + 1.702 x s (1 - s), two values per packed-f32 instruction (v_pk_mul_f32 / v_pk_fma_f32)
     typedef float pn_f2 __attribute__((ext_vector_type(2)));
-    const pn_f2 xx = {E.x[0], E.x[1]}, sg = {E.ce[0], E.ce[1]}, av = {acc_h[0][mb][2 * q], acc_h[0][mb][2 * q + 1]};
+    const pn_f2 xx = {E.x[un][0], E.x[un][1]}, sg = {E.ce[un][0], E.ce[un][1]}, av = {acc_h[0][mb][2 * q], acc_h[0][mb][2 * q + 1]};
     const pn_f2 t = (xx * 1.702f) * sg;
     const pn_f2 dd = av * (t * (1.0f - sg) + sg);
     const float d[2] = {dd[0], dd[1]};
@@ -806,8 +813,8 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
     // the two 16-step phases; the flags are compile-time so that every step is ONE basic block (the scheduler interleaves the
     // epilogue half-unit with the MFMAs only inside a block)
-    auto fc_phase = [&](int c, auto has_copy) __attribute__((always_inline)) {            // c_fc(c) (|| side outputs of chunk c-1)
-        constexpr bool COPY = decltype(has_copy)::value;
+    auto fc_phase = [&](int c, auto has_copy, auto then_proj) __attribute__((always_inline)) {            // c_fc(c) (|| side outputs of chunk c-1)
+        constexpr bool COPY = decltype(has_copy)::value, THEN_PROJ = decltype(then_proj)::value;
         const int hb = c & 1;
         pn_static_for<0, 16>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
@@ -815,6 +822,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
             MlpXFrags& nxt = (J & 1) ? FA : FB;
             if (!(MODE & 4)) {
                 if constexpr (J < 15) mlp_load_x_fc<J + 1>(nxt, XA);     // (the next phase's first fragments: after the slot barrier)
+                else if constexpr (THEN_PROJ) mlp_load_x_proj<0>(nxt, XA, hb ^ 1);   // (balanced: c_proj(c-1)'s first steps follow in this slot)
             }
             if (!(MODE & 1)) mlp_mma_fc(WQ[J % D], cur, acc_h);
             if constexpr (BWD) {        // pre-activations of THIS chunk, consumed by the epilogue a phase later
@@ -838,18 +846,23 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-    auto proj_phase = [&](int c, auto has_proj, auto has_epi) __attribute__((always_inline)) {   // c_proj(c-1) MFMAs || epilogue(c)
+    // c_proj(c-1) steps [J0, J1) (k steps of 16 over hidden panel c-1) || epilogue(c) half-units.  UNITS = 1: half-unit J at step J
+    // (the round-2 schedule: one 16-step phase); UNITS = 2: half-units 2 (J - 8), 2 (J - 8) + 1 at step J (J = 8 .. 15: the balanced
+    // schedule's second slot); UNITS = 0: none (its first slot, and body(8)).
+    auto proj_steps = [&](int c, auto has_proj, auto has_epi, auto j0, auto j1, auto units) __attribute__((always_inline)) {
         constexpr bool PROJ = decltype(has_proj)::value, EPI = decltype(has_epi)::value;
-        constexpr bool ARITH = EPI && !(MODE & (8 | 32));
+        constexpr int J0 = decltype(j0)::value, J1 = decltype(j1)::value, UNITS = decltype(units)::value;
+        constexpr bool ARITH = EPI && UNITS > 0 && !(MODE & (8 | 32));
         const int hb = c & 1;
-        pn_static_for<0, 16>([&](auto jc) {
+        pn_static_for<J0, J1>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
+            constexpr int U0 = UNITS == 2 ? 2 * (J - 8) : J, U1 = U0 + 1;       // half-units of this step (U1 only with UNITS == 2)
             MlpXFrags& cur = (J & 1) ? FB : FA;
             MlpXFrags& nxt = (J & 1) ? FA : FB;
             MlpWFrags& W = WQ[J % D];
             if constexpr (PROJ) {
                 if (!(MODE & 4)) {
-                    if constexpr (J < 15) mlp_load_x_proj<J + 1>(nxt, XA, hb ^ 1);
+                    if constexpr (J + 1 < J1) mlp_load_x_proj<J + 1>(nxt, XA, hb ^ 1);     // (the next range's first fragments: after its barrier)
                 }
                 if constexpr (!EPI && !BWD) {       // body(8): the side outputs of chunk 7 under c_proj(7)
                     if (!(MODE & (8 | 16))) mlp_copy_step8<J>(CP, lds, a.h_pre, a.h_act, row0, 7, (7));
@@ -864,31 +877,47 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (PROJ) { if (!(MODE & 1)) acc_o[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[0], cur.f[0], acc_o[0][0], 0, 0, 0); }
             if constexpr (ARITH && BWD) {
-                mlp_bepi_p1<J>(BE, HP);
-                asm volatile("" : "+v"(acc_o[0][1]), "+v"(BE.ce[0]), "+v"(BE.ce[1]));
+                mlp_bepi_p1<U0>(BE, HP);
+                asm volatile("" : "+v"(acc_o[0][1]), "+v"(BE.ce[U0 & 1][0]), "+v"(BE.ce[U0 & 1][1]));
             } else if constexpr (ARITH) {
-                mlp_epi_p1<J>(ES, acc_h);
-                asm volatile("" : "+v"(acc_o[0][1]), "+v"(ES.ce[0]), "+v"(ES.ce[1]));
+                mlp_epi_p1<U0>(ES, acc_h);
+                asm volatile("" : "+v"(acc_o[0][1]), "+v"(ES.ce[U0 & 1][0]), "+v"(ES.ce[U0 & 1][1]));
             }
             if constexpr (PROJ) { if (!(MODE & 1)) acc_o[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[0], cur.f[1], acc_o[0][1], 0, 0, 0); }
             if constexpr (ARITH && BWD) {
-                mlp_bepi_p2(BE);
-                asm volatile("" : "+v"(acc_o[1][0]), "+v"(BE.ce[0]), "+v"(BE.ce[1]));
+                mlp_bepi_p2<U0>(BE);
+                if constexpr (UNITS == 2) mlp_bepi_p1<U1>(BE, HP);
+                asm volatile("" : "+v"(acc_o[1][0]), "+v"(BE.ce[0][0]), "+v"(BE.ce[0][1]), "+v"(BE.ce[1][0]), "+v"(BE.ce[1][1]));
             } else if constexpr (ARITH) {
-                mlp_epi_p2(ES);
-                asm volatile("" : "+v"(acc_o[1][0]), "+v"(ES.ce[0]), "+v"(ES.ce[1]));
+                mlp_epi_p2<U0>(ES);
+                if constexpr (UNITS == 2) mlp_epi_p1<U1>(ES, acc_h);
+                asm volatile("" : "+v"(acc_o[1][0]), "+v"(ES.ce[0][0]), "+v"(ES.ce[0][1]), "+v"(ES.ce[1][0]), "+v"(ES.ce[1][1]));
             }
             if constexpr (PROJ) { if (!(MODE & 1)) acc_o[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[1], cur.f[0], acc_o[1][0], 0, 0, 0); }
             if constexpr (ARITH && BWD) {
-                mlp_bepi_p3<J>(BE, acc_h, lds, hb, wave, lane);
-                asm volatile("" : "+v"(acc_o[1][1]), "+v"(BE.w[J & 1][(J >> 1) & 3]), "+v"(BE.cs[2 * (J >> 1)]), "+v"(BE.cs[2 * (J >> 1) + 1]));
+                mlp_bepi_p3<U0>(BE, acc_h, lds, hb, wave, lane);
+                if constexpr (UNITS == 2) mlp_bepi_p2<U1>(BE);
+                asm volatile("" : "+v"(acc_o[1][1]), "+v"(BE.w[U0 & 1][(U0 >> 1) & 3]), "+v"(BE.cs[2 * (U0 >> 1)]), "+v"(BE.cs[2 * (U0 >> 1) + 1]),
+                             "+v"(BE.ce[1][0]), "+v"(BE.ce[1][1]));
             } else if constexpr (ARITH) {
-                mlp_epi_p3<J>(ES, acc_h, lds, hb, wave, lane);
-                asm volatile("" : "+v"(acc_o[1][1]), "+v"(ES.pre[J & 3]), "+v"(ES.act[J & 3]));
+                mlp_epi_p3<U0>(ES, acc_h, lds, hb, wave, lane);
+                if constexpr (UNITS == 2) mlp_epi_p2<U1>(ES);
+                asm volatile("" : "+v"(acc_o[1][1]), "+v"(ES.pre[U0 & 3]), "+v"(ES.act[U0 & 3]), "+v"(ES.ce[1][0]), "+v"(ES.ce[1][1]));
             }
             if constexpr (PROJ) {
                 if (!(MODE & 1)) acc_o[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[1], cur.f[1], acc_o[1][1], 0, 0, 0);
-                if (!(MODE & 2)) {  // c_proj(c-1) J+8, else the first half of the next body's first phase
+            }
+            if constexpr (ARITH && UNITS == 2) {      // the second half-unit's last piece: behind the step's last MFMA
+                if constexpr (BWD) {
+                    mlp_bepi_p3<U1>(BE, acc_h, lds, hb, wave, lane);
+                    asm volatile("" : "+v"(BE.w[U1 & 1][(U1 >> 1) & 3]), "+v"(BE.cs[2 * (U1 >> 1)]), "+v"(BE.cs[2 * (U1 >> 1) + 1]));
+                } else {
+                    mlp_epi_p3<U1>(ES, acc_h, lds, hb, wave, lane);
+                    asm volatile("" : "+v"(ES.pre[U1 & 3]), "+v"(ES.act[U1 & 3]));
+                }
+            }
+            if constexpr (PROJ) {
+                if (!(MODE & 2)) {  // c_proj(c-1) J+D, else the first steps of the next body's first phase
                     if constexpr (J + D < 16) mlp_load_w(W, ppj + (long)((c - 1) * 16 + J + D) * TILE, wave, lane);
                     else if constexpr (EPI)     // c <= 7: body(c+1) starts with c_fc(c+1), body(8) with c_proj(7)
                         mlp_load_w(W, c < 7 ? pfc + (long)((c + 1) * 16 + J + D - 16) * TILE : ppj + (long)((7) * 16 + J + D - 16) * TILE,
@@ -946,21 +975,67 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     if (grp) slot_barrier();
     // body(0) and body(8) are peeled as straight-line code around the loop: as if / else arms INSIDE the loop every extra variant of
     // a phase cost ~300 spilled registers at the joins
+    using C0 = std::integral_constant<int, 0>;
+    using C8 = std::integral_constant<int, 8>;
+    using C16 = std::integral_constant<int, 16>;
+    using U0_ = std::integral_constant<int, 0>;
+    using U1_ = std::integral_constant<int, 1>;
+    using U2_ = std::integral_constant<int, 2>;
+#if TAN_MLP_BALANCED
+    // BALANCED SLOTS (round 5).  The round-2 schedule put c_fc(c) -- 64 MFMAs -- in one slot and c_proj(c-1) + epilogue(c) -- 64 MFMAs
+    // interleaved with ~2 k cycles of QuickGELU / pack / LDS writes in the same wave's instruction stream -- in the other; with the two
+    // wave groups one slot apart, every slot lasted as long as its epilogue wave (5.2 k cycles without any memory traffic) while the
+    // c_fc wave of the same SIMD sat at the slot barrier for half of it: tools/lab/mlp_lab.py, `MODE` 22 / 86, DESIGN.md section 6.
+    // Now the slot boundary sits behind the first HALF of c_proj(c-1): k steps 0 .. 7 contract over the EARLY group's half of hidden
+    // panel c-1, which that group finished a whole slot ago, so they need no barrier behind c_fc(c):
+    //     slot X: c_fc(c) + c_proj(c-1)[k 0..7]   96 MFMAs           slot Y: c_proj(c-1)[k 8..15] || epilogue(c), two half-units a step
+    // The tile order of the weight ring, the hidden-panel buffers and the side-output copy steps are what they were (a step keeps its
+    // index J); the epilogue moves entirely into slot Y because the (single) pre-activation panel is still being copied out by the
+    // group's other waves during c_fc(c).
     start_h();
-    tick(); fc_phase(0, F_{}); tick();
+    tick(); fc_phase(0, F_{}, F_{}); tick();
     slot_barrier();
-    tick(); proj_phase(0, F_{}, T_{}); tick();
+    tick(); proj_steps(0, F_{}, T_{}, C8{}, C16{}, U2_{}); tick();
     after_epi(0);
     slot_barrier();
     mlp_load_x_fc<0>(FA, XA);
     __builtin_amdgcn_sched_barrier(0);
     for (int c = 1; c < 8; ++c) {
         start_h();
-        tick(); fc_phase(c, T_{}); tick();
+        tick(); fc_phase(c, T_{}, T_{});
+        proj_steps(c, T_{}, T_{}, C0{}, C8{}, U0_{}); tick();
+        slot_barrier();
+        mlp_load_x_proj<8>(FA, XA, (c & 1) ^ 1);                    // the late group's half of hidden panel c-1
+        __builtin_amdgcn_sched_barrier(0);
+        tick(); proj_steps(c, T_{}, T_{}, C8{}, C16{}, U2_{}); tick();
+        after_epi(c);
+        slot_barrier();
+        if (c < 7) mlp_load_x_fc<0>(FA, XA);                        // fragments of the next body's first step
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    mlp_load_x_proj<0>(FA, XA, 1);                                   // body(8): c_proj(7), hidden panel 7 & 1
+    __builtin_amdgcn_sched_barrier(0);
+    tick(); proj_steps(8, T_{}, F_{}, C0{}, C8{}, U0_{});
+    slot_barrier();
+    mlp_load_x_proj<8>(FA, XA, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    proj_steps(8, T_{}, F_{}, C8{}, C16{}, U0_{}); tick();
+#else
+    start_h();
+    tick(); fc_phase(0, F_{}, F_{}); tick();
+    slot_barrier();
+    tick(); proj_steps(0, F_{}, T_{}, C0{}, C16{}, U1_{}); tick();
+    after_epi(0);
+    slot_barrier();
+    mlp_load_x_fc<0>(FA, XA);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = 1; c < 8; ++c) {
+        start_h();
+        tick(); fc_phase(c, T_{}, F_{}); tick();
         slot_barrier();
         mlp_load_x_proj<0>(FA, XA, (c & 1) ^ 1);                    // c_proj(c-1) reads hidden panel (c-1) & 1
         __builtin_amdgcn_sched_barrier(0);
-        tick(); proj_phase(c, T_{}, T_{}); tick();
+        tick(); proj_steps(c, T_{}, T_{}, C0{}, C16{}, U1_{}); tick();
         after_epi(c);
         slot_barrier();
         if (c < 7) mlp_load_x_fc<0>(FA, XA);                        // fragments of the next body's first step
@@ -969,7 +1044,8 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     slot_barrier();                                                  // (slot of the empty phase "c_fc(8)")
     mlp_load_x_proj<0>(FA, XA, 1);                                   // c_proj(7) reads hidden panel 7 & 1
     __builtin_amdgcn_sched_barrier(0);
-    tick(); proj_phase(8, T_{}, F_{}); tick();
+    tick(); proj_steps(8, T_{}, F_{}, C0{}, C16{}, U1_{}); tick();
+#endif
     if (!grp) slot_barrier();
     tick();
     if (MODE & 1) {          // stream-only experiment: keep the loaded fragments alive
