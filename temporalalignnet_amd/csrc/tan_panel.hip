@@ -118,9 +118,6 @@ constexpr int MLP_KDF = 32, MLP_KDP = 16, MLP_TILE = 16384, MLP_TF = 512 / MLP_K
 #ifndef TAN_MLP_D
 #define TAN_MLP_D 4
 #endif
-#ifndef TAN_MLP_BALANCED
-#define TAN_MLP_BALANCED 1
-#endif
 constexpr int MLP_D = TAN_MLP_D;                 // weight prefetch distance in steps (4: as fast as 8 once the weights are requested up front, 32 registers less)
 constexpr int MLP_XN_OFF = 0, MLP_H_OFF = 65536, MLP_PRE_OFF = 131072, MLP_LDS = 163840;   // input panel | hidden x2 | pre-activation
 static_assert(PN_WAVES == 8, "eight waves: two groups of four, one wave of each per SIMD");
@@ -846,9 +843,9 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-    // c_proj(c-1) steps [J0, J1) (k steps of 16 over hidden panel c-1) || epilogue(c) half-units.  UNITS = 1: half-unit J at step J
-    // (the round-2 schedule: one 16-step phase); UNITS = 2: half-units 2 (J - 8), 2 (J - 8) + 1 at step J (J = 8 .. 15: the balanced
-    // schedule's second slot); UNITS = 0: none (its first slot, and body(8)).
+    // c_proj(c-1) steps [J0, J1) (k steps of 16 over hidden panel c-1) || epilogue(c) half-units.  UNITS = 2: half-units 2 (J - 8),
+    // 2 (J - 8) + 1 at step J (J = 8 .. 15: the second slot of a body); UNITS = 0: none (the first slot, and body(8)).  (Round 2's
+    // schedule -- c_fc(c) | c_proj(c-1) with half-unit J at step J -- is in the history: `git log -S"U1_" -- tan_panel.hip`.)
     auto proj_steps = [&](int c, auto has_proj, auto has_epi, auto j0, auto j1, auto units) __attribute__((always_inline)) {
         constexpr bool PROJ = decltype(has_proj)::value, EPI = decltype(has_epi)::value;
         constexpr int J0 = decltype(j0)::value, J1 = decltype(j1)::value, UNITS = decltype(units)::value;
@@ -856,7 +853,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
         const int hb = c & 1;
         pn_static_for<J0, J1>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
-            constexpr int U0 = UNITS == 2 ? 2 * (J - 8) : J, U1 = U0 + 1;       // half-units of this step (U1 only with UNITS == 2)
+            constexpr int U0 = UNITS == 2 ? 2 * (J - 8) : 0, U1 = U0 + 1;       // half-units of this step
             MlpXFrags& cur = (J & 1) ? FB : FA;
             MlpXFrags& nxt = (J & 1) ? FA : FB;
             MlpWFrags& W = WQ[J % D];
@@ -979,9 +976,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     using C8 = std::integral_constant<int, 8>;
     using C16 = std::integral_constant<int, 16>;
     using U0_ = std::integral_constant<int, 0>;
-    using U1_ = std::integral_constant<int, 1>;
     using U2_ = std::integral_constant<int, 2>;
-#if TAN_MLP_BALANCED
     // BALANCED SLOTS (round 5).  The round-2 schedule put c_fc(c) -- 64 MFMAs -- in one slot and c_proj(c-1) + epilogue(c) -- 64 MFMAs
     // interleaved with ~2 k cycles of QuickGELU / pack / LDS writes in the same wave's instruction stream -- in the other; with the two
     // wave groups one slot apart, every slot lasted as long as its epilogue wave (5.2 k cycles without any memory traffic) while the
@@ -1020,32 +1015,6 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     mlp_load_x_proj<8>(FA, XA, 1);
     __builtin_amdgcn_sched_barrier(0);
     proj_steps(8, T_{}, F_{}, C8{}, C16{}, U0_{}); tick();
-#else
-    start_h();
-    tick(); fc_phase(0, F_{}, F_{}); tick();
-    slot_barrier();
-    tick(); proj_steps(0, F_{}, T_{}, C0{}, C16{}, U1_{}); tick();
-    after_epi(0);
-    slot_barrier();
-    mlp_load_x_fc<0>(FA, XA);
-    __builtin_amdgcn_sched_barrier(0);
-    for (int c = 1; c < 8; ++c) {
-        start_h();
-        tick(); fc_phase(c, T_{}, F_{}); tick();
-        slot_barrier();
-        mlp_load_x_proj<0>(FA, XA, (c & 1) ^ 1);                    // c_proj(c-1) reads hidden panel (c-1) & 1
-        __builtin_amdgcn_sched_barrier(0);
-        tick(); proj_steps(c, T_{}, T_{}, C0{}, C16{}, U1_{}); tick();
-        after_epi(c);
-        slot_barrier();
-        if (c < 7) mlp_load_x_fc<0>(FA, XA);                        // fragments of the next body's first step
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    slot_barrier();                                                  // (slot of the empty phase "c_fc(8)")
-    mlp_load_x_proj<0>(FA, XA, 1);                                   // c_proj(7) reads hidden panel 7 & 1
-    __builtin_amdgcn_sched_barrier(0);
-    tick(); proj_steps(8, T_{}, F_{}, C0{}, C16{}, U1_{}); tick();
-#endif
     if (!grp) slot_barrier();
     tick();
     if (MODE & 1) {          // stream-only experiment: keep the loaded fragments alive
