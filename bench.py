@@ -133,7 +133,8 @@ def traffic_profile(stage, batch_size, seq_len):
     tag = {(1, 128, 64): "", (2, 128, 64): "stage2_b128_", (1, 32, 256): "cfg4_len256_b32_"}.get((stage, batch_size, seq_len))
     if tag is None:
         return None
-    for rnd in ("r04", "r03", "r02", "r01"):
+    rounds = sorted({f[:3] for f in os.listdir(os.path.join(ROOT, "profiles")) if f[:1] == "r" and f[1:3].isdigit() and f[3:4] == "_"}, reverse=True)
+    for rnd in rounds:
         rel = f"profiles/{rnd}_{tag}pmc_traffic.json"
         path = os.path.join(ROOT, rel)
         if os.path.exists(path):
