@@ -72,15 +72,65 @@ def bf16_case(rng, it):
     return ok
 
 
+EVAL = bool(os.environ.get("SOAK_EVAL"))       # the forward alone: no-grad (EMA / evaluation) against training mode, and against the oracle
+
+
+def eval_case(rng, it):
+    """`TemporalAligner.forward` on random shapes, alignability head on: every output of the no-grad forward (which skips the tensors only
+    a backward reads: other kernel instantiations) is BIT-identical to the training-mode forward's; in fp32 every output equals the oracle's
+    (`tan_ref.forward`) to 2e-4, in bf16 to 3e-2 (cosine logits live in [-1, 1])."""
+    from oracle import tan_ref
+    from temporalalignnet_amd.tan_model import TemporalAligner
+    T = int(rng.choice([8, 16, 31, 47, 48, 56, 64, 64, 65, 79, 96, 128, 129, 200, 256, 270]))
+    nmax = int(rng.choice([1, 2, 5, 8, 15, 16, 17, 24, 33]))
+    cfg = dict(dtype=str(rng.choice(["fp32", "bf16", "bf16"])), B=int(rng.choice([1, 2, 3, 4, 8, 16])), T=T, nmin=int(rng.integers(1, nmax + 1)), nmax=nmax,
+               vpad=int(rng.choice([0, 0, 3, T // 4])), E=int(rng.integers(1, 3)), D=int(rng.integers(3, 4)), seed=int(rng.integers(1, 10000)))
+    params = synth.make_params(cfg["seed"], cfg["E"], cfg["D"], True)
+    m = TemporalAligner(num_encoder_layers=cfg["E"], num_decoder_layers=cfg["D"], use_alignability_head=1, language_model=None,
+                        compute_dtype=cfg["dtype"], random_pos_start=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.cuda()
+    b_np = synth.make_batch(cfg["seed"] + 1, B=cfg["B"], T=T, n_min=cfg["nmin"], n_max=cfg["nmax"], video_pad_tail=cfg["vpad"])
+    t = train_ref.to_torch_batch(b_np)
+    d = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in t.items()}
+    with torch.no_grad():
+        quiet = m(d["video"], d["text_embed"], d["padding_mask"], d["text_padding_mask"].bool(), None)
+    loud = m(d["video"], d["text_embed"], d["padding_mask"], d["text_padding_mask"].bool(), None)
+    torch.cuda.synchronize()
+    ref = tan_ref.forward({k: torch.from_numpy(v) for k, v in params.items()}, t["video"], t["text_embed"], t["padding_mask"], t["text_padding_mask"].bool(),
+                          E=cfg["E"], D=cfg["D"], use_alignability_head=True, random_pos_start=False)
+    ok, notes = True, []
+    tol = 2e-4 if cfg["dtype"] == "fp32" else 3e-2
+    valid_t = ~t["text_padding_mask"].bool()
+    for k in loud:
+        if not torch.is_tensor(loud[k]):
+            continue
+        if not torch.equal(quiet[k], loud[k].detach()):
+            ok = False
+            notes.append((k, "no-grad differs"))
+        if k in ref and torch.is_tensor(ref[k]) and ref[k].shape == loud[k].shape:
+            a, c = loud[k].detach().float().cpu(), ref[k].detach().float()
+            fin = torch.isfinite(c)          # (padded frames of a fully padded ... the reference's own -inf / NaN entries are compared as a pattern)
+            if not torch.equal(torch.isfinite(a), fin) and cfg["vpad"] == 0:
+                ok = False
+                notes.append((k, "finite pattern"))
+            err = float((a - c)[fin & torch.isfinite(a)].abs().max()) if bool((fin & torch.isfinite(a)).any()) else 0.0
+            if err > tol * max(1.0, float(c[fin].abs().max())):
+                ok = False
+                notes.append((k, err))
+    print("ok  " if ok else "FAIL", cfg, "outputs", sorted(k for k in loud if torch.is_tensor(loud[k]))[:8], notes[:5], flush=True)
+    return ok
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     torch.set_num_threads(16)
     bad = nan_cases = stage2 = 0
     for it in range(n):
-        if BF16:
+        if BF16 or EVAL:
             try:
-                bad += 0 if bf16_case(rng, it) else 1
+                bad += 0 if (eval_case if EVAL else bf16_case)(rng, it) else 1
             except Exception as e:
                 print("EXCEPTION", repr(e)[:300], flush=True)
                 bad += 1
