@@ -229,25 +229,6 @@ __global__ __launch_bounds__(256, 2) void simnce_kernel(SimArgs a) {
 // (a `vmcnt(0)` + barrier per K step, compiler-ordered) is.
 // Column sums: the 128 columns of a tile are final when the tile is done (a column tile is visited once per workgroup), so the two
 // row-waves store their halves straight to colpart rows (2 * panel + wm): no LDS accumulators, no atomics.
-constexpr int S_T32 = 128 * 32 * 2;   // 8 KiB text tile of a 32-deep K step
-
-// [128 rows][4 x 16-B slots], slot = chunk ^ ((row >> 2) & 3): 512 pieces of 16 B, two per thread of a four-wave group
-__device__ __forceinline__ void s_stage32(const bf16_t* __restrict__ P, long ld, int outer0, int OUT, int k0, char* lds_tile, int gw,
-                                          int lane) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int piece = gw * 2 + i;
-        const int row = piece * 16 + (lane >> 2), slot = lane & 3;
-        const int chunk = slot ^ ((row >> 2) & 3);
-        const int gr = min(outer0 + row, OUT - 1);
-        __builtin_amdgcn_global_load_lds((sgptr_t)(P + (long)gr * ld + k0 + chunk * 8), (slptr_t)(lds_tile + piece * 1024), 16, 0, 0);
-    }
-}
-__device__ __forceinline__ bf16x8 s_frag32(const char* lds_tile, int o0, int ks, int lane) {
-    const int row = o0 + (lane & 31), chunk = (ks >> 3) + (lane >> 5);
-    return *reinterpret_cast<const bf16x8*>(lds_tile + row * 64 + (chunk ^ ((row >> 2) & 3)) * 16);
-}
-
 template <int MODE>
 __device__ __forceinline__ void tile_done_res(const TileCtx& c, f32x16 (&acc)[2][2], float (&rowacc)[2][16], float* colrow, int ct) {
     const int c0 = ct * 128, R = c.R, Mp = c.Mp, lane = c.lane;
@@ -473,24 +454,38 @@ __global__ __launch_bounds__(512) void simnce_res_kernel(SimArgs a) {
             BF& Bf = ring[KS % RD];
             bf16x8(&af)[2] = (KS & 1) ? afB : afA;          // frame fragments: read from LDS one step ahead
             bf16x8(&an)[2] = (KS & 1) ? afA : afB;
-            {
+#ifndef TAN_SIM_LAB
+#define TAN_SIM_LAB 0      // tools/lab timing ablations (results wrong, nothing dead): 1 no text ring loads, 2 no frame-fragment reads, 4 no kept-e stores, 8 no tile epilogue
+#endif
+            if constexpr (!(TAN_SIM_LAB & 2)) {
                 constexpr int KN = (KS + 1) & 31;
                 const char* vn_ = lds + (KN >> 2) * S_TILE;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) an[i] = s_frag(vn_, wm * 64 + i * 32, (KN & 3) * 16, lane);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(an[i]));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], Bf.f[j], acc[i][j], 0, 0, 0);
-            {
+            if constexpr (!(TAN_SIM_LAB & 1)) {
                 if constexpr (KS + RD < 32) load_b(Bf, ct_, KS + RD);
                 else if (more) load_b(Bf, ctn_, KS + RD - 32);
+            } else {
+                asm volatile("" : "+v"(Bf.f[0]), "+v"(Bf.f[1]));
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        if (MODE == 0 && a.ekeep) c.dl = a.ekeep + ((((long)s * npanel + panel) * nct + ct_) * 4 + gw) * 4096;
-        tile_done_res<MODE>(c, acc, rowacc, colrow, ct_);
+        if (MODE == 0 && a.ekeep && !(TAN_SIM_LAB & 4)) c.dl = a.ekeep + ((((long)s * npanel + panel) * nct + ct_) * 4 + gw) * 4096;
+        if constexpr (!(TAN_SIM_LAB & 8)) tile_done_res<MODE>(c, acc, rowacc, colrow, ct_);
+        else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[i][j]));
+        }
     }
 
     if (MODE == 0) {
