@@ -434,6 +434,26 @@ __global__ __launch_bounds__(64 * NKB, 2) void attn_bwd_short_kernel(AttnArgs a)
     const int C = a.H * DH, L = a.L;
     const long ld = 3L * C;
     const bf16_t* base = (const bf16_t*)a.qkv + (long)b * L * ld + h * DH;
+    // STAGGERED START (round 5).  A launch of B * H >= 1024 workgroups is exactly one round of the chip (four per CU) and ran in lock
+    // step: every workgroup loads (40-60 KB), then every workgroup multiplies, then every workgroup stores -- HBM idles through the
+    // arithmetic and the CUs through the transfers: 21.9 us for 61 MB (L = 64).  Groups of 256 workgroups (in dispatch order) now start
+    // a few microseconds apart (`s_sleep`: the wave leaves the issue slots to the others), so that one group's transfers run under
+    // another's arithmetic: L <= 64 four phases 48 x 64 clk apart 21.9 -> 18.6 us, L <= 96 two phases 64 x 64 clk apart 31.9 -> 29.2 us
+    // stand-alone (other spacings / group sizes: tools/lab records in DESIGN.md section 6), 4.106 -> 4.071 ms per step (ABBA x2).
+    // Smaller launches do not fill a round and start at once.
+#ifndef TAN_ATTN_STAGGER
+#define TAN_ATTN_STAGGER 1     // (0: the A/B build of tools/lab/build_variant.sh)
+#endif
+    if (TAN_ATTN_STAGGER && gridDim.x >= 1024) {
+        const int ph = (blockIdx.x >> 8) & (NKB == 2 ? 3 : 1);
+        if (NKB == 2) {
+            if (ph > 0) __builtin_amdgcn_s_sleep(48);
+            if (ph > 1) __builtin_amdgcn_s_sleep(48);
+            if (ph > 2) __builtin_amdgcn_s_sleep(48);
+        } else if (NKB == 3 && ph) {
+            __builtin_amdgcn_s_sleep(64);
+        }
+    }
     stage_images<NKB>(smem, 0, 3, base, C, ld, L, wave, lane);
     stage_images<NKB>(smem, 3, 1, (const bf16_t*)a.d_o + (long)b * L * C + h * DH, 0, C, L, wave, lane);
     const unsigned char* kp = a.keypad ? a.keypad + (long)b * L : nullptr;

@@ -143,6 +143,8 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void attnblk_fwd_kerne
     const char* const pwa = a.pw_qkv;
     const char* const pwb = a.pw_out;
 
+    // (a staggered start of half the workgroups -- which pays in the attention backward, tan_attn.hip -- does nothing here: 46 / 71 us
+    //  with and without; one workgroup per CU, the side outputs already leave at different times per wave)
     // the weight stream does not depend on the activations: start it first (ring slots 0..3 = GEMM-a(0) steps 0..3)
     AbWFrags WQ[D];
     pn_static_for<0, D>([&](auto jc) {
