@@ -436,22 +436,23 @@ __global__ __launch_bounds__(64 * NKB, 2) void attn_bwd_short_kernel(AttnArgs a)
     const bf16_t* base = (const bf16_t*)a.qkv + (long)b * L * ld + h * DH;
     // STAGGERED START (round 5).  A launch of B * H >= 1024 workgroups is exactly one round of the chip (four per CU) and ran in lock
     // step: every workgroup loads (40-60 KB), then every workgroup multiplies, then every workgroup stores -- HBM idles through the
-    // arithmetic and the CUs through the transfers: 21.9 us for 61 MB (L = 64).  Groups of 256 workgroups (in dispatch order) now start
+    // arithmetic and the CUs through the transfers: 21.9 us for 61 MB (L = 64).  Groups of 128 / 256 workgroups (in dispatch order) now start
     // a few microseconds apart (`s_sleep`: the wave leaves the issue slots to the others), so that one group's transfers run under
-    // another's arithmetic: L <= 64 four phases 48 x 64 clk apart 21.9 -> 18.6 us, L <= 96 two phases 64 x 64 clk apart 31.9 -> 29.2 us
-    // stand-alone (other spacings / group sizes: tools/lab records in DESIGN.md section 6), 4.106 -> 4.071 ms per step (ABBA x2).
+    // another's arithmetic: L <= 64 four phases of groups of 128, 48 x 64 clk apart, 21.9 -> 17.6 us; L <= 96 two phases of groups of 256,
+    // 48 x 64 clk apart, 31.9 -> 28.3 us stand-alone (other spacings / group sizes: DESIGN.md section 6); 4.065 -> 4.046 ms per step
+    // with the first parameter set (ABBA x3).
     // Smaller launches do not fill a round and start at once.
 #ifndef TAN_ATTN_STAGGER
 #define TAN_ATTN_STAGGER 1     // (0: the A/B build of tools/lab/build_variant.sh)
 #endif
     if (TAN_ATTN_STAGGER && gridDim.x >= 1024) {
-        const int ph = (blockIdx.x >> 8) & (NKB == 2 ? 3 : 1);
+        const int ph = NKB == 2 ? (blockIdx.x >> 7) & 3 : (blockIdx.x >> 8) & 1;
         if (NKB == 2) {
             if (ph > 0) __builtin_amdgcn_s_sleep(48);
             if (ph > 1) __builtin_amdgcn_s_sleep(48);
             if (ph > 2) __builtin_amdgcn_s_sleep(48);
         } else if (NKB == 3 && ph) {
-            __builtin_amdgcn_s_sleep(64);
+            __builtin_amdgcn_s_sleep(48);
         }
     }
     stage_images<NKB>(smem, 0, 3, base, C, ld, L, wave, lane);
