@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--global-negatives", action="store_true", help="row f3: NCE negatives from every rank (W similarity sweeps)")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--timer-every", type=int, default=20, help="HIP-event kernel timer samples one timed step in n (the middle one)")
+    ap.add_argument("--timer-every", type=int, default=10, help="HIP-event kernel timer samples one timed step in n (the middle one of each n: two of the default 20)")
     ap.add_argument("--timer-stride", type=int, default=4, help="the kernel timer brackets every n-th launch of the MFMA family in the sampled step")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra driver-timed configurations (stage 2, len=256) of the N=1 run")
     ap.add_argument("--extra-steps", type=int, default=10)
@@ -237,9 +237,12 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
         iso = None
         online = trainer.online
         if getattr(online, "overlap_stacks", False):
-            online.overlap_stacks = False
-            if stage == 2:
-                model.target.overlap_stacks = False
+            # the SAME schedule (the two-chain step where the timed steps ran it) with every stream of the step collapsed onto one:
+            # `serialize_streams` (engine._run_chains); a step under autograd serialises by switching the stack overlap off
+            chained = bool(getattr(trainer, "_last_step_chains", False))
+            attr = "serialize_streams" if chained else "overlap_stacks"
+            for mod in [online] + ([model.target] if stage == 2 else []):
+                setattr(mod, attr, chained)
             trainer.step(batch)
             torch.cuda.synchronize()
             L.tan_prof_stride(1)                   # the untimed extra steps bracket every launch
@@ -252,10 +255,10 @@ def run_config(a, world, rank, dev, stage, batch_size, seq_len, steps, warmup, t
             fam = [k for k in FAMILY if cnt2[k] > 0]
             t2, w2, c2 = sum(ms2[k] for k in fam), sum(work2[k] for k in fam), sum(cnt2[k] for k in fam)
             iso = {"achieved": round(w2 / (t2 * 1e-3) / 1e12, 1), "avg_launch_us": round(t2 * 1e3 / c2, 2),
-                   "gemm_ms_per_step": round(t2 / 3, 3), "note": "same kernels, stacks serialised on one stream (3 extra steps)"}
-            online.overlap_stacks = True
-            if stage == 2:
-                model.target.overlap_stacks = True
+                   "gemm_ms_per_step": round(t2 / 3, 3), "two_chain_step": bool(getattr(trainer, "_last_step_chains", False)),
+                   "note": "the same step schedule and kernels with every stream of the step collapsed onto one (3 extra steps)"}
+            for mod in [online] + ([model.target] if stage == 2 else []):
+                setattr(mod, attr, not chained)
         L.tan_prof_enable(0, 0)
         stride = max(1, a.timer_stride)
         # every stride-th launch was bracketed: a kind's time per step = its sampled time scaled by (all its work / its sampled work)
@@ -321,6 +324,8 @@ def main():
         print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); reporting n_gpus={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    if os.environ.get("TAN_DIST_SHARE_GPU") == "1":       # tests: N ranks on fewer GPUs (gloo: RCCL refuses two ranks on one device)
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     global SETTLE_S

@@ -107,8 +107,13 @@ def nce(scaled_logits, tgt_cols, keep_cols):
 
 
 def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding_mask, logits, args,
-             abs_text_pos=None):
-    """get_loss -- loss.py:55-422.  Returns (loss_dict, aux)."""
+             abs_text_pos=None, decisions=None):
+    """get_loss -- loss.py:55-422.  Returns (loss_dict, aux).
+    `decisions` (tests only, never set by the golden pinning): the DISCRETE results of the no-grad sections taken from the caller
+    instead of computed here -- "tgt" [B,T,N] {0,1} (the de-duplicated agreement target of loss.py:88-229, same-video blocks),
+    "th_mask" [M] bool (loss.py:286) and "lab" [M] in {0,1,2} (loss.py:309-328) over the non-padded sentences.  A bf16 forward flips
+    a few of these decisions near their thresholds; with them pinned the loss is a smooth function of the logits and its gradient can
+    be compared with a norm-relative bound (the decisions themselves are compared bit for bit in fp32 mode)."""
     cotrain = args.model == "cotrain"
     B, T, _ = video_seq.shape
     N = text_embed.shape[1]
@@ -124,7 +129,12 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
     tgt_raw, _, _ = mask_from_time(input_data["start"], input_data["end"], T, N)     # [B,N,T] bool
     binary_tgt = _block_diag(tgt_raw.permute(0, 2, 1).float(), B)                    # [B,T,B,N]
 
-    if args.learn_agreement:
+    fixed = decisions or {}
+    if args.learn_agreement and "tgt" in fixed:
+        assert cotrain, "pinned targets: the 'init' in-place leak depends on the self-labelling path"
+        tgt_full = _block_diag(fixed["tgt"].float(), B)
+        out["iou-threshold"] = torch.tensor(0.5)
+    elif args.learn_agreement:
         with torch.no_grad():
             if cotrain:
                 src_j = logits["ema-logits_joint"] / TEMPERATURE if args.sim == "cos" else logits["ema-logits_joint"]
@@ -201,6 +211,8 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
             zj = (mj - mj.mean()) / mj.std()
             metric = -(zd + zj)
             th_mask = metric <= torch.quantile(metric.float(), args.loss_threshold, -1, keepdim=True)
+            if "th_mask" in fixed:
+                th_mask = fixed["th_mask"].bool()
             tgt_th = tgt_cols.clone()
             tgt_th[:, ~th_mask] = 0
             rows_pos_th = tgt_th.sum(-1) > 0
@@ -226,6 +238,8 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
                 if abs_text_pos is not None:
                     centre = abs_text_pos[keep, :].mean(-1)
                     lab = lab.masked_fill((centre < 0.2) | (centre > 0.8), 0.0)
+                if "lab" in fixed:
+                    lab = fixed["lab"].float()
                 aux["t_align_th_mask"] = lab
             a_dual = logits["dual_logits_alignability"][..., 0][keep][cols_pos]
             a_joint = logits["joint_logits_alignability"][:, 2, :, 0][keep][cols_pos]   # stage index 2 hard-coded

@@ -41,7 +41,10 @@ def init_from_env(backend: str | None = None):
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # TAN_DIST_BACKEND=gloo: the same launcher / rank / barrier path without RCCL (tests: two ranks sharing ONE GPU)
+            backend = os.environ.get("TAN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            if os.environ.get("TAN_DIST_SHARE_GPU") == "1" and torch.cuda.is_available():
+                local = local % torch.cuda.device_count()
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -692,14 +692,19 @@ class _AlignerEngine(_WorkspaceMixin):
         d_lang_raw = torch.empty(Mp, Cw, dtype=cd, device=dev)
         d_x0 = torch.empty(R, Cw, dtype=cd, device=dev)
         main, side = torch.cuda.current_stream(), self._side_stream(dev)
+        # `serialize_streams` (bench.py's `roofline.isolated`): the same schedule with both chains and the weight-gradient tails on the
+        # CURRENT stream -- every kernel of the step runs alone on the chip, in the order the two host threads happen to issue them
+        serial = bool(getattr(self, "serialize_streams", False))
+        if serial:
+            side = main
         side.wait_stream(main)
         # The weight-gradient launches of the LAST blocks of each stack's backward feed only the optimizer: they run on an otherwise idle
         # role stream next to the stack's remaining dX kernels and the embeddings' backward (tan_encoder_desc.dw_tail).  Joint chain (the
         # longer one): blocks 1 and 0; video chain: block 0.  Measured (ms per step, ABBA x2 on one box): none 4.58, (1, 1) 4.50 / 4.44,
         # (2, 1) 4.40, (3, 1) 4.40, (2, 2) 4.45, (6, 1) 4.47 -- earlier than the last ~0.4 ms of the chain there are no idle CUs to give.
         tail_j, tail_v = 2, 1
-        aux_j = _lib.role_stream(dev, "loss")
-        aux_v = _lib.role_stream(dev, "opt")
+        aux_j = main if serial else _lib.role_stream(dev, "loss")
+        aux_v = main if serial else _lib.role_stream(dev, "opt")
         # data parallel with gradient buckets: a layer's event must mean "every gradient of the layer is final" on the stack's own stream,
         # so the weight gradients stay on the chains; the bucket all-reduces are issued by the hook, from THIS thread, video first
         hook = self._grad_ready_hook
@@ -713,17 +718,19 @@ class _AlignerEngine(_WorkspaceMixin):
         self._joint_terms = (joint_terms, joint_ready)
 
         def joint_chain():
-            dst_j = torch.empty(Sd, B * L, Cw, dtype=cd, device=dev)
-            d_xj = torch.empty(B * L, Cw, dtype=cd, device=dev)
-            if prev.get("joint") is not None:      # the joint stack's weights of this step
-                torch.cuda.current_stream().wait_event(prev["joint"])
-            ej = self._run_joint_stack(None, None, vmask_u8, tmask_u8, B, T, N, True, pre=(fe["ej"], fe["xj"], fe["keypad"]))
-            stages = [ej.stage(s) for s in range(Sd)]
-            dj = [dst_j[s] for s in range(Sd)]
-            # frame rows b*L + t and sentence rows b*L + T + k of the SAME stage buffers (tan_model.py:207-209), and of their gradients
-            v_j, t_j = family("joint", stages, (L, 0), stages, (L, T), dj, dj)
-            joint_terms.append((v_j, t_j, torch.cuda.current_stream().record_event()))
-            joint_ready.set()
+            try:
+                dst_j = torch.empty(Sd, B * L, Cw, dtype=cd, device=dev)
+                d_xj = torch.empty(B * L, Cw, dtype=cd, device=dev)
+                if prev.get("joint") is not None:      # the joint stack's weights of this step
+                    torch.cuda.current_stream().wait_event(prev["joint"])
+                ej = self._run_joint_stack(None, None, vmask_u8, tmask_u8, B, T, N, True, pre=(fe["ej"], fe["xj"], fe["keypad"]))
+                stages = [ej.stage(s) for s in range(Sd)]
+                dj = [dst_j[s] for s in range(Sd)]
+                # frame rows b*L + t and sentence rows b*L + T + k of the SAME stage buffers (tan_model.py:207-209), and of their gradients
+                v_j, t_j = family("joint", stages, (L, 0), stages, (L, T), dj, dj)
+                joint_terms.append((v_j, t_j, torch.cuda.current_stream().record_event()))
+            finally:
+                joint_ready.set()          # (also on failure: `mid` must not wait out its timeout for terms that will never come)
             if zero_ev is not None:
                 torch.cuda.current_stream().wait_event(zero_ev)
             self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dj, d_xj, dw_stream=dw_j, dw_tail=tail_j)
@@ -747,7 +754,12 @@ class _AlignerEngine(_WorkspaceMixin):
                 after_video_bwd()
         out_ev["video"] = aux_v.record_event()
         if mid is not None:                      # (main stream, behind the video stack's backward: e.g. the loss's masked means, which
-            mid()                                #  would otherwise sit between the embeddings' backward and the optimizer launch)
+            try:                                 #  would otherwise sit between the embeddings' backward and the optimizer launch)
+                mid()
+            except BaseException:
+                if fut.done() and fut.exception() is not None:      # the joint chain failed first: that is the error to report
+                    raise fut.exception()
+                raise
         ej, v_j, t_j, d_xj, keep = fut.result()
         if hook is not None:
             with torch.cuda.stream(side):

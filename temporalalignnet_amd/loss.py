@@ -352,11 +352,13 @@ _SIMFAM = os.environ.get("TAN_SIMFAM", "1") != "0"
 _SIMFAM_NORM = os.environ.get("TAN_SIMFAM_NORM", "1") != "0"
 
 
-def simfam_ok(S, N, Mc, dtype):
+def simfam_ok(S, N, Mc, dtype, T=64):
     """Shapes `tan_simfam_fwd / bwd` take (include/tan_hip.h): bf16, <= 8 stages, <= 32 sentences per video, sweep columns a multiple
-    of 8 within the resident sweep's limit."""
+    of 8 within the resident sweep's limit, and a [T, N] same-video block the finishing launch can hold twice in a CU's LDS (the bound
+    of `tan_simfam_fwd`: anything larger takes the separate-launch path instead of failing with BAD_ARG -- ADVICE r5)."""
+    fin_lds = 4 * (2 * T * N + T + 256 + 96) + 4 * 32 + 32 + T + 16
     return (_SIMFAM and dtype == torch.bfloat16 and S <= 8 and N <= 32 and Mc % 8 == 0 and Mc < 32768
-            and Mc <= _lib.lib().tan_simnce_max_cols())
+            and fin_lds <= 160 * 1024 and Mc <= _lib.lib().tan_simnce_max_cols())
 
 
 def _ptr8(tensors):
@@ -381,7 +383,7 @@ def nce_family_stages(x_video, v_grp, x_text, t_grp, d_video, d_text, tgt, col_i
     R, Mp = B * T, B * N
     dev, cd, Cw = x_video[0].device, x_video[0].dtype, x_video[0].shape[-1]
     Mc = nv[0].shape[0] if nv is not None else Mp
-    if not (simfam_ok(S, N, Mc, cd) and Cw == 512 and St in (1, S)):
+    if not (simfam_ok(S, N, Mc, cd, T) and Cw == 512 and St in (1, S)):
         vn = torch.empty(S, R, Cw, dtype=cd, device=dev)
         tn = torch.empty(St, Mp, Cw, dtype=cd, device=dev)
         inv_v, inv_t = torch.empty(S * R, device=dev), torch.empty(St * Mp, device=dev)
@@ -411,9 +413,11 @@ def nce_family_stages(x_video, v_grp, x_text, t_grp, d_video, d_text, tgt, col_i
     rowsum, possum_v, inv_v, v_terms, colsum, possum_t, t_terms, inv_t, acc = (f32[a:a + n] for a, n in zip(offs, sizes))
     vn = torch.empty(S, R, Cw, dtype=bf, device=dev)
     tn = torch.empty(St, Mc, Cw, dtype=bf, device=dev)
-    ekeep = torch.empty(L.tan_simnce_keep_elems(S, R, Mc), dtype=bf, device=dev)
+    n_keep, n_ws = L.tan_simnce_keep_elems(S, R, Mc), L.tan_simfam_ws_bytes(S, St, B, T, N, Mc)       # (`long`: restype c_long, _lib.lib())
+    assert n_keep > 0 and n_ws > 0, (n_keep, n_ws)
+    ekeep = torch.empty(n_keep, dtype=bf, device=dev)
     dl = torch.empty(S * R * Mc + 256, dtype=bf, device=dev)      # (+ slack: the 256-wide tiles of tan_gemm_atb read past a ragged Mc)
-    ws = torch.empty(L.tan_simfam_ws_bytes(S, St, B, T, N, Mc), dtype=torch.uint8, device=dev)
+    ws = torch.empty(n_ws, dtype=torch.uint8, device=dev)
     d.vn, d.inv_v, d.tn, d.inv_t = vn.data_ptr(), inv_v.data_ptr(), tn.data_ptr(), inv_t.data_ptr()
     d.rowsum, d.colsum, d.possum_v, d.possum_t = rowsum.data_ptr(), colsum.data_ptr(), possum_v.data_ptr(), possum_t.data_ptr()
     d.e_keep, d.ws = ekeep.data_ptr(), ws.data_ptr()

@@ -106,6 +106,7 @@ class TemporalAligner(_AlignerEngine, nn.Module):
         import threading
         self._ws_lock = threading.Lock()
         self.overlap_stacks = True        # run the video and joint stacks on two HIP streams
+        self.serialize_streams = False    # measurement: the two-chain step with every stream collapsed onto the current one
         self._side = None
         self._issuer = None               # helper thread issuing the side-stream stack (see _on_side)
         self._lp_cache = {}
@@ -123,9 +124,24 @@ class TemporalAligner(_AlignerEngine, nn.Module):
             f.drain()
         return super().state_dict(*args, **kwargs)
 
+    def _drain_pending(self):
+        """The current stream waits for what a pipelined `Trainer.step` left running on its role streams (the stacks' last weight
+        gradients, the optimizer launches of their matrices, the weight images): every accessor through which code OUTSIDE the step can
+        reach the parameter tensors calls this first.  A no-op inside the step and when nothing is pending."""
+        f = self.__dict__.get("_flat")
+        if f is not None:
+            f.drain()
+
+    def named_parameters(self, *args, **kwargs):
+        """(`parameters()` goes through here too.)  Reads / writes of `p.data` on the current stream after a pipelined step are ordered
+        behind that step's optimizer launches."""
+        self._drain_pending()
+        return super().named_parameters(*args, **kwargs)
+
     def invalidate_shadow(self):
         """Call after writing parameters in place other than through the optimizer kernel / load_state_dict (e.g.
         `p.data.copy_(...)`): the next forward re-casts the bf16 shadow weights from the f32 masters."""
+        self._drain_pending()
         f = self.__dict__.get("_flat")
         if f is not None:
             f.shadow_version = -1
@@ -472,6 +488,8 @@ class TemporalAligner(_AlignerEngine, nn.Module):
 
     # checkpoint compatibility: the released checkpoint spells the language model `lang_model.` (train/main.py:467-469)
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # (called before the children's: an optimizer launch a pipelined step left in flight must not overwrite what is copied in)
+        self._drain_pending()
         for k in list(state_dict.keys()):
             if k.startswith(prefix + "lang_model."):
                 state_dict[prefix + "bert." + k[len(prefix + "lang_model."):]] = state_dict.pop(k)
@@ -502,6 +520,18 @@ class TwinTemporalAligner(nn.Module):
     @property
     def lang_model(self):
         return self.bert
+
+    def named_parameters(self, *args, **kwargs):
+        """nn.Module walks `_parameters` of the submodules itself: the twins' own accessors are not on that path, so the work a pipelined
+        step left on its role streams is waited for here."""
+        for m in (self.online, self.target):
+            m._drain_pending()
+        return super().named_parameters(*args, **kwargs)
+
+    def state_dict(self, *args, **kwargs):
+        for m in (self.online, self.target):
+            m._drain_pending()
+        return super().state_dict(*args, **kwargs)
 
     # train/main.py:466-469 adds the stage-1 language-model tensors at top level under `lang_model.`; the attribute is `bert`
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):

@@ -118,6 +118,7 @@ class _GradReducer:
     def __init__(self, tr):
         self.tr, self.flat, self.mode = tr, tr.online.flat_grad(), tr.ddp_mode
         self.done, self.pending, self.n = [], {}, 0
+        self.stack_events = {}            # two-chain step: per stack, the event behind its reduction on the stack's role stream
         self.wire = None
         if tr.ddp_grad_dtype == "bf16":
             w = tr.__dict__.get("_wire")
@@ -175,6 +176,10 @@ class _GradReducer:
         return self.mode == "buckets"
 
     def finish(self):
+        cur = torch.cuda.current_stream()
+        for ev in self.stack_events.values():      # (the stacks' reductions ran on their role streams)
+            cur.wait_event(ev)
+        self.stack_events = {}
         for lo, hi in uncovered_ranges(self.done, self.flat.numel()):        # whatever has not been reduced yet
             self.reduce(lo, hi)
         for tag in list(self.pending):
@@ -230,6 +235,9 @@ class Trainer:
         # the communication time the step could not hide behind backward ("exposed"); comm_events collects the pairs
         self.time_comm = False
         self.comm_events = []
+        # tests: keep what get_loss decided without gradient (agreement targets, threshold mask, alignability labels) in `last_aux`
+        self.keep_aux = False
+        self.last_aux = None
 
     # -------------------------------------------------------------- optimizer state
     def _ensure_state(self):
@@ -395,7 +403,9 @@ class Trainer:
                                      fused=fused)
             logits = {**logits, **{f"ema-{k}": v for k, v in ema.items()}}
         loss_dict = get_loss(batch, batch["video"], batch["text_embed"], batch["padding_mask"], batch["text_padding_mask"],
-                             logits, a, batch.get("abs_text_pos"))
+                             logits, a, batch.get("abs_text_pos"), return_aux=self.keep_aux)
+        if self.keep_aux:
+            loss_dict, self.last_aux = loss_dict
         if self._zero_ev is not None:                  # the gradient buffer's fill ran on a side stream next to the forward
             torch.cuda.current_stream().wait_event(self._zero_ev)
             self._zero_ev = None
@@ -483,6 +493,10 @@ class Trainer:
                 # (main host thread, current stream = the one that carries the stack's last weight gradients) data parallel: the stack's
                 # slice of the gradient is summed over ranks first; then its matrices may be stepped
                 reduced = ddp.stack_done(which) if ddp is not None else True
+                if ddp is not None:
+                    # the remainder's optimizer launch (main stream) reads this stack's bias / LayerNorm gradients: behind the stack's
+                    # collective AND the bf16 wire's cast back to f32, which run on this role stream
+                    ddp.stack_events[which] = torch.cuda.current_stream().record_event()
                 if early and reduced:
                     self.early_update(which, gs)
             if early or ddp is not None:
@@ -494,8 +508,8 @@ class Trainer:
             # the joint family's terms were final ~1.5 ms earlier on their stream; issued at the end of the step the launch sat between
             # the embeddings' backward and the optimizer launch (4.126 -> 4.078 ms per step, ABBA x2 of 60 steps)
             terms, ready = m._joint_terms
-            if not ready.wait(timeout=60.0):
-                raise _lib.TanHipError("the joint chain did not reach its loss family")
+            if not ready.wait(timeout=60.0) or not terms:
+                raise _lib.TanHipError("the joint chain did not reach its loss family")      # (`_run_chains` re-raises the chain's own error)
             v_j_, t_j_, ev_j = terms[0]
             main.wait_event(ev_j)
             v_d_, t_d_ = m._dual_terms
@@ -735,6 +749,8 @@ class Trainer:
                 loss_dict = self.forward_backward(batch)
             except BaseException:
                 self._ddp = None
+                self._join_role_streams(dev0)          # nothing of the failed step is recorded in `pending`: join what it enqueued
+                fl.pending = {}
                 if self.__dict__.pop("_early", None):
                     # `early_update` has already stepped a stack's matrices with this step's count: the parameters are half way between
                     # two steps and a retried step would apply AdamW to them twice -- say so instead of going on
@@ -780,6 +796,17 @@ class Trainer:
         self.batches_seen += 1
         self._resume_bump = 0
         return loss_dict
+
+    def _join_role_streams(self, dev):
+        """The current stream waits for everything enqueued on the step's role streams (the failure path of `step`)."""
+        if dev.type != "cuda":
+            return
+        from .loss import _side_stream
+        cur = torch.cuda.current_stream()
+        streams = [_lib.role_stream(dev, r) for r in ("loss", "opt")] + [_side_stream(dev), self.online._side_stream(dev)]
+        for st in streams:
+            if st is not None and st.cuda_stream != cur.cuda_stream:
+                cur.wait_stream(st)
 
     def allreduce_alone_ms(self, reps=5):
         """bench.py: the gradient collectives of one step issued back to back on an otherwise idle GPU (the same ranges as `step`

@@ -77,6 +77,9 @@ def test_every_entry_point_gets_argtypes_from_the_header():
         assert fn.restype is res and list(fn.argtypes) == args, name
     # a plain Python int for a `long` parameter now converts (no GPU work: the call is rejected for its NULL pointers)
     assert L.tan_reduce_add(None, None, 2, 1 << 33, None) == -1
+    # ... and a `long` RESULT beyond 2^31 comes back whole (the kept exponentials of B = 1024, S * R * Mc = 3.2e9 elements)
+    assert L.tan_simnce_keep_elems(6, 65536, 8192) == 6 * 65536 * 8192
+    assert L.tan_simfam_ws_bytes(6, 6, 128, 64, 16, 1344) > 0
 
 
 def test_reference_import_names_resolve_with_one_sys_path_entry():
