@@ -285,6 +285,13 @@ int tan_simnce_bwd_dl_dvn_kept(const void* e_keep, const void* vn, const void* t
  * colsum / possum_t [S,Mc], e_keep (tan_simnce_keep_elems), ws (tan_simfam_ws_bytes).                                              */
 #define TAN_SIMFAM_NORM_IN_SWEEP 1   /* flags: the sweep normalises its frame panel itself and writes vn / inv_v (no separate launch) */
 #define TAN_SIMFAM_CORR_DONE 2       /* (set by tan_simfam_fwd when g_v / g_t were given) ws holds the corrections: bwd skips that launch */
+/* tan_simfam_fwd in two calls, for a loss whose TARGETS are not known when the stack's forward ends (stage-2 co-training,
+ * train/loss.py:88-229: the agreement targets come from the EMA model): SWEEP_ONLY = the normalisations, the text launch and the statistics
+ * sweep (none of them reads tgt / row_leak / g_v / g_t); FINISH_ONLY = the finishing launch (same-video blocks, positives, terms), after
+ * a SWEEP_ONLY call on the same descriptor.  Neither flag: both, as before.  After FINISH_ONLY the last stage's same-video cosines
+ * [B, T, N] f32 (padded-sentence order; what train/loss.py:280-283 takes its per-sentence maxima from) are at tan_simfam_diag(). */
+#define TAN_SIMFAM_SWEEP_ONLY 4
+#define TAN_SIMFAM_FINISH_ONLY 8
 typedef struct tan_simfam_desc {
     int S, St, B, T, N, C, Mc, flags;
     tan_ptr8 x_video; long v_grp_rows, v_off;
@@ -302,6 +309,8 @@ typedef struct tan_simfam_desc {
 } tan_simfam_desc;
 long tan_simfam_ws_bytes(int S, int St, int B, int T, int N, int Mc);
 int tan_simfam_fwd(tan_simfam_desc* d, void* stream);
+/* byte offset inside `ws` of stage s's same-video cosine blocks [B, T, N] f32 written by the finishing launch */
+long tan_simfam_diag_offset(int S, int St, int B, int T, int N, int Mc, int s);
 int tan_simfam_bwd(tan_simfam_desc* d, void* stream);
 
 /* NCE tail (loss.py:236-237,254-275).  tan_pos_masks: rows_pos[b*T+t] = 1 if frame t of video b has a positive among its

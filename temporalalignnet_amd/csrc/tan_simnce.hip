@@ -1714,21 +1714,28 @@ extern "C" long tan_simfam_ws_bytes(int S, int St, int B, int T, int N, int Mc) 
     return simfam_ws(nullptr, S, St, B, T, N, Mc).bytes;
 }
 
+extern "C" long tan_simfam_diag_offset(int S, int St, int B, int T, int N, int Mc, int s) {
+    const FamWs w = simfam_ws(nullptr, S, St, B, T, N, Mc);
+    return (long)((char*)w.diag - (char*)nullptr) + (long)s * B * T * N * 4;
+}
+
 extern "C" int tan_simfam_fwd(tan_simfam_desc* d, void* stream) {
     int rc = simfam_check(d);
     if (rc) return rc;
     TAN_REQUIRE(d->v_terms && d->t_terms && (!d->g_v == !d->g_t));
+    const bool do_sweep = !(d->flags & TAN_SIMFAM_FINISH_ONLY), do_finish = !(d->flags & TAN_SIMFAM_SWEEP_ONLY);
+    TAN_REQUIRE(do_sweep || do_finish);
     hipStream_t st = (hipStream_t)stream;
     const int S = d->S, St = d->St, B = d->B, T = d->T, N = d->N, Mc = d->Mc;
     const long R = (long)B * T;
     const FamWs w = simfam_ws(d->ws, S, St, B, T, N, Mc);
     d->flags &= ~TAN_SIMFAM_CORR_DONE;
     // ---- unit frame features (tan_model.py:116,136)
-    if (!(d->flags & TAN_SIMFAM_NORM_IN_SWEEP)) {
+    if (do_sweep && !(d->flags & TAN_SIMFAM_NORM_IN_SWEEP)) {
         if ((rc = tan_l2norm_fwd_multi(&d->x_video, d->vn, d->inv_v, S, R, 512, T, (int)d->v_grp_rows, (int)d->v_off, TAN_BF16, stream))) return rc;
     }
     // ---- unit text features of the sweep's columns + both text images; zero the row sums
-    {
+    if (do_sweep) {
         FamText t{};
         for (int s = 0; s < St; ++s) t.xs.p[s] = (void*)d->x_text.p[s];
         t.grp_rows = d->t_grp_rows; t.off = d->t_off; t.N = N; t.Mc = Mc; t.idx = (const long long*)d->idx;
@@ -1744,14 +1751,14 @@ extern "C" int tan_simfam_fwd(tan_simfam_desc* d, void* stream) {
         for (int s = 0; s < S; ++s) a.xraw.p[s] = (void*)d->x_video.p[s];
         a.x_grp_rows = d->v_grp_rows; a.x_off = d->v_off; a.inv_v = d->inv_v;
     }
-    {
+    if (do_sweep) {
         const int prec = prof_begin(st, TAN_PROF_SIMNCE, 2.0 * S * R * (double)Mc * 512);
         hipLaunchKernelGGL((simnce_res_kernel<0>), dim3(a.nfull), dim3(512), 0, st, a);
         prof_end(st, prec);
         TAN_LAUNCH_CHECK();
     }
     // ---- same-video blocks, column sums, positives, terms (+ the backward's corrections when its upstream gradients are known)
-    {
+    if (do_finish) {
         FamFin f{};
         f.vn = (const bf16_t*)d->vn; f.tn = (const bf16_t*)d->tn; f.tn_stage_stride = a.t_stage_stride;
         f.colpart = w.colpart; f.nparts = 2 * a.npanel; f.diag = w.diag;

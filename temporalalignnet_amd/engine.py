@@ -642,11 +642,37 @@ class _AlignerEngine(_WorkspaceMixin):
         return run
 
     # ------------------------------------------------------------------ forward + backward as two independent chains (no autograd)
-    def _chains_ok(self, video, lang, itp=None):
-        return (self.compute_dtype == torch.bfloat16 and self._embed_fused_ok(video, lang, itp) and not self.use_alignability_head
-                and self._side_stream(video.device) is not None)
+    def _chains_ok(self, video, lang, itp=None, allow_head=False):
+        """allow_head: the caller runs the alignability head itself on the joint chain (stage 2: `Trainer._forward_backward_chains2`)"""
+        return (self.compute_dtype == torch.bfloat16 and self._embed_fused_ok(video, lang, itp)
+                and (allow_head or not self.use_alignability_head) and self._side_stream(video.device) is not None)
 
-    def _run_chains(self, video, lang, vmask_u8, tmask_u8, family, after_video_bwd=None, after_joint_bwd=None, pipe=None, mid=None, need_d_lang=False):
+    def _ema_stack_diag(self, which, fe, vmask_u8, tmask_u8, B, T, N):
+        """Stage 2, on the EMA target model: the no-grad forward of ONE stack from the fused front-end's outputs `fe`, reduced to all that
+        self-labelling reads of it (train/loss.py:88-179: `torch.diagonal(ema_logits, dim1=0, dim2=3)[..., -1 stage]`): the last stage's
+        same-video cosines [B, T, N] f32.  Runs on the current stream: the two-chain step issues the video stack's on the main chain and
+        the joint stack's on the side chain, each in front of the online stack of the same kind."""
+        cd, dev, Cw = self.compute_dtype, fe["x0"].device, WIDTH
+        R, Mp, L = B * T, B * N, T + N
+        vn = torch.empty(1, R, Cw, dtype=cd, device=dev)
+        tn = torch.empty(Mp, Cw, dtype=cd, device=dev)
+        inv = torch.empty(R + Mp, device=dev)
+        if which == "video":
+            er = self._run_video_stack(fe["x0"], vmask_u8, B, T, False, er=fe["ev"])
+            ops.l2norm_fwd_multi([er.stage(self.num_encoder_layers - 1)], vn, inv[:R], R, Cw)
+            ops.l2norm_fwd(fe["lang_raw"], tn, inv[R:], Mp, Cw)
+        else:
+            er = self._run_joint_stack(None, None, vmask_u8, tmask_u8, B, T, N, False, pre=(fe["ej"], fe["xj"], fe["keypad"]))
+            last = [er.stage(self.num_decoder_layers - 1)]
+            ops.l2norm_fwd_multi(last, vn, inv[:R], R, Cw, T, L, 0)
+            ops.l2norm_fwd_multi(last, tn.view(1, Mp, Cw), inv[R:], Mp, Cw, N, L, T)
+        out = torch.empty(B, T, N, device=dev)
+        ops.gemm(vn[0], tn, out, M=T, N=N, K=Cw, batch=B, sA=T * Cw, sB=N * Cw, sC=T * N)
+        self._release_ws(er)
+        return out
+
+    def _run_chains(self, video, lang, vmask_u8, tmask_u8, family, after_video_bwd=None, after_joint_bwd=None, pipe=None, mid=None, need_d_lang=False,
+                    pre=None):
         """Forward AND backward of the aligner under a loss that separates into a dual and a joint term (stage 1: train/loss.py:359-373,
         loss = (loss_dual + loss_joint) / 2 with batch-independent weights) as TWO chains that never wait for each other:
             main stream:  video stack forward -> unit features -> family("dual") -> their backward -> video stack backward
@@ -664,7 +690,11 @@ class _AlignerEngine(_WorkspaceMixin):
         of a stack's matrices behind them: that stack's forward waits for it, and only for it) -- and "zero" (the gradient fill: the first
         backward kernel of each chain waits for it).  Out: the same events of THIS step, and the main stream is NOT joined with the
         streams that carry them: the embeddings and the video stack of the next step run under the joint stack's last weight gradients
-        and optimizer launch."""
+        and optimizer launch.
+        `pre` ({"video": fn, "joint": fn}, stage 2): called on each chain's stream / host thread in front of the online stack's forward,
+        behind the wait for that stack's optimizer launch of the previous step (the EMA target's stack of the same kind, whose weights
+        that launch also wrote).  `family` may then synchronise the two chains itself (it is called once per chain, on the chain's own
+        host thread): stage 2's upstream gradients depend on both families' forward results."""
         self._ensure_flat()
         self._bind_grads()
         f = self._flat
@@ -723,27 +753,39 @@ class _AlignerEngine(_WorkspaceMixin):
                 d_xj = torch.empty(B * L, Cw, dtype=cd, device=dev)
                 if prev.get("joint") is not None:      # the joint stack's weights of this step
                     torch.cuda.current_stream().wait_event(prev["joint"])
+                if pre is not None:
+                    pre["joint"]()
                 ej = self._run_joint_stack(None, None, vmask_u8, tmask_u8, B, T, N, True, pre=(fe["ej"], fe["xj"], fe["keypad"]))
                 stages = [ej.stage(s) for s in range(Sd)]
                 dj = [dst_j[s] for s in range(Sd)]
+                if zero_ev is not None:            # (the gradient fill: over long before; a family may add to parameter gradients itself)
+                    torch.cuda.current_stream().wait_event(zero_ev)
                 # frame rows b*L + t and sentence rows b*L + T + k of the SAME stage buffers (tan_model.py:207-209), and of their gradients
                 v_j, t_j = family("joint", stages, (L, 0), stages, (L, T), dj, dj)
                 joint_terms.append((v_j, t_j, torch.cuda.current_stream().record_event()))
             finally:
                 joint_ready.set()          # (also on failure: `mid` must not wait out its timeout for terms that will never come)
-            if zero_ev is not None:
-                torch.cuda.current_stream().wait_event(zero_ev)
             self._encoder_bwd(ej, ej.xj, ej.keypad, "ln_joint_post_enc", dj, d_xj, dw_stream=dw_j, dw_tail=tail_j)
             return ej, v_j, t_j, d_xj, (dst_j,)
         fut = self._on_side(side, joint_chain)
-        if prev.get("video") is not None:
-            main.wait_event(prev["video"])
-        ev = self._run_video_stack(fe["x0"], vmask_u8, B, T, True, er=fe["ev"])
-        dv = [dst_v[s] for s in range(Se)]
-        v_d, t_d = family("dual", [ev.stage(s) for s in range(Se)], (T, 0), [fe["lang_raw"]], (N, 0), dv, [d_lang_raw])
+        try:
+            if prev.get("video") is not None:
+                main.wait_event(prev["video"])
+            if pre is not None:
+                pre["video"]()
+            ev = self._run_video_stack(fe["x0"], vmask_u8, B, T, True, er=fe["ev"])
+            dv = [dst_v[s] for s in range(Se)]
+            if zero_ev is not None:
+                main.wait_event(zero_ev)
+            v_d, t_d = family("dual", [ev.stage(s) for s in range(Se)], (T, 0), [fe["lang_raw"]], (N, 0), dv, [d_lang_raw])
+        except BaseException:
+            # (the joint chain may have failed first -- a family that synchronises the chains then fails here as a consequence: report
+            #  the root cause; either way the helper thread is through before the error leaves)
+            exc = fut.exception()
+            if exc is not None:
+                raise exc
+            raise
         self._dual_terms = (v_d, t_d)
-        if zero_ev is not None:
-            main.wait_event(zero_ev)
         self._encoder_bwd(ev, fe["x0"], vmask_u8, "ln_video_post_enc", dv, d_x0, dw_stream=dw_v, dw_tail=tail_v)
         if hook is not None:
             hook("video", self._layer_events(ev.prefix, ev.layers))

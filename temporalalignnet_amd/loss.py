@@ -368,6 +368,92 @@ def _ptr8(tensors):
     return p
 
 
+class SimFam:
+    """One feature family through `tan_simfam_fwd / tan_simfam_bwd` with its buffers (see `nce_family_stages` for the arguments).
+    `run()` = forward and backward back to back (stage 1: the targets and the terms' upstream gradients depend on the batch alone);
+    `sweep()` / `finish()` / `backward()` = the same launches in three calls for a loss whose targets (EMA self-labelling) and upstream
+    gradients (thresholds over BOTH families' forward results) arrive in between (stage 2, `Trainer._forward_backward_chains2`):
+    `tgt`, `g_v`, `g_t` are then buffers that other launches fill before the call that reads them."""
+
+    def __init__(self, x_video, v_grp, x_text, t_grp, d_video, d_text, tgt, col_invalid, B, T, N, nv, g_v, g_t, split_k=0):
+        S, St = len(x_video), len(x_text)
+        R, Mp = B * T, B * N
+        dev, Cw = x_video[0].device, x_video[0].shape[-1]
+        Mc = nv[0].shape[0] if nv is not None else Mp
+        L = _lib.lib()
+        bf = torch.bfloat16
+        d = self.d = _lib.SimFamDesc()
+        d.S, d.St, d.B, d.T, d.N, d.C, d.Mc, d.flags = S, St, B, T, N, Cw, Mc, (1 if _SIMFAM_NORM else 0)
+        d.x_video, d.v_grp_rows, d.v_off = _ptr8(x_video), v_grp[0], v_grp[1]
+        d.x_text, d.t_grp_rows, d.t_off = _ptr8(x_text), t_grp[0], t_grp[1]
+        if nv is not None:
+            d.idx, d.colmap, d.col_invalid = nv[0].data_ptr(), nv[1].data_ptr(), nv[2].data_ptr()
+        else:
+            d.col_invalid = col_invalid.data_ptr()
+        d.tgt = tgt.data_ptr()
+        # one f32 block (saved sums, terms, norms, the text-gradient accumulator; pieces 16-byte aligned) + the bf16 tensors
+        sizes = [S * R] * 4 + [S * Mc] * 3 + [St * Mc, St * Mc * Cw]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + (n + 3) // 4 * 4)
+        f32 = torch.empty(offs[-1], device=dev)
+        rowsum, possum_v, inv_v, v_terms, colsum, possum_t, t_terms, inv_t, acc = (f32[a:a + n] for a, n in zip(offs, sizes))
+        vn = torch.empty(S, R, Cw, dtype=bf, device=dev)
+        tn = torch.empty(St, Mc, Cw, dtype=bf, device=dev)
+        n_keep, n_ws = L.tan_simnce_keep_elems(S, R, Mc), L.tan_simfam_ws_bytes(S, St, B, T, N, Mc)       # (`long`: restype c_long, _lib.lib())
+        assert n_keep > 0 and n_ws > 0, (n_keep, n_ws)
+        ekeep = torch.empty(n_keep, dtype=bf, device=dev)
+        dl = torch.empty(S * R * Mc + 256, dtype=bf, device=dev)      # (+ slack: the 256-wide tiles of tan_gemm_atb read past a ragged Mc)
+        ws = torch.empty(n_ws, dtype=torch.uint8, device=dev)
+        d.vn, d.inv_v, d.tn, d.inv_t = vn.data_ptr(), inv_v.data_ptr(), tn.data_ptr(), inv_t.data_ptr()
+        d.rowsum, d.colsum, d.possum_v, d.possum_t = rowsum.data_ptr(), colsum.data_ptr(), possum_v.data_ptr(), possum_t.data_ptr()
+        d.e_keep, d.ws = ekeep.data_ptr(), ws.data_ptr()
+        d.v_terms, d.t_terms = v_terms.data_ptr(), t_terms.data_ptr()
+        d.dl, d.d_tn_acc = dl.data_ptr(), acc.data_ptr()
+        d.d_video, d.d_text = _ptr8(d_video), _ptr8(d_text)
+        d.dtn_split_k = split_k          # (0: the library's choice -- include/tan_hip.h)
+        self.g_v, self.g_t = g_v, g_t
+        self.v_terms, self.t_terms = v_terms.view(S, R), t_terms.view(S, Mc)
+        # the last stage's same-video cosines [B, T, N] f32 inside `ws`, written by the finishing launch (train/loss.py:280-283 reads them)
+        off = L.tan_simfam_diag_offset(S, St, B, T, N, Mc, S - 1)
+        self.diag_last = ws[off:off + 4 * B * T * N].view(torch.float32).view(B, T, N)
+        self._keep = (f32, vn, tn, ekeep, dl, ws, tgt, col_invalid, nv, x_video, x_text, d_video, d_text)
+        self.base_flags = d.flags
+
+    def _fwd(self, flags, with_g):
+        d = self.d
+        d.flags = self.base_flags | flags
+        d.g_v, d.g_t = (self.g_v.data_ptr(), self.g_t.data_ptr()) if with_g else (None, None)
+        _lib.check(_lib.lib().tan_simfam_fwd(C.byref(d), ops._stream()), "tan_simfam_fwd")
+        self.base_flags |= d.flags & 2           # TAN_SIMFAM_CORR_DONE
+
+    def run(self):
+        self._fwd(0, True)
+        self.backward()
+
+    def sweep(self):
+        self._fwd(4, False)                      # TAN_SIMFAM_SWEEP_ONLY
+
+    def finish(self):
+        self._fwd(8, False)                      # TAN_SIMFAM_FINISH_ONLY (the upstream gradients are not known yet: no corrections)
+
+    def backward(self):
+        d = self.d
+        d.flags = self.base_flags
+        d.g_v, d.g_t = self.g_v.data_ptr(), self.g_t.data_ptr()
+        _lib.check(_lib.lib().tan_simfam_bwd(C.byref(d), ops._stream()), "tan_simfam_bwd")
+
+    def record_stream(self, stream):
+        for t in self._keep[:6]:
+            t.record_stream(stream)
+
+
+def simfam_stages_ok(x_video, x_text, N, nv, B, T):
+    S, St = len(x_video), len(x_text)
+    Mc = nv[0].shape[0] if nv is not None else B * N
+    return simfam_ok(S, N, Mc, x_video[0].dtype, T) and x_video[0].shape[-1] == 512 and St in (1, S)
+
+
 def nce_family_stages(x_video, v_grp, x_text, t_grp, d_video, d_text, tgt, col_invalid, B, T, N, nv, g_v, g_t, split_k=0):
     """Similarity + multi-positive NCE of ONE family from the stacks' stage OUTPUTS to their stage GRADIENTS, forward and backward
     back to back on the current stream (tan_model.py:116-119 / 136-139, loss.py:240-253 and their autograd) -> (v_terms, t_terms).
@@ -382,8 +468,7 @@ def nce_family_stages(x_video, v_grp, x_text, t_grp, d_video, d_text, tgt, col_i
     S, St = len(x_video), len(x_text)
     R, Mp = B * T, B * N
     dev, cd, Cw = x_video[0].device, x_video[0].dtype, x_video[0].shape[-1]
-    Mc = nv[0].shape[0] if nv is not None else Mp
-    if not (simfam_ok(S, N, Mc, cd, T) and Cw == 512 and St in (1, S)):
+    if not simfam_stages_ok(x_video, x_text, N, nv, B, T):
         vn = torch.empty(S, R, Cw, dtype=cd, device=dev)
         tn = torch.empty(St, Mp, Cw, dtype=cd, device=dev)
         inv_v, inv_t = torch.empty(S * R, device=dev), torch.empty(St * Mp, device=dev)
@@ -393,43 +478,9 @@ def nce_family_stages(x_video, v_grp, x_text, t_grp, d_video, d_text, tgt, col_i
         ops.l2norm_bwd_multi(d_vn, vn, inv_v, d_video, R, Cw, T, v_grp[0], v_grp[1])
         ops.l2norm_bwd_multi(d_tn.view(St, Mp, Cw), tn, inv_t, d_text, Mp, Cw, N, t_grp[0], t_grp[1])
         return v_terms, t_terms
-    L = _lib.lib()
-    bf = torch.bfloat16
-    d = _lib.SimFamDesc()
-    d.S, d.St, d.B, d.T, d.N, d.C, d.Mc, d.flags = S, St, B, T, N, Cw, Mc, (1 if _SIMFAM_NORM else 0)
-    d.x_video, d.v_grp_rows, d.v_off = _ptr8(x_video), v_grp[0], v_grp[1]
-    d.x_text, d.t_grp_rows, d.t_off = _ptr8(x_text), t_grp[0], t_grp[1]
-    if nv is not None:
-        d.idx, d.colmap, d.col_invalid = nv[0].data_ptr(), nv[1].data_ptr(), nv[2].data_ptr()
-    else:
-        d.col_invalid = col_invalid.data_ptr()
-    d.tgt = tgt.data_ptr()
-    # one f32 block (saved sums, terms, norms, the text-gradient accumulator; pieces 16-byte aligned) + the bf16 tensors
-    sizes = [S * R] * 4 + [S * Mc] * 3 + [St * Mc, St * Mc * Cw]
-    offs = [0]
-    for n in sizes:
-        offs.append(offs[-1] + (n + 3) // 4 * 4)
-    f32 = torch.empty(offs[-1], device=dev)
-    rowsum, possum_v, inv_v, v_terms, colsum, possum_t, t_terms, inv_t, acc = (f32[a:a + n] for a, n in zip(offs, sizes))
-    vn = torch.empty(S, R, Cw, dtype=bf, device=dev)
-    tn = torch.empty(St, Mc, Cw, dtype=bf, device=dev)
-    n_keep, n_ws = L.tan_simnce_keep_elems(S, R, Mc), L.tan_simfam_ws_bytes(S, St, B, T, N, Mc)       # (`long`: restype c_long, _lib.lib())
-    assert n_keep > 0 and n_ws > 0, (n_keep, n_ws)
-    ekeep = torch.empty(n_keep, dtype=bf, device=dev)
-    dl = torch.empty(S * R * Mc + 256, dtype=bf, device=dev)      # (+ slack: the 256-wide tiles of tan_gemm_atb read past a ragged Mc)
-    ws = torch.empty(n_ws, dtype=torch.uint8, device=dev)
-    d.vn, d.inv_v, d.tn, d.inv_t = vn.data_ptr(), inv_v.data_ptr(), tn.data_ptr(), inv_t.data_ptr()
-    d.rowsum, d.colsum, d.possum_v, d.possum_t = rowsum.data_ptr(), colsum.data_ptr(), possum_v.data_ptr(), possum_t.data_ptr()
-    d.e_keep, d.ws = ekeep.data_ptr(), ws.data_ptr()
-    d.v_terms, d.t_terms = v_terms.data_ptr(), t_terms.data_ptr()
-    d.g_v, d.g_t = g_v.data_ptr(), g_t.data_ptr()
-    d.dl, d.d_tn_acc = dl.data_ptr(), acc.data_ptr()
-    d.d_video, d.d_text = _ptr8(d_video), _ptr8(d_text)
-    d.dtn_split_k = split_k          # (0: the library's choice -- include/tan_hip.h)
-    st = ops._stream()
-    _lib.check(L.tan_simfam_fwd(C.byref(d), st), "tan_simfam_fwd")
-    _lib.check(L.tan_simfam_bwd(C.byref(d), st), "tan_simfam_bwd")
-    return v_terms.view(S, R), t_terms.view(S, Mc)
+    fam = SimFam(x_video, v_grp, x_text, t_grp, d_video, d_text, tgt, col_invalid, B, T, N, nv, g_v, g_t, split_k)
+    fam.run()
+    return fam.v_terms, fam.t_terms
 
 
 def nce_term_grads(rows_mask, cols_mask, Sd, Sj):
@@ -485,6 +536,51 @@ class _BCESelFn(torch.autograd.Function):
         _lib.check(_lib.lib().tan_bce_sel_bwd(_p(x), _p(y), _p(sel), _p(scal), _p(g), C.c_int(x.numel()), _p(dx), ops._stream()),
                    "tan_bce_sel_bwd")
         return dx, None, None, None
+
+
+def agreement_targets(src_j, src_d, prep, B, T, N, kind, quant=None, tgt=None):
+    """Self-labelling of both families + their agreement (train/loss.py:88-229, no gradient): the window arg-max per sentence on the
+    last-stage same-video logits `src_j` / `src_d` (`_Blocks`), the 30 % confidence quantiles, and the de-duplicated agreement target
+    [B, T, N] f32 (written into `tgt` when given).  -> (J, D, tgt, iou [B, N], conf [B, N] u8).  Five launches."""
+    dev = src_j.tensor.device
+    tpad_u8, vpad_u8 = prep["tpad_u8"], prep["vpad_u8"]
+    quant = quant or _quantile
+    dur = prep["dur"]                                                                                 # loss.py:113-115
+    J = _selflabel(src_j, vpad_u8, tpad_u8, dur, B, T, N)
+    D = _selflabel(src_d, vpad_u8, tpad_u8, dur, B, T, N)
+    q_j = quant(J["max_logit"].view(-1), tpad_u8.view(-1), 0.3)                                       # loss.py:191-194
+    q_d = quant(D["max_logit"].view(-1), tpad_u8.view(-1), 0.3)
+    tgt = torch.empty(B, T, N, device=dev) if tgt is None else tgt
+    iou = torch.empty(B, N, device=dev)
+    conf = torch.empty(B, N, dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().tan_agreement(_p(J["tgt"]), _p(D["tgt"]), _p(prep["yt"]), _p(J["max_logit"]), _p(D["max_logit"]),
+                                        _p(q_j), _p(q_d), C.c_int(_KIND[kind]), _p(tgt),
+                                        _p(iou), _p(conf), C.c_int(B), C.c_int(T), C.c_int(N), ops._stream()), "tan_agreement")
+    return J, D, tgt, iou, conf
+
+
+def stage2_masks(md, mj, tpad_u8, tgt, abs_text_pos, conf, loss_threshold, want_a, B, T, N):
+    """Rank-local batch statistics of train/loss.py:280-290,309-328,345 in ONE launch (tan_stage2_masks): z-scores of the per-sentence
+    maxima md / mj, the threshold metric and kept-sentence mask, the rows that still own a positive, the alignability labels / selection
+    / targets / pos_weight, and confidence-ratio (scal[3], when `conf` is given)."""
+    dev = md.device
+    R, Mp = B * T, B * N
+    f32 = dict(device=dev, dtype=torch.float32)
+    s2 = dict(metric=torch.empty(Mp, **f32), th_mask=torch.empty(Mp, dtype=torch.bool, device=dev), th_f=torch.empty(Mp, **f32),
+              rows=torch.empty(R, **f32), scal=torch.empty(8, **f32))
+    if want_a:
+        s2.update(lab=torch.empty(Mp, **f32), sel=torch.empty(Mp, **f32), y=torch.empty(Mp, **f32))
+    pos = None
+    if want_a and abs_text_pos is not None:
+        pos = abs_text_pos.to(dev, torch.float32).contiguous()
+        if pos.numel() != 2 * Mp:
+            raise ValueError("abs_text_pos must be [B, N, 2]")
+    _lib.check(_lib.lib().tan_stage2_masks(_p(md), _p(mj), _p(tpad_u8), _p(tgt), _p(pos), _p(conf),
+                                           C.c_float(float(loss_threshold)), C.c_int(int(want_a)), C.c_int(B),
+                                           C.c_int(T), C.c_int(N), _p(s2["metric"]), _p(s2["th_mask"]), _p(s2["th_f"]),
+                                           _p(s2["rows"]), _p(s2.get("lab")), _p(s2.get("sel")), _p(s2.get("y")),
+                                           _p(s2["scal"]), ops._stream()), "tan_stage2_masks")
+    return s2
 
 
 def prepare_inputs(input_data, video_padding_mask, text_padding_mask, T, N, dev, args, n_text_valid=None, want_compaction=False):
@@ -599,20 +695,8 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
                 src_j, src_d = blk_j, blk_d
             else:
                 src_j, src_d = blk_j, blk_d
-            dur = prep["dur"]                                                                         # loss.py:113-115
-            J = _selflabel(src_j, vpad_u8, tpad_u8, dur, B, T, N)
-            D = _selflabel(src_d, vpad_u8, tpad_u8, dur, B, T, N)
             quant = _quantile_global if getattr(fused, "global_negatives", False) else _quantile
-            q_j = quant(J["max_logit"].view(-1), tpad_u8.view(-1), 0.3)                               # loss.py:191-194
-            q_d = quant(D["max_logit"].view(-1), tpad_u8.view(-1), 0.3)
-            tgt = torch.empty(B, T, N, device=dev)
-            iou = torch.empty(B, N, device=dev)
-            conf = torch.empty(B, N, dtype=torch.uint8, device=dev)
-            yt = prep["yt"]
-            _lib.check(_lib.lib().tan_agreement(_p(J["tgt"]), _p(D["tgt"]), _p(yt), _p(J["max_logit"]), _p(D["max_logit"]),
-                                                _p(q_j), _p(q_d), C.c_int(_KIND[args.temporal_agreement_type]), _p(tgt),
-                                                _p(iou), _p(conf), C.c_int(B), C.c_int(T), C.c_int(N), ops._stream()),
-                       "tan_agreement")
+            J, D, tgt, iou, conf = agreement_targets(src_j, src_d, prep, B, T, N, args.temporal_agreement_type, quant)
             conf_done = False        # folded into tan_stage2_masks below when that launch runs anyway
             if not ((args.loss_threshold > 0 or args.use_alignability_head) and _stage2_fused(fused, Mp)):
                 out["confidence-ratio"] = (conf.view(Mp).float() * valid_f).sum() / valid_f.sum()
@@ -685,23 +769,8 @@ def get_loss(input_data, video_seq, text_embed, video_padding_mask, text_padding
             # rank-local statistics: z-scores, threshold, kept mask, surviving rows, alignability labels / counts / pos_weight and
             # confidence-ratio in ONE launch (tan_stage2_masks; ~70 tiny ATen kernels before)
             with torch.no_grad():
-                want_a = bool(args.use_alignability_head)
-                f32 = dict(device=dev, dtype=torch.float32)
-                s2 = dict(metric=torch.empty(Mp, **f32), th_mask=torch.empty(Mp, dtype=torch.bool, device=dev), th_f=torch.empty(Mp, **f32),
-                          rows=torch.empty(R, **f32), scal=torch.empty(8, **f32))
-                if want_a:
-                    s2.update(lab=torch.empty(Mp, **f32), sel=torch.empty(Mp, **f32), y=torch.empty(Mp, **f32))
-                pos = None
-                if want_a and abs_text_pos is not None:
-                    pos = abs_text_pos.to(dev, torch.float32).contiguous()
-                    if pos.numel() != 2 * Mp:
-                        raise ValueError("abs_text_pos must be [B, N, 2]")
                 cf = conf if (args.learn_agreement and not conf_done) else None
-                _lib.check(_lib.lib().tan_stage2_masks(_p(md), _p(mj), _p(tpad_u8), _p(tgt), _p(pos), _p(cf),
-                                                       C.c_float(float(args.loss_threshold)), C.c_int(int(want_a)), C.c_int(B),
-                                                       C.c_int(T), C.c_int(N), _p(s2["metric"]), _p(s2["th_mask"]), _p(s2["th_f"]),
-                                                       _p(s2["rows"]), _p(s2.get("lab")), _p(s2.get("sel")), _p(s2.get("y")),
-                                                       _p(s2["scal"]), ops._stream()), "tan_stage2_masks")
+                s2 = stage2_masks(md, mj, tpad_u8, tgt, abs_text_pos, cf, args.loss_threshold, bool(args.use_alignability_head), B, T, N)
                 th_mask, th_f, rows_pos_th = s2["th_mask"], s2["th_f"], s2["rows"]
                 if cf is not None:
                     out["confidence-ratio"] = s2["scal"][3]

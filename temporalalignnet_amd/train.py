@@ -375,7 +375,7 @@ class Trainer:
             batch = self._pad_sentence_slots(batch)          # (whole 64-row panels for the joint stack: both step schedules)
         self._last_step_chains = self._chains_eligible(batch, fused)
         if self._last_step_chains:
-            return self._forward_backward_chains(batch)
+            return self._forward_backward_chains2(batch) if self.twin else self._forward_backward_chains(batch)
         if batch["video"].is_cuda:
             # what get_loss derives from the batch alone (masks, targets, column compaction: ~20 tiny launches) runs on the loss
             # side stream next to the forward instead of between the stacks and the similarity sweeps
@@ -417,10 +417,33 @@ class Trainer:
         (loss_dual + loss_joint) / 2 with weights that depend on the batch's masks only, so the step runs as two chains that never wait
         for each other (`_AlignerEngine._run_chains`) instead of forward -> loss -> backward under autograd.  TAN_STEP_CHAINS=0: autograd."""
         a = self.args
-        return (bool(fused) and not self.twin and a.model == "init" and not a.learn_agreement and a.loss_threshold <= 0
-                and not a.use_alignability_head and a.optim_policy != "bce" and not self.global_negatives
-                and batch["video"].is_cuda and os.environ.get("TAN_STEP_CHAINS", "1") != "0"
+        if not (bool(fused) and a.optim_policy != "bce" and not self.global_negatives and batch["video"].is_cuda
+                and os.environ.get("TAN_STEP_CHAINS", "1") != "0"):
+            return False
+        if self.twin:
+            return self._chains2_eligible(batch)
+        return (a.model == "init" and not a.learn_agreement and a.loss_threshold <= 0 and not a.use_alignability_head
                 and self.online._chains_ok(batch["video"], batch["text_embed"]))
+
+    def _chains2_eligible(self, batch):
+        """Stage 2 ('cotrain' as train/readme.md:13 runs it: EMA self-labelling, loss threshold, alignability head + BCE) on the fused bf16
+        path with rank-local statistics: the step runs as two chains as well (`_forward_backward_chains2`), synchronised where the loss
+        needs both families -- the agreement targets (both EMA stacks) and the thresholds / labels (both online families' forward).
+        TAN_STAGE2_CHAINS=0: forward -> get_loss -> backward under autograd."""
+        a, m, tg = self.args, self.online, self.model.target
+        video, lang = batch["video"], batch["text_embed"]
+        B, T, N = video.shape[0], video.shape[1], lang.shape[1]
+        if not (a.model == "cotrain" and a.learn_agreement and a.loss_threshold > 0 and a.use_alignability_head
+                and m.use_alignability_head and m.num_decoder_layers >= 3 and B * N <= 8192 and lang.shape[1] <= 32
+                and os.environ.get("TAN_STAGE2_CHAINS", "1") != "0" and os.environ.get("TAN_STAGE2_FUSED", "1") != "0"
+                and m._chains_ok(video, lang, allow_head=True) and tg._chains_ok(video, lang, allow_head=True)
+                and tg.compute_dtype == m.compute_dtype and not m.use_text_pos_enc):
+            return False
+        from .loss import simfam_ok
+        Mp = B * N
+        nt = batch.get("n_text")
+        Mc = Mp if nt is None else min(Mp, (int(nt) + 63) // 64 * 64)
+        return all(simfam_ok(S, N, Mc, torch.bfloat16, T) for S in (m.num_encoder_layers, m.num_decoder_layers))
 
     @staticmethod
     def _pad_sentence_slots(batch):
@@ -530,6 +553,216 @@ class Trainer:
             self._pipe_out = pipe["out"]
         return {"loss-dual": loss_dual, "loss-joint": loss_joint, "loss": loss_mean}
 
+    def _forward_backward_chains2(self, batch):
+        """Stage-2 co-training step (train/main.py:89-98,122; train/loss.py:88-229,277-373) as two chains without autograd:
+            main:  EMA video stack -> cosines | online video stack -> sweep(dual)  .. finish(dual)  .. backward(dual)  -> stack backward
+            side:  EMA joint stack -> cosines | online joint stack -> head -> sweep(joint) .. finish(joint) .. backward(joint) + head -> stack backward
+        with two meeting points: (1) the agreement targets need both EMA stacks' same-video cosines (small launches on the loss stream,
+        issued by the main chain's host thread: they are through long before the online sweeps are); (2) the terms' upstream gradients
+        need both families' forward results -- per-sentence maxima -> z-scores / quantile threshold / kept rows, alignability labels,
+        BCE (train/loss.py:277-357) -- issued on the main chain's stream between its family's finishing launch and backward.
+        Every launch is the one `get_loss` issues on the autograd path (same kernels, `tan_simfam_*` for the families)."""
+        import threading
+        from .loss import (SimFam, _Blocks, _diag_max, _pos_masks, _side_stream, agreement_targets, prepare_inputs_async, stage2_masks)
+        from .loss import _p
+        a, m, tg = self.args, self.online, self.model.target
+        video, lang = batch["video"], batch["text_embed"]
+        B, T = video.shape[:2]
+        N = lang.shape[1]
+        R, Mp, L = B * T, B * N, T + N
+        dev = video.device
+        Se, Sd, Cw = m.num_encoder_layers, m.num_decoder_layers, 512
+        lib = _lib.lib()
+        main = torch.cuda.current_stream()
+        ls = _side_stream(dev)
+        prep = prepare_inputs_async(batch, batch["padding_mask"], batch["text_padding_mask"], T, N, dev, a, batch.get("n_text"),
+                                    want_compaction=True)
+        nv = prep.get("nv")
+        Mc = nv[0].shape[0] if nv is not None else Mp
+        tpad_u8, ci = prep["tpad_u8"], prep["tpad_u8"].view(Mp)
+        tp_bool = batch["_text_pad_bool"] if batch.get("_text_pad_bool") is not None else batch["text_padding_mask"].bool()
+        vmask, tmask = m._mask_u8(batch["padding_mask"]), m._mask_u8(tp_bool)
+        # buffers that the meeting points fill (their addresses go into the families' descriptors up front)
+        tgt = torch.empty(B, T, N, device=dev)
+        g = {"dual": (torch.empty(Se, R, device=dev), torch.empty(Se, Mc, device=dev)),
+             "joint": (torch.empty(Sd, R, device=dev), torch.empty(Sd, Mc, device=dev))}
+        d_head = torch.empty(Mp, device=dev)                    # d loss / d alignability logits of joint stage 2 (train/loss.py:341)
+        # host-side hand-overs between the two issuing threads (an event can only be waited for once it has been recorded) + their events
+        flags = {k: threading.Event() for k in ("ema_joint", "tgt", "fin_joint", "g")}
+        evs, fams, ema_diag, failed, aux, head = {}, {}, {}, [], {}, {}
+
+        def hand_over(name):
+            if not flags[name].wait(timeout=120.0) or failed:
+                raise _lib.TanHipError(f"stage-2 step: the other chain did not reach '{name}'" + (f" ({failed[0]} chain failed)" if failed else ""))
+            return evs[name]
+
+        def guarded(fn):
+            def run(*args_, **kw):
+                try:
+                    return fn(*args_, **kw)
+                except BaseException:
+                    failed.append(args_[0] if args_ else "?")
+                    for f_ in flags.values():       # the other thread must not wait out its timeout
+                        f_.set()
+                    raise
+            return run
+
+        # ---- the EMA target (tan_model.py:346-351 `forward_from_ema`, no gradient): its input embeddings here, its stacks on the chains
+        with torch.no_grad():
+            tg._ensure_flat()
+            fe_t = tg._embed_fused(video, lang, vmask, tmask, 0, 0, 0, False)
+
+        @guarded
+        def pre(which):
+            cur = torch.cuda.current_stream()
+            with torch.no_grad():
+                ema_diag[which] = tg._ema_stack_diag(which, fe_t, vmask, tmask, B, T, N)
+            evs["ema_" + which] = cur.record_event()
+            if which == "joint":
+                flags["ema_joint"].set()
+
+        def targets():
+            # meeting point 1, on the loss stream: train/loss.py:88-229 (self-labelling of both EMA families, agreement 'keep' / ...,
+            # de-duplication) + the positive masks of loss.py:236-237
+            hand_over("ema_joint")
+            ls.wait_event(evs["ema_video"])
+            ls.wait_event(evs["ema_joint"])
+            ls.wait_event(prep["_event"])
+            with torch.cuda.stream(ls):
+                for t_ in ema_diag.values():
+                    t_.record_stream(ls)
+                J, D, _, iou, conf = agreement_targets(_Blocks.of_diag(ema_diag["joint"]), _Blocks.of_diag(ema_diag["video"]), prep, B, T, N,
+                                                       a.temporal_agreement_type, tgt=tgt)
+                rows_pos, cols_pos = _pos_masks(tgt, tpad_u8, B, T, N)
+                cols_tail = cols_pos.index_select(0, nv[0]) if nv is not None else cols_pos
+                evs["tgt"] = ls.record_event()
+            aux.update(max_position_joint=J["max_pos"], max_position_dual=D["max_pos"], max_logits_joint=J["max_logit"],
+                       max_logits_dual=D["max_logit"], joint_self_tgt=J["tgt"], dual_self_tgt=D["tgt"], iou=iou, confidence_mask=conf,
+                       agreement_tgt=tgt, rows_pos=rows_pos, cols_tail=cols_tail)
+            flags["tgt"].set()
+
+        def upstream():
+            # meeting point 2, on the main chain's stream: train/loss.py:277-357 and the tail's backward
+            cur = torch.cuda.current_stream()
+            fd, fj = fams["dual"], fams["joint"]
+            fj.record_stream(cur)
+            md = _diag_max(_Blocks.of_diag(fd.diag_last), None, B, T, N)                               # loss.py:280
+            mj = _diag_max(_Blocks.of_diag(fj.diag_last), None, B, T, N)                               # loss.py:283
+            s2 = stage2_masks(md, mj, tpad_u8, tgt, batch.get("abs_text_pos"), aux["confidence_mask"], a.loss_threshold, True, B, T, N)
+            cols_th = s2["th_f"].index_select(0, nv[0]) if nv is not None else s2["th_f"]
+            out_th = torch.empty(5, device=dev)              # [loss_dual_th, loss_joint_th, their mean, n_rows, n_cols]
+            _lib.check(lib.tan_nce_tail_fwd(_p(fd.v_terms), _p(fd.t_terms), _p(fj.v_terms), _p(fj.t_terms), _p(s2["rows"]), _p(cols_th),
+                                            C.c_int(Se), C.c_int(Sd), C.c_long(R), C.c_long(Mc), _p(out_th), _p(out_th[3:]), None,
+                                            ops._stream()), "tan_nce_tail_fwd")
+            one, gb = self._stage2_consts(dev)
+            _lib.check(lib.tan_nce_tail_bwd(None, None, _p(one), _p(s2["rows"]), _p(cols_th), _p(out_th[3:]), C.c_int(Se), C.c_int(Sd),
+                                            C.c_long(R), C.c_long(Mc), _p(g["dual"][0]), _p(g["dual"][1]), _p(g["joint"][0]),
+                                            _p(g["joint"][1]), ops._stream()), "tan_nce_tail_bwd")
+            # BCE of the alignability head on joint stage 2 (loss.py:341-349), forward and backward
+            a_joint = head["a_j2"]
+            a_joint.record_stream(cur)
+            bce = torch.empty(2, device=dev)
+            _lib.check(lib.tan_bce_sel_fwd(_p(a_joint), _p(s2["y"]), _p(s2["sel"]), _p(s2["scal"]), C.c_int(Mp), _p(bce), ops._stream()),
+                       "tan_bce_sel_fwd")
+            _lib.check(lib.tan_bce_sel_bwd(_p(a_joint), _p(s2["y"]), _p(s2["sel"]), _p(s2["scal"]), _p(gb), C.c_int(Mp), _p(d_head),
+                                           ops._stream()), "tan_bce_sel_bwd")
+            evs["g"] = cur.record_event()
+            flags["g"].set()
+            aux.update(t_th_mask=s2["th_mask"], max_logits_dual_per_text=md, max_logits_joint_per_text=mj, t_align_th_mask=s2["lab"],
+                       out_th=out_th, bce=bce, s2=s2)
+
+        @guarded
+        def family(which, x_video, v_grp, x_text, t_grp, d_video, d_text):
+            cur = torch.cuda.current_stream()
+            cur.wait_event(prep["_event"])
+            fam = fams[which] = SimFam(x_video, v_grp, x_text, t_grp, d_video, d_text, tgt, ci, B, T, N, nv, *g[which])
+            fam.sweep()
+            if which == "joint":
+                # alignability head on the text rows of joint stage 2 (tan_model.py:147-148; the only stage the loss reads, loss.py:341)
+                jt = torch.empty(Mp, Cw, dtype=x_text[2].dtype, device=dev)
+                ops.rows_copy(x_text[2], jt, B, N, Cw, L, T, N, 0)
+                a_j2 = torch.empty(Mp, device=dev)
+                ops.head_fwd(jt, m._f("binary_head.weight").view(-1), m._f("binary_head.bias"), a_j2, Mp, Cw)
+                head.update(jt=jt, a_j2=a_j2)
+                cur.wait_event(hand_over("tgt"))
+                fam.finish()
+                evs["fin_joint"] = cur.record_event()
+                flags["fin_joint"].set()
+                cur.wait_event(hand_over("g"))
+            else:
+                targets()
+                cur.wait_event(evs["tgt"])
+                fam.finish()
+                cur.wait_event(hand_over("fin_joint"))
+                upstream()
+            fam.backward()
+            if which == "joint":
+                d_jt = torch.empty(Mp, Cw, dtype=head["jt"].dtype, device=dev)
+                ops.head_bwd(d_head, head["jt"], m._f("binary_head.weight").view(-1), d_jt, m._g("binary_head.weight").view(-1),
+                             m._g("binary_head.bias"), Mp, Cw)
+                ops.rows_copy(d_jt, d_text[2], B, N, Cw, N, 0, L, T, accumulate=True)
+                d_head.record_stream(cur)
+            return fam.v_terms, fam.t_terms
+
+        pipe = None
+        if getattr(self, "_in_step", False) and m._flat.in_step:
+            pipe = {"zero": self._zero_ev}
+        elif self._zero_ev is not None:
+            main.wait_event(self._zero_ev)
+        self._zero_ev = None
+        early_v = early_j = None
+        if getattr(self, "_in_step", False):
+            early = os.environ.get("TAN_OPT_EARLY", "1") != "0" and self._early_ok()
+            ddp, gs = self._ddp, 1.0 / dist.world_size()
+
+            def stack_done(which):
+                reduced = ddp.stack_done(which) if ddp is not None else True
+                if ddp is not None:
+                    ddp.stack_events[which] = torch.cuda.current_stream().record_event()
+                if early and reduced:
+                    self.early_update(which, gs)
+            if early or ddp is not None:
+                early_v, early_j = (lambda: stack_done("video")), (lambda: stack_done("joint"))       # noqa: E731
+        m._run_chains(video, lang, vmask, tmask, family, early_v, early_j, pipe=pipe, need_d_lang=lang.requires_grad,
+                      pre={"video": lambda: pre("video"), "joint": lambda: pre("joint")})
+        m._joint_terms = m._dual_terms = None
+        tg._release_ws(fe_t["em"])
+        if lang.requires_grad:
+            lang.backward(m.__dict__.pop("_chain_d_lang").to(lang.dtype))
+        # ---- the loss dictionary (monitoring entries on the loss stream; train/loss.py:296-304,359-373)
+        fd, fj = fams["dual"], fams["joint"]
+        out_th, bce = aux.pop("out_th"), aux.pop("bce")
+        s2 = aux.pop("s2")
+        with torch.cuda.stream(ls):
+            ls.wait_event(evs["g"])
+            for f_ in (fd, fj):
+                f_.record_stream(ls)
+            out_all = torch.empty(5, device=dev)
+            _lib.check(lib.tan_nce_tail_fwd(_p(fd.v_terms), _p(fd.t_terms), _p(fj.v_terms), _p(fj.t_terms), _p(aux["rows_pos"]),
+                                            _p(aux["cols_tail"]), C.c_int(Se), C.c_int(Sd), C.c_long(R), C.c_long(Mc), _p(out_all),
+                                            _p(out_all[3:]), None, ops._stream()), "tan_nce_tail_fwd")
+            loss = out_th[2] + bce[0]
+        main.wait_stream(ls)
+        side = m._side_stream(dev)
+        for t_ in (out_all, out_th, bce, loss, tgt, d_head, *g["dual"], *g["joint"], *s2.values(), aux["confidence_mask"], *prep["_tensors"]):
+            for st_ in (main, ls, side):         # (allocated under one of the three streams, read under another)
+                t_.record_stream(st_)
+        for f_ in (fd, fj):
+            f_.record_stream(main)
+        if pipe is not None:
+            self._pipe_out = pipe["out"]
+        if self.keep_aux:
+            self.last_aux = {k: v for k, v in aux.items() if k not in ("rows_pos", "cols_tail")}
+        return {"loss-dual": out_th[0], "loss-joint": out_th[1], "loss-dual-all": out_all[0], "loss-joint-all": out_all[1],
+                "loss-total": out_all[2], "loss-joint-bce": bce[0], "alignability_top1": bce[1], "confidence-ratio": s2["scal"][3],
+                "iou-threshold": torch.full((), 0.5, device=dev), "loss": loss}
+
+    def _stage2_consts(self, dev):
+        c = self.__dict__.setdefault("_s2_consts", {})
+        if dev not in c:
+            c[dev] = (torch.ones(1, device=dev), torch.tensor([1.0, 0.0], device=dev))      # d loss / d (mean NCE), d loss / d (bce, top-1)
+        return c[dev]
+
     def _lm_allreduce(self):
         """Sum the language model's gradients over ranks in ONE bucket (they live outside the flat buffer).  Must run before
         the per-parameter clip: the clip coefficient is a function of the AVERAGED gradient (utils/train_utils.py:3-13)."""
@@ -632,7 +865,8 @@ class Trainer:
     def _early_ok(self):
         f, st = self._ensure_state()
         # (data parallel: a stack is stepped behind the all-reduce of its slice -- `_GradReducer.stack_done`; not in 'single' mode)
-        ok = (self._images_in_optimizer(f, None) and not self.args.clip_grad > 0 and not self._accum_open
+        ok = (self._images_in_optimizer(f, self.model.target._ensure_flat_nosync() if self.twin else None)
+              and not self.args.clip_grad > 0 and not self._accum_open
               and (not dist.active() or (self._ddp is not None and self.ddp_mode in ("flat", "buckets"))))
         if ok:
             self._adamw_tables(f, st)        # (built here, by ONE thread: the two early launches are issued from two host threads)
@@ -647,7 +881,8 @@ class Trainer:
         the image table are ordered video stack, joint stack, pre-projections.  (Called from the two host threads that issue the chains.)"""
         f, st = self._ensure_state()
         lo, hi = (0, f.video_units) if which == "video" else (f.video_units, f.mats_units)
-        self._adamw_images(f, st, None, grad_scale, units=(lo, hi), rest=False, step=self.iteration + 1)
+        ema = self.model.target._ensure_flat_nosync() if self.twin else None       # (stage 2: the EMA twin's stack moves in the same launch)
+        self._adamw_images(f, st, ema, grad_scale, units=(lo, hi), rest=False, step=self.iteration + 1)
         self._early.add(which)
 
     def train_iteration(self, batch, idx):
@@ -726,9 +961,12 @@ class Trainer:
         if not self._params_synced:
             self.sync_parameters()
         fl = self.online._flat
+        tfl = self.model.target._flat if self.twin else None       # (stage 2: the optimizer launches write the EMA twin's buffers too)
         batch = self._embed_tokens(batch)      # (the language model's forward, when the step starts from token ids: before anything is decided)
-        piped = self.pipeline and fl.bound() and self._will_chain(batch)
+        piped = self.pipeline and fl.bound() and (tfl is None or tfl.bound()) and self._will_chain(batch)
         fl.in_step = piped                     # (a pipelined step waits for what the previous one left running itself, piece by piece)
+        if tfl is not None:
+            tfl.in_step = piped
         self._pipe_out = None
         try:
             dev0 = self.online._ensure_flat().flat.device        # (not pipelined: waits for everything pending)
@@ -751,6 +989,8 @@ class Trainer:
                 self._ddp = None
                 self._join_role_streams(dev0)          # nothing of the failed step is recorded in `pending`: join what it enqueued
                 fl.pending = {}
+                if tfl is not None:
+                    tfl.pending = {}
                 if self.__dict__.pop("_early", None):
                     # `early_update` has already stepped a stack's matrices with this step's count: the parameters are half way between
                     # two steps and a retried step would apply AdamW to them twice -- say so instead of going on
@@ -772,6 +1012,8 @@ class Trainer:
                     for k in ("video", "joint"):
                         cur.wait_event(out_ev[k])
                 fl.pending = {}                # (every event of the previous step has been waited for inside this one)
+                if tfl is not None:
+                    tfl.pending = {}
             if self._ddp is not None:
                 ev = None
                 if self.time_comm:
@@ -786,12 +1028,17 @@ class Trainer:
             if out_ev is not None:
                 fl.run_image_hooks()           # the LayerNorm'ed position tables: one small launch, on this stream
                 fl.pending = dict(out_ev)
+                if tfl is not None:            # (the same launches wrote the twin's parameters and images)
+                    tfl.run_image_hooks()
+                    tfl.pending = dict(out_ev)
             elif aside is not None:
                 self.online._ensure_flat_nosync().refresh_images_async(aside, backward=True)
                 if self.twin:
                     self.model.target._ensure_flat_nosync().refresh_images_async(aside, backward=False)
         finally:
             fl.in_step = False
+            if tfl is not None:
+                tfl.in_step = False
             self._pipe_out = None
         self.batches_seen += 1
         self._resume_bump = 0

@@ -472,15 +472,18 @@ def _three_steps_both_schedules(monkeypatch, make_trainer, batches, reps=20, gra
     return init_cat, flats["plain"][0], flats["bench"], first, chained
 
 
-def _assert_same_up_to_atomics(init, ref, runs, moved=1e-3):
+def _assert_same_up_to_atomics(init, ref, runs, moved=1e-3, mean_tol=3e-5):
     """parameters equal up to the order of the f32 gradient atomics (the bound of the B = 8 test, lr 1e-3)"""
     assert torch.isfinite(ref).all() and (ref - init).abs().max().item() > moved
+    worst = (0.0, 0.0)
     for i, f in enumerate(runs):
         d = (f - ref).abs()
-        assert d.max().item() <= 6.5e-3 and d.mean().item() <= 3e-5, (i, d.max().item(), d.mean().item())
+        worst = (max(worst[0], d.max().item()), max(worst[1], d.mean().item()))
+        assert d.max().item() <= 6.5e-3 and d.mean().item() <= mean_tol, (i, d.max().item(), d.mean().item())
         if i:
             dd = (f - runs[0]).abs()
-            assert dd.max().item() <= 6.5e-3 and dd.mean().item() <= 3e-5, (i, dd.max().item(), dd.mean().item())
+            assert dd.max().item() <= 6.5e-3 and dd.mean().item() <= mean_tol, (i, dd.max().item(), dd.mean().item())
+    print("largest (max, mean) |parameter difference| to the plain schedule over the repetitions:", worst)
 
 
 def _assert_norm_relative(grads, ref_params, what):
@@ -565,8 +568,10 @@ def test_stage2_benchmarked_step_at_full_size_matches_the_plain_step_the_oracle_
     from temporalalignnet_amd.train import to_device_batch
     batches = [to_device_batch(synth.make_batch(23 + i, B=B, T=T, n_min=4, n_max=16)) for i in range(3)]
     init, plain, runs, (grads, ld, aux), chained = _three_steps_both_schedules(monkeypatch, make, batches)
-    print("stage-2 benchmarked schedule ran as chains:", chained)
-    _assert_same_up_to_atomics(init, plain, runs)          # (i), (iii)
+    assert chained
+    # (twice the stage-1 mean bound: the atomics' noise of step k moves a few sentences across the quantile thresholds of step k + 1 --
+    #  the autograd schedule against itself reads 3.06e-5 on run 5 of 20, GPUTEST r6)
+    _assert_same_up_to_atomics(init, plain, runs, mean_tol=6e-5)          # (i), (iii)
     # ---- (ii)
     torch.set_num_threads(min(32, torch.get_num_threads()))
     b_np = synth.make_batch(23, B=B, T=T, n_min=4, n_max=16)
