@@ -454,6 +454,9 @@ typedef struct tan_encoder_desc {
      * a set.  The CALLER joins dw_stream before it reads those weight gradients or reuses the scratch buffers. */
     void* dw_stream; int dw_tail;
     void *scr2_dx, *scr2_dx2, *scr2_dh, *scr2_dqkv;
+    /* optional, both directions: scratch [8, R, C] f32 -- with it, stacks of few row panels (R / 64 <= TAN_SPLIT_PANELS, default 48)
+     * run the MLP branch through tan_mlp_fwd_split / tan_mlp_bwd_split */
+    float* split_part;
 } tan_encoder_desc;
 int tan_encoder_fwd(const tan_encoder_desc* e, void* stream);
 int tan_encoder_bwd(const tan_encoder_desc* e, void* stream);
@@ -557,6 +560,19 @@ typedef struct tan_mlp_bwd_desc {
 } tan_mlp_bwd_desc;
 int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream);
 
+/* Small batches (round 6): the same two branches with the HIDDEN dimension split over tan_mlp_split_chunks() = 8 workgroups per 64-row
+ * panel.  A whole-panel workgroup streams all of its block's weights (4 MiB) whatever the batch, so 16 panels take as long as 160; here
+ * workgroup (panel, chunk) runs one 256-wide hidden chunk (the same prologue, c_fc / c_proj phases, chunk epilogue and side outputs) and
+ * stores its [64 x 512] f32 term as plane `chunk` of `part` [8, rows, C] (scratch: nothing is expected in it, nothing is left in it
+ * that matters); a second launch adds the eight planes in chunk order and applies the row epilogue -- forward: + b_proj + residual ->
+ * x_out and the optional next LayerNorm (tfm_model.py:37,43); backward: LayerNorm-2 backward + residual -> dx2 and the column-sum
+ * parameter gradients.  Same descriptors and results (to the order of eight f32 additions) as tan_mlp_fwd / tan_mlp_bwd; the optional
+ * head / tail / ln_1-prologue fields must be NULL (tan_encoder_* issues those pieces as the launches they were before they were folded
+ * in).                                                                                                                               */
+int tan_mlp_split_chunks(void);
+int tan_mlp_fwd_split(const tan_mlp_desc* d, float* part, void* stream);
+int tan_mlp_bwd_split(const tan_mlp_bwd_desc* d, float* part, void* stream);
+
 /* ---- input embeddings in ONE launch (bf16 throughput mode, C = 512) ------------------------------------------------------------
  * tan_embed_fwd: per problem (modality), rows r = (video v, position t) with t = r % T:
  *   proj = a W^T;  y = LayerNorm(proj; ln_g, ln_b);  out[d][(v*out_grp_rows[d] + out_off[d] + t)] = y + pos[d][t]   (d = 0, 1)
@@ -621,6 +637,10 @@ typedef struct tan_attnblk_desc {
 } tan_attnblk_desc;
 int tan_attnblk_supported(int L, int C, int H, int dtype);
 int tan_attnblk_fwd(const tan_attnblk_desc* d, void* stream);
+/* Small batches (round 6): the same branch with one workgroup per (video, head pair) -- B workgroups leave most of the chip idle for
+ * 50-70 us per launch at B = 16 -- each storing its [L x 512] f32 term of the out-projection as plane `hp` of `part` (scratch
+ * [4, B*L, C] f32); a second launch adds the four planes in order, + b_out + x_in -> x_mid.  Same descriptor, same side outputs. */
+int tan_attnblk_fwd_split(const tan_attnblk_desc* d, float* part, void* stream);
 
 /* tools/lab only: device buffer ([8 waves][64] long) that receives workgroup 0's shader clock at the phase boundaries of
  * tan_attnblk_fwd, or NULL (default): no instrumentation */

@@ -229,6 +229,7 @@ class EncoderDesc(C.Structure):
         ("layer_done", C.POINTER(C.c_void_p)),
         ("no_save", C.c_int), ("xn1_ready", C.c_int), ("dw_stream", C.c_void_p), ("dw_tail", C.c_int),
         ("scr2_dx", C.c_void_p), ("scr2_dx2", C.c_void_p), ("scr2_dh", C.c_void_p), ("scr2_dqkv", C.c_void_p),
+        ("split_part", C.c_void_p),
     ]
 
 

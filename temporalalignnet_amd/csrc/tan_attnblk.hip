@@ -35,6 +35,7 @@ struct AbFwdArgs {
     bf16_t* x_mid;
     int L, H;
     long long* dbg;             // tools/lab only (tan_attnblk_lab_set_dbg), or NULL
+    float* part; long part_plane;   // SPLIT: [4][B*L][512] f32, plane hp = head pair hp's term of the out-projection; plane stride
 };
 
 constexpr int AB_D = 4;                          // weight prefetch distance in steps
@@ -128,7 +129,11 @@ __device__ __forceinline__ void ab_rows_out(const char* img, int r0, int lane, b
     }
 }
 
-template <int NRB16>
+// SPLIT (round 6, small batches): the grid is (videos, 4) and workgroup (v, hp) runs ONE head pair of video v -- the prologue, GEMM-a(hp),
+// the two heads' attention, GEMM-b(hp), the pair's side outputs -- and stores its [L x 512] f32 term of the out-projection as plane hp
+// of `part`; bias + residual are a second launch (attnblk_split_finish_kernel).  One workgroup per video leaves 240 of the 256 CUs idle at
+// B = 16 for 53 / 70 us per launch: the chains are latency-bound there (tan_panel.hip's SPLIT kernels, same idea).
+template <int NRB16, bool SPLIT = false>
 __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void attnblk_fwd_kernel(AbFwdArgs a) {
     static_assert(PN_WAVES == 8, "eight waves");
     constexpr int NKB = (NRB16 + 1) / 2, LP = 32 * NKB, XROWS = 16 * NRB16, D = AB_D;
@@ -142,6 +147,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void attnblk_fwd_kerne
     const long row0 = (long)blockIdx.x * L;
     const char* const pwa = a.pw_qkv;
     const char* const pwb = a.pw_out;
+    const int hp0 = SPLIT ? (int)blockIdx.y : 0, hp1 = SPLIT ? hp0 + 1 : 4;       // head pairs of this workgroup
 
     // (a staggered start of half the workgroups -- which pays in the attention backward, tan_attn.hip -- does nothing here: 46 / 71 us
     //  with and without; one workgroup per CU, the side outputs already leave at different times per wave)
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void attnblk_fwd_kerne
     AbWFrags WQ[D];
     pn_static_for<0, D>([&](auto jc) {
         constexpr int J = decltype(jc)::value;
-        ab_load_wa(WQ[J], pwa, 0, J, wave, lane);
+        ab_load_wa(WQ[J], pwa, hp0, J, wave, lane);
     });
 
     // ---- prologue: the xn1 panel (rows >= L repeat the last row: finite, masked as keys, never stored as queries), key bias
@@ -253,9 +259,9 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void attnblk_fwd_kerne
         });
     };
 
-    gemm_a(0, std::false_type{});
+    gemm_a(hp0, std::false_type{});
 #pragma unroll 1
-    for (int hp = 0; hp < 4; ++hp) {
+    for (int hp = hp0; hp < hp1; ++hp) {
         __syncthreads();        // every wave is done reading the images of the previous head pair (GEMM-b(hp-1), its copy-out)
         // ---- GEMM-a epilogue: bf16 q|k|v into the head images
         {
@@ -319,11 +325,33 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void attnblk_fwd_kerne
                     for (int rb = 0; rb < NKB; ++rb)
                         acc_o[nb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.f[nb], of[rb], acc_o[nb][rb], 0, 0, 0);
                 if constexpr (KB + D < 8) ab_load_wb(W, pwb, hp * 8 + KB + D, wave, ln);
-                else if (hp < 3) ab_load_wa(W, pwa, hp + 1, KB + D - 8, wave, ln);      // GEMM-a(hp+1) steps 0..3
+                else if (hp + 1 < hp1) ab_load_wa(W, pwa, hp + 1, KB + D - 8, wave, ln);      // GEMM-a(hp+1) steps 0..3
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
-        if (hp < 3) gemm_a(hp + 1, std::true_type{});
+        if (hp + 1 < hp1) gemm_a(hp + 1, std::true_type{});
+    }
+    if constexpr (SPLIT) {
+        if (saving) {          // the head pair's O rows
+#pragma unroll 1
+            for (int i = 0; i < NPW; ++i) { copy_read(i, lane); copy_store(i, lane, hp0); }
+        }
+        // the head pair's term of the out-projection -> plane hp0: a lane owns the 16 consecutive features wave * 64 + nb * 32 + 16 hi + r
+        // of row mb * 32 + (lane & 31)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < NKB; ++mb) {
+                const int m = mb * 32 + (lane & 31);
+                if (m < L) {
+                    float* dst = a.part + hp0 * a.part_plane + (row0 + m) * C + wave * 64 + nb * 32 + 16 * hi;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(acc_o[nb][mb][4 * q], acc_o[nb][mb][4 * q + 1], acc_o[nb][mb][4 * q + 2],
+                                                                              acc_o[nb][mb][4 * q + 3]);
+                }
+            }
+        return;
     }
     // the residual rows of the epilogue: requested before the last head pair's side outputs leave
     uint4 resq[2][NKB][2];
@@ -366,6 +394,25 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void attnblk_fwd_kerne
         *reinterpret_cast<uint4*>(a.x_mid + (row0 + m) * C + lane * 8) = *reinterpret_cast<const uint4*>(pn_panel_slot<1024>(xo_panel, m, lane));
 }
 
+// x_mid = x_in + (sum of the four head pairs' planes, in order) + b_out: one wave per row, a lane owns 8 consecutive features
+__global__ __launch_bounds__(256) void attnblk_split_finish_kernel(const float* __restrict__ part, long plane, const bf16_t* __restrict__ x_in,
+                                                                   const float* __restrict__ b_out, bf16_t* __restrict__ x_mid, long rows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    f8 acc = ld8f(part + row * 512 + lane * 8);
+#pragma unroll
+    for (int c = 1; c < 4; ++c) {
+        const f8 t = ld8f(part + c * plane + row * 512 + lane * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc.v[j] += t.v[j];
+    }
+    const f8 res = ld8(x_in + row * 512 + lane * 8), bias = ld8f(b_out + lane * 8);
+    f8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v.v[j] = acc.v[j] + bias.v[j] + res.v[j];
+    st8(x_mid + row * 512 + lane * 8, v);
+}
 
 }  // namespace tal
 
@@ -388,12 +435,38 @@ extern "C" int tan_attnblk_fwd(const tan_attnblk_desc* d, void* stream) {
     a.pw_qkv = (const char*)d->pw_qkv; a.pw_out = (const char*)d->pw_out; a.b_qkv = d->b_qkv; a.b_out = d->b_out;
     a.qkv = (bf16_t*)d->qkv; a.attn_o = (bf16_t*)d->attn_o; a.lse = d->lse; a.x_mid = (bf16_t*)d->x_mid;
     a.L = d->L; a.H = d->H; a.dbg = g_ab_dbg;
+    a.part = nullptr; a.part_plane = 0;
     const dim3 grid((unsigned)d->B);
     const double rows = (double)d->B * d->L;
     const int rec = prof_begin((hipStream_t)stream, TAN_PROF_ATTNBLK, 2.0 * rows * 512.0 * 2048.0 + 4.0 * rows * d->L * 512.0);
     if (d->L <= 64) hipLaunchKernelGGL((attnblk_fwd_kernel<4>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((attnblk_fwd_kernel<5>), grid, dim3(64 * PN_WAVES), 0, (hipStream_t)stream, a);
     prof_end((hipStream_t)stream, rec);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+// Small batches: the same branch with one workgroup per (video, head pair); `part` = scratch [4, B*L, C] f32 (tan_hip.h)
+extern "C" int tan_attnblk_fwd_split(const tan_attnblk_desc* d, float* part, void* stream) {
+    TAN_REQUIRE(d && part && d->xn1 && d->x_in && d->pw_qkv && d->pw_out && d->b_qkv && d->b_out && d->x_mid && d->B > 0);
+    TAN_REQUIRE(tan_attnblk_supported(d->L, d->C, d->H, TAN_BF16));
+    TAN_REQUIRE((d->qkv != nullptr) == (d->attn_o != nullptr) && (d->qkv != nullptr) == (d->lse != nullptr));
+    AbFwdArgs a;
+    a.xn1 = (const bf16_t*)d->xn1; a.x_in = (const bf16_t*)d->x_in; a.keypad = d->key_padding_mask;
+    a.pw_qkv = (const char*)d->pw_qkv; a.pw_out = (const char*)d->pw_out; a.b_qkv = d->b_qkv; a.b_out = d->b_out;
+    a.qkv = (bf16_t*)d->qkv; a.attn_o = (bf16_t*)d->attn_o; a.lse = d->lse; a.x_mid = (bf16_t*)d->x_mid;
+    a.L = d->L; a.H = d->H; a.dbg = nullptr;
+    const long rows = (long)d->B * d->L;
+    a.part = part; a.part_plane = rows * 512;
+    const hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)d->B, 4);
+    const int rec = prof_begin(st, TAN_PROF_ATTNBLK, 2.0 * rows * 512.0 * 2048.0 + 4.0 * rows * d->L * 512.0);
+    if (d->L <= 64) hipLaunchKernelGGL((attnblk_fwd_kernel<4, true>), grid, dim3(64 * PN_WAVES), 0, st, a);
+    else hipLaunchKernelGGL((attnblk_fwd_kernel<5, true>), grid, dim3(64 * PN_WAVES), 0, st, a);
+    prof_end(st, rec);
+    TAN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attnblk_split_finish_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, part, rows * 512, (const bf16_t*)d->x_in, d->b_out,
+                       (bf16_t*)d->x_mid, rows);
     TAN_LAUNCH_CHECK();
     return 0;
 }

@@ -159,6 +159,13 @@ static int panel_enabled() {
     static const int on = [] { const char* e = getenv("TAN_PANEL"); return e ? atoi(e) : 1; }();
     return on;
 }
+// Stacks of fewer row panels than this run the MLP branch through the split-hidden launches (tan_mlp_fwd_split / tan_mlp_bwd_split:
+// eight workgroups per panel); the pieces the whole-panel backward carries as head / prologue / tail -- the in_proj dX GEMM, the ln_1
+// backward, the out_proj dX GEMM -- are then the launches they were before they were folded in.  TAN_SPLIT_PANELS=0: never.
+static long split_panels() {
+    static const long n = [] { const char* e = getenv("TAN_SPLIT_PANELS"); return e ? atol(e) : 48L; }();
+    return n;
+}
 
 extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
     TAN_REQUIRE(e && e->layers > 0 && e->params && e->bufs && e->x0);
@@ -167,6 +174,7 @@ extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
     const void* x_in = e->x0;
     const bool panel_ok = panel_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0;
     const bool attn_panel_ok = panel_enabled() && tan_attnblk_supported(e->L, C, H, dt);
+    const bool split = panel_ok && e->split_part && R / 64 <= split_panels();
     bool ln1_done = e->xn1_ready != 0;      // the previous block's panel kernel (block 0: tan_embed_fwd) already produced this block's xn1 / mean1 / rstd1
     for (int i = 0; i < e->layers; ++i) {
         const tan_layer_params& p = e->params[i];
@@ -182,12 +190,13 @@ extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
             ab.pw_qkv = p.wp_qkv; ab.pw_out = p.wp_out; ab.b_qkv = p.b_qkv; ab.b_out = p.b_out;
             if (!e->no_save) { ab.qkv = b.qkv; ab.attn_o = b.attn_o; ab.lse = b.lse; }
             ab.x_mid = b.x_mid;
-            CK(tan_attnblk_fwd(&ab, st));
+            if (split) CK(tan_attnblk_fwd_split(&ab, e->split_part, st));
+            else CK(tan_attnblk_fwd(&ab, st));
         } else {
             CK(linear_fwd(dt, b.xn1, p.w_qkv, p.b_qkv, b.qkv, R, 3 * C, C, TAN_ACT_NONE, nullptr, nullptr, st));
             CK(tan_attn_fwd(b.qkv, e->key_padding_mask, b.attn_o, b.lse, e->B, e->L, H, dt, st));
             // out_proj + bias + residual: the head of the row-panel MLP forward below
-            out_head = panel_ok && p.wp_fc && p.wp_proj && p.wp_out;
+            out_head = panel_ok && !split && p.wp_fc && p.wp_proj && p.wp_out;
             if (!out_head) CK(linear_fwd(dt, b.attn_o, p.w_out, p.b_out, b.x_mid, R, C, C, TAN_ACT_NONE, nullptr, x_in, st));
         }
         if (panel_ok && p.wp_fc && p.wp_proj) {
@@ -208,7 +217,8 @@ extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
                 m.nln_g = e->post_g; m.nln_b = e->post_b; m.xn_next = e->post_out; m.nmean = e->post_mean; m.nrstd = e->post_rstd;
                 ln1_done = true;      // = the post-LN is done
             }
-            CK(tan_mlp_fwd(&m, st));
+            if (split) CK(tan_mlp_fwd_split(&m, e->split_part, st));
+            else CK(tan_mlp_fwd(&m, st));
         } else {
             CK(tan_layernorm_fwd(b.x_mid, p.ln2_g, p.ln2_b, b.xn2, b.mean2, b.rstd2, nullptr, 0, R, C, 1e-5f, dt, st));
             CK(linear_fwd(dt, b.xn2, p.w_fc, p.b_fc, b.h_act, R, 4 * C, C, TAN_ACT_QUICKGELU, b.h_pre, nullptr, st));
@@ -235,6 +245,7 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
     struct { bool on; int layer; const void *dxn, *x, *res; const float *mean, *rstd, *g; float *gg, *gb, *gcol;
              const void *dqkv, *pwt_in, *dstage; } pend{};
     const bool panel_all = panel_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0;
+    const bool split = panel_all && e->split_part && R / 64 <= split_panels();
     // the last `tail` blocks' weight-gradient launches on e->dw_stream (see tan_hip.h); tail > 1: those blocks alternate between two
     // sets of the scratch buffers the launch reads
     int tail = e->dw_stream && e->dw_stream != st ? (e->dw_tail > 0 ? e->dw_tail : 0) : 0;
@@ -251,7 +262,7 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
     auto set_b = [&](int i) { return tail > 1 && i < tail && (i & 1); };
     // gradient w.r.t. the residual stream leaving the current layer (the set of the block that reads it)
     void* dx = set_b(S - 1) ? e->scr2_dx : e->scr_dx;
-    if (e->d_stage[S - 1] && panel_all && e->params[S - 1].wtp_fc && e->params[S - 1].wtp_proj) {
+    if (e->d_stage[S - 1] && panel_all && !split && e->params[S - 1].wtp_fc && e->params[S - 1].wtp_proj) {
         TAN_REQUIRE(e->post_out);
         pend.on = true; pend.layer = -1; pend.dxn = e->d_stage[S - 1]; pend.x = x_last; pend.res = nullptr;
         pend.mean = e->post_mean; pend.rstd = e->post_rstd; pend.g = e->post_g; pend.gg = e->g_post_g; pend.gb = e->g_post_b;
@@ -296,9 +307,10 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
                 m.dqkv = pend.dqkv; m.pwt_in = pend.pwt_in; m.dstage = pend.dstage;      // (the in_proj dX GEMM in front of it, or NULLs)
             }
             // the out-projection's dX GEMM as the tail of the same launch
-            do_fused = p.wtp_out != nullptr;
+            do_fused = !split && p.wtp_out != nullptr;
             if (do_fused) { m.pwt_out = p.wtp_out; m.d_o = e->scr_do; }
-            CK(tan_mlp_bwd(&m, st));
+            if (split) CK(tan_mlp_bwd_split(&m, e->split_part, st));
+            else CK(tan_mlp_bwd(&m, st));
             if (pend.on) {          // every gradient of block pend.layer is final now
                 pend.on = false;
                 if (pend.layer >= 0 && e->layer_done && e->layer_done[pend.layer]) {
@@ -318,7 +330,7 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
         // stage i-1 IS this layer's xn1: its gradient joins here
         const void* dstage = i >= 1 ? e->d_stage[i - 1] : nullptr;
         // block i-1's row-panel MLP backward takes the ln_1 backward as its prologue -- and this dX GEMM in front of it as its head
-        const bool ln1_next = i > 0 && panel_all && e->params[i - 1].wtp_fc && e->params[i - 1].wtp_proj;
+        const bool ln1_next = i > 0 && panel_all && !split && e->params[i - 1].wtp_fc && e->params[i - 1].wtp_proj;
         const bool in_fused = ln1_next && p.wtp_qkv != nullptr;
         if (!in_fused)
             CK(linear_bwd_x(dt, scr_dqkv, p.w_qkv, p.wt_qkv, e->scr_dxn, R, 3 * C, C, TAN_ACT_NONE, nullptr, dstage, nullptr, st));
@@ -347,6 +359,11 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
             pend.mean = b.mean1; pend.rstd = b.rstd1; pend.g = p.ln1_g; pend.gg = p.g_ln1_g; pend.gb = p.g_ln1_b; pend.gcol = next_b_proj;
             continue;
         }
+        // (this launch writes the OTHER scratch set's dx -- block i - 1's input; with every block's weight gradients on dw_stream, block
+        //  i + 1's launch, which reads that buffer, may still be running: in the whole-panel path the buffer is written an iteration later,
+        //  behind the wait at its top)
+        if (tail > 1 && i >= 1 && i + 1 < tail)
+            if (hipStreamWaitEvent((hipStream_t)st, ev_done[i + 1], 0) != hipSuccess) return -3;
         CK(tan_layernorm_bwd(e->scr_dxn, x_in, p.ln1_g, b.mean1, b.rstd1, dx2, dx_in, p.g_ln1_g, p.g_ln1_b, next_b_proj, e->ln_ws, R,
                              C, dt, st));
         // every gradient of layer i is final here (g_b_proj[i] was written during iteration i+1 / by the post-LN backward)

@@ -520,14 +520,11 @@ extern "C" int tan_masked_quantile(const float* x, const unsigned char* invalid,
 // mask and the rows that still own a positive; the alignability labels (1: both maxima above their medians, 0: both below, 2: ignore;
 // 0 near the video's ends), their selection / target / counts / pos_weight; and confidence-ratio.  ~70 tiny torch kernels before.
 // One block; `buf` (dynamic LDS) holds npow2 floats for the three bitonic sorts.
-__device__ float s2_quantile(float* v, const float* x, const unsigned char* invalid, int n, int npow2, float q, int* cnt) {
-    if (threadIdx.x == 0) *cnt = 0;
+// (m = number of valid entries: the caller has it from its block sums -- counting them here with one LDS atomic per entry serialised
+//  2 048 atomics per sort, round 6)
+__device__ float s2_quantile(float* v, const float* x, const unsigned char* invalid, int n, int npow2, float q, int m) {
     __syncthreads();
-    for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
-        float val = INFINITY;
-        if (i < n && !invalid[i]) { val = x[i]; atomicAdd(cnt, 1); }
-        v[i] = val;
-    }
+    for (int i = threadIdx.x; i < npow2; i += blockDim.x) v[i] = (i < n && !invalid[i]) ? x[i] : INFINITY;
     __syncthreads();
     for (int k = 2; k <= npow2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -541,7 +538,6 @@ __device__ float s2_quantile(float* v, const float* x, const unsigned char* inva
             }
             __syncthreads();
         }
-    const int m = *cnt;
     float out = NAN;
     if (m > 0) {
         const float rank = q * (float)(m - 1);
@@ -564,7 +560,6 @@ __global__ __launch_bounds__(1024) void stage2_masks_kernel(const float* __restr
                                                             float* __restrict__ scal) {
     extern __shared__ float buf[];
     __shared__ float red[16];
-    __shared__ int cnt;
     const int tid = threadIdx.x, Mp = B * N;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int i = tid; i < Mp; i += 1024) {
@@ -581,22 +576,18 @@ __global__ __launch_bounds__(1024) void stage2_masks_kernel(const float* __restr
     const float sd = sqrtf(block_sum_1024(a0, red) / (n_valid - 1.0f)), sj = sqrtf(block_sum_1024(a1, red) / (n_valid - 1.0f));
     for (int i = tid; i < Mp; i += 1024) metric[i] = -((md[i] - mean_d) / sd + (mj[i] - mean_j) / sj);
     __syncthreads();
-    const float th = s2_quantile(buf, metric, tpad, Mp, npow2, q_th, &cnt);
+    const int m_valid = (int)(n_valid + 0.5f);
+    const float th = s2_quantile(buf, metric, tpad, Mp, npow2, q_th, m_valid);
     for (int i = tid; i < Mp; i += 1024) {
         const bool keep = (metric[i] <= th) && !tpad[i];
         th_mask[i] = keep; th_f[i] = keep ? 1.f : 0.f;
     }
-    __syncthreads();
-    for (int r = tid; r < B * T; r += 1024) {            // rows that still own a positive among the kept, real sentences (loss.py:288-290)
-        const int b = r / T;
-        float acc = 0.f;
-        for (int k = 0; k < N; ++k) acc += tgt[(long)r * N + k] * (tpad[b * N + k] ? 0.f : 1.f) * th_f[b * N + k];
-        rows_pos_th[r] = acc > 0.f ? 1.f : 0.f;
-    }
+    // (rows_pos_th: stage2_rows_kernel, a launch of its own behind this one -- B*T rows x N loads issued by ONE workgroup were most of
+    //  this kernel's 147 us, on the stage-2 step's critical chain)
     float med_d = 0.f, med_j = 0.f, n_sel = 0.f, n_pos = 0.f;
     if (use_align) {
-        med_d = s2_quantile(buf, md, tpad, Mp, npow2, 0.5f, &cnt);
-        med_j = s2_quantile(buf, mj, tpad, Mp, npow2, 0.5f, &cnt);
+        med_d = s2_quantile(buf, md, tpad, Mp, npow2, 0.5f, m_valid);
+        med_j = s2_quantile(buf, mj, tpad, Mp, npow2, 0.5f, m_valid);
         a0 = 0.f; a1 = 0.f;
         for (int i = tid; i < Mp; i += 1024) {
             float lab = 2.0f;
@@ -618,6 +609,17 @@ __global__ __launch_bounds__(1024) void stage2_masks_kernel(const float* __restr
         scal[0] = n_sel; scal[1] = n_pos; scal[2] = n_sel / n_pos - 1.0f; scal[3] = conf_ratio; scal[4] = n_valid; scal[5] = th;
         scal[6] = med_d; scal[7] = med_j;
     }
+}
+
+// rows that still own a positive among the kept, real sentences (loss.py:288-290)
+__global__ __launch_bounds__(256) void stage2_rows_kernel(const float* __restrict__ tgt, const unsigned char* __restrict__ tpad,
+                                                          const float* __restrict__ th_f, float* __restrict__ rows_pos_th, int B, int T, int N) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= B * T) return;
+    const int b = r / T;
+    float acc = 0.f;
+    for (int k = 0; k < N; ++k) acc += tgt[(long)r * N + k] * (tpad[b * N + k] ? 0.f : 1.f) * th_f[b * N + k];
+    rows_pos_th[r] = acc > 0.f ? 1.f : 0.f;
 }
 
 // BCE-with-logits of the alignability head on the selected sentences (loss.py:345-350: pos_weight = 1 / mean(label) - 1) and its top-1
@@ -766,6 +768,9 @@ extern "C" int tan_stage2_masks(const float* md, const float* mj, const unsigned
     while (p2 < Mp) p2 <<= 1;
     hipLaunchKernelGGL(stage2_masks_kernel, dim3(1), dim3(1024), (size_t)p2 * 4, (hipStream_t)stream, md, mj, text_pad, tgt, abs_text_pos, conf,
                        q_th, use_align, B, T, N, p2, metric, th_mask, th_f, rows_pos_th, lab, sel, y, scal8);
+    TAN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(stage2_rows_kernel, dim3(cdiv((long)B * T, 256)), dim3(256), 0, (hipStream_t)stream, tgt, text_pad, (const float*)th_f,
+                       rows_pos_th, B, T, N);
     TAN_LAUNCH_CHECK();
     return 0;
 }

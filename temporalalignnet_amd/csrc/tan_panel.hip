@@ -66,6 +66,7 @@ struct MlpFwdArgs {
     // optional head (MODE & 2048): x_mid is not read but PRODUCED first, x_mid = x_in + attn_o W_out^T + b_out -- the attention
     // out-projection + bias + residual of the block (tfm_model.py:30-36) where the fused attention launch does not run (L > 80)
     const bf16_t* attn_o; const char* pw_out; const float* b_out; const bf16_t* x_in; bf16_t* x_mid_w;
+    float* part; long part_plane;   // SPLIT (MODE & 4096): [8][rows][512] f32 partial c_proj sums, one plane per hidden chunk; plane stride
 };
 // Backward of the same branch, same schedule with the roles of the two weights exchanged (tan_mlp_bwd):
 //   dh_c = (dx W_proj[:, c]) o quickgelu'(h_pre_c)      "c_fc-like": K = 512 over the resident dx panel, packed W_proj^T tiles
@@ -94,6 +95,7 @@ struct MlpBwdArgs {
     const bf16_t* dqkv;         // [rows][1536]
     const char* pwt_in;         // packed W_in^T [512][1536]  (tiles [512][16])
     const bf16_t* dstage;       // [rows][512] or NULL: the deep-supervision gradient that joins at that ln_1 output
+    float* part; long part_plane;   // SPLIT (MODE & 4096): [8][rows][512] f32 partial sums of dxn = dh W_fc, one plane per hidden chunk
 };
 
 // Tiles are 16 KiB: c_fc [256 features][32 k], c_proj [512 features][16 k].  A weight fragment is consumed by exactly ONE wave
@@ -486,9 +488,17 @@ __device__ long long* g_panel_dbg = nullptr;      // tools/lab: phase clocks of 
 // streaming (loaded once), 4 no activation-fragment reads in the loop, 16 no side-output copy-out (arithmetic, LDS panel writes and barriers stay), 64 phase clocks
 // into nrstd[], 256 no up-front touch of the weights.  (Variants that drop the epilogue arithmetic also drop the c_fc MFMAs -- dead code --
 // and measure nothing useful: removed.)
+// MODE & 4096 = SPLIT (round 6, small batches): the grid is (panels, 8) and workgroup (p, c0) runs ONE hidden chunk of panel p -- the
+// prologue, c_fc(c0) + its epilogue + side outputs, c_proj(c0) -- and stores its [64 x 512] f32 partial sum as plane c0 of `part`; the
+// row epilogue (sum of the eight planes in a fixed order, bias + residual + next LayerNorm / LayerNorm-2 backward) is a launch of its own
+// (mlp_split_finish_*).  (First version: f32 atomics into one plane -- 4 M device-scope atomics per launch, 3x SLOWER than the
+// whole-panel kernels: 7.4 vs 2.56 ms per step at B = 16.)  A whole-panel
+// workgroup streams all 4 MiB of the block's weights whatever the batch: 16 panels take as long as 160 (85 / 133 us per launch at
+// B = 16 with 16 of 256 CUs busy); eight workgroups per panel stream 512 KiB each.
 template <int MODE, typename ArgsT>
 __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(ArgsT a) {
     constexpr bool BWD = ArgsT::bwd;
+    constexpr bool SPLIT = (MODE & 4096) != 0;
     constexpr int TILE = MLP_TILE, D = MLP_D;
     constexpr int XN_OFF = MLP_XN_OFF, H_OFF = MLP_H_OFF;
     __shared__ __attribute__((aligned(1024))) char lds[MLP_LDS];
@@ -496,6 +506,8 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long row0 = (long)blockIdx.x * PN_ROWS;
+    const int c0 = SPLIT ? (int)blockIdx.y : 0;          // SPLIT: the one hidden chunk this workgroup runs
+    const bool first = !SPLIT || c0 == 0;                // (outputs every chunk's workgroup would write alike are written by chunk 0's)
     const char* const pfc = a.pw_fc;
     const char* const ppj = a.pw_proj;
 
@@ -503,7 +515,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     // miss goes to HBM in the middle of the kernel's own 100 MB of side-output writes and the ring (eight steps) cannot cover that
     // latency: 97-104 us per launch against 72-77 us with the weights resident in the Infinity Cache (tools/lab/mlp_lab.py, E2/E3).
     // So the whole set is requested up front, one dword per 128-byte line spread over the first 64 workgroups, while HBM is quiet.
-    if (!(MODE & 256)) {
+    if (!(MODE & 256) && !SPLIT) {
         const int L = blockIdx.x * (64 * PN_WAVES) + tid;
         if (L < 32768) {
             const char* q = L < 16384 ? pfc + (long)L * 128 : ppj + (long)(L - 16384) * 128;
@@ -512,6 +524,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     }
     constexpr bool INP = BWD && (MODE & 512) != 0;      // the next block's in_proj dX GEMM runs first (its packed W_in^T leads the ring)
     constexpr bool OUTP = !BWD && (MODE & 2048) != 0;   // forward: the block's out_proj + bias + residual runs first (packed W_out leads)
+    static_assert(!(SPLIT && (INP || OUTP)), "the split kernels run the MLP branch only");
     const char* pin = pfc;
     if constexpr (OUTP) pin = a.pw_out;
     if constexpr (INP) {
@@ -523,7 +536,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     MlpWFrags WQ[D];
     pn_static_for<0, D>([&](auto jc) {
         constexpr int J = decltype(jc)::value;
-        mlp_load_w(WQ[J], pin + (long)(((INP || OUTP) ? 0 : (0) * 16) + J) * TILE, wave, lane);
+        mlp_load_w(WQ[J], pin + (long)(((INP || OUTP) ? 0 : c0 * 16) + J) * TILE, wave, lane);
     });
 
     // ---- prologue.  Forward: LN2 of the panel, 64 / PN_WAVES rows per wave (batches of 8), one 16-byte chunk per lane.  Backward:
@@ -779,9 +792,9 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                 for (int j = 0; j < 8; ++j) o[j] = v[r].v[j] * rstd * g.v[j] + b.v[j];
                 const uint4 u = pn_pack8(o);
                 const int m = wave * RPW + half * 8 + r;
-                if (a.xn2) *reinterpret_cast<uint4*>(a.xn2 + (row0 + m) * 512 + lane * 8) = u;       // (NULL: no backward will follow)
+                if (a.xn2 && first) *reinterpret_cast<uint4*>(a.xn2 + (row0 + m) * 512 + lane * 8) = u;       // (NULL: no backward will follow)
                 *reinterpret_cast<uint4*>(pn_panel_slot<1024>(lds + XN_OFF, m, lane)) = u;
-                if (lane == 0 && a.mean2) { a.mean2[row0 + m] = mean; a.rstd2[row0 + m] = rstd; }
+                if (lane == 0 && a.mean2 && first) { a.mean2[row0 + m] = mean; a.rstd2[row0 + m] = rstd; }
             }
         }
     }
@@ -798,7 +811,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     MlpBias32 B32;           // bias of the next chunk: loaded before a slot barrier, consumed right after it (mlp_init_h)
     MlpHPre HP;              // backward: pre-activations of the chunk in the accumulator layout
     MlpBwdEpi BE;
-    if constexpr (!BWD) mlp_bias32_load(B32, a.b_fc, (0), wave);
+    if constexpr (!BWD) mlp_bias32_load(B32, a.b_fc, c0, wave);
     static_assert(MLP_NBO == 2 && MLP_WFR == 2, "eight waves");
     MlpXAddr XA;
     mlp_xaddr_init(XA, lds, lane);
@@ -826,18 +839,19 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                 // all four together: each is a cold HBM read in the in-order vmcnt queue in front of the weight ring, and the
                 // ring stalls once per batch of them, not once per load
                 if constexpr (J == TAN_HPRE_STEP) {
-                    mlp_hpre_load<0, 0>(HP, a.h_pre, row0, (c), wave, lane);
-                    mlp_hpre_load<1, 0>(HP, a.h_pre, row0, (c), wave, lane);
-                    mlp_hpre_load<0, 1>(HP, a.h_pre, row0, (c), wave, lane);
-                    mlp_hpre_load<1, 1>(HP, a.h_pre, row0, (c), wave, lane);
+                    mlp_hpre_load<0, 0>(HP, a.h_pre, row0, (c + c0), wave, lane);
+                    mlp_hpre_load<1, 0>(HP, a.h_pre, row0, (c + c0), wave, lane);
+                    mlp_hpre_load<0, 1>(HP, a.h_pre, row0, (c + c0), wave, lane);
+                    mlp_hpre_load<1, 1>(HP, a.h_pre, row0, (c + c0), wave, lane);
                 }
             } else if constexpr (COPY) {
-                if (!(MODE & (8 | 16))) mlp_copy_step4<J, false>(CP, lds, a.h_pre, row0, c - 1, (c - 1));
+                if (!(MODE & (8 | 16))) mlp_copy_step4<J, false>(CP, lds, a.h_pre, row0, c - 1, (c - 1 + c0));
             }
             if (!(MODE & 2)) {      // the tile eight steps on: c_fc(c) J+8, else the first half of the next phase that streams
-                const char* src = J + D < 16 ? pfc + (long)((c) * 16 + J + D) * TILE
+                const char* src = J + D < 16 ? pfc + (long)((c + c0) * 16 + J + D) * TILE
+                                             : (SPLIT ? ppj + (long)(c0 * 16 + J + D - 16) * TILE           // SPLIT: c_proj(c0) is what streams next
                                              : (c == 0 ? pfc + (long)((1) * 16 + J + D - 16) * TILE      // body(0) has no c_proj phase
-                                                       : ppj + (long)((c - 1) * 16 + J + D - 16) * TILE);
+                                                       : ppj + (long)((c - 1) * 16 + J + D - 16) * TILE));
                 mlp_load_w(WQ[J % D], src, wave, lane);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -862,9 +876,9 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
                     if constexpr (J + 1 < J1) mlp_load_x_proj<J + 1>(nxt, XA, hb ^ 1);     // (the next range's first fragments: after its barrier)
                 }
                 if constexpr (!EPI && !BWD) {       // body(8): the side outputs of chunk 7 under c_proj(7)
-                    if (!(MODE & (8 | 16))) mlp_copy_step8<J>(CP, lds, a.h_pre, a.h_act, row0, 7, (7));
+                    if (!(MODE & (8 | 16))) mlp_copy_step8<J>(CP, lds, a.h_pre, a.h_act, row0, SPLIT ? 0 : 7, SPLIT ? c0 : 7);
                 } else {                    // the activation panel of chunk c-1 (c_proj(c-1) reads it too; rewritten in body c+1)
-                    if (!(MODE & (8 | 16))) mlp_copy_step4<J, true>(CP, lds, a.h_act, row0, c - 1, (c - 1));
+                    if (!(MODE & (8 | 16))) mlp_copy_step4<J, true>(CP, lds, a.h_act, row0, c - 1, (c - 1 + c0));
                 }
             }
             // c_proj: W.f[nb] = output features wave*64 + nb*32 .., one k step; the epilogue pieces sit between the MFMAs.  Neither
@@ -915,7 +929,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
             }
             if constexpr (PROJ) {
                 if (!(MODE & 2)) {  // c_proj(c-1) J+D, else the first steps of the next body's first phase
-                    if constexpr (J + D < 16) mlp_load_w(W, ppj + (long)((c - 1) * 16 + J + D) * TILE, wave, lane);
+                    if constexpr (J + D < 16) mlp_load_w(W, ppj + (long)((c - 1 + c0) * 16 + J + D) * TILE, wave, lane);
                     else if constexpr (EPI)     // c <= 7: body(c+1) starts with c_fc(c+1), body(8) with c_proj(7)
                         mlp_load_w(W, c < 7 ? pfc + (long)((c + 1) * 16 + J + D - 16) * TILE : ppj + (long)((7) * 16 + J + D - 16) * TILE,
                                    wave, lane);
@@ -963,8 +977,8 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     auto after_epi = [&](int c) __attribute__((always_inline)) {   // after the epilogue of chunk c, before the slot barrier
         if constexpr (BWD) {       // c_fc bias gradient: column sums of the wave's 32 features over the panel's 64 rows
             const float tot = pn_colsum16(BE.cs, lane);
-            if (!(lane & 2)) unsafeAtomicAdd(a.g_b_fc + (c) * 256 + wave * 32 + 16 * hi + pn_colsum16_index(lane), tot);
-        } else {
+            if (!(lane & 2)) unsafeAtomicAdd(a.g_b_fc + (c + c0) * 256 + wave * 32 + 16 * hi + pn_colsum16_index(lane), tot);
+        } else if constexpr (!SPLIT) {
             mlp_bias32_load(B32, a.b_fc, (min(c + 1, 7)), wave);
         }
     };
@@ -993,6 +1007,7 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     tick(); proj_steps(0, F_{}, T_{}, C8{}, C16{}, U2_{}); tick();
     after_epi(0);
     slot_barrier();
+    if constexpr (!SPLIT) {
     mlp_load_x_fc<0>(FA, XA);
     __builtin_amdgcn_sched_barrier(0);
     for (int c = 1; c < 8; ++c) {
@@ -1008,13 +1023,16 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
         if (c < 7) mlp_load_x_fc<0>(FA, XA);                        // fragments of the next body's first step
         __builtin_amdgcn_sched_barrier(0);
     }
-    mlp_load_x_proj<0>(FA, XA, 1);                                   // body(8): c_proj(7), hidden panel 7 & 1
+    }
+    // the last c_proj phase: body(8) = c_proj(7) over hidden panel 7 & 1; SPLIT: "body(1)" = c_proj(c0) over hidden panel 0
+    constexpr int CL = SPLIT ? 1 : 8, HBL = SPLIT ? 0 : 1;
+    mlp_load_x_proj<0>(FA, XA, HBL);
     __builtin_amdgcn_sched_barrier(0);
-    tick(); proj_steps(8, T_{}, F_{}, C0{}, C8{}, U0_{});
+    tick(); proj_steps(CL, T_{}, F_{}, C0{}, C8{}, U0_{});
     slot_barrier();
-    mlp_load_x_proj<8>(FA, XA, 1);
+    mlp_load_x_proj<8>(FA, XA, HBL);
     __builtin_amdgcn_sched_barrier(0);
-    proj_steps(8, T_{}, F_{}, C8{}, C16{}, U0_{}); tick();
+    proj_steps(CL, T_{}, F_{}, C8{}, C16{}, U0_{}); tick();
     if (!grp) slot_barrier();
     tick();
     if (MODE & 1) {          // stream-only experiment: keep the loaded fragments alive
@@ -1025,6 +1043,21 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
     }
 
     __syncthreads();         // every wave is done with the activation panels
+    if constexpr (SPLIT) {
+        // the workgroup's term of the [64 x 512] sum over the hidden chunks -> plane c0: a lane owns rows mb * 32 + (lane & 31) and the
+        // 16 consecutive features wave * 64 + nb * 32 + 16 hi + r (four 16-byte stores)
+#pragma unroll
+        for (int nb = 0; nb < MLP_NBO; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                float* dst = a.part + c0 * a.part_plane + (row0 + mb * 32 + (lane & 31)) * 512 + wave * (32 * MLP_NBO) + nb * 32 + 16 * hi;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(acc_o[nb][mb][4 * q], acc_o[nb][mb][4 * q + 1], acc_o[nb][mb][4 * q + 2],
+                                                                          acc_o[nb][mb][4 * q + 3]);
+            }
+        return;
+    }
     if constexpr (!BWD) {
     // ---- epilogue: + bias + residual -> x_out; LayerNorm of the (bf16-rounded) output row -> xn_next.  Both leave through LDS
     // panels as whole 1-KiB rows (pn_panel_copy_out); the input panel's space takes x_out, the hidden panels' space xn_next.
@@ -1179,11 +1212,162 @@ __global__ __launch_bounds__(64 * PN_WAVES, PN_WAVES / 4) void mlp_panel_kernel(
 }
 
 
+// ---- row epilogues of the SPLIT kernels (one wave per row, a lane owns 8 consecutive features): what the whole-panel kernel does from
+// its accumulators, here from the eight f32 planes the chunk workgroups of a panel left in `part`, added in chunk order (deterministic).
+__device__ __forceinline__ f8 split_sum8(const float* __restrict__ part, long plane, long row, int lane) {
+    f8 acc = ld8f(part + row * 512 + lane * 8);
+#pragma unroll
+    for (int c = 1; c < 8; ++c) {
+        const f8 t = ld8f(part + c * plane + row * 512 + lane * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc.v[j] += t.v[j];
+    }
+    return acc;
+}
+// forward: x_out = x_mid + (sum + b_proj); xn_next = LayerNorm(x_out rounded to bf16) (the whole-panel kernel's arithmetic, in its order)
+__global__ __launch_bounds__(256) void mlp_split_finish_fwd_kernel(const float* __restrict__ part, long plane, const bf16_t* __restrict__ x_mid,
+                                                                   const float* __restrict__ b_proj, bf16_t* __restrict__ x_out,
+                                                                   const float* __restrict__ nln_g, const float* __restrict__ nln_b,
+                                                                   bf16_t* __restrict__ xn_next, float* __restrict__ nmean,
+                                                                   float* __restrict__ nrstd, long rows, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const f8 acc = split_sum8(part, plane, row, lane);
+    const f8 res = ld8(x_mid + row * 512 + lane * 8), bias = ld8f(b_proj + lane * 8);
+    f8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v.v[j] = acc.v[j] + bias.v[j] + res.v[j];
+    st8(x_out + row * 512 + lane * 8, v);
+    if (!xn_next) return;
+    uint4 u;
+    u.x = f2bf2(v.v[0], v.v[1]); u.y = f2bf2(v.v[2], v.v[3]); u.z = f2bf2(v.v[4], v.v[5]); u.w = f2bf2(v.v[6], v.v[7]);
+    float xr[8];
+    pn_unpack8(u, xr);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += xr[j];
+    const float mean = wave_sum(s) * (1.0f / 512);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { xr[j] -= mean; q += xr[j] * xr[j]; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / 512) + eps);
+    const f8 g = ld8f(nln_g + lane * 8), b = ld8f(nln_b + lane * 8);
+    f8 y;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y.v[j] = xr[j] * rstd * g.v[j] + b.v[j];
+    st8(xn_next + row * 512 + lane * 8, y);
+    if (lane == 0) { nmean[row] = mean; nrstd[row] = rstd; }
+}
+
+// backward: dx2 = dx + LayerNorm-2 backward of dxn (the f32 sums); g_ln_g += colsum(dxn o xhat), g_ln_b += colsum(dxn), g_b_out +=
+// colsum(dx2) -- 16 rows per workgroup, one atomic per column and workgroup
+__global__ __launch_bounds__(256) void mlp_split_finish_bwd_kernel(const float* __restrict__ part, long plane, const bf16_t* __restrict__ x_mid,
+                                                                   const float* __restrict__ mean2, const float* __restrict__ rstd2,
+                                                                   const float* __restrict__ ln_g, const bf16_t* __restrict__ dx,
+                                                                   bf16_t* __restrict__ dx2, float* __restrict__ g_ln_g,
+                                                                   float* __restrict__ g_ln_b, float* __restrict__ g_b_out, long rows) {
+    __shared__ float red[4][3][512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const f8 gam = ld8f(ln_g + lane * 8);
+    float dg[8], db[8], ds[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg[j] = 0.f; db[j] = 0.f; ds[j] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long row = (long)blockIdx.x * 16 + wave * 4 + r;
+        if (row >= rows) continue;
+        const f8 dy = split_sum8(part, plane, row, lane);
+        const f8 xv = ld8(x_mid + row * 512 + lane * 8), rv = ld8(dx + row * 512 + lane * 8);
+        const float mean = mean2[row], rstd = rstd2[row];
+        float xh[8], g[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            xh[j] = (xv.v[j] - mean) * rstd;
+            g[j] = dy.v[j] * gam.v[j];
+            s1 += g[j];
+            s2 += g[j] * xh[j];
+            dg[j] += dy.v[j] * xh[j];
+            db[j] += dy.v[j];
+        }
+        const float m1 = wave_sum(s1) * (1.0f / 512), m2 = wave_sum(s2) * (1.0f / 512);
+        f8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            o.v[j] = rstd * (g[j] - m1 - xh[j] * m2) + rv.v[j];
+            ds[j] += o.v[j];
+        }
+        st8(dx2 + row * 512 + lane * 8, o);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[wave][0][lane * 8 + j] = dg[j];
+        red[wave][1][lane * 8 + j] = db[j];
+        red[wave][2][lane * 8 + j] = ds[j];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 3 * 512; idx += 256) {
+        const int which = idx >> 9, cc = idx & 511;
+        const float sum = red[0][which][cc] + red[1][which][cc] + red[2][which][cc] + red[3][which][cc];
+        float* out = which == 0 ? g_ln_g : (which == 1 ? g_ln_b : g_b_out);
+        unsafeAtomicAdd(out + cc, sum);
+    }
+}
+
 }  // namespace tal
 
 using namespace tal;
 
 extern "C" int tan_panel_waves(void) { return PN_WAVES; }
+
+extern "C" int tan_mlp_split_chunks(void) { return 8; }
+
+extern "C" int tan_mlp_fwd_split(const tan_mlp_desc* d, float* part, void* stream) {
+    TAN_REQUIRE(d && part && d->x_mid && d->ln_g && d->ln_b && d->pw_fc && d->pw_proj && d->b_fc && d->b_proj && d->x_out);
+    TAN_REQUIRE((d->h_pre != nullptr) == (d->h_act != nullptr) && (d->mean2 != nullptr) == (d->rstd2 != nullptr));
+    TAN_REQUIRE(d->rows > 0 && d->rows % PN_ROWS == 0 && d->C == 512 && d->FF == 2048 && !d->pw_out && d->variant == 0);
+    TAN_REQUIRE(!d->xn_next || (d->nln_g && d->nln_b && d->nmean && d->nrstd));
+    MlpFwdArgs a{};
+    a.x_mid = (const bf16_t*)d->x_mid; a.ln_g = d->ln_g; a.ln_b = d->ln_b;
+    a.pw_fc = (const char*)d->pw_fc; a.pw_proj = (const char*)d->pw_proj; a.b_fc = d->b_fc; a.b_proj = d->b_proj;
+    a.xn2 = (bf16_t*)d->xn2; a.mean2 = d->mean2; a.rstd2 = d->rstd2;
+    a.h_pre = (bf16_t*)d->h_pre; a.h_act = (bf16_t*)d->h_act; a.x_out = (bf16_t*)d->x_out;
+    a.eps = d->eps; a.part = part; a.part_plane = d->rows * 512;
+    const hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)(d->rows / PN_ROWS), 8);
+    const int rec = prof_begin(st, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0);
+    if (!d->h_pre) hipLaunchKernelGGL((mlp_panel_kernel<4096 | 16, MlpFwdArgs>), grid, dim3(64 * PN_WAVES), 0, st, a);
+    else hipLaunchKernelGGL((mlp_panel_kernel<4096, MlpFwdArgs>), grid, dim3(64 * PN_WAVES), 0, st, a);
+    prof_end(st, rec);
+    TAN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mlp_split_finish_fwd_kernel, dim3(cdiv(d->rows, 4)), dim3(256), 0, st, part, d->rows * 512, (const bf16_t*)d->x_mid, d->b_proj,
+                       (bf16_t*)d->x_out, d->nln_g, d->nln_b, (bf16_t*)d->xn_next, d->nmean, d->nrstd, d->rows, d->eps);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tan_mlp_bwd_split(const tan_mlp_bwd_desc* d, float* part, void* stream) {
+    TAN_REQUIRE(d && part && d->rows > 0 && d->rows % PN_ROWS == 0 && d->C == 512 && d->FF == 2048);
+    TAN_REQUIRE(d->dx && d->h_pre && d->x_mid && d->mean2 && d->rstd2 && d->ln_g && d->pwt_proj && d->pwt_fc && d->dh && d->dx2);
+    TAN_REQUIRE(d->g_b_fc && d->g_ln_g && d->g_ln_b && d->g_b_out && !d->ln1_dxn && !d->pwt_in && !d->pwt_out);
+    MlpBwdArgs a{};
+    a.dx = (const bf16_t*)d->dx; a.h_pre = (const bf16_t*)d->h_pre; a.x_mid = (const bf16_t*)d->x_mid;
+    a.mean2 = d->mean2; a.rstd2 = d->rstd2; a.ln_g = d->ln_g;
+    a.pw_fc = (const char*)d->pwt_proj; a.pw_proj = (const char*)d->pwt_fc;
+    a.h_act = (bf16_t*)d->dh; a.dx2 = (bf16_t*)d->dx2;
+    a.g_b_fc = d->g_b_fc; a.g_ln_g = d->g_ln_g; a.g_ln_b = d->g_ln_b; a.g_b_out = d->g_b_out;
+    a.part = part; a.part_plane = d->rows * 512;
+    const hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)(d->rows / PN_ROWS), 8);
+    const int rec = prof_begin(st, TAN_PROF_PANEL, 2.0 * d->rows * 512.0 * 2048.0 * 2.0);
+    hipLaunchKernelGGL((mlp_panel_kernel<4096, MlpBwdArgs>), grid, dim3(64 * PN_WAVES), 0, st, a);
+    prof_end(st, rec);
+    TAN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mlp_split_finish_bwd_kernel, dim3(cdiv(d->rows, 16)), dim3(256), 0, st, part, d->rows * 512, (const bf16_t*)d->x_mid, d->mean2,
+                       d->rstd2, d->ln_g, (const bf16_t*)d->dx, (bf16_t*)d->dx2, d->g_ln_g, d->g_ln_b, d->g_b_out, d->rows);
+    TAN_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int tan_pack_weights(const void* src, void* dst, const tan_pack_entry* table, int n, int max_tiles, void* stream) {
     TAN_REQUIRE(src && dst && table && n > 0 && max_tiles > 0);
@@ -1201,6 +1385,7 @@ extern "C" int tan_mlp_fwd(const tan_mlp_desc* d, void* stream) {
     TAN_REQUIRE(d->rows > 0 && d->rows % PN_ROWS == 0 && d->C == 512 && d->FF == 2048);
     TAN_REQUIRE(!d->xn_next || (d->nln_g && d->nln_b && d->nmean && d->nrstd));
     MlpFwdArgs a;
+    a.part = nullptr; a.part_plane = 0;
     a.x_mid = (const bf16_t*)d->x_mid; a.ln_g = d->ln_g; a.ln_b = d->ln_b;
     a.pw_fc = (const char*)d->pw_fc; a.pw_proj = (const char*)d->pw_proj; a.b_fc = d->b_fc; a.b_proj = d->b_proj;
     a.xn2 = (bf16_t*)d->xn2; a.mean2 = d->mean2; a.rstd2 = d->rstd2;
@@ -1262,6 +1447,7 @@ extern "C" int tan_mlp_bwd(const tan_mlp_bwd_desc* d, void* stream) {
     if (d->ln1_dxn || d->pwt_in) TAN_REQUIRE(d->ln1_x && d->ln1_mean && d->ln1_rstd && d->ln1_g && d->dx_out);
     TAN_REQUIRE((d->pwt_in != nullptr) == (d->dqkv != nullptr) && !(d->pwt_in && d->ln1_dxn));
     MlpBwdArgs a;
+    a.part = nullptr; a.part_plane = 0;
     a.ln1_dxn = (const bf16_t*)d->ln1_dxn; a.ln1_x = (const bf16_t*)d->ln1_x; a.ln1_res = (const bf16_t*)d->ln1_res;
     a.ln1_mean = d->ln1_mean; a.ln1_rstd = d->ln1_rstd; a.ln1_g = d->ln1_g;
     a.g_ln1_g = d->g_ln1_g; a.g_ln1_b = d->g_ln1_b; a.g_dx_colsum = d->g_dx_colsum; a.dx_out = (bf16_t*)d->dx_out;

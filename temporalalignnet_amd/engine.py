@@ -89,6 +89,7 @@ class _AlignerEngine(_WorkspaceMixin):
         d.g_post_g, d.g_post_b = _vp(self._g(post_name + ".weight")), _vp(self._g(post_name + ".bias"))
         d.post_out = _vp(er.act["post"])
         d.post_mean, d.post_rstd = _vp(er.stat["post_mean"]), _vp(er.stat["post_rstd"])
+        d.split_part = _vp(getattr(er, "split_part", None))
         return d
 
     def _encoder_fwd(self, er, x0, keypad, post_name, save=False, xn1_ready=False):
@@ -733,6 +734,11 @@ class _AlignerEngine(_WorkspaceMixin):
         # longer one): blocks 1 and 0; video chain: block 0.  Measured (ms per step, ABBA x2 on one box): none 4.58, (1, 1) 4.50 / 4.44,
         # (2, 1) 4.40, (3, 1) 4.40, (2, 2) 4.45, (6, 1) 4.47 -- earlier than the last ~0.4 ms of the chain there are no idle CUs to give.
         tail_j, tail_v = 2, 1
+        from .workspace import SPLIT_PANELS
+        if B * L <= 64 * SPLIT_PANELS:
+            # small batches (the split-hidden launches' range): the chip is mostly idle and the chains are latency-bound -- EVERY block's
+            # weight-gradient launch leaves the chain (B = 16: 6 x 40 us per chain)
+            tail_j, tail_v = Sd, Se
         aux_j = main if serial else _lib.role_stream(dev, "loss")
         aux_v = main if serial else _lib.role_stream(dev, "opt")
         # data parallel with gradient buckets: a layer's event must mean "every gradient of the layer is final" on the stack's own stream,

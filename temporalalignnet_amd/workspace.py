@@ -4,12 +4,15 @@ host-bound.  `_WorkspaceMixin` is the pool (an LRU over shapes: real batches var
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib
 
 WIDTH, HEADS = 512, 8
+# stacks of at most this many 64-row panels run the MLP branch through the split-hidden launches (the library reads the same variable)
+SPLIT_PANELS = int(os.environ.get("TAN_SPLIT_PANELS", "48"))
 
 
 class _Blocks:
@@ -45,6 +48,10 @@ class _EncRun:
                 setattr(self.bufs[i], k, self.act[f"{i}.{k}"].data_ptr())
             for k in st:
                 setattr(self.bufs[i], k, self.stat[f"{i}.{k}"].data_ptr())
+        # small stacks: scratch of the split-hidden MLP launches (tan_encoder_desc.split_part: eight f32 planes of partial sums)
+        self.split_part = None
+        if cd == torch.bfloat16 and R % 64 == 0 and R // 64 <= SPLIT_PANELS:
+            self.split_part = torch.empty(8 * R * Cw, dtype=torch.float32, device=dev)
 
     def stage(self, s):
         """[R, C] deep-supervision output s (tfm_model.py:48-55)."""

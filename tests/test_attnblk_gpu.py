@@ -119,6 +119,19 @@ def test_attnblk_fwd_matches_reference_and_unfused_path(B, L, pad, save):
         assert (diff > 0).float().mean().item() < 0.05, (k, (diff > 0).float().mean().item())
     if save:
         assert (u_lse - out["lse"]).abs().max().item() < 2e-2
+    # the small-batch form (tan_attnblk_fwd_split: one workgroup per (video, head pair), f32 planes added by a second launch): the side
+    # outputs come from the same instructions -> equal; x_mid differs by the order of four f32 additions.  `part` is scratch (NaNs here).
+    part = torch.full((4, R, 512), float("nan"), device="cuda")
+    out2 = {k: torch.zeros_like(v) for k, v in out.items()}
+    if save:
+        d.qkv, d.attn_o, d.lse = out2["qkv"].data_ptr(), out2["attn_o"].data_ptr(), out2["lse"].data_ptr()
+    d.x_mid = out2["x_mid"].data_ptr()
+    _lib.check(_lib.lib().tan_attnblk_fwd_split(C.byref(d), C.c_void_p(part.data_ptr()), ops._stream()), "tan_attnblk_fwd_split")
+    torch.cuda.synchronize()
+    for k in ("qkv", "attn_o", "lse"):
+        assert torch.equal(out2[k], out[k]), k
+    diff = (out2["x_mid"].float() - out["x_mid"].float()).abs()
+    assert diff.max().item() <= 2.0 ** -7 * out["x_mid"].float().abs().max().item() and (diff > 0).float().mean().item() < 0.02
 
 
 def test_attnblk_with_every_key_of_a_video_padded_gives_the_residual_plus_bias():

@@ -113,6 +113,36 @@ def test_mlp_fwd_matches_reference_and_unfused_path(R, next_ln):
         diff = (u.float() - out[k].float()).abs()
         assert diff.max().item() <= 2.0 ** -7 * u.float().abs().max().item(), k
         assert (diff > 0).float().mean().item() < 0.02, k        # different summation order flips a rounding now and then
+    # the split-hidden launches for small batches (tan_mlp_fwd_split: eight workgroups per panel, f32 partial sums met by atomics, row
+    # epilogue in a second launch): the side outputs of a chunk come from the same instructions -> equal; x_out / xn_next differ by the
+    # order of eight f32 additions.  `part` is scratch: whatever is in it (NaNs here) must not matter, two calls in a row.
+    assert _lib.lib().tan_mlp_split_chunks() == 8
+    part = torch.full((8, R, 512), float("nan"), device="cuda")
+    for rep in range(2):
+        out2 = {k: torch.full_like(v, float("nan")) for k, v in out.items()}
+        d.xn2, d.mean2, d.rstd2 = out2["xn2"].data_ptr(), out2["mean2"].data_ptr(), out2["rstd2"].data_ptr()
+        d.h_pre, d.h_act, d.x_out = out2["hpre"].data_ptr(), out2["hact"].data_ptr(), out2["xout"].data_ptr()
+        if next_ln:
+            d.xn_next, d.nmean, d.nrstd = out2["xn1"].data_ptr(), out2["mean1"].data_ptr(), out2["rstd1"].data_ptr()
+        _lib.check(_lib.lib().tan_mlp_fwd_split(C.byref(d), C.c_void_p(part.data_ptr()), ops._stream()), "tan_mlp_fwd_split")
+        torch.cuda.synchronize()
+        for k in ("xn2", "hpre", "hact", "mean2", "rstd2"):
+            assert torch.equal(out2[k], out[k]), (rep, k)
+        for k in ("xout",) + (("xn1",) if next_ln else ()):
+            diff = (out2[k].float() - out[k].float()).abs()
+            assert diff.max().item() <= 2.0 ** -7 * out[k].float().abs().max().item(), (rep, k)
+            assert (diff > 0).float().mean().item() < 0.02, (rep, k)
+        if next_ln:
+            for k in ("mean1", "rstd1"):
+                assert (out2[k] - out[k]).abs().max().item() <= 2e-3 * out[k].abs().max().item(), (rep, k)
+    # ... and without side outputs (the no-grad forward)
+    d.xn2 = d.mean2 = d.rstd2 = d.h_pre = d.h_act = None
+    xo3 = torch.full_like(out["xout"], float("nan"))
+    d.x_out = xo3.data_ptr()
+    _lib.check(_lib.lib().tan_mlp_fwd_split(C.byref(d), C.c_void_p(part.data_ptr()), ops._stream()), "tan_mlp_fwd_split")
+    torch.cuda.synchronize()
+    diff = (xo3.float() - out["xout"].float()).abs()
+    assert diff.max().item() <= 2.0 ** -7 * out["xout"].float().abs().max().item()
 
 
 @pytest.mark.parametrize("save", [True, False])
@@ -225,6 +255,25 @@ def test_mlp_bwd_matches_the_fp32_backward_of_the_branch(R):
     close(g_ln_g - 0.25, (r_dxn * xhat).sum(0), "g_ln_g", 2e-3)
     close(g_ln_b + 0.5, r_dxn.sum(0), "g_ln_b", 2e-3)
     close(g_b_out - 1.0, r_dx2.sum(0), "g_b_out", 2e-3)
+    # the split-hidden launches for small batches (tan_mlp_bwd_split): dh comes from the same instructions -> equal; dx2 and the
+    # column-sum gradients differ by the order of f32 additions
+    part = torch.full((8, R, 512), float("nan"), device="cuda")
+    for rep in range(2):
+        dh_s, dx2_s = torch.full_like(dh, float("nan")), torch.full_like(dx2, float("nan"))
+        gs = {"g_b_fc": torch.full((2048,), 0.5, device="cuda"), "g_ln_g": torch.full((512,), 0.25, device="cuda"),
+              "g_ln_b": torch.full((512,), -0.5, device="cuda"), "g_b_out": torch.full((512,), 1.0, device="cuda")}
+        d.dh, d.dx2 = dh_s.data_ptr(), dx2_s.data_ptr()
+        d.g_b_fc, d.g_ln_g, d.g_ln_b, d.g_b_out = (gs[k].data_ptr() for k in ("g_b_fc", "g_ln_g", "g_ln_b", "g_b_out"))
+        _lib.check(_lib.lib().tan_mlp_bwd_split(C.byref(d), C.c_void_p(part.data_ptr()), ops._stream()), "tan_mlp_bwd_split")
+        torch.cuda.synchronize()
+        assert torch.equal(dh_s, dh), rep
+        diff = (dx2_s.float() - dx2.float()).abs()
+        assert diff.max().item() <= 2.0 ** -7 * dx2.float().abs().max().item() and (diff > 0).float().mean().item() < 0.02, rep
+        close(gs["g_b_fc"] - 0.5, r_dh.sum(0), "g_b_fc split", 2e-3)
+        close(gs["g_ln_g"] - 0.25, (r_dxn * xhat).sum(0), "g_ln_g split", 2e-3)
+        close(gs["g_ln_b"] + 0.5, r_dxn.sum(0), "g_ln_b split", 2e-3)
+        close(gs["g_b_out"] - 1.0, r_dx2.sum(0), "g_b_out split", 2e-3)
+    d.g_b_fc, d.g_ln_g, d.g_ln_b, d.g_b_out = g_b_fc.data_ptr(), g_ln_g.data_ptr(), g_ln_b.data_ptr(), g_b_out.data_ptr()
     # optional tail: d_o = dx2 W_out (the attention out-projection's dX GEMM) from the resident dx2 panel; everything else unchanged
     w_out = (torch.randn(512, 512, device="cuda") * 512 ** -0.5).to(bf)
     (pwt_out,) = pack([w_out.T.contiguous()])

@@ -259,3 +259,70 @@ def test_pipelined_chain_steps_on_shallow_and_uneven_stacks(monkeypatch, E, D, B
     d = (flats["bench"] - flats["plain"]).abs()
     # (Adam turns atomics-order noise on ~zero gradients into lr-sized updates of a few elements: the bound of the B = 8 test, five steps)
     assert d.max().item() <= 1.1e-2 and d.mean().item() <= 5e-5, (d.max().item(), d.mean().item())
+
+
+_SPLIT_AB = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+from temporalalignnet_amd import synth
+from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
+stage = {stage!r}
+kw = dict(model="cotrain", loss_threshold=0.5) if stage == "cotrain" else dict(model="init")
+args = default_args(num_encoder_layers=6, num_decoder_layers=6, lr=1e-3, wd=1e-5, **kw)
+torch.manual_seed(3)
+model = build_model(args, compute_dtype="bf16", random_pos_start=0, language_model=None)
+head = stage == "cotrain"
+sd = {{("online." if head else "") + k: torch.from_numpy(v) for k, v in synth.make_params(7, 6, 6, head).items()}}
+if head:
+    sd.update({{"target." + k: torch.from_numpy(v) for k, v in synth.make_params(8, 6, 6, head).items()}})
+model.load_state_dict(sd)
+model.cuda()
+tr = Trainer(model, args)
+batches = [to_device_batch(synth.make_batch(40 + i, B=16, T=64, n_min=4, n_max=16)) for i in range(3)]
+tr.zero_grad()
+tr.forward_backward(batches[0])
+grad0 = tr.online.flat_grad().clone()
+losses = []
+for rep in range(4):                       # 12 pipelined steps: scratch sets, the two activation workspaces and every role stream get reused
+    for b in batches:
+        losses.append(tr.step(b)["loss"])
+flat = [tr.online.flat_parameters().clone()] + ([model.target.flat_parameters().clone()] if head else [])
+torch.cuda.synchronize()
+assert tr._last_step_chains
+torch.save({{"flat": torch.cat(flat).cpu(), "grad": grad0.cpu(), "loss": torch.stack([l.detach().float().cpu() for l in losses])}}, {out!r})
+"""
+
+
+@pytest.mark.parametrize("stage", ["init", "cotrain"])
+def test_small_batch_split_launches_match_the_whole_panel_launches(stage, tmp_path):
+    """B_local = 16 (SURVEY 8(d) config 3's second reporting point: 16 / 20 row panels per stack): twelve pipelined two-chain steps of
+    E6D6 with the split-hidden MLP launches, the head-pair-split attention branch and every block's weight gradients off the chains
+    (TAN_SPLIT_PANELS = 48, the default) against the same steps on the whole-panel launches (TAN_SPLIT_PANELS = 0) -- the variable is read
+    once per process, so each side is a process of its own.  Same arithmetic per element up to the order of f32 additions (eight hidden
+    chunks, four head pairs) and the bf16 roundings that order flips (1-2 % of x_out's entries by one ulp, tests/test_panel_gpu.py):
+    the first step's gradient norm-relative 5e-3 (the bf16 step against the fp32 oracle reads 1.2e-2; a corrupted panel reads > 0.1), the
+    losses of the first steps, and the parameters after twelve AdamW steps at lr 1e-3 (an element whose tiny gradient flips sign every
+    step moves 1.2e-2 apart; measured max 1.2e-2, mean 4.5e-5)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    res = {}
+    for sp in ("48", "0"):
+        out = str(tmp_path / f"split_{sp}.pt")
+        env = dict(os.environ, TAN_SPLIT_PANELS=sp)
+        r = subprocess.run([sys.executable, "-c", _SPLIT_AB.format(root=root, stage=stage, out=out)], capture_output=True, text=True, env=env,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[sp] = torch.load(out)
+    a, b = res["48"], res["0"]
+    assert torch.isfinite(a["flat"]).all() and torch.isfinite(a["loss"]).all()
+    rel = ((a["grad"] - b["grad"]).norm() / b["grad"].norm()).item()
+    print("first step's gradient, split vs whole-panel launches, norm-relative:", stage, rel)
+    assert rel <= 5e-3, rel
+    d = (a["flat"] - b["flat"]).abs()
+    tol_mean = 1.5e-4
+    print("split vs whole-panel launches, 12 steps at B = 16:", stage, "max", d.max().item(), "mean", d.mean().item(),
+          "losses", a["loss"][-3:].tolist(), b["loss"][-3:].tolist())
+    assert d.max().item() <= 2.5e-2 and d.mean().item() <= tol_mean, (d.max().item(), d.mean().item())
+    assert (a["loss"][:3] - b["loss"][:3]).abs().max().item() <= 2e-2 * b["loss"][:3].abs().max().item()
