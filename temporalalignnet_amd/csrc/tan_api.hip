@@ -1,5 +1,7 @@
 // Library-level entry points: version and the optional in-stream kernel timer used by bench.py's roofline line.
 #include <atomic>
+#include <chrono>
+#include <mutex>
 #include <vector>
 
 #include "tan_common.h"
@@ -18,6 +20,12 @@ struct ProfState {
     std::vector<double> work;
 };
 static ProfState g_prof;
+// Two host threads issue the step's two chains.  When both chains share ONE stream (bench.py's `isolated` reading) a bracket
+// [event, launch, event] of one thread must not take the other thread's launch in: brackets are mutually exclusive (held from prof_begin
+// to prof_end, a few microseconds of host time; only while the timer is on).  Without it the reading was bimodal: 5.2 or 6.8 ms.
+// (A timed try-lock and a per-thread "held" flag: an error return between prof_begin and prof_end must not hang the next launch.)
+static std::timed_mutex g_prof_bracket;
+static thread_local bool t_prof_held = false;
 
 int prof_begin(hipStream_t st, int kind, double work) {
     ProfState& p = g_prof;
@@ -30,11 +38,15 @@ int prof_begin(hipStream_t st, int kind, double work) {
     if (i >= p.cap) return -1;
     p.kind[i] = kind;
     p.work[i] = work;
+    if (!t_prof_held) t_prof_held = g_prof_bracket.try_lock_for(std::chrono::milliseconds(20));
     (void)hipEventRecord(p.ev[2 * i], st);
     return i;
 }
 void prof_end(hipStream_t st, int rec) {
-    if (rec >= 0) (void)hipEventRecord(g_prof.ev[2 * rec + 1], st);
+    if (rec >= 0) {
+        (void)hipEventRecord(g_prof.ev[2 * rec + 1], st);
+        if (t_prof_held) { g_prof_bracket.unlock(); t_prof_held = false; }
+    }
 }
 
 }  // namespace tal

@@ -581,13 +581,20 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
             st4(dx + r * C + c, o);
         }
     }
+    // the four waves meet in LDS first: ONE atomic per column and workgroup (every wave of 256 workgroups adding to the same 513
+    // addresses -- 0.5 M device-scope atomics on 2 KiB -- took 103 us for 2 048 rows, on the stage-2 step's joint chain)
+    __shared__ float red[4][C + 4];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = (i * 64 + lane) * 4;
-        unsafeAtomicAdd(dw + c + 0, acc[i].x); unsafeAtomicAdd(dw + c + 1, acc[i].y);
-        unsafeAtomicAdd(dw + c + 2, acc[i].z); unsafeAtomicAdd(dw + c + 3, acc[i].w);
+        red[wv][c] = acc[i].x; red[wv][c + 1] = acc[i].y; red[wv][c + 2] = acc[i].z; red[wv][c + 3] = acc[i].w;
     }
-    if (lane == 0) unsafeAtomicAdd(db, accb);
+    if (lane == 0) red[wv][C] = accb;
+    __syncthreads();
+    for (int c = threadIdx.x; c <= C; c += 256) {
+        const float v = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+        unsafeAtomicAdd(c < C ? dw + c : db, v);
+    }
 }
 
 // linear interpolation of a [L_in, C] table to [L_out, C], align_corners=False (F.interpolate, tan_model.py:157-160)
@@ -838,7 +845,7 @@ extern "C" int tan_head_bwd(const float* dout, const void* x, const float* w, vo
                             int C, int accumulate_dx, int dtype, void* stream) {
     TAN_REQUIRE(dout && x && w && dx && dw && db && rows > 0);
     hipStream_t st = (hipStream_t)stream;
-    const int nblk = (int)min((long)256, (long)cdiv(rows, ROWS_PER_BLOCK));      // (64 blocks walked 48 rows per wave one after the other: 63 us)
+    const int nblk = (int)min((long)256, (long)cdiv(rows, 4 * ROWS_PER_BLOCK));  // (>= 4 rows per wave; one atomic per column and workgroup)
     DISPATCH_T(dtype, DISPATCH_NCH(C, hipLaunchKernelGGL((head_bwd_kernel<T, NCH>), dim3(nblk), dim3(256), 0, st, dout,
                                                          (const T*)x, w, (T*)dx, dw, db, rows, accumulate_dx)));
     TAN_LAUNCH_CHECK();

@@ -43,6 +43,8 @@ def run(cfg, chains):
         if s == 0:
             eligible = STAGE2 or tr._chains_eligible(b, tr.fused_loss)
         losses.append(tr.step(b)["loss"])
+        if STAGE2 and s == 0:
+            eligible = bool(tr.__dict__.get("_last_step_chains"))       # (the two-chain co-training step, or its autograd fallback)
     torch.cuda.synchronize()
     tr.online._ensure_flat()
     return [float(x) for x in losses], tr.online.flat_parameters().clone(), tr.online._flat, eligible
