@@ -292,6 +292,10 @@ int tan_simnce_bwd_dl_dvn_kept(const void* e_keep, const void* vn, const void* t
  * [B, T, N] f32 (padded-sentence order; what train/loss.py:280-283 takes its per-sentence maxima from) are at tan_simfam_diag(). */
 #define TAN_SIMFAM_SWEEP_ONLY 4
 #define TAN_SIMFAM_FINISH_ONLY 8
+/* d_tn_acc is already ZERO when tan_simfam_bwd is called (the caller cleared it off the critical chain): the corrections launch does
+ * not clear it (16 MB for the joint family at B = 128: 86 us in front of the one-pass kernel when it is the first thing after the
+ * stage-2 step's meeting point) */
+#define TAN_SIMFAM_ACC_ZEROED 16
 typedef struct tan_simfam_desc {
     int S, St, B, T, N, C, Mc, flags;
     tan_ptr8 x_video; long v_grp_rows, v_off;

@@ -526,6 +526,64 @@ __device__ float s2_quantile(float* v, const float* x, const unsigned char* inva
     __syncthreads();
     for (int i = threadIdx.x; i < npow2; i += blockDim.x) v[i] = (i < n && !invalid[i]) ? x[i] : INFINITY;
     __syncthreads();
+    if (m > 0) {
+        // Two order statistics by RADIX SELECT on order-preserving keys instead of a sort: four passes of a 256-bin histogram (LDS
+        // atomics, 2-8 entries per thread) narrow the key of the k-th smallest entry byte by byte; exact (it IS the entry the sort puts at
+        // position k).  ~2 us per pass where the 66 barrier-separated stages of the bitonic sort took ~23 us per quantile at n = 2 048 --
+        // three quantiles were most of this one-workgroup launch on the stage-2 step's critical section.  (An n^2 rank count, tried
+        // first, is 4 M comparisons on ONE CU: 800 us.)
+        __shared__ unsigned hist[256];
+        __shared__ unsigned sel_prefix, sel_k;
+        const float rank = q * (float)(m - 1);
+        const float lo = floorf(rank);
+        const int il = (int)lo, ih = min(il + 1, m - 1);
+        float res[2];
+        for (int which = 0; which < 2; ++which) {
+            if (which == 1 && ih == il) { res[1] = res[0]; break; }
+            if (threadIdx.x == 0) { sel_prefix = 0u; sel_k = (unsigned)(which ? ih : il); }
+            unsigned mask = 0u;
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+                __syncthreads();
+                const unsigned prefix = sel_prefix;
+                for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                    if (invalid[i]) continue;
+                    const unsigned b = __float_as_uint(v[i]);
+                    const unsigned key = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+                    if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+                }
+                __syncthreads();
+                if (threadIdx.x < 64) {          // wave 0: the bin that holds entry number sel_k of the surviving keys
+                    const int l = threadIdx.x;
+                    const unsigned h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+                    const unsigned tot = h0 + h1 + h2 + h3;
+                    unsigned inc = tot;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const unsigned t = __shfl_up(inc, o, 64);
+                        if (l >= o) inc += t;
+                    }
+                    const unsigned before = inc - tot, k = sel_k;
+                    if (k >= before && k < inc) {          // exactly one lane
+                        unsigned r = k - before, bin;
+                        if (r < h0) bin = 0;
+                        else if ((r -= h0) < h1) bin = 1;
+                        else if ((r -= h1) < h2) bin = 2;
+                        else { r -= h2; bin = 3; }
+                        sel_prefix = prefix | ((unsigned)(4 * l + bin) << shift);
+                        sel_k = r;
+                    }
+                }
+                mask |= 255u << shift;
+                __syncthreads();
+            }
+            const unsigned key = sel_prefix;
+            res[which] = __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+            __syncthreads();
+        }
+        const float w = rank - lo, a = res[0], b2 = res[1];
+        return (w < 0.5f) ? a + w * (b2 - a) : b2 - (b2 - a) * (1.0f - w);  // at::lerp
+    }
     for (int k = 2; k <= npow2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
@@ -550,8 +608,8 @@ __device__ float s2_quantile(float* v, const float* x, const unsigned char* inva
     return out;
 }
 
-__global__ __launch_bounds__(1024) void stage2_masks_kernel(const float* __restrict__ md, const float* __restrict__ mj,
-                                                            const unsigned char* __restrict__ tpad, const float* __restrict__ tgt,
+__global__ __launch_bounds__(1024) void stage2_masks_kernel(const float* __restrict__ md_g, const float* __restrict__ mj_g,
+                                                            const unsigned char* __restrict__ tpad_g, const float* __restrict__ tgt,
                                                             const float* __restrict__ abs_pos, const unsigned char* __restrict__ conf,
                                                             float q_th, int use_align, int B, int T, int N, int npow2,
                                                             float* __restrict__ metric, unsigned char* __restrict__ th_mask,
@@ -561,11 +619,24 @@ __global__ __launch_bounds__(1024) void stage2_masks_kernel(const float* __restr
     extern __shared__ float buf[];
     __shared__ float red[16];
     const int tid = threadIdx.x, Mp = B * N;
+    // ONE global round trip: the maxima and the pad flags live in LDS from here on (a dozen dependent phases, each behind a global
+    // load of the same few KiB, were most of this launch's 80 us -- on the stage-2 step's critical section between the two chains)
+    float* const mdS = buf + npow2;
+    float* const mjS = mdS + Mp;
+    float* const metS = mjS + Mp;
+    unsigned char* const padS = reinterpret_cast<unsigned char*>(metS + Mp);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int i = tid; i < Mp; i += 1024) {
-        const float v = tpad[i] ? 0.f : 1.f;
-        a0 += v; a1 += md[i] * v; a2 += mj[i] * v; a3 += (conf ? (float)conf[i] : 0.f) * v;
+        const float d_ = md_g[i], j_ = mj_g[i];
+        const unsigned char p_ = tpad_g[i];
+        mdS[i] = d_; mjS[i] = j_; padS[i] = p_;
+        const float v = p_ ? 0.f : 1.f;
+        a0 += v; a1 += d_ * v; a2 += j_ * v; a3 += (conf ? (float)conf[i] : 0.f) * v;
     }
+    __syncthreads();
+    const float* const md = mdS;
+    const float* const mj = mjS;
+    const unsigned char* const tpad = padS;
     const float n_valid = block_sum_1024(a0, red), mean_d = block_sum_1024(a1, red) / n_valid, mean_j = block_sum_1024(a2, red) / n_valid;
     const float conf_ratio = block_sum_1024(a3, red) / n_valid;
     a0 = 0.f; a1 = 0.f;
@@ -574,12 +645,15 @@ __global__ __launch_bounds__(1024) void stage2_masks_kernel(const float* __restr
         a0 += dd * dd * v; a1 += dj * dj * v;
     }
     const float sd = sqrtf(block_sum_1024(a0, red) / (n_valid - 1.0f)), sj = sqrtf(block_sum_1024(a1, red) / (n_valid - 1.0f));
-    for (int i = tid; i < Mp; i += 1024) metric[i] = -((md[i] - mean_d) / sd + (mj[i] - mean_j) / sj);
+    for (int i = tid; i < Mp; i += 1024) {
+        const float mt = -((md[i] - mean_d) / sd + (mj[i] - mean_j) / sj);
+        metric[i] = mt; metS[i] = mt;
+    }
     __syncthreads();
     const int m_valid = (int)(n_valid + 0.5f);
-    const float th = s2_quantile(buf, metric, tpad, Mp, npow2, q_th, m_valid);
+    const float th = s2_quantile(buf, metS, tpad, Mp, npow2, q_th, m_valid);
     for (int i = tid; i < Mp; i += 1024) {
-        const bool keep = (metric[i] <= th) && !tpad[i];
+        const bool keep = (metS[i] <= th) && !tpad[i];
         th_mask[i] = keep; th_f[i] = keep ? 1.f : 0.f;
     }
     // (rows_pos_th: stage2_rows_kernel, a launch of its own behind this one -- B*T rows x N loads issued by ONE workgroup were most of
@@ -764,9 +838,13 @@ extern "C" int tan_stage2_masks(const float* md, const float* mj, const unsigned
     TAN_REQUIRE(!use_align || (lab && sel && y));
     const int Mp = B * N;
     TAN_REQUIRE(Mp <= 8192);
-    int p2 = 1;
+    int p2 = 4;                      // (>= 4: the rank-counting quantile reads the buffer in 16-byte pieces)
     while (p2 < Mp) p2 <<= 1;
-    hipLaunchKernelGGL(stage2_masks_kernel, dim3(1), dim3(1024), (size_t)p2 * 4, (hipStream_t)stream, md, mj, text_pad, tgt, abs_text_pos, conf,
+    const size_t lds = ((size_t)p2 + 3 * (size_t)Mp) * 4 + (size_t)Mp;          // sort buffer | md | mj | metric | pad flags
+    static std::atomic<unsigned long long> lds_done{0};
+    const hipError_t attr = ensure_dyn_lds((const void*)stage2_masks_kernel, 152 * 1024, lds_done);      // (+ ~1.2 KiB of static LDS; 8192 sentences need 139 KiB)
+    if (attr != hipSuccess) return (int)attr;
+    hipLaunchKernelGGL(stage2_masks_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, md, mj, text_pad, tgt, abs_text_pos, conf,
                        q_th, use_align, B, T, N, p2, metric, th_mask, th_f, rows_pos_th, lab, sel, y, scal8);
     TAN_LAUNCH_CHECK();
     hipLaunchKernelGGL(stage2_rows_kernel, dim3(cdiv((long)B * T, 256)), dim3(256), 0, (hipStream_t)stream, tgt, text_pad, (const float*)th_f,

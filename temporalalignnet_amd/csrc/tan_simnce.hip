@@ -1801,7 +1801,8 @@ extern "C" int tan_simfam_bwd(tan_simfam_desc* d, void* stream) {
     a.diag = w.diag; a.corr = w.corr;
     if (!(d->flags & TAN_SIMFAM_CORR_DONE)) {
         hipLaunchKernelGGL(simnce_corr_kernel, dim3(B, S), dim3(256), 0, st, (const float*)w.diag, a.tgt, a.col_invalid, a.row_leak,
-                           (const float*)a.possum_v, a.possum_t, a.g_v, a.g_t, w.corr, B, T, N, a.colmap, Mc, d->d_tn_acc, (long)St * Mc * 512);
+                           (const float*)a.possum_v, a.possum_t, a.g_v, a.g_t, w.corr, B, T, N, a.colmap, Mc,
+                           (d->flags & TAN_SIMFAM_ACC_ZEROED) ? nullptr : d->d_tn_acc, (long)St * Mc * 512);
         TAN_LAUNCH_CHECK();
     }
     // ---- d logits + d v_hat in one pass, the normalisation's backward as the epilogue -> the stack's stage-gradient rows

@@ -784,11 +784,11 @@ class _AlignerEngine(_WorkspaceMixin):
             if zero_ev is not None:
                 main.wait_event(zero_ev)
             v_d, t_d = family("dual", [ev.stage(s) for s in range(Se)], (T, 0), [fe["lang_raw"]], (N, 0), dv, [d_lang_raw])
-        except BaseException:
-            # (the joint chain may have failed first -- a family that synchronises the chains then fails here as a consequence: report
-            #  the root cause; either way the helper thread is through before the error leaves)
+        except BaseException as main_exc:
+            # (a family that synchronises the chains fails on BOTH threads when one of them does: report the root cause, not the
+            #  "other chain did not arrive" that follows from it; either way the helper thread is through before the error leaves)
             exc = fut.exception()
-            if exc is not None:
+            if exc is not None and getattr(main_exc, "tan_consequence", False) and not getattr(exc, "tan_consequence", False):
                 raise exc
             raise
         self._dual_terms = (v_d, t_d)

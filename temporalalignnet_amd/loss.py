@@ -413,6 +413,7 @@ class SimFam:
         d.d_video, d.d_text = _ptr8(d_video), _ptr8(d_text)
         d.dtn_split_k = split_k          # (0: the library's choice -- include/tan_hip.h)
         self.g_v, self.g_t = g_v, g_t
+        self._acc = acc
         self.v_terms, self.t_terms = v_terms.view(S, R), t_terms.view(S, Mc)
         # the last stage's same-video cosines [B, T, N] f32 inside `ws`, written by the finishing launch (train/loss.py:280-283 reads them)
         off = L.tan_simfam_diag_offset(S, St, B, T, N, Mc, S - 1)
@@ -432,6 +433,8 @@ class SimFam:
         self.backward()
 
     def sweep(self):
+        self._acc.zero_()                        # the text-gradient accumulator, cleared here instead of in the backward's first launch
+        self.base_flags |= 16                    # TAN_SIMFAM_ACC_ZEROED
         self._fwd(4, False)                      # TAN_SIMFAM_SWEEP_ONLY
 
     def finish(self):

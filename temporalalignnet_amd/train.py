@@ -593,7 +593,9 @@ class Trainer:
 
         def hand_over(name):
             if not flags[name].wait(timeout=120.0) or failed:
-                raise _lib.TanHipError(f"stage-2 step: the other chain did not reach '{name}'" + (f" ({failed[0]} chain failed)" if failed else ""))
+                err = _lib.TanHipError(f"stage-2 step: the other chain did not reach '{name}'" + (f" ({failed[0]} chain failed)" if failed else ""))
+                err.tan_consequence = True          # (`_run_chains` reports the other thread's error instead)
+                raise err
             return evs[name]
 
         def guarded(fn):
