@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates profiles/ on an MI355X box: run as  gpurun -- 'bash tools/refresh_profiles.sh'  (writes under gpurun_out/refresh/);
-# then `bash tools/install_profiles.sh r05` copies gpurun_out/refresh/* over profiles/r05_*.  Counters are collected in their own passes (--pmc with --kernel-trace only).
+# then `bash tools/install_profiles.sh r06` copies gpurun_out/refresh/* over profiles/r06_*.  Counters are collected in their own passes (--pmc with --kernel-trace only).
 set -x
 R=$PWD; O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
@@ -31,6 +31,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc2_$c -- python $R/bench.py --stage 2 --steps 10 --warmup 5 --settle-s 0 --no-cpu-baseline --no-kernel-timer > /dev/null 2> $O/stage2_pmc_$c.err
 done
 python $R/tools/pmc_summary.py $(find /tmp/pmc2_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/pmc2_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/stage2_b128_pmc_traffic.json > $O/stage2_b128_pmc_traffic.txt
+# ---- SURVEY 8(d) config 3's small-batch point (B_local = 16, both stages): the split-hidden / head-pair-split launches of round 6
+for st in 1 2; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b16_$st -- python $R/bench.py --stage $st --batch 16 --steps 20 --warmup 5 --settle-s 0 --no-cpu-baseline --no-kernel-timer --no-extra > $O/b16_stage${st}_bench_under_rocprof.json 2> $O/b16_stage${st}.err
+  cp $(find /tmp/prof_b16_$st -name "*kernel_stats.csv" | head -1) $O/b16_stage${st}_kernel_stats.csv
+done
 # ---- where the step's time is (events per stream, host running ahead) and the step against the batch size
 cd $R
 python tools/stack_timeline.py > $O/stack_timeline.txt 2>/dev/null
