@@ -166,6 +166,13 @@ static long split_panels() {
     static const long n = [] { const char* e = getenv("TAN_SPLIT_PANELS"); return e ? atol(e) : 48L; }();
     return n;
 }
+// ... and the BACKWARD's MLP branch only up to this many panels: split, it is five launches (in_proj dX GEMM, ln_1 backward, the split
+// launch, its row epilogue, out_proj dX GEMM: 26 + 13 + 70 + 23 + 25 us at B = 32) where the whole-panel launch is one (128 us); at
+// B = 16 (16 / 20 panels) 26 + 14 + 40 + 15 + 26 against 133.  min(TAN_SPLIT_BWD_PANELS, TAN_SPLIT_PANELS).
+static long split_bwd_panels() {
+    static const long n = [] { const char* e = getenv("TAN_SPLIT_BWD_PANELS"); const long v = e ? atol(e) : 24L; return v < split_panels() ? v : split_panels(); }();
+    return n;
+}
 
 extern "C" int tan_encoder_fwd(const tan_encoder_desc* e, void* st) {
     TAN_REQUIRE(e && e->layers > 0 && e->params && e->bufs && e->x0);
@@ -245,7 +252,7 @@ extern "C" int tan_encoder_bwd(const tan_encoder_desc* e, void* st) {
     struct { bool on; int layer; const void *dxn, *x, *res; const float *mean, *rstd, *g; float *gg, *gb, *gcol;
              const void *dqkv, *pwt_in, *dstage; } pend{};
     const bool panel_all = panel_enabled() && dt == TAN_BF16 && C == 512 && R % 64 == 0;
-    const bool split = panel_all && e->split_part && R / 64 <= split_panels();
+    const bool split = panel_all && e->split_part && R / 64 <= split_bwd_panels();
     // the last `tail` blocks' weight-gradient launches on e->dw_stream (see tan_hip.h); tail > 1: those blocks alternate between two
     // sets of the scratch buffers the launch reads
     int tail = e->dw_stream && e->dw_stream != st ? (e->dw_tail > 0 ? e->dw_tail : 0) : 0;
