@@ -3,8 +3,11 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 from temporalalignnet_amd import synth
 from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
-args = default_args(model="init")
+KIND = os.environ.get("KIND", "init")
+args = default_args(model=KIND, **({"loss_threshold": 0.5} if KIND == "cotrain" else {}))
 model = build_model(args, compute_dtype="bf16").cuda()
+if KIND == "cotrain":
+    model._copy_param()
 tr = Trainer(model, args)
 b = to_device_batch(synth.make_batch(888, B=16, T=64, n_min=4, n_max=16))
 for _ in range(5):
