@@ -337,3 +337,38 @@ def test_small_batch_split_launches_match_the_whole_panel_launches(stage, tmp_pa
           "losses", a["loss"][-3:].tolist(), b["loss"][-3:].tolist())
     assert d.max().item() <= 2.5e-2 and d.mean().item() <= tol_mean, (d.max().item(), d.mean().item())
     assert (a["loss"][:3] - b["loss"][:3]).abs().max().item() <= tol_loss * b["loss"][:3].abs().max().item()
+
+
+@pytest.mark.parametrize("switches", [{}, {"TAN_STEP_PIPELINE": "0"}, {"TAN_OPT_EARLY": "0"}, {"TAN_OPT_IMAGES": "0"},
+                                      {"TAN_STEP_PIPELINE": "0", "TAN_OPT_EARLY": "0", "TAN_OPT_IMAGES": "0"}])
+def test_stage2_chain_step_matches_the_autograd_step_under_every_schedule_switch(monkeypatch, switches):
+    """Stage 2 ('cotrain': EMA forward, self-labelling, threshold 0.5, alignability head + BCE) in bf16 at B = 8: `Trainer.step` as two
+    chains with two meeting points (`_forward_backward_chains2`) against forward -> EMA forward -> get_loss -> loss.backward() under
+    autograd (TAN_STAGE2_CHAINS=0), with the step pipelined or joined, the stacks' optimizer launches early or at the end, the weight
+    images from the optimizer launch or rebuilt: every entry of the first step's loss dict, and the online AND EMA parameters after three
+    steps (same kernels on the same values up to the order of f32 atomics; a batch this small has no sentence near a threshold).
+    train/main.py:89-98,112-122; train/loss.py:88-229,277-373."""
+    from temporalalignnet_amd import synth
+    from temporalalignnet_amd.train import to_device_batch
+    batches = [to_device_batch(synth.make_batch(310 + i, B=8, T=64, n_min=4, n_max=12)) for i in range(3)]
+    res = {}
+    for tag, chains in (("autograd", "0"), ("chains", "1")):
+        monkeypatch.setenv("TAN_STAGE2_CHAINS", chains)
+        for k in ("TAN_STEP_PIPELINE", "TAN_OPT_EARLY", "TAN_OPT_IMAGES"):
+            monkeypatch.delenv(k, raising=False)
+        if chains == "1":
+            for k, v in switches.items():
+                monkeypatch.setenv(k, v)
+        tr, _ = _trainer(seed=21, dtype="bf16", model="cotrain", loss_threshold=0.5)
+        tr.model._copy_param()
+        lds = [tr.step(b) for b in batches]
+        assert bool(tr.__dict__.get("_last_step_chains")) == (chains == "1")
+        flat = torch.cat([tr.online.flat_parameters().clone(), tr.model.target.flat_parameters().clone()])
+        torch.cuda.synchronize()
+        res[tag] = ({k: float(v) for k, v in lds[0].items()}, flat)
+    (l0, p0), (l1, p1) = res["autograd"], res["chains"]
+    assert set(l0) == set(l1), (sorted(l0), sorted(l1))
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 2e-3 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
+    d = (p1 - p0).abs()
+    assert torch.isfinite(p1).all() and d.max().item() <= 6.5e-3 and d.mean().item() <= 6e-5, (d.max().item(), d.mean().item())
