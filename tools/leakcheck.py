@@ -4,10 +4,13 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from temporalalignnet_amd import synth
 from temporalalignnet_amd.train import Trainer, build_model, default_args, to_device_batch
-args = default_args(model="init")
-m = build_model(args, compute_dtype="bf16").cuda(); m.random_pos_start = 1
+KIND = os.environ.get("KIND", "init")
+args = default_args(model=KIND, **({"loss_threshold": 0.5} if KIND == "cotrain" else {}))
+m = build_model(args, compute_dtype="bf16").cuda()
+if KIND == "cotrain": m._copy_param()
+else: m.random_pos_start = 1
 tr = Trainer(m, args, iter_per_epoch=2890, warmup=1000); tr.iteration = 1000
-b = to_device_batch(synth.make_batch(888, B=32, T=64, n_min=4, n_max=16))
+b = to_device_batch(synth.make_batch(888, B=int(os.environ.get("B", 32)), T=64, n_min=4, n_max=16))
 def live():
     c = collections.Counter()
     for o in gc.get_objects():
