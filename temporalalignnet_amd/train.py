@@ -376,6 +376,12 @@ class Trainer:
         self._last_step_chains = self._chains_eligible(batch, fused)
         if self._last_step_chains:
             return self._forward_backward_chains2(batch) if self.twin else self._forward_backward_chains(batch)
+        # (`step` decided on pipelining from `_will_chain` before this point; should the two ever disagree, the autograd schedule below must
+        #  not start under the previous step's pending optimizer launches: wait for them here, on this stream)
+        for fl_ in [self.online._flat] + ([self.model.target._flat] if self.twin else []):
+            if fl_.in_step:
+                fl_.in_step = False
+                fl_.drain()
         if batch["video"].is_cuda:
             # what get_loss derives from the batch alone (masks, targets, column compaction: ~20 tiny launches) runs on the loss
             # side stream next to the forward instead of between the stacks and the similarity sweeps
@@ -969,6 +975,8 @@ class Trainer:
         fl = self.online._flat
         tfl = self.model.target._flat if self.twin else None       # (stage 2: the optimizer launches write the EMA twin's buffers too)
         batch = self._embed_tokens(batch)      # (the language model's forward, when the step starts from token ids: before anything is decided)
+        if self.online.compute_dtype == torch.bfloat16 and batch["video"].is_cuda and "text_embed" in batch:
+            batch = self._pad_sentence_slots(batch)      # (before the schedule is decided: stage 2's eligibility depends on the padded N)
         piped = self.pipeline and fl.bound() and (tfl is None or tfl.bound()) and self._will_chain(batch)
         fl.in_step = piped                     # (a pipelined step waits for what the previous one left running itself, piece by piece)
         if tfl is not None:
